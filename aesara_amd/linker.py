@@ -1,0 +1,90 @@
+"""``HipLinker`` — the drop-in ``aesara.link`` Linker for MI355X (gfx950).
+
+Boundary: subclasses ``aesara.link.basic.JITLinker`` (reference
+link/basic.py:580) and implements exactly its three abstract methods + ``output_filter``:
+
+* ``fgraph_convert`` (:589)  -> lowers the rewritten FunctionGraph to a launch ``Plan``
+* ``jit_compile``   (:609)  -> binds the plan to the device executor (C-ABI ``libaesara_hip.so``)
+* ``create_thunk_inputs`` (:595) -> the storage cells of ``fgraph.inputs``
+* ``output_filter`` (:612) -> device arrays are returned as is (JAX precedent,
+  tests/link/jax/test_basic.py:75-79) or converted to ``numpy`` when ``return_numpy=True``
+
+Registration mirrors the JAX/Numba modes (compile/mode.py:448-455): ``register()`` adds linker
+``"hip"`` (mode.py:54 ``register_linker``) and mode ``"HIP"`` (mode.py:525 ``register_mode``).
+The rewrite query excludes ``inplace`` (destroy maps are handled by the executor's buffer
+planner instead), ``cxx_only`` and ``c_blas`` exactly like the non-C backends.
+
+This module needs the reference front end (``import aesara``); everything below it
+(plan, executor, C-ABI) does not.
+"""
+from __future__ import annotations
+
+from aesara.compile.mode import Mode, register_linker, register_mode
+from aesara.graph.rewriting.db import RewriteDatabaseQuery
+from aesara.link.basic import JITLinker
+
+from .lower import lower_fgraph
+
+HIP_QUERY = RewriteDatabaseQuery(
+    include=["fast_run"], exclude=["cxx_only", "inplace", "c_blas", "BlasOpt_inplace"]
+)
+
+
+class HipLinker(JITLinker):
+    """A ``Linker`` that runs a whole ``FunctionGraph`` as HIP kernels on an MI355X."""
+
+    def __init__(self, *args, return_numpy=False, use_graph=False, executor_factory=None,
+                 **kwargs):
+        super().__init__(*args, **kwargs)
+        self.return_numpy = return_numpy
+        self.use_graph = use_graph
+        # test hook: lets CPU-only tests substitute a checker for the device executor.
+        self.executor_factory = executor_factory
+        self.plan = None
+
+    # -- JITLinker API ---------------------------------------------------------------
+    def fgraph_convert(self, fgraph, order=None, input_storage=None, output_storage=None,
+                       storage_map=None, **kwargs):
+        self.plan = lower_fgraph(fgraph, order=order, name=getattr(fgraph, "name", None)
+                                 or "fgraph", inner_rewriter=hip_mode.optimizer)
+        return self.plan
+
+    def jit_compile(self, plan):
+        if self.executor_factory is not None:
+            return self.executor_factory(plan)
+        from .executor import PlanExecutor  # imports the C-ABI; fails loudly if missing
+
+        ex = PlanExecutor(plan, use_graph=self.use_graph)
+        self.executor = ex
+        return ex
+
+    def create_thunk_inputs(self, storage_map):
+        return [storage_map[n] for n in self.fgraph.inputs]
+
+    def output_filter(self, var, out):
+        if self.return_numpy and hasattr(out, "detach"):
+            return out.detach().cpu().numpy()
+        return out
+
+
+hip_linker = HipLinker()
+hip_mode = Mode(hip_linker, HIP_QUERY)
+
+_registered = False
+
+
+def register():
+    """Idempotently register linker ``"hip"`` and mode ``"HIP"`` with the reference."""
+    global _registered
+    if _registered:
+        return hip_mode
+    try:
+        register_linker("hip", hip_linker)
+    except ValueError:
+        pass
+    try:
+        register_mode("HIP", hip_mode)
+    except ValueError:
+        pass
+    _registered = True
+    return hip_mode

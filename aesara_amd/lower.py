@@ -1,0 +1,397 @@
+"""Lower a rewritten Aesara ``FunctionGraph`` to a :class:`aesara_amd.plan.Plan`.
+
+This is the per-Op "dispatch" layer of the HIP linker — the analogue of ``jax_funcify`` /
+``numba_funcify`` (reference link/jax/dispatch/basic.py:38-58), except that an Op is turned
+into a *plan node* (plain data) rather than a Python callable, so the device executor can run
+it through the C-ABI without any Aesara object.  Aesara is imported lazily: this module is
+only used where the reference front end is installed.
+
+Every handler cites the reference Op it restates.
+"""
+from __future__ import annotations
+
+from functools import singledispatch
+
+import numpy as np
+
+from .plan import Node, Plan
+
+# scalar Op class name (reference aesara/scalar/basic.py, scalar/math.py) -> plan scalar op name
+SCALAR_OP_NAMES = {
+    "Add": "add", "Mul": "mul", "Sub": "sub", "TrueDivide": "true_div",
+    "FloorDivide": "int_div", "Mod": "mod", "Pow": "pow", "Neg": "neg", "Abs": "abs",
+    "Sgn": "sgn", "Sqr": "sqr", "Sqrt": "sqrt", "Exp": "exp", "Exp2": "exp2",
+    "Expm1": "expm1", "Log": "log", "Log2": "log2", "Log10": "log10", "Log1p": "log1p",
+    "Sin": "sin", "Cos": "cos", "Tan": "tan", "ArcSin": "arcsin", "ArcCos": "arccos",
+    "ArcTan": "arctan", "ArcTan2": "arctan2", "Sinh": "sinh", "Cosh": "cosh", "Tanh": "tanh",
+    "ArcSinh": "arcsinh", "ArcCosh": "arccosh", "ArcTanh": "arctanh",
+    "Ceil": "ceil", "Floor": "floor", "Trunc": "trunc",
+    "RoundHalfToEven": "round_half_to_even",
+    "RoundHalfAwayFromZero": "round_half_away_from_zero",
+    "Reciprocal": "reciprocal", "Identity": "identity", "Cast": "cast", "Second": "second",
+    "Switch": "switch", "Clip": "clip", "ScalarMaximum": "maximum",
+    "ScalarMinimum": "minimum", "LT": "lt", "GT": "gt", "LE": "le", "GE": "ge", "EQ": "eq",
+    "NEQ": "neq", "AND": "and", "OR": "or", "XOR": "xor", "Invert": "invert",
+    "IsNan": "isnan", "IsInf": "isinf", "Sigmoid": "sigmoid", "Softplus": "softplus",
+    "Erf": "erf", "Erfc": "erfc", "Log1mexp": "log1mexp", "Deg2Rad": "deg2rad",
+    "Rad2Deg": "rad2deg",
+}
+
+
+class UnsupportedOp(NotImplementedError):
+    """Raised for Ops outside the hot path: the linker reports them loudly."""
+
+
+def lower_scalar_op(scalar_op, n_in):
+    """``ScalarOp`` / ``Composite`` -> scalar expression dict (see plan.py docstring).
+
+    Reference: ``Composite.fgraph`` scalar/basic.py:4128, ``c_code_template`` :4250 (walks the
+    inner scalar graph in toposort order assigning one temporary per scalar Apply).
+    """
+    from aesara.scalar.basic import Composite, ScalarConstant
+
+    cls = type(scalar_op).__name__
+    if isinstance(scalar_op, Composite):
+        fg = scalar_op.fgraph
+        refs = {v: ["i", k] for k, v in enumerate(fg.inputs)}
+        nodes = []
+        for sn in fg.toposort():
+            ins = []
+            for v in sn.inputs:
+                if v in refs:
+                    ins.append(refs[v])
+                elif isinstance(v, ScalarConstant):
+                    ins.append(["c", _pyscalar(v.data), str(v.type.dtype)])
+                else:  # pragma: no cover
+                    raise UnsupportedOp(f"dangling scalar variable {v}")
+            sub = lower_scalar_op(sn.op, len(sn.inputs))
+            if len(sub["nodes"]) != 1:
+                # nested Composite: splice it in
+                base = len(nodes)
+                for n2 in sub["nodes"]:
+                    nodes.append({"op": n2["op"], "dtype": n2["dtype"],
+                                  "in": [_rebase(r, ins, base) for r in n2["in"]]})
+                for v, r in zip(sn.outputs, sub["out"]):
+                    refs[v] = _rebase(r, ins, base)
+                continue
+            for k, v in enumerate(sn.outputs):
+                if k > 0:
+                    raise UnsupportedOp("multi-output scalar op inside Composite")
+                nodes.append({"op": sub["nodes"][0]["op"], "in": ins,
+                              "dtype": str(v.type.dtype)})
+                refs[v] = ["t", len(nodes) - 1]
+        outs = []
+        for v in fg.outputs:
+            if v in refs:
+                outs.append(refs[v])
+            elif isinstance(v, ScalarConstant):
+                outs.append(["c", _pyscalar(v.data), str(v.type.dtype)])
+            else:  # pragma: no cover
+                raise UnsupportedOp("composite output not computed")
+        return {"n_in": n_in, "nodes": nodes, "out": outs}
+    if cls not in SCALAR_OP_NAMES:
+        raise UnsupportedOp(f"scalar op {cls} is outside the HIP hot path")
+    name = SCALAR_OP_NAMES[cls]
+    # dtype filled in by the caller (needs the Apply's output type)
+    return {"n_in": n_in,
+            "nodes": [{"op": name, "in": [["i", k] for k in range(n_in)], "dtype": None}],
+            "out": [["t", 0]]}
+
+
+def _rebase(r, ins, base):
+    if r[0] == "i":
+        return ins[r[1]]
+    if r[0] == "t":
+        return ["t", r[1] + base]
+    return r
+
+
+def _pyscalar(x):
+    x = np.asarray(x)
+    if x.dtype.kind == "b":
+        return bool(x)
+    if x.dtype.kind in "iu":
+        return int(x)
+    v = float(x)
+    return v
+
+
+# --------------------------------------------------------------------------------------
+# per-Op lowering (singledispatch on the Op class, like jax_funcify)
+# --------------------------------------------------------------------------------------
+@singledispatch
+def hip_lower(op, node, ctx):
+    raise UnsupportedOp(
+        f"{type(op).__name__} has no HIP lowering (outside the hot path of SURVEY §8a)")
+
+
+class _Ctx:
+    def __init__(self, plan, inner_rewriter=None):
+        self.plan = plan
+        self.vmap = {}
+        self.inner_rewriter = inner_rewriter
+
+    def vid(self, v):
+        from aesara.graph.basic import Constant
+
+        if v in self.vmap:
+            return self.vmap[v]
+        if isinstance(v, Constant):
+            data = np.asarray(v.data)
+            if data.size > 4096:
+                raise UnsupportedOp("large graph constants are not embedded in plans")
+            vid = self.plan.add_const(data, dtype=v.type.dtype, name=None)
+            # keep static broadcast pattern of the constant's type
+            self.plan.vars[vid].shape = _static_shape(v.type)
+            self.vmap[v] = vid
+            return vid
+        raise KeyError(f"variable {v} not produced by any lowered node")
+
+    def new(self, v):
+        t = v.type
+        if not hasattr(t, "dtype"):
+            raise UnsupportedOp(f"non-tensor variable type {t}")
+        shape = _static_shape(t)
+        vid = self.plan.new_var(t.dtype, shape, getattr(v, "name", None))
+        self.vmap[v] = vid
+        return vid
+
+    def emit(self, opname, node, params=None, inputs=None):
+        ins = [self.vid(i) for i in (node.inputs if inputs is None else inputs)]
+        outs = [self.new(o) for o in node.outputs]
+        self.plan.nodes.append(Node(opname, ins, outs, params or {}))
+
+
+def _static_shape(t):
+    if hasattr(t, "shape") and t.shape is not None and hasattr(t, "ndim"):
+        return [None if s is None else int(s) for s in t.shape]
+    return []  # aesara.scalar ScalarType (0-d)
+
+
+def lower_fgraph(fgraph, order=None, name="fgraph", inner_rewriter=None) -> Plan:
+    """FunctionGraph -> Plan.  ``order`` is the linker's schedule (``Linker.schedule``,
+    link/basic.py:222); defaults to ``fgraph.toposort()``.  ``inner_rewriter`` is applied to
+    a clone of every Scan inner graph (the reference rewrites it lazily when ``Scan.fn`` is
+    compiled with ``mode_instance``, scan/op.py:1431-1459)."""
+    _register_handlers()
+    plan = Plan(name, {}, [], [], [])
+    ctx = _Ctx(plan, inner_rewriter)
+    for v in fgraph.inputs:
+        plan.inputs.append(ctx.new(v))
+    for node in (order if order is not None else fgraph.toposort()):
+        hip_lower(node.op, node, ctx)
+    plan.outputs = [ctx.vid(o) for o in fgraph.outputs]
+    return plan
+
+
+_registered = False
+
+
+def _register_handlers():
+    """Register lowering handlers (deferred: needs Aesara importable)."""
+    global _registered
+    if _registered:
+        return
+    _registered = True
+
+    from aesara.compile.ops import DeepCopyOp, ViewOp
+    from aesara.scan.op import Scan
+    from aesara.tensor.basic import (Alloc, AllocEmpty, Join, MakeVector, ScalarFromTensor,
+                                     TensorFromScalar)
+    from aesara.tensor.blas import BatchedDot, Dot22, Dot22Scalar, Gemm, Gemv, Ger
+    from aesara.tensor.elemwise import CAReduce, DimShuffle, Elemwise
+    from aesara.tensor.math import Dot
+    from aesara.tensor.shape import Reshape, Shape, Shape_i, SpecifyShape, Unbroadcast
+    from aesara.tensor.subtensor import (AdvancedIncSubtensor1, AdvancedSubtensor1,
+                                         IncSubtensor, Subtensor)
+
+    @hip_lower.register(Elemwise)
+    def _(op, node, ctx):
+        # reference: tensor/elemwise.py:304 Elemwise (perform :725, _c_all :835)
+        s = lower_scalar_op(op.scalar_op, len(node.inputs))
+        if len(s["nodes"]) == 1 and s["nodes"][0]["dtype"] is None:
+            s["nodes"][0]["dtype"] = str(node.outputs[0].type.dtype)
+        if len(s["out"]) != len(node.outputs):
+            raise UnsupportedOp("Elemwise output arity mismatch")
+        ctx.emit("Elemwise", node, {"scalar": s})
+
+    @hip_lower.register(CAReduce)
+    def _(op, node, ctx):
+        # reference: tensor/elemwise.py:1221 CAReduce; acc rule _acc_dtype :1371; perform :1495
+        sname = SCALAR_OP_NAMES.get(type(op.scalar_op).__name__)
+        if sname not in ("add", "mul", "maximum", "minimum", "and", "or", "xor"):
+            raise UnsupportedOp(f"CAReduce over scalar op {op.scalar_op}")
+        idtype = node.inputs[0].type.dtype
+        odtype = node.outputs[0].type.dtype
+        if hasattr(op, "_acc_dtype"):
+            acc = op._acc_dtype(idtype)
+        else:
+            acc = getattr(op, "acc_dtype", None) or odtype
+        axis = op.axis
+        if axis is not None:
+            nd = node.inputs[0].type.ndim
+            axis = sorted(int(a) % nd if nd else int(a) for a in axis)
+        ctx.emit("CAReduce", node, {"scalar_op": sname, "axis": axis, "acc_dtype": str(acc)})
+
+    @hip_lower.register(DimShuffle)
+    def _(op, node, ctx):
+        # reference: tensor/elemwise.py:39 DimShuffle (view; perform :222)
+        ctx.emit("DimShuffle", node, {"new_order": [x if x == "x" else int(x)
+                                                    for x in op.new_order]})
+
+    @hip_lower.register(Dot)
+    def _(op, node, ctx):
+        # reference: tensor/math.py:1879 Dot (1-d/2-d only)
+        ctx.emit("Dot", node)
+
+    @hip_lower.register(Dot22)
+    def _(op, node, ctx):
+        # reference: tensor/blas.py:1659 Dot22
+        ctx.emit("Dot22", node)
+
+    @hip_lower.register(Dot22Scalar)
+    def _(op, node, ctx):
+        # reference: tensor/blas.py:1954 Dot22Scalar
+        ctx.emit("Dot22Scalar", node)
+
+    @hip_lower.register(Gemm)
+    def _(op, node, ctx):
+        # reference: tensor/blas.py:872 Gemm: inputs (z, a, x, y, b) -> b*z + a*dot(x, y)
+        ctx.emit("Gemm", node, {"inplace": bool(op.inplace)})
+
+    @hip_lower.register(Gemv)
+    def _(op, node, ctx):
+        # reference: tensor/blas.py:231 Gemv: inputs (y, alpha, A, x, beta) -> beta*y + alpha*A.x
+        ctx.emit("Gemv", node, {"inplace": bool(op.inplace)})
+
+    @hip_lower.register(Ger)
+    def _(op, node, ctx):
+        # reference: tensor/blas.py:330 Ger: inputs (A, alpha, x, y) -> A + alpha*outer(x, y)
+        ctx.emit("Ger", node, {"destructive": bool(op.destructive)})
+
+    @hip_lower.register(BatchedDot)
+    def _(op, node, ctx):
+        # reference: tensor/blas.py:2179 BatchedDot
+        ctx.emit("BatchedDot", node)
+
+    @hip_lower.register(Alloc)
+    def _(op, node, ctx):
+        # reference: tensor/basic.py:1389 Alloc(value, *shape)
+        ctx.emit("Alloc", node)
+
+    @hip_lower.register(AllocEmpty)
+    def _(op, node, ctx):
+        # reference: tensor/basic.py:3833 AllocEmpty(*shape)
+        ctx.emit("AllocEmpty", node, {"dtype": str(op.dtype)})
+
+    @hip_lower.register(MakeVector)
+    def _(op, node, ctx):
+        # reference: tensor/basic.py:1629 MakeVector
+        ctx.emit("MakeVector", node, {"dtype": str(op.dtype)})
+
+    @hip_lower.register(Join)
+    def _(op, node, ctx):
+        # reference: tensor/basic.py:2142 Join(axis, *tensors)
+        ctx.emit("Join", node)
+
+    @hip_lower.register(ScalarFromTensor)
+    def _(op, node, ctx):
+        ctx.emit("ScalarFromTensor", node)
+
+    @hip_lower.register(TensorFromScalar)
+    def _(op, node, ctx):
+        ctx.emit("TensorFromScalar", node)
+
+    @hip_lower.register(Shape_i)
+    def _(op, node, ctx):
+        # reference: tensor/shape.py:189 Shape_i
+        ctx.emit("Shape_i", node, {"i": int(op.i)})
+
+    @hip_lower.register(Shape)
+    def _(op, node, ctx):
+        ctx.emit("Shape", node)
+
+    @hip_lower.register(Reshape)
+    def _(op, node, ctx):
+        # reference: tensor/shape.py:589 Reshape(x, shape)
+        ctx.emit("Reshape", node, {"ndim": int(op.ndim)})
+
+    @hip_lower.register(Unbroadcast)
+    def _(op, node, ctx):
+        # reference: tensor/shape.py:939 Unbroadcast (type-level no-op view)
+        ctx.emit("ViewOp", node)
+
+    @hip_lower.register(SpecifyShape)
+    def _(op, node, ctx):
+        ctx.emit("SpecifyShape", node)
+
+    @hip_lower.register(ViewOp)
+    def _(op, node, ctx):
+        ctx.emit("ViewOp", node)
+
+    @hip_lower.register(DeepCopyOp)
+    def _(op, node, ctx):
+        # reference: compile/ops.py:149 DeepCopyOp (inserted by insert_deepcopy types.py:1172)
+        ctx.emit("DeepCopyOp", node)
+
+    def _idx_list(idx_list):
+        # reference: tensor/subtensor.py:682 Subtensor.idx_list — slices whose entries are
+        # either None, python ints, or scalar *Types* standing for a dynamic input.
+        out = []
+        for e in idx_list:
+            if isinstance(e, slice):
+                out.append({"slice": [_idx_entry(e.start), _idx_entry(e.stop),
+                                      _idx_entry(e.step)]})
+            else:
+                out.append({"index": _idx_entry(e)})
+        return out
+
+    def _idx_entry(e):
+        if e is None:
+            return None
+        if isinstance(e, (int, np.integer)):
+            return int(e)
+        return "in"  # dynamic: consumes the next extra input
+
+    @hip_lower.register(Subtensor)
+    def _(op, node, ctx):
+        ctx.emit("Subtensor", node, {"idx_list": _idx_list(op.idx_list)})
+
+    @hip_lower.register(IncSubtensor)
+    def _(op, node, ctx):
+        # reference: tensor/subtensor.py:1454 IncSubtensor(x, y, *idx)
+        ctx.emit("IncSubtensor", node, {
+            "idx_list": _idx_list(op.idx_list),
+            "set_instead_of_inc": bool(op.set_instead_of_inc),
+            "inplace": bool(op.inplace)})
+
+    @hip_lower.register(AdvancedSubtensor1)
+    def _(op, node, ctx):
+        # reference: tensor/subtensor.py:1925 AdvancedSubtensor1(x, ilist)
+        ctx.emit("AdvancedSubtensor1", node)
+
+    @hip_lower.register(AdvancedIncSubtensor1)
+    def _(op, node, ctx):
+        # reference: tensor/subtensor.py:2128 AdvancedIncSubtensor1(x, y, ilist)
+        ctx.emit("AdvancedIncSubtensor1", node, {
+            "set_instead_of_inc": bool(op.set_instead_of_inc), "inplace": bool(op.inplace)})
+
+    @hip_lower.register(Scan)
+    def _(op, node, ctx):
+        # reference: scan/op.py:637 Scan; info layout scan/op.py:206 ScanInfo.  The inner
+        # fgraph is lowered recursively; the executor owns the step loop (K10).
+        info = op.info
+        if info.n_mit_mot or info.as_while or info.n_shared_outs:
+            raise UnsupportedOp("Scan with mit-mot / while / shared outputs (SURVEY §7 hard part 6)")
+        inner_fg = op.fgraph.clone()
+        if ctx.inner_rewriter is not None:
+            ctx.inner_rewriter.rewrite(inner_fg)
+        inner = lower_fgraph(inner_fg, name="scan_inner", inner_rewriter=ctx.inner_rewriter)
+        ctx.emit("Scan", node, {
+            "n_seqs": info.n_seqs,
+            "mit_sot_in_slices": [list(map(int, t)) for t in info.mit_sot_in_slices],
+            "sit_sot_in_slices": [list(map(int, t)) for t in info.sit_sot_in_slices],
+            "n_nit_sot": info.n_nit_sot,
+            "n_non_seqs": info.n_non_seqs,
+            "inner": inner,
+        })

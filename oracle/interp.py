@@ -1,0 +1,372 @@
+"""ORACLE — CPU (NumPy) restatement of the reference's per-Op algorithms for the hot path.
+
+TEST INFRASTRUCTURE ONLY.  Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg may import this module; the product package ``aesara_amd`` never does
+(its device path fails loudly when the HIP library is missing).
+
+Parity pinning: the reference holds no golden vectors for this path (every
+numeric test compares against a NumPy restatement with tolerances).  This oracle is therefore
+pinned against *outputs of the reference itself run in the authoring container* —
+``oracle/gen_golden.py`` compiles each fixture graph with the reference's own C/py linkers
+(``Mode("cvm", "fast_run")``) and stores the outputs under ``tests/golden/``;
+``tests/test_oracle_golden.py`` checks this interpreter against those vectors (bit-exact for
+integer/index ops, reference tolerances tensor/math.py:83-96 for floating point).
+
+``run_plan(plan, inputs)`` interprets a :class:`aesara_amd.plan.Plan` (plain data; no Aesara).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+# ----------------------------------------------------------------------------------------
+# scalar ops — reference: aesara/scalar/basic.py (`impl` / `c_code` of each ScalarOp)
+# ----------------------------------------------------------------------------------------
+
+
+def _softplus(x):
+    # scalar/math.py:1133 Softplus.c_code thresholds (-37, 18, 33.3)
+    x = np.asarray(x)
+    with np.errstate(over="ignore", under="ignore"):
+        return np.where(x < -37.0, np.exp(x),
+                        np.where(x < 18.0, np.log1p(np.exp(np.minimum(x, 18.0))),
+                                 np.where(x < 33.3, x + np.exp(-x), x))).astype(x.dtype)
+
+
+def _sigmoid(x):
+    # scalar/math.py:1110 Sigmoid.c_code: 1/(1+exp(-x))
+    x = np.asarray(x)
+    with np.errstate(over="ignore"):
+        return (1.0 / (1.0 + np.exp(-x))).astype(x.dtype)
+
+
+def _log1mexp(x):
+    # scalar/math.py Log1mexp: x < -log(2) ? log1p(-exp(x)) : log(-expm1(x))
+    x = np.asarray(x)
+    with np.errstate(all="ignore"):
+        return np.where(x < -0.6931471805599453, np.log1p(-np.exp(x)), np.log(-np.expm1(x)))
+
+
+def _erf(x):
+    from scipy import special
+    return special.erf(x)
+
+
+def _erfc(x):
+    from scipy import special
+    return special.erfc(x)
+
+
+def _round_away(x):
+    # scalar/basic.py:2799 RoundHalfAwayFromZero
+    return np.where(x < 0, np.ceil(x - 0.5), np.floor(x + 0.5))
+
+
+_UNARY = {
+    "neg": np.negative, "abs": np.abs, "sgn": np.sign, "sqr": np.square, "sqrt": np.sqrt,
+    "exp": np.exp, "exp2": np.exp2, "expm1": np.expm1, "log": np.log, "log2": np.log2,
+    "log10": np.log10, "log1p": np.log1p, "sin": np.sin, "cos": np.cos, "tan": np.tan,
+    "arcsin": np.arcsin, "arccos": np.arccos, "arctan": np.arctan, "sinh": np.sinh,
+    "cosh": np.cosh, "tanh": np.tanh, "arcsinh": np.arcsinh, "arccosh": np.arccosh,
+    "arctanh": np.arctanh, "ceil": np.ceil, "floor": np.floor, "trunc": np.trunc,
+    "round_half_to_even": np.around, "round_half_away_from_zero": _round_away,
+    "reciprocal": np.reciprocal, "identity": lambda x: x, "invert": np.invert,
+    "isnan": np.isnan, "isinf": np.isinf, "sigmoid": _sigmoid, "softplus": _softplus,
+    "erf": _erf, "erfc": _erfc, "log1mexp": _log1mexp, "deg2rad": np.deg2rad,
+    "rad2deg": np.rad2deg,
+}
+
+_BINARY = {
+    "sub": np.subtract, "true_div": np.true_divide, "int_div": np.floor_divide,
+    "mod": np.mod, "pow": np.power, "arctan2": np.arctan2,
+    "lt": np.less, "gt": np.greater, "le": np.less_equal, "ge": np.greater_equal,
+    "eq": np.equal, "neq": np.not_equal,
+}
+
+_NARY = {"add": np.add, "mul": np.multiply, "maximum": np.maximum, "minimum": np.minimum,
+         "and": np.bitwise_and, "or": np.bitwise_or, "xor": np.bitwise_xor}
+
+_FLOAT_FUNCS = {"sqrt", "exp", "exp2", "expm1", "log", "log2", "log10", "log1p", "sin", "cos",
+                "tan", "arcsin", "arccos", "arctan", "sinh", "cosh", "tanh", "arcsinh",
+                "arccosh", "arctanh", "sigmoid", "softplus", "erf", "erfc", "log1mexp",
+                "deg2rad", "rad2deg", "reciprocal", "true_div", "arctan2"}
+
+
+def eval_scalar_expr(s, ins):
+    """Evaluate a plan scalar expression on broadcast-compatible ndarrays ``ins``.
+
+    Mirrors ``Composite.py_perform`` (scalar/basic.py:4075) / the per-temp C code of
+    ``c_code_template`` (:4250): one temporary per scalar node, each stored in the node's
+    declared dtype.
+    """
+    temps = []
+
+    def get(r):
+        if r[0] == "i":
+            return ins[r[1]]
+        if r[0] == "t":
+            return temps[r[1]]
+        return np.asarray(r[1], dtype=r[2])
+
+    with np.errstate(all="ignore"):
+        for n in s["nodes"]:
+            op, dt = n["op"], np.dtype(n["dtype"])
+            a = [get(r) for r in n["in"]]
+            if op in _FLOAT_FUNCS and dt.kind == "f":
+                a = [x.astype(dt) if x.dtype != dt and op not in ("true_div", "arctan2") else x
+                     for x in a]
+            if op in _UNARY:
+                r = _UNARY[op](a[0])
+            elif op in _BINARY:
+                if op in ("true_div", "arctan2"):
+                    r = _BINARY[op](a[0].astype(dt), a[1].astype(dt))
+                elif op in ("int_div", "mod") and dt.kind in "iu":
+                    # integer x // 0 and x % 0: reference C raises ZeroDivisionError
+                    # (scalar/basic.py:2068, :2186); NumPy/our device path return 0.
+                    r = _BINARY[op](a[0], a[1])
+                else:
+                    r = _BINARY[op](a[0], a[1])
+            elif op in _NARY:
+                r = a[0]
+                if op in ("add", "mul"):
+                    r = r.astype(dt)
+                for x in a[1:]:
+                    r = _NARY[op](r, x.astype(dt) if op in ("add", "mul") else x)
+            elif op == "cast":
+                r = a[0].astype(dt)
+            elif op == "second":
+                r = np.broadcast_arrays(a[0], a[1])[1]
+            elif op == "switch":
+                r = np.where(a[0] != 0, a[1], a[2])
+            elif op == "clip":
+                # scalar/basic.py:2342 Clip: x < min ? min : x > max ? max : x
+                r = np.where(a[0] < a[1], a[1], np.where(a[0] > a[2], a[2], a[0]))
+            else:
+                raise NotImplementedError(f"oracle: scalar op {op}")
+            temps.append(np.asarray(r).astype(dt, copy=False))
+    return [get(r) for r in s["out"]]
+
+
+# ----------------------------------------------------------------------------------------
+# tensor ops
+# ----------------------------------------------------------------------------------------
+_REDUCE = {"add": np.add, "mul": np.multiply, "maximum": np.maximum, "minimum": np.minimum,
+           "and": np.bitwise_and, "or": np.bitwise_or, "xor": np.bitwise_xor}
+
+
+def careduce(x, scalar_op, axis, acc_dtype, out_dtype):
+    """reference: tensor/elemwise.py:1495 CAReduce.perform — ``ufunc.reduce`` applied axis by
+    axis with ``dtype=acc_dtype`` and a final cast to the output dtype (:1506-1513)."""
+    ufunc = _REDUCE[scalar_op]
+    if axis is None:
+        axis = list(range(x.ndim))
+    v = x
+    acc = np.dtype(acc_dtype)
+    for a in sorted(axis, reverse=True):
+        if v.shape[a] == 0 and scalar_op in ("maximum", "minimum"):
+            raise ValueError("zero-size array to reduction operation which has no identity")
+        if acc.kind == "b" or scalar_op in ("maximum", "minimum"):
+            v = ufunc.reduce(v, a)
+        else:
+            v = ufunc.reduce(v, a, dtype=acc)
+    return np.asarray(v, dtype=acc).astype(out_dtype)
+
+
+def dimshuffle(x, new_order):
+    """reference: tensor/elemwise.py:222 DimShuffle.perform (transpose, drop, then expand)."""
+    keep = [d for d in new_order if d != "x"]
+    dropped = [d for d in range(x.ndim) if d not in keep]
+    for d in dropped:
+        if x.shape[d] != 1:
+            raise ValueError("Cannot drop a non-broadcastable dimension")
+    v = x.transpose(keep + dropped)
+    shape = [v.shape[keep.index(d)] if d != "x" else 1 for d in new_order]
+    return v.reshape(shape)
+
+
+def gemm(z, a, x, y, b):
+    """reference: tensor/blas.py:984 Gemm.perform — z*b + a*dot(x, y) (b==0 ignores z)."""
+    dt = z.dtype
+    a = np.asarray(a, dt)
+    b = np.asarray(b, dt)
+    if b == 0.0:
+        r = a * np.dot(x, y) if a != 1.0 else np.dot(x, y)
+    else:
+        r = b * z + a * np.dot(x, y)
+    return np.asarray(r, dtype=dt)
+
+
+def gemv(y, alpha, A, x, beta):
+    """reference: tensor/blas.py:279 Gemv.perform — beta*y + alpha*dot(A, x)."""
+    dt = y.dtype
+    out = np.asarray(alpha, dt) * np.dot(A, x)
+    if np.asarray(beta) != 0:
+        out = out + np.asarray(beta, dt) * y
+    return np.asarray(out, dtype=dt)
+
+
+def _resolve_idx(idx_list, extra):
+    """reference: tensor/subtensor.py:756 Subtensor.perform / get_idx_list."""
+    extra = list(extra)
+
+    def ent(e):
+        if e == "in":
+            return int(np.asarray(extra.pop(0)))
+        return e
+
+    out = []
+    for e in idx_list:
+        if "slice" in e:
+            st, sp, se = (ent(t) for t in e["slice"])
+            out.append(slice(st, sp, se))
+        else:
+            out.append(ent(e["index"]))
+    assert not extra
+    return tuple(out)
+
+
+def scan(p, inputs, run_inner):
+    """reference: scan/op.py:1673 Scan.perform / scan_perform.pyx:71 (sit-sot, mit-sot,
+    nit-sot, sequences, non-sequences; circular output buffers of length ``store_steps``)."""
+    n_seqs = p["n_seqs"]
+    mit = p["mit_sot_in_slices"]
+    sit = p["sit_sot_in_slices"]
+    n_nit = p["n_nit_sot"]
+    n_steps = int(np.asarray(inputs[0]))
+    if n_steps < 0:
+        raise IndexError(f"Scan was asked to run for negative number of step {n_steps}")
+    seqs = inputs[1:1 + n_seqs]
+    for k, sq in enumerate(seqs):
+        if sq.shape[0] < n_steps:
+            raise ValueError(f"Sequence {k} has shape {sq.shape} but the Scan's required "
+                             f"number of steps is {n_steps}")
+    n_rec = len(mit) + len(sit)
+    rec_init = inputs[1 + n_seqs:1 + n_seqs + n_rec]
+    nit_len = [int(np.asarray(v)) for v in inputs[1 + n_seqs + n_rec:1 + n_seqs + n_rec + n_nit]]
+    non_seqs = inputs[1 + n_seqs + n_rec + n_nit:]
+    taps = [list(t) for t in mit] + [list(t) for t in sit]
+    mintaps = [min(t) for t in taps] + [0] * n_nit
+    outs = [np.array(v, copy=True) for v in rec_init] + [None] * n_nit
+    store = [v.shape[0] for v in rec_init] + nit_len
+    if n_steps == 0:
+        return outs[:n_rec] + [None] * n_nit
+    pos = [(-mintaps[k]) % store[k] for k in range(n_rec + n_nit)]
+    for i in range(n_steps):
+        args = [sq[i] for sq in seqs]
+        for k in range(n_rec):
+            for t in taps[k]:
+                args.append(outs[k][(pos[k] + t) % store[k]].copy())
+        args.extend(non_seqs)
+        res = run_inner(args)
+        for k in range(n_rec):
+            outs[k][pos[k]] = res[k]
+        for j in range(n_nit):
+            k = n_rec + j
+            if i == 0:
+                outs[k] = np.empty((store[k],) + np.shape(res[k]), dtype=np.asarray(res[k]).dtype)
+            outs[k][pos[k]] = res[k]
+        pos = [(pp + 1) % st for pp, st in zip(pos, store)]
+    # rotate circular buffers into chronological order (op.py:2115-2150)
+    for k in range(n_rec + n_nit):
+        if store[k] < n_steps - mintaps[k] and pos[k] < store[k]:
+            outs[k] = np.concatenate([outs[k][pos[k]:], outs[k][:pos[k]]], axis=0)
+        elif store[k] > n_steps - mintaps[k]:
+            outs[k][n_steps - mintaps[k]:] = 0
+    return outs
+
+
+def run_plan(plan, inputs):
+    """Interpret ``plan`` on NumPy arrays; returns the list of outputs."""
+    env = {}
+    for vid, v in plan.vars.items():
+        if v.const is not None:
+            env[vid] = v.const_value()
+    assert len(inputs) == len(plan.inputs), (len(inputs), len(plan.inputs))
+    for vid, x in zip(plan.inputs, inputs):
+        env[vid] = np.asarray(x)
+    for n in plan.nodes:
+        a = [env[i] for i in n.inputs]
+        p = n.params
+        op = n.op
+        ov = [plan.vars[o] for o in n.outputs]
+        if op == "Elemwise":
+            # reference: tensor/elemwise.py:725 Elemwise.perform (shape check :733-735)
+            nd = max((x.ndim for x in a), default=0)
+            for d in range(nd):
+                sizes = {x.shape[d] for x in a if x.shape[d] != 1}
+                if len(sizes) > 1:
+                    raise ValueError(f"Shapes on dimension {d} do not match")
+            res = eval_scalar_expr(p["scalar"], a)
+            shape = np.broadcast_shapes(*[x.shape for x in a]) if a else ()
+            r = [np.broadcast_to(x, shape).astype(o.dtype) for x, o in zip(res, ov)]
+        elif op == "CAReduce":
+            r = [careduce(a[0], p["scalar_op"], p["axis"], p["acc_dtype"], ov[0].dtype)]
+        elif op == "DimShuffle":
+            r = [dimshuffle(a[0], p["new_order"])]
+        elif op in ("Dot", "Dot22"):
+            r = [np.asarray(np.dot(a[0], a[1]), dtype=ov[0].dtype)]
+        elif op == "Dot22Scalar":
+            r = [np.asarray(np.dot(a[0], a[1]) * a[2], dtype=ov[0].dtype)]
+        elif op == "Gemm":
+            r = [gemm(*a)]
+        elif op == "Gemv":
+            r = [gemv(*a)]
+        elif op == "Ger":
+            # reference: tensor/blas.py:330 Ger.perform: A + alpha * outer(x, y)
+            r = [np.asarray(a[0] + a[1] * np.outer(a[2], a[3]), dtype=ov[0].dtype)]
+        elif op == "BatchedDot":
+            # reference: tensor/blas.py:2224 BatchedDot.perform
+            r = [np.asarray(np.matmul(a[0], a[1]), dtype=ov[0].dtype)]
+        elif op == "Alloc":
+            # reference: tensor/basic.py:1427 Alloc.perform
+            shape = tuple(int(np.asarray(s)) for s in a[1:])
+            r = [np.array(np.broadcast_to(a[0], shape), dtype=ov[0].dtype)]
+        elif op == "AllocEmpty":
+            shape = tuple(int(np.asarray(s)) for s in a)
+            r = [np.zeros(shape, dtype=p["dtype"])]  # contents unspecified in the reference
+        elif op == "MakeVector":
+            r = [np.array([np.asarray(x) for x in a], dtype=p["dtype"])]
+        elif op == "Join":
+            ax = int(np.asarray(a[0]))
+            r = [np.concatenate(a[1:], axis=ax).astype(ov[0].dtype)]
+        elif op in ("ScalarFromTensor", "TensorFromScalar", "ViewOp", "SpecifyShape"):
+            r = [a[0]]
+        elif op == "DeepCopyOp":
+            r = [np.array(a[0], copy=True)]
+        elif op == "Shape_i":
+            r = [np.asarray(a[0].shape[p["i"]], dtype="int64")]
+        elif op == "Shape":
+            r = [np.asarray(a[0].shape, dtype="int64")]
+        elif op == "Reshape":
+            r = [np.reshape(a[0], tuple(int(s) for s in np.asarray(a[1])))]
+        elif op == "Subtensor":
+            r = [a[0][_resolve_idx(p["idx_list"], a[1:])]]
+        elif op == "IncSubtensor":
+            # reference: tensor/subtensor.py:1556 IncSubtensor.perform
+            x = np.array(a[0], copy=True)
+            idx = _resolve_idx(p["idx_list"], a[2:])
+            if p["set_instead_of_inc"]:
+                x[idx] = a[1]
+            else:
+                x[idx] += a[1]
+            r = [x]
+        elif op == "AdvancedSubtensor1":
+            # reference: tensor/subtensor.py:1953 (x.take(i, axis=0)); IndexError when out of range
+            r = [a[0].take(a[1], axis=0)]
+        elif op == "AdvancedIncSubtensor1":
+            # reference: tensor/subtensor.py:2128 (np.add.at semantics for inc)
+            x = np.array(a[0], copy=True)
+            if p["set_instead_of_inc"]:
+                x[a[2]] = a[1]
+            else:
+                np.add.at(x, a[2], a[1])
+            r = [x]
+        elif op == "Scan":
+            inner = p["inner"]
+            r = scan(p, a, lambda args: run_plan(inner, args))
+        else:
+            raise NotImplementedError(f"oracle: op {op}")
+        for o, val in zip(n.outputs, r):
+            env[o] = val
+    return [env[o] for o in plan.outputs]
