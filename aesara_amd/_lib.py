@@ -1,0 +1,147 @@
+"""ctypes binding of the C-ABI ``libaesara_hip.so`` (include/aesara_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or does not export the
+declared ABI, importing this module raises ``HipLibraryMissing`` — loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("AESARA_HIP_LIB", os.path.join(_HERE, "libaesara_hip.so"))
+
+AHIP_MAXD = 6
+AHIP_MAXOPS = 32
+ABI_VERSION = 1
+
+DTYPE_CODES = {
+    "bool": 0, "int8": 1, "int16": 2, "int32": 3, "int64": 4,
+    "uint8": 5, "uint16": 6, "uint32": 7, "uint64": 8,
+    "float32": 9, "float64": 10,
+}
+
+AHIP_OK, AHIP_EINVAL, AHIP_EHIP, AHIP_ECOMPILE, AHIP_EINDEX, AHIP_ENOSUP = 0, -1, -2, -3, -4, -5
+
+
+class HipLibraryMissing(ImportError):
+    pass
+
+
+class HipError(RuntimeError):
+    pass
+
+
+class DeviceInfo(C.Structure):
+    _fields_ = [
+        ("device", C.c_int32), ("cu_count", C.c_int32), ("wavefront_size", C.c_int32),
+        ("max_threads_per_block", C.c_int32), ("total_mem", C.c_int64),
+        ("lds_per_block", C.c_int64), ("clock_khz", C.c_int32), ("l2_bytes", C.c_int32),
+        ("arch", C.c_char * 64), ("name", C.c_char * 128),
+    ]
+
+
+vp, i64, i32, u32, sz = C.c_void_p, C.c_int64, C.c_int, C.c_uint32, C.c_size_t
+p_i64 = C.POINTER(C.c_int64)
+p_vp = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes).  This table IS the Python view of include/aesara_hip.h;
+# tests/test_abi.py checks that every symbol declared in the header is listed and exported.
+SIGNATURES = {
+    "ahip_abi_version": (i32, []),
+    "ahip_init": (i32, [i32]),
+    "ahip_last_error": (C.c_char_p, []),
+    "ahip_get_device_info": (i32, [C.POINTER(DeviceInfo)]),
+    "ahip_stream_synchronize": (i32, [vp]),
+    "ahip_compile": (i32, [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), i32, p_vp,
+                           C.POINTER(sz)]),
+    "ahip_free_code": (i32, [vp]),
+    "ahip_module_load": (i32, [vp, sz, p_vp]),
+    "ahip_module_get_function": (i32, [vp, C.c_char_p, p_vp]),
+    "ahip_module_unload": (i32, [vp]),
+    "ahip_launch": (i32, [vp, u32, u32, u32, u32, u32, u32, u32, vp, sz, vp]),
+    "ahip_elemwise": (i32, [vp, i32, p_i64, i32, p_vp, p_i64, i32, i32, vp]),
+    "ahip_reduce_ws_bytes": (sz, []),
+    "ahip_elemwise_reduce_all": (i32, [vp, vp, i32, p_i64, i32, p_vp, p_i64, i32, i32, vp, vp,
+                                       sz, vp]),
+    "ahip_elemwise_reduce_axis": (i32, [vp, i32, i32, i32, p_i64, i32, p_vp, p_i64, i32, vp,
+                                        i32, vp]),
+    "ahip_gemm": (i32, [i32, i64, i64, i64, vp, vp, i64, i64, vp, i64, i64, vp, vp, i64, i64,
+                        vp, i64, i64, vp]),
+    "ahip_gemm_batched": (i32, [i32, i64, i64, i64, i64, vp, vp, i64, i64, i64, vp, i64, i64,
+                                i64, vp, vp, i64, i64, i64, vp, i64, i64, i64, vp]),
+    "ahip_gemv_ws_bytes": (sz, [i32, i64, i64]),
+    "ahip_gemv": (i32, [i32, i64, i64, vp, vp, i64, i64, vp, i64, vp, vp, i64, vp, i64, vp, sz,
+                        vp]),
+    "ahip_ger": (i32, [i32, i64, i64, vp, vp, i64, vp, i64, vp, i64, i64, vp, i64, i64, vp]),
+    "ahip_copy_strided": (i32, [i32, i32, p_i64, vp, p_i64, vp, p_i64, i32, vp]),
+    "ahip_fill": (i32, [i32, vp, vp, i64, vp]),
+    "ahip_take_rows": (i32, [i32, vp, i64, i64, i64, vp, i32, i64, i64, vp, i64, vp, vp]),
+    "ahip_scatter_rows": (i32, [i32, vp, i64, i64, i64, vp, i32, i64, i64, vp, i64, i32, vp,
+                                vp]),
+    "ahip_graph_begin": (i32, [vp]),
+    "ahip_graph_end": (i32, [vp, p_vp]),
+    "ahip_graph_launch": (i32, [vp, vp]),
+    "ahip_graph_destroy": (i32, [vp]),
+    "ahip_event_create": (i32, [p_vp]),
+    "ahip_event_record": (i32, [vp, vp]),
+    "ahip_event_elapsed_ms": (i32, [vp, vp, C.POINTER(C.c_float)]),
+    "ahip_event_destroy": (i32, [vp]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` or `make -C aesara_amd/csrc`.  There is no CPU fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise HipLibraryMissing(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryMissing(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ahip_abi_version() != ABI_VERSION:
+        raise HipLibraryMissing("libaesara_hip.so ABI version mismatch; rebuild")
+    return lib
+
+
+lib = _load()
+
+
+def check(rc):
+    """Translate a C-ABI return code into the reference's exception types."""
+    if rc == 0:
+        return
+    msg = (lib.ahip_last_error() or b"").decode("utf-8", "replace")
+    if rc == AHIP_EINVAL:
+        raise ValueError(msg)
+    if rc == AHIP_EINDEX:
+        raise IndexError(msg)
+    if rc == AHIP_ENOSUP:
+        raise NotImplementedError(msg)
+    raise HipError(f"[{rc}] {msg}")
+
+
+def compile_source(source: str, name: str = "k.hip", options=("-O3",)) -> bytes:
+    """HIP source -> gfx950 code object (hiprtc; works without a GPU)."""
+    opts = (C.c_char_p * len(options))(*[o.encode() for o in options])
+    code = C.c_void_p()
+    size = C.c_size_t()
+    check(lib.ahip_compile(source.encode(), name.encode(), opts, len(options), C.byref(code),
+                           C.byref(size)))
+    try:
+        return C.string_at(code, size.value)
+    finally:
+        lib.ahip_free_code(code)
+
+
+def device_info() -> DeviceInfo:
+    info = DeviceInfo()
+    check(lib.ahip_get_device_info(C.byref(info)))
+    return info

@@ -1,0 +1,50 @@
+// Shared helpers for the libaesara_hip.so translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/aesara_hip.h"
+
+void ahip_set_error(const char* fmt, ...);
+
+#define AHIP_CHECK_HIP(expr)                                                              \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      ahip_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,     \
+                     __LINE__);                                                           \
+      return AHIP_EHIP;                                                                   \
+    }                                                                                     \
+  } while (0)
+
+#define AHIP_REQUIRE(cond, ...)     \
+  do {                              \
+    if (!(cond)) {                  \
+      ahip_set_error(__VA_ARGS__);  \
+      return AHIP_EINVAL;           \
+    }                               \
+  } while (0)
+
+static inline int ahip_itemsize(int dt) {
+  switch (dt) {
+    case AHIP_BOOL: case AHIP_I8: case AHIP_U8: return 1;
+    case AHIP_I16: case AHIP_U16: return 2;
+    case AHIP_I32: case AHIP_U32: case AHIP_F32: return 4;
+    case AHIP_I64: case AHIP_U64: case AHIP_F64: return 8;
+    default: return 0;
+  }
+}
+
+struct ahip_module_s { hipModule_t mod; };
+struct ahip_func_s { hipFunction_t fn; };
+
+int ahip_cu_count();  // cached after ahip_init / first use
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// 8 XCDs on MI355X: workgroup b is dispatched to XCD b % 8 (speed hint only, never correctness).
+#define AHIP_NUM_XCD 8

@@ -1,0 +1,128 @@
+// Launch side of the generated fused Elemwise / CAReduce kernels (K1, K2, K3).
+// The kernels themselves are produced at run time by aesara_amd/codegen.py and compiled with
+// hiprtc (runtime.hip); this file packs their `ahip_ew_args` block, sizes the grid and
+// launches.  Reference loops replaced: tensor/elemwise.py:835 Elemwise._c_all,
+// :1522 CAReduce._c_all, elemwise_cgen.py:228/305/502.
+#include "common.h"
+
+#define AHIP_MAX_PARTIALS 4096
+
+
+static int pack_args(ahip_ew_args* a, int nd, const int64_t* shape, int nops, void* const* ptrs,
+                     const int64_t* strides) {
+  AHIP_REQUIRE(nd >= 1 && nd <= AHIP_MAXD, "nd=%d outside [1,%d]", nd, AHIP_MAXD);
+  AHIP_REQUIRE(nops >= 1 && nops <= AHIP_MAXOPS, "nops=%d outside [1,%d]", nops, AHIP_MAXOPS);
+  memset(a, 0, sizeof(*a));
+  int64_t n = 1;
+  for (int d = 0; d < nd; ++d) {
+    AHIP_REQUIRE(shape[d] >= 0, "negative extent");
+    a->shape[d] = shape[d];
+    n *= shape[d];
+  }
+  a->n = n;
+  a->nd = nd;
+  a->nops = nops;
+  for (int k = 0; k < nops; ++k) {
+    a->ptr[k] = ptrs[k];
+    for (int d = 0; d < nd; ++d) a->stride[k][d] = strides[(size_t)k * nd + d];
+  }
+  return AHIP_OK;
+}
+
+static int launch(ahip_fn_t k, uint32_t gx, uint32_t gy, uint32_t block, const ahip_ew_args* a,
+                  void* stream) {
+  size_t sz = sizeof(*a);
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, const_cast<ahip_ew_args*>(a),
+                    HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+  AHIP_CHECK_HIP(hipModuleLaunchKernel(k->fn, gx, gy, 1, block, 1, 1, 0, as_stream(stream),
+                                       nullptr, config));
+  return AHIP_OK;
+}
+
+// Memory-bound streaming kernels: enough workgroups to fill 256 CUs x 8 resident blocks,
+// grid-stride over the rest (guide: Guideline 11).
+static uint32_t stream_grid(int64_t items, int block) {
+  int64_t want = (items + block - 1) / block;
+  int64_t cap = (int64_t)ahip_cu_count() * 8;
+  if (want > cap) want = cap;
+  if (want < 1) want = 1;
+  return (uint32_t)want;
+}
+
+extern "C" {
+
+size_t ahip_reduce_ws_bytes(void) { return (size_t)AHIP_MAX_PARTIALS * 8; }
+
+int ahip_elemwise(ahip_fn_t k, int nd, const int64_t* shape, int nops, void* const* ptrs,
+                  const int64_t* strides, int vec, int block, void* stream) {
+  AHIP_REQUIRE(k != nullptr, "null kernel");
+  AHIP_REQUIRE(vec >= 1 && block >= 64 && block % 64 == 0, "bad vec/block");
+  ahip_ew_args a;
+  int rc = pack_args(&a, nd, shape, nops, ptrs, strides);
+  if (rc) return rc;
+  if (a.n == 0) return AHIP_OK;
+  AHIP_REQUIRE(shape[nd - 1] % vec == 0, "inner extent %lld not divisible by vec %d",
+               (long long)shape[nd - 1], vec);
+  int64_t items = a.n / vec;
+  return launch(k, stream_grid(items, block), 1, block, &a, stream);
+}
+
+int ahip_elemwise_reduce_all(ahip_fn_t k_main, ahip_fn_t k_fin, int nd, const int64_t* shape,
+                             int nops, void* const* ptrs, const int64_t* strides, int vec,
+                             int block, void* out, void* ws, size_t ws_bytes, void* stream) {
+  AHIP_REQUIRE(k_main && k_fin && out && ws, "null argument");
+  AHIP_REQUIRE(ws_bytes >= ahip_reduce_ws_bytes(), "workspace too small");
+  AHIP_REQUIRE(vec >= 1 && block >= 64 && block % 64 == 0, "bad vec/block");
+  ahip_ew_args a;
+  int rc = pack_args(&a, nd, shape, nops, ptrs, strides);
+  if (rc) return rc;
+  a.ws = ws;
+  a.out = out;
+  uint32_t grid = 0;
+  if (a.n > 0) {
+    AHIP_REQUIRE(shape[nd - 1] % vec == 0, "inner extent not divisible by vec");
+    int64_t items = a.n / vec;
+    // one partial per workgroup; 4 workgroups of 256 threads per CU keeps 16 waves/CU of
+    // 32-byte-per-lane loads in flight (HBM-bound) while the finalize stays tiny.
+    int64_t want = (items + block - 1) / block;
+    int64_t cap = (int64_t)ahip_cu_count() * 4;
+    if (cap > AHIP_MAX_PARTIALS) cap = AHIP_MAX_PARTIALS;
+    if (want > cap) want = cap;
+    grid = (uint32_t)want;
+    rc = launch(k_main, grid, 1, block, &a, stream);
+    if (rc) return rc;
+  }
+  a.aux0 = grid;  // number of valid partials
+  return launch(k_fin, 1, 1, 256, &a, stream);
+}
+
+int ahip_elemwise_reduce_axis(ahip_fn_t k, int mode, int nk, int nr, const int64_t* shape,
+                              int nops, void* const* ptrs, const int64_t* strides, int nslices,
+                              void* out_or_ws, int block, void* stream) {
+  AHIP_REQUIRE(k && out_or_ws, "null argument");
+  AHIP_REQUIRE(nk >= 1 && nr >= 1 && nk + nr <= AHIP_MAXD, "bad nk/nr");
+  AHIP_REQUIRE(block >= 64 && block % 64 == 0 && nslices >= 1, "bad block/nslices");
+  ahip_ew_args a;
+  int rc = pack_args(&a, nk + nr, shape, nops, ptrs, strides);
+  if (rc) return rc;
+  int64_t nkept = 1, nred = 1;
+  for (int d = 0; d < nk; ++d) nkept *= shape[d];
+  for (int d = nk; d < nk + nr; ++d) nred *= shape[d];
+  if (nkept == 0) return AHIP_OK;
+  a.n = nkept;
+  a.aux0 = nred;
+  a.aux1 = nslices;
+  a.out = out_or_ws;
+  uint32_t gx, gy = 1;
+  if (mode == 0) {  // row: one wavefront per output element
+    AHIP_REQUIRE(nslices == 1, "row mode does not slice");
+    int waves = block / 64;
+    gx = (uint32_t)((nkept + waves - 1) / waves);
+  } else {          // col: one thread per output element, reduce run optionally sliced
+    gx = (uint32_t)((nkept + block - 1) / block);
+    gy = (uint32_t)nslices;
+  }
+  return launch(k, gx, gy, block, &a, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,190 @@
+// K9 — integer row gather / scatter (bit-exact index handling).
+//
+// Replaces tensor/subtensor.py:1925 AdvancedSubtensor1 (perform :1953: x.take(idx, axis=0)) and
+// :2128 AdvancedIncSubtensor1 (inc: np.add.at semantics, set: last write wins).
+// Index handling mirrors NumPy: a negative index wraps once (idx + nrows); anything still out
+// of range is reported through *bad_index and the row is skipped.
+#include "common.h"
+
+namespace {
+
+template <typename I>
+__device__ __forceinline__ bool resolve(const I* idx, int64_t i, int64_t stride, int64_t nrows,
+                                        int64_t* bad, int64_t* out) {
+  int64_t v = (int64_t)idx[i * stride];
+  int64_t w = v < 0 ? v + nrows : v;
+  if (w < 0 || w >= nrows) {
+    unsigned long long code = (unsigned long long)(v >= 0 ? v + 1 : v);
+    atomicCAS(reinterpret_cast<unsigned long long*>(bad), 0ULL, code);
+    return false;
+  }
+  *out = w;
+  return true;
+}
+
+struct IdxArgs {
+  const void* src; void* dst; const void* idx;
+  int64_t nrows, src_rs, dst_rs, row_elems, nidx, idx_stride;
+  int64_t* bad;
+};
+
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void take_rows_kernel(IdxArgs a) {
+  const T* __restrict__ src = static_cast<const T*>(a.src);
+  T* __restrict__ dst = static_cast<T*>(a.dst);
+  const int64_t total = a.nidx * a.row_elems;
+  for (int64_t f = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; f < total;
+       f += (int64_t)gridDim.x * blockDim.x) {
+    int64_t i = f / a.row_elems, e = f - i * a.row_elems, r;
+    if (resolve(static_cast<const I*>(a.idx), i, a.idx_stride, a.nrows, a.bad, &r))
+      dst[i * a.dst_rs + e] = src[r * a.src_rs + e];
+  }
+}
+
+template <typename T> __device__ __forceinline__ void atomic_acc(T* p, T v) { atomicAdd(p, v); }
+// 8/16-bit and 64-bit signed integers: CAS on the containing word (exact modular arithmetic)
+template <typename T>
+__device__ __forceinline__ void atomic_acc_small(T* p, T v) {
+  uintptr_t addr = reinterpret_cast<uintptr_t>(p);
+  unsigned* word = reinterpret_cast<unsigned*>(addr & ~uintptr_t(3));
+  unsigned shift = (unsigned)(addr & 3) * 8;
+  unsigned mask = (sizeof(T) == 1 ? 0xFFu : 0xFFFFu) << shift;
+  unsigned old = *word, assumed;
+  do {
+    assumed = old;
+    unsigned cur = (assumed & mask) >> shift;
+    unsigned nv = (unsigned)(T)((T)cur + v) & (sizeof(T) == 1 ? 0xFFu : 0xFFFFu);
+    old = atomicCAS(word, assumed, (assumed & ~mask) | (nv << shift));
+  } while (old != assumed);
+}
+template <> __device__ __forceinline__ void atomic_acc<int8_t>(int8_t* p, int8_t v) { atomic_acc_small(p, v); }
+template <> __device__ __forceinline__ void atomic_acc<uint8_t>(uint8_t* p, uint8_t v) { atomic_acc_small(p, v); }
+template <> __device__ __forceinline__ void atomic_acc<int16_t>(int16_t* p, int16_t v) { atomic_acc_small(p, v); }
+template <> __device__ __forceinline__ void atomic_acc<uint16_t>(uint16_t* p, uint16_t v) { atomic_acc_small(p, v); }
+template <> __device__ __forceinline__ void atomic_acc<int64_t>(int64_t* p, int64_t v) {
+  atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v);
+}
+template <> __device__ __forceinline__ void atomic_acc<uint64_t>(uint64_t* p, uint64_t v) {
+  atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v);
+}
+template <> __device__ __forceinline__ void atomic_acc<int32_t>(int32_t* p, int32_t v) { atomicAdd(p, v); }
+template <> __device__ __forceinline__ void atomic_acc<uint32_t>(uint32_t* p, uint32_t v) { atomicAdd(p, v); }
+
+// inc: fully parallel, one atomic per element (integers exact; floats commutative up to rounding)
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void scatter_add_kernel(IdxArgs a) {
+  const T* __restrict__ src = static_cast<const T*>(a.src);
+  T* dst = static_cast<T*>(a.dst);
+  const int64_t total = a.nidx * a.row_elems;
+  for (int64_t f = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; f < total;
+       f += (int64_t)gridDim.x * blockDim.x) {
+    int64_t i = f / a.row_elems, e = f - i * a.row_elems, r;
+    if (resolve(static_cast<const I*>(a.idx), i, a.idx_stride, a.nrows, a.bad, &r))
+      atomic_acc<T>(dst + r * a.dst_rs + e, src[i * a.src_rs + e]);
+  }
+}
+
+// set: NumPy semantics are sequential (the last duplicate wins), so each thread owns one column
+// element and walks the index list in order.
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void scatter_set_kernel(IdxArgs a) {
+  const T* __restrict__ src = static_cast<const T*>(a.src);
+  T* dst = static_cast<T*>(a.dst);
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < a.row_elems;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = 0; i < a.nidx; ++i) {
+      int64_t r;
+      if (resolve(static_cast<const I*>(a.idx), i, a.idx_stride, a.nrows, a.bad, &r))
+        dst[r * a.dst_rs + e] = src[i * a.src_rs + e];
+    }
+  }
+}
+
+unsigned grid_for(int64_t items) {
+  int64_t want = (items + 255) / 256;
+  int64_t cap = (int64_t)ahip_cu_count() * 8;
+  if (want > cap) want = cap;
+  if (want < 1) want = 1;
+  return (unsigned)want;
+}
+
+template <typename T, typename I>
+int run(int which, IdxArgs& a, hipStream_t s) {
+  if (which == 0)
+    hipLaunchKernelGGL((take_rows_kernel<T, I>), dim3(grid_for(a.nidx * a.row_elems)), dim3(256), 0, s, a);
+  else if (which == 1)
+    hipLaunchKernelGGL((scatter_add_kernel<T, I>), dim3(grid_for(a.nidx * a.row_elems)), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((scatter_set_kernel<T, I>), dim3(grid_for(a.row_elems)), dim3(256), 0, s, a);
+  AHIP_CHECK_HIP(hipGetLastError());
+  return AHIP_OK;
+}
+
+template <typename T>
+int by_index(int which, int idx_dtype, IdxArgs& a, hipStream_t s) {
+  switch (idx_dtype) {
+    case AHIP_I8: return run<T, int8_t>(which, a, s);
+    case AHIP_I16: return run<T, int16_t>(which, a, s);
+    case AHIP_I32: return run<T, int32_t>(which, a, s);
+    case AHIP_I64: return run<T, int64_t>(which, a, s);
+    case AHIP_U8: return run<T, uint8_t>(which, a, s);
+    case AHIP_U16: return run<T, uint16_t>(which, a, s);
+    case AHIP_U32: return run<T, uint32_t>(which, a, s);
+    case AHIP_U64: return run<T, uint64_t>(which, a, s);
+    default: ahip_set_error("index dtype %d is not an integer type", idx_dtype); return AHIP_EINVAL;
+  }
+}
+
+int dispatch(int which, int dtype, int idx_dtype, IdxArgs& a, hipStream_t s) {
+  if (which != 1) {  // pure data movement: by item size
+    switch (ahip_itemsize(dtype)) {
+      case 1: return by_index<uint8_t>(which, idx_dtype, a, s);
+      case 2: return by_index<uint16_t>(which, idx_dtype, a, s);
+      case 4: return by_index<uint32_t>(which, idx_dtype, a, s);
+      case 8: return by_index<uint64_t>(which, idx_dtype, a, s);
+      default: ahip_set_error("bad dtype %d", dtype); return AHIP_EINVAL;
+    }
+  }
+  switch (dtype) {
+    case AHIP_I8: return by_index<int8_t>(which, idx_dtype, a, s);
+    case AHIP_I16: return by_index<int16_t>(which, idx_dtype, a, s);
+    case AHIP_I32: return by_index<int32_t>(which, idx_dtype, a, s);
+    case AHIP_I64: return by_index<int64_t>(which, idx_dtype, a, s);
+    case AHIP_U8: return by_index<uint8_t>(which, idx_dtype, a, s);
+    case AHIP_U16: return by_index<uint16_t>(which, idx_dtype, a, s);
+    case AHIP_U32: return by_index<uint32_t>(which, idx_dtype, a, s);
+    case AHIP_U64: return by_index<uint64_t>(which, idx_dtype, a, s);
+    case AHIP_F32: return by_index<float>(which, idx_dtype, a, s);
+    case AHIP_F64: return by_index<double>(which, idx_dtype, a, s);
+    default: ahip_set_error("scatter-add unsupported for dtype %d", dtype); return AHIP_ENOSUP;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ahip_take_rows(int dtype, const void* src, int64_t nrows, int64_t src_rs, int64_t row_elems,
+                   const void* idx, int idx_dtype, int64_t nidx, int64_t idx_stride, void* dst,
+                   int64_t dst_rs, int64_t* bad_index, void* stream) {
+  AHIP_REQUIRE(nrows >= 0 && row_elems >= 0 && nidx >= 0, "negative extent");
+  if (nidx == 0 || row_elems == 0) return AHIP_OK;
+  AHIP_REQUIRE(idx && dst && bad_index, "null argument");
+  AHIP_REQUIRE(src != nullptr || nrows == 0, "null src");
+  IdxArgs a{src, dst, idx, nrows, src_rs, dst_rs, row_elems, nidx, idx_stride, bad_index};
+  return dispatch(0, dtype, idx_dtype, a, as_stream(stream));
+}
+
+int ahip_scatter_rows(int dtype, void* dst, int64_t nrows, int64_t dst_rs, int64_t row_elems,
+                      const void* idx, int idx_dtype, int64_t nidx, int64_t idx_stride,
+                      const void* src, int64_t src_rs, int accumulate, int64_t* bad_index,
+                      void* stream) {
+  AHIP_REQUIRE(nrows >= 0 && row_elems >= 0 && nidx >= 0, "negative extent");
+  if (nidx == 0 || row_elems == 0) return AHIP_OK;
+  AHIP_REQUIRE(idx && src && bad_index, "null argument");
+  AHIP_REQUIRE(dst != nullptr || nrows == 0, "null dst");
+  IdxArgs a{src, dst, idx, nrows, src_rs, dst_rs, row_elems, nidx, idx_stride, bad_index};
+  return dispatch(accumulate ? 1 : 2, dtype, idx_dtype, a, as_stream(stream));
+}
+
+}  // extern "C"

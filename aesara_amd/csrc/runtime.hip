@@ -1,0 +1,227 @@
+// Runtime part of the C-ABI: init, errors, hiprtc compilation, module/kernel handles,
+// hipGraph capture/replay, stream-side event timing.  See include/aesara_hip.h.
+#include <hip/hiprtc.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+static thread_local char g_err[8192] = "";
+static int g_cu_count = 0;
+
+void ahip_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int ahip_cu_count() {
+  if (g_cu_count == 0) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
+      g_cu_count = p.multiProcessorCount;
+    else
+      g_cu_count = 256;
+  }
+  return g_cu_count;
+}
+
+struct ahip_graph_s { hipGraph_t graph; hipGraphExec_t exec; };
+struct ahip_event_s { hipEvent_t ev; };
+
+extern "C" {
+
+int ahip_abi_version(void) { return AHIP_ABI_VERSION; }
+
+const char* ahip_last_error(void) { return g_err; }
+
+int ahip_init(int device_ordinal) {
+  int n = 0;
+  AHIP_CHECK_HIP(hipGetDeviceCount(&n));
+  AHIP_REQUIRE(device_ordinal >= 0 && device_ordinal < n, "device %d out of range (%d devices)",
+               device_ordinal, n);
+  AHIP_CHECK_HIP(hipSetDevice(device_ordinal));
+  hipDeviceProp_t p;
+  AHIP_CHECK_HIP(hipGetDeviceProperties(&p, device_ordinal));
+  g_cu_count = p.multiProcessorCount;
+  return AHIP_OK;
+}
+
+int ahip_get_device_info(ahip_device_info* out) {
+  AHIP_REQUIRE(out != nullptr, "null out");
+  int dev = 0;
+  AHIP_CHECK_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t p;
+  AHIP_CHECK_HIP(hipGetDeviceProperties(&p, dev));
+  memset(out, 0, sizeof(*out));
+  out->device = dev;
+  out->cu_count = p.multiProcessorCount;
+  out->wavefront_size = p.warpSize;
+  out->max_threads_per_block = p.maxThreadsPerBlock;
+  out->total_mem = (int64_t)p.totalGlobalMem;
+  out->lds_per_block = (int64_t)p.sharedMemPerBlock;
+  out->clock_khz = p.clockRate;
+  out->l2_bytes = p.l2CacheSize;
+  snprintf(out->arch, sizeof(out->arch), "%s", p.gcnArchName);
+  snprintf(out->name, sizeof(out->name), "%s", p.name);
+  return AHIP_OK;
+}
+
+int ahip_stream_synchronize(void* stream) {
+  AHIP_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
+  return AHIP_OK;
+}
+
+// ---- hiprtc ------------------------------------------------------------------------------
+int ahip_compile(const char* source, const char* name, const char* const* options, int n_options,
+                 void** code_out, size_t* size_out) {
+  AHIP_REQUIRE(source && code_out && size_out, "null argument");
+  hiprtcProgram prog;
+  hiprtcResult r = hiprtcCreateProgram(&prog, source, name ? name : "aesara_hip_kernel.hip", 0,
+                                       nullptr, nullptr);
+  if (r != HIPRTC_SUCCESS) {
+    ahip_set_error("hiprtcCreateProgram: %s", hiprtcGetErrorString(r));
+    return AHIP_ECOMPILE;
+  }
+  std::vector<const char*> opts;
+  bool has_arch = false;
+  for (int i = 0; i < n_options; ++i) {
+    opts.push_back(options[i]);
+    if (strstr(options[i], "--offload-arch")) has_arch = true;
+  }
+  if (!has_arch) opts.push_back("--offload-arch=gfx950");
+  r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
+  if (r != HIPRTC_SUCCESS) {
+    size_t ls = 0;
+    hiprtcGetProgramLogSize(prog, &ls);
+    std::string log(ls + 1, '\0');
+    if (ls) hiprtcGetProgramLog(prog, &log[0]);
+    ahip_set_error("hiprtc compile failed (%s):\n%.7000s", hiprtcGetErrorString(r), log.c_str());
+    hiprtcDestroyProgram(&prog);
+    return AHIP_ECOMPILE;
+  }
+  size_t cs = 0;
+  hiprtcGetCodeSize(prog, &cs);
+  void* buf = malloc(cs);
+  if (!buf) {
+    hiprtcDestroyProgram(&prog);
+    ahip_set_error("out of host memory");
+    return AHIP_EINVAL;
+  }
+  hiprtcGetCode(prog, (char*)buf);
+  hiprtcDestroyProgram(&prog);
+  *code_out = buf;
+  *size_out = cs;
+  return AHIP_OK;
+}
+
+int ahip_free_code(void* code) {
+  free(code);
+  return AHIP_OK;
+}
+
+int ahip_module_load(const void* code, size_t size, ahip_module_t* out) {
+  AHIP_REQUIRE(code && out && size > 0, "null argument");
+  hipModule_t m;
+  AHIP_CHECK_HIP(hipModuleLoadData(&m, code));
+  *out = new ahip_module_s{m};
+  return AHIP_OK;
+}
+
+int ahip_module_get_function(ahip_module_t m, const char* kernel_name, ahip_fn_t* out) {
+  AHIP_REQUIRE(m && kernel_name && out, "null argument");
+  hipFunction_t f;
+  AHIP_CHECK_HIP(hipModuleGetFunction(&f, m->mod, kernel_name));
+  *out = new ahip_func_s{f};
+  return AHIP_OK;
+}
+
+int ahip_module_unload(ahip_module_t m) {
+  if (!m) return AHIP_OK;
+  AHIP_CHECK_HIP(hipModuleUnload(m->mod));
+  delete m;
+  return AHIP_OK;
+}
+
+int ahip_launch(ahip_fn_t f, uint32_t gx, uint32_t gy, uint32_t gz, uint32_t bx, uint32_t by,
+                uint32_t bz, uint32_t shmem_bytes, const void* kernarg, size_t kernarg_size,
+                void* stream) {
+  AHIP_REQUIRE(f != nullptr, "null kernel");
+  AHIP_REQUIRE(gx > 0 && gy > 0 && gz > 0 && bx > 0, "empty launch");
+  size_t sz = kernarg_size;
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, const_cast<void*>(kernarg),
+                    HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+  AHIP_CHECK_HIP(hipModuleLaunchKernel(f->fn, gx, gy, gz, bx, by, bz, shmem_bytes,
+                                       as_stream(stream), nullptr, config));
+  return AHIP_OK;
+}
+
+// ---- hipGraph capture / replay -----------------------------------------------------------
+int ahip_graph_begin(void* stream) {
+  AHIP_CHECK_HIP(hipStreamBeginCapture(as_stream(stream), hipStreamCaptureModeThreadLocal));
+  return AHIP_OK;
+}
+
+int ahip_graph_end(void* stream, ahip_graph_t* out) {
+  AHIP_REQUIRE(out != nullptr, "null out");
+  hipGraph_t g = nullptr;
+  AHIP_CHECK_HIP(hipStreamEndCapture(as_stream(stream), &g));
+  hipGraphExec_t e = nullptr;
+  hipError_t err = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
+  if (err != hipSuccess) {
+    hipGraphDestroy(g);
+    ahip_set_error("hipGraphInstantiate failed: %s", hipGetErrorString(err));
+    return AHIP_EHIP;
+  }
+  *out = new ahip_graph_s{g, e};
+  return AHIP_OK;
+}
+
+int ahip_graph_launch(ahip_graph_t g, void* stream) {
+  AHIP_REQUIRE(g != nullptr, "null graph");
+  AHIP_CHECK_HIP(hipGraphLaunch(g->exec, as_stream(stream)));
+  return AHIP_OK;
+}
+
+int ahip_graph_destroy(ahip_graph_t g) {
+  if (!g) return AHIP_OK;
+  hipGraphExecDestroy(g->exec);
+  hipGraphDestroy(g->graph);
+  delete g;
+  return AHIP_OK;
+}
+
+// ---- events ------------------------------------------------------------------------------
+int ahip_event_create(ahip_event_t* out) {
+  AHIP_REQUIRE(out != nullptr, "null out");
+  hipEvent_t e;
+  AHIP_CHECK_HIP(hipEventCreate(&e));
+  *out = new ahip_event_s{e};
+  return AHIP_OK;
+}
+
+int ahip_event_record(ahip_event_t e, void* stream) {
+  AHIP_REQUIRE(e != nullptr, "null event");
+  AHIP_CHECK_HIP(hipEventRecord(e->ev, as_stream(stream)));
+  return AHIP_OK;
+}
+
+int ahip_event_elapsed_ms(ahip_event_t start, ahip_event_t stop, float* ms) {
+  AHIP_REQUIRE(start && stop && ms, "null argument");
+  AHIP_CHECK_HIP(hipEventSynchronize(stop->ev));
+  AHIP_CHECK_HIP(hipEventElapsedTime(ms, start->ev, stop->ev));
+  return AHIP_OK;
+}
+
+int ahip_event_destroy(ahip_event_t e) {
+  if (!e) return AHIP_OK;
+  hipEventDestroy(e->ev);
+  delete e;
+  return AHIP_OK;
+}
+
+}  // extern "C"

@@ -215,6 +215,17 @@ def _register_handlers():
             raise UnsupportedOp("Elemwise output arity mismatch")
         ctx.emit("Elemwise", node, {"scalar": s})
 
+    from aesara.scalar.basic import ScalarOp
+
+    @hip_lower.register(ScalarOp)
+    def _(op, node, ctx):
+        # a ScalarOp applied directly to 0-d ScalarType variables (index arithmetic around
+        # Subtensor/Scan, scalar/basic.py:1082): same expression, 0-d operands, host-evaluated
+        s = lower_scalar_op(op, len(node.inputs))
+        if len(s["nodes"]) == 1 and s["nodes"][0]["dtype"] is None:
+            s["nodes"][0]["dtype"] = str(node.outputs[0].type.dtype)
+        ctx.emit("Elemwise", node, {"scalar": s})
+
     @hip_lower.register(CAReduce)
     def _(op, node, ctx):
         # reference: tensor/elemwise.py:1221 CAReduce; acc rule _acc_dtype :1371; perform :1495
@@ -278,6 +289,13 @@ def _register_handlers():
     def _(op, node, ctx):
         # reference: tensor/basic.py:1389 Alloc(value, *shape)
         ctx.emit("Alloc", node)
+
+    from aesara.tensor.extra_ops import BroadcastTo
+
+    @hip_lower.register(BroadcastTo)
+    def _(op, node, ctx):
+        # reference: tensor/extra_ops.py BroadcastTo(x, *shape) — a broadcast (stride-0) view
+        ctx.emit("BroadcastTo", node)
 
     @hip_lower.register(AllocEmpty)
     def _(op, node, ctx):

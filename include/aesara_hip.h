@@ -1,0 +1,216 @@
+/*
+ * aesara_hip.h — C-ABI of libaesara_hip.so, the MI355X (gfx950) execution shim behind the
+ * Aesara HIP linker.  Plain C linkage: pointers, sizes and integer codes only (no C++ or
+ * torch types), loadable with ctypes/cffi/dlopen.
+ *
+ * Every entry point cites the reference code path it replaces (paths relative to the
+ * reference tree, aesara-devs/aesara @ 2024-10-08).
+ *
+ * Conventions
+ *   - return value: 0 = ok, <0 = error (AHIP_E*); ahip_last_error() returns a thread-local
+ *     message for the last non-zero return on this thread.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Nothing here
+ *     synchronises implicitly except where documented.
+ *   - memory ownership: every device buffer is owned by the caller (PyTorch-ROCm allocations
+ *     in the Python host); the shim never allocates or frees user-visible device memory.
+ *     Workspaces are caller-provided.
+ *   - strides are in ELEMENTS (not bytes); stride 0 == broadcast along that dim.
+ *   - dtype codes: enum ahip_dtype (NumPy names).
+ */
+#ifndef AESARA_HIP_H
+#define AESARA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AHIP_ABI_VERSION 1
+#define AHIP_MAXD 6    /* max collapsed dims handed to a generated kernel            */
+#define AHIP_MAXOPS 32 /* max operands (inputs + outputs) of one fused Elemwise kernel */
+
+enum ahip_status {
+  AHIP_OK = 0,
+  AHIP_EINVAL = -1,   /* bad argument (-> ValueError)                    */
+  AHIP_EHIP = -2,     /* HIP runtime error (-> RuntimeError)             */
+  AHIP_ECOMPILE = -3, /* hiprtc compilation failed (log in last_error)   */
+  AHIP_EINDEX = -4,   /* index out of bounds (-> IndexError)             */
+  AHIP_ENOSUP = -5    /* unsupported dtype/layout combination            */
+};
+
+enum ahip_dtype {
+  AHIP_BOOL = 0, AHIP_I8 = 1, AHIP_I16 = 2, AHIP_I32 = 3, AHIP_I64 = 4,
+  AHIP_U8 = 5, AHIP_U16 = 6, AHIP_U32 = 7, AHIP_U64 = 8,
+  AHIP_F32 = 9, AHIP_F64 = 10
+};
+
+typedef struct ahip_module_s* ahip_module_t;
+typedef struct ahip_func_s* ahip_fn_t;
+typedef struct ahip_graph_s* ahip_graph_t;
+typedef struct ahip_event_s* ahip_event_t;
+
+/* Kernel-argument block of every GENERATED fused Elemwise(+CAReduce) kernel
+ *   extern "C" __global__ void k(ahip_ew_args a);
+ * (generator: aesara_amd/codegen.py).  Operands are ordered inputs then outputs.            */
+typedef struct ahip_ew_args {
+  int64_t n;                              /* total number of output elements (kept x reduced) */
+  int64_t shape[AHIP_MAXD];               /* collapsed iteration shape, outermost first       */
+  int64_t stride[AHIP_MAXOPS][AHIP_MAXD]; /* per-operand strides (elements), 0 = broadcast    */
+  void* ptr[AHIP_MAXOPS];                 /* operand base pointers                            */
+  void* ws;                               /* reduction workspace (partials), may be NULL      */
+  void* out;                              /* reduction result pointer, may be NULL            */
+  int64_t aux0;                           /* kernel-specific (e.g. #kept elements, #slices)   */
+  int64_t aux1;
+  int32_t nd;                             /* number of valid dims in shape/stride             */
+  int32_t nops;
+} ahip_ew_args;
+
+typedef struct ahip_device_info {
+  int32_t device;
+  int32_t cu_count;
+  int32_t wavefront_size;
+  int32_t max_threads_per_block;
+  int64_t total_mem;
+  int64_t lds_per_block;
+  int32_t clock_khz;
+  int32_t l2_bytes;
+  char arch[64];
+  char name[128];
+} ahip_device_info;
+
+/* ---- runtime ------------------------------------------------------------------------ */
+/* replaces: nothing in the reference has a device (config.device accepts only "cpu",
+ * configdefaults.py:331-336); this is the backend's analogue of cmodule.py's dlimport. */
+int ahip_abi_version(void);
+int ahip_init(int device_ordinal);
+const char* ahip_last_error(void);
+int ahip_get_device_info(ahip_device_info* out);
+int ahip_stream_synchronize(void* stream);
+
+/* ---- runtime compilation of generated kernels ------------------------------------------
+ * replaces: link/c/cmodule.py:2047 GCC_compiler.compile_str + :1240 ModuleCache.module_from_key
+ * (the reference compiles per-Op C++ with g++ and dlopens it; here HIP source -> gfx950 code
+ * object via hiprtc, cached by the host keyed on sha256(source)).                            */
+int ahip_compile(const char* source, const char* name, const char* const* options, int n_options,
+                 void** code_out, size_t* size_out); /* works without a GPU (cross-compiles) */
+int ahip_free_code(void* code);
+int ahip_module_load(const void* code, size_t size, ahip_module_t* out);
+int ahip_module_get_function(ahip_module_t m, const char* kernel_name, ahip_fn_t* out);
+int ahip_module_unload(ahip_module_t m);
+/* raw launch of a loaded kernel with an opaque kernarg block */
+int ahip_launch(ahip_fn_t f, uint32_t gx, uint32_t gy, uint32_t gz, uint32_t bx, uint32_t by,
+                uint32_t bz, uint32_t shmem_bytes, const void* kernarg, size_t kernarg_size,
+                void* stream);
+
+/* ---- K1/K3: fused broadcast Elemwise ----------------------------------------------------
+ * replaces: tensor/elemwise.py:725 Elemwise.perform / :835 _c_all (C loop nest generated by
+ * elemwise_cgen.py:228 make_loop / :305 make_reordered_loop) with the scalar body of
+ * scalar/basic.py ScalarOp.c_code / :4250 Composite.c_code_template.
+ * `k` must be a kernel generated for (nd, operand layout classes, vector width `vec`,
+ * threads `block`); the shim packs ahip_ew_args, sizes the grid (grid-stride, capped at
+ * cu_count*8 workgroups... see elemwise_launch.hip) and launches.                            */
+int ahip_elemwise(ahip_fn_t k, int nd, const int64_t* shape, int nops, void* const* ptrs,
+                  const int64_t* strides /* [nops*nd] */, int vec, int block, void* stream);
+
+/* ---- K2: Elemwise fused into a full CAReduce (axis=None) --------------------------------
+ * replaces: tensor/elemwise.py:1495 CAReduce.perform / :1522 _c_all (make_loop_careduce,
+ * elemwise_cgen.py:502) applied to the output of the Elemwise above, without materialising
+ * the intermediate.  Two generated kernels: `k_main` writes one partial per workgroup into
+ * `ws` (>= ahip_reduce_ws_bytes()), `k_fin` folds the partials in a fixed order
+ * (deterministic) and stores the cast result to `out`.                                       */
+size_t ahip_reduce_ws_bytes(void);
+int ahip_elemwise_reduce_all(ahip_fn_t k_main, ahip_fn_t k_fin, int nd, const int64_t* shape,
+                             int nops, void* const* ptrs, const int64_t* strides, int vec,
+                             int block, void* out, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- K2: axis CAReduce (optionally with a fused Elemwise producer) ----------------------
+ * The iteration space is [kept dims (nk) | reduced dims (nr)], both already collapsed by the
+ * host; shape/strides cover nk+nr dims in that order.  mode 0 ("row"): one wavefront per
+ * output element, lanes stride over the reduced run.  mode 1 ("col"): one thread per output
+ * element, reduced dims walked sequentially; `nslices`>1 splits the reduced run over
+ * gridDim.y and writes [nslices, n_kept] partials into `ws` for a second pass.              */
+int ahip_elemwise_reduce_axis(ahip_fn_t k, int mode, int nk, int nr, const int64_t* shape,
+                              int nops, void* const* ptrs, const int64_t* strides, int nslices,
+                              void* out_or_ws, int block, void* stream);
+
+/* ---- K4/K6: GEMM on MFMA ------------------------------------------------------------------
+ * replaces: tensor/blas.py:518 GemmRelated / :872 Gemm (build_gemm_call :836 -> sgemm_/dgemm_
+ * :767-820), :1659 Dot22, :1954 Dot22Scalar, :2179 BatchedDot (batch_gemm :2241) and the
+ * NumPy-C-API fallback tensor/c_code/alt_blas_template.c.
+ * C[M,N] = alpha * A[M,K] @ B[K,N] + beta * Cin[M,N]; all operands are addressed with explicit
+ * (row, col) element strides so the 8 unit-stride layouts of encode_strides_in_unit (:719)
+ * and arbitrary views are handled without copies.  beta == 0 ignores Cin (no NaN propagation,
+ * like BLAS).  Cin may alias C.  dtype: AHIP_F32 or AHIP_F64.  batch strides in elements.     */
+int ahip_gemm(int dtype, int64_t M, int64_t N, int64_t K, const void* alpha, const void* A,
+              int64_t a_rs, int64_t a_cs, const void* B, int64_t b_rs, int64_t b_cs,
+              const void* beta, const void* Cin, int64_t ci_rs, int64_t ci_cs, void* C,
+              int64_t c_rs, int64_t c_cs, void* stream);
+int ahip_gemm_batched(int dtype, int64_t batch, int64_t M, int64_t N, int64_t K,
+                      const void* alpha, const void* A, int64_t a_bs, int64_t a_rs, int64_t a_cs,
+                      const void* B, int64_t b_bs, int64_t b_rs, int64_t b_cs, const void* beta,
+                      const void* Cin, int64_t ci_bs, int64_t ci_rs, int64_t ci_cs, void* C,
+                      int64_t c_bs, int64_t c_rs, int64_t c_cs, void* stream);
+
+/* ---- K5: GEMV / GER (HBM-bound BLAS2) -----------------------------------------------------
+ * replaces: tensor/blas.py:231 Gemv (perform :279), tensor/blas_c.py:611 CGemv (gemv_c_code
+ * :369), tensor/blas.py:330 Ger / blas_c.py:328 CGer.
+ * y_out[M] = alpha * A[M,N] @ x[N] + beta * y_in[M]  (beta == 0 ignores y_in; y_in may alias).
+ * `ws` is scratch for the column-accumulate layout (a_rs > a_cs transposed views); size from
+ * ahip_gemv_ws_bytes().                                                                        */
+size_t ahip_gemv_ws_bytes(int dtype, int64_t M, int64_t N);
+int ahip_gemv(int dtype, int64_t M, int64_t N, const void* alpha, const void* A, int64_t a_rs,
+              int64_t a_cs, const void* x, int64_t incx, const void* beta, const void* y_in,
+              int64_t incy_in, void* y_out, int64_t incy_out, void* ws, size_t ws_bytes,
+              void* stream);
+/* A_out[M,N] = A_in + alpha * x[M] y[N]^T */
+int ahip_ger(int dtype, int64_t M, int64_t N, const void* alpha, const void* x, int64_t incx,
+             const void* y, int64_t incy, const void* A_in, int64_t ai_rs, int64_t ai_cs,
+             void* A_out, int64_t ao_rs, int64_t ao_cs, void* stream);
+
+/* ---- K7/K8: fill and strided copy / set / inc ---------------------------------------------
+ * replaces: tensor/basic.py:1389 Alloc (perform :1427, PyArray_CopyInto broadcast :1441-1490),
+ * tensor/subtensor.py:1454 IncSubtensor (perform :1556), DimShuffle materialisation
+ * (tensor/c_code/dimshuffle.c), compile/ops.py:149 DeepCopyOp, tensor/basic.py:2142 Join.
+ * dst[i...] (op)= src[i...] over `shape` with per-side element strides (0 = broadcast src).
+ * accumulate: 0 = set, 1 = += .  itemsize-only copies use dtype for the add.                  */
+int ahip_copy_strided(int dtype, int nd, const int64_t* shape, const void* src,
+                      const int64_t* sstrides, void* dst, const int64_t* dstrides, int accumulate,
+                      void* stream);
+int ahip_fill(int dtype, const void* value /* host scalar */, void* dst, int64_t n, void* stream);
+
+/* ---- K9: integer row gather / scatter (bit-exact) ------------------------------------------
+ * replaces: tensor/subtensor.py:1925 AdvancedSubtensor1 (perform :1953, x.take(idx, axis=0)) and
+ * :2128 AdvancedIncSubtensor1 (np.add.at / set).  Rows are `row_elems` contiguous-or-strided
+ * elements (src_rs/dst_rs = element stride between rows, inner dims must be contiguous).
+ * Negative indices wrap once (idx + nrows); an index still out of range is reported through
+ * *bad_index (device int64, caller-zeroed; first offending value+1 is stored) and the call
+ * still returns 0 — the host raises IndexError after its next sync point.                      */
+int ahip_take_rows(int dtype, const void* src, int64_t nrows, int64_t src_rs, int64_t row_elems,
+                   const void* idx, int idx_dtype, int64_t nidx, int64_t idx_stride, void* dst,
+                   int64_t dst_rs, int64_t* bad_index, void* stream);
+int ahip_scatter_rows(int dtype, void* dst, int64_t nrows, int64_t dst_rs, int64_t row_elems,
+                      const void* idx, int idx_dtype, int64_t nidx, int64_t idx_stride,
+                      const void* src, int64_t src_rs, int accumulate, int64_t* bad_index,
+                      void* stream);
+
+/* ---- H1/K10: launch-list capture & replay (the CVM analogue) --------------------------------
+ * replaces: link/vm.py:388 Loop.__call__ / link/c/c_code/lazylinker_c.c:752 CLazyLinker_call and
+ * the per-step VM entry of scan/scan_perform.pyx:418.  Everything launched on `stream` between
+ * begin and end is recorded into one hipGraph; replay costs one host call per eval.            */
+int ahip_graph_begin(void* stream);
+int ahip_graph_end(void* stream, ahip_graph_t* out);
+int ahip_graph_launch(ahip_graph_t g, void* stream);
+int ahip_graph_destroy(ahip_graph_t g);
+
+/* ---- timing on the launch stream (bench.py roofline leg) ----------------------------------- */
+int ahip_event_create(ahip_event_t* out);
+int ahip_event_record(ahip_event_t e, void* stream);
+int ahip_event_elapsed_ms(ahip_event_t start, ahip_event_t stop, float* ms); /* syncs on stop */
+int ahip_event_destroy(ahip_event_t e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AESARA_HIP_H */

@@ -14,7 +14,7 @@ cp -r "$REF/aesara" "$OVL/"; chmod -R u+w "$OVL"
 # 1. hatch-vcs generated version file absent from the archive (aesara/version.py:1-8)
 echo '__version__ = "2.9.4+ref"' > "$OVL/aesara/_version.py"
 # 2. NumPy-2 C-API: PyArray_DESCR(x)->elsize is gone (tensor/blas.py:575,2474; blas_headers.py:1083)
-sed -i -E 's/PyArray_DESCR\(([^)]*\)?)\)->elsize/PyArray_ITEMSIZE(\1)/g' \
+sed -i -E 's/PyArray_DESCR\(([^)]*\)s?)\)->elsize/PyArray_ITEMSIZE(\1)/g' \
     "$OVL/aesara/tensor/blas.py" "$OVL/aesara/tensor/blas_headers.py"
 # 3. regenerate the vendored Cython scan loop with the installed Cython (scan/scan_perform_ext.py:3-7)
 (cd "$OVL/aesara/scan" && cython -3 scan_perform.pyx -o c_code/scan_perform.c >/dev/null 2>&1 || true)

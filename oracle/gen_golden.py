@@ -1,0 +1,604 @@
+#!/usr/bin/env python
+"""Generate the golden parity fixtures under tests/golden/ by RUNNING THE REFERENCE.
+
+TEST INFRASTRUCTURE ONLY — runs in the authoring container (needs /root/reference); the GPU
+box only consumes the committed outputs.
+
+For every case below this script
+  1. builds the graph with the reference front end (cases mirror the reference's own tests:
+     tests/tensor/test_elemwise.py TestBroadcast :212 / TestCAReduce :412 / TestDimShuffle :47,
+     tests/tensor/test_blas.py TestGemm :104 / BaseGemv :1545 / test_batched_dot :2650,
+     tests/tensor/test_subtensor.py, tests/scan/test_basic.py, plus BASELINE.json configs 1-5),
+  2. evaluates it with the reference's default linker ``Mode("cvm", "fast_run")`` (C thunks),
+  3. lowers it with the HIP linker's rewrite query to a Plan (aesara_amd.lower) and evaluates
+     that plan with the NumPy oracle (oracle/interp.py) — generation FAILS if the oracle
+     disagrees with the reference (this is how the oracle is pinned),
+  4. writes tests/golden/cases.json (plans + input recipes + tolerances) and
+     tests/golden/<case>.npz (the reference's outputs).
+
+Usage:  python oracle/gen_golden.py [--only PATTERN]
+"""
+import argparse
+import fnmatch
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import ref_overlay  # noqa: E402
+
+ae = ref_overlay.import_reference()
+import aesara.tensor as at  # noqa: E402
+from aesara.compile.mode import Mode  # noqa: E402
+from aesara.tensor.type import TensorType  # noqa: E402
+
+import interp  # noqa: E402
+from golden_inputs import make_input  # noqa: E402
+
+from aesara_amd.linker import HIP_QUERY, HipLinker  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+REF_MODE = Mode("cvm", "fast_run")
+
+CASES = []
+
+
+REF_PY = set()  # cases evaluated with the reference's Python linker (see batched_dot)
+
+
+def case(name, exact=False, rtol=None, atol=None, ref_py=False):
+    def deco(fn):
+        if ref_py:
+            REF_PY.add(name)
+        CASES.append((name, fn, exact, rtol, atol))
+        return fn
+    return deco
+
+
+def T(dtype, shape, name=None):
+    return TensorType(dtype, shape=tuple(None if s != 1 else 1 for s in shape))(name)
+
+
+def N(shape, dtype="float64", seed=0, scale=1.0, shift=0.0, view=None):
+    d = {"kind": "normal", "seed": seed, "shape": list(shape), "dtype": dtype, "scale": scale,
+         "shift": shift}
+    if view:
+        d["view"] = view
+    return d
+
+
+def U(shape, dtype="float64", seed=0, low=0.0, high=1.0, view=None):
+    d = {"kind": "uniform", "seed": seed, "shape": list(shape), "dtype": dtype, "low": low,
+         "high": high}
+    if view:
+        d["view"] = view
+    return d
+
+
+def I(shape, dtype="int32", seed=0, low=-10, high=10):  # noqa: E743
+    return {"kind": "randint", "seed": seed, "shape": list(shape), "dtype": dtype, "low": low,
+            "high": high}
+
+
+def B(shape, seed=0, p=0.5, dtype="bool"):
+    return {"kind": "bernoulli", "seed": seed, "shape": list(shape), "dtype": dtype, "p": p}
+
+
+def K(value, dtype, shape=()):
+    return {"kind": "const", "shape": list(shape), "dtype": dtype, "value": value}
+
+
+# ---------------------------------------------------------------------------------------
+# Elemwise (TestBroadcast shapes)
+# ---------------------------------------------------------------------------------------
+BCAST = [((3, 5), (3, 5)), ((3, 5), (1, 5)), ((3, 5), (3, 1)), ((1, 5), (5, 1)),
+         ((1, 1), (1, 1)), ((1000,), (1000,)), ((40, 40), (40, 40)),
+         ((2, 3, 4, 5), (2, 3, 4, 5)), ((2, 3, 4, 5), (1, 3, 1, 5)),
+         ((2, 3, 4, 5), (1, 1, 1, 1)), ((), ())]
+
+for _i, (_xs, _ys) in enumerate(BCAST):
+    for _dt in ("float64", "float32"):
+        def _mk(xs=_xs, ys=_ys, dt=_dt):
+            x, y = T(dt, xs, "x"), T(dt, ys, "y")
+            return [x, y], [x + y, x * y - x], [U(xs, dt, 1), U(ys, dt, 2)]
+        case(f"ew_bcast{_i}_{_dt}")(_mk)
+
+
+@case("ew_weird_strides")
+def _():
+    x, y = at.dmatrix("x"), at.dmatrix("y")
+    return [x, y], [x + y, at.exp(x) * y], [
+        N((6, 5), view={"kind": "step", "step": 2}), N((6, 5), seed=3, view={"kind": "transpose"})]
+
+
+@case("ew_same_inputs")
+def _():
+    x = at.dmatrix("x")
+    return [x], [x + x, x * x + x], [N((7, 9))]
+
+
+@case("ew_transcendental_f64", rtol=1e-12, atol=1e-12)
+def _():
+    x, y = at.dmatrix("x"), at.dmatrix("y")
+    e = at.tanh(x) * at.sigmoid(y) + at.softplus(x - y) + at.log1p(at.exp(-abs(x))) + \
+        at.sqrt(abs(y)) + at.sqr(x) / (1 + at.sqr(y)) + at.cos(x) * at.sin(y) + at.erf(x)
+    return [x, y], [e], [N((33, 65), scale=2.0), N((33, 65), seed=5, scale=2.0)]
+
+
+@case("ew_transcendental_f32", rtol=2e-5, atol=2e-5)
+def _():
+    x, y = at.fmatrix("x"), at.fmatrix("y")
+    e = at.tanh(x) * at.sigmoid(y) + at.softplus(x - y) + at.log1p(at.exp(-abs(x))) + \
+        at.sqrt(abs(y)) + at.sqr(x) / (1 + at.sqr(y)) + at.expm1(x * 0.1) + at.log(abs(y) + 1)
+    return [x, y], [e], [N((33, 65), "float32", scale=2.0), N((33, 65), "float32", 5, 2.0)]
+
+
+@case("ew_softplus_ranges", rtol=1e-12, atol=0)
+def _():
+    x = at.dvector("x")
+    return [x], [at.softplus(x), at.sigmoid(x)], [U((4000,), low=-60.0, high=60.0)]
+
+
+@case("ew_int_ops", exact=True)
+def _():
+    a, b = at.imatrix("a"), at.imatrix("b")
+    bb = at.switch(at.eq(b, 0), 3, b)
+    return [a, b], [a // bb, a % bb, a * a - b, a & b, a | b, a ^ b, ~a, abs(a), -a,
+                    at.maximum(a, b), at.minimum(a, b), at.sgn(a)], \
+        [I((17, 23), seed=1, low=-50, high=50), I((17, 23), seed=2, low=-7, high=8)]
+
+
+@case("ew_int8_uint8", exact=True)
+def _():
+    a, b = at.bmatrix("a"), TensorType("uint8", shape=(None, None))("b")
+    return [a, b], [a + a, a * a, b + b, b * b, a // 3, b % 7, at.cast(a, "int32") + b], \
+        [I((9, 31), "int8", 1, -128, 128), I((9, 31), "uint8", 2, 0, 256)]
+
+
+@case("ew_compare_switch_clip", exact=True)
+def _():
+    x, y = at.dmatrix("x"), at.dmatrix("y")
+    return [x, y], [at.lt(x, y), at.ge(x, y), at.eq(x, x), at.neq(x, y),
+                    at.switch(at.gt(x, 0), x, y), at.clip(x, -0.5, 0.5),
+                    at.and_(at.lt(x, y), at.gt(x, 0)), at.cast(x * 10, "int32"),
+                    at.isnan(x / x * 0 + x), at.floor(x * 3), at.ceil(x * 3), at.round(x * 3)], \
+        [N((21, 13)), N((21, 13), seed=9)]
+
+
+@case("ew_bool_ops", exact=True)
+def _():
+    a, b = TensorType("bool", shape=(None,))("a"), TensorType("bool", shape=(None,))("b")
+    return [a, b], [a & b, a | b, a ^ b, ~a, at.cast(a, "int8") + at.cast(b, "int8")], \
+        [B((100,), 1), B((100,), 2)]
+
+
+@case("ew_mixed_dtypes", rtol=1e-6, atol=1e-6)
+def _():
+    a, x, z = at.bvector("a"), at.fvector("x"), at.dvector("z")
+    return [a, x, z], [a * x, x + z, a / 3, at.true_div(a, a + 130), at.cast(z, "float32") * x], \
+        [I((257,), "int8", 1, -100, 100), N((257,), "float32", 2), N((257,), seed=3)]
+
+
+@case("ew_6d", rtol=1e-12, atol=1e-12)
+def _():
+    x = TensorType("float64", shape=(None,) * 6)("x")
+    y = TensorType("float64", shape=(None, 1, None, 1, None, 1))("y")
+    return [x, y], [x * y + 1], [N((2, 3, 2, 3, 2, 3)), N((2, 1, 2, 1, 2, 1), seed=4)]
+
+
+# ---------------------------------------------------------------------------------------
+# DimShuffle (TestDimShuffle patterns) — output forces a materialising copy
+# ---------------------------------------------------------------------------------------
+DS = [((2, 3), (1, "x", 0)), ((1, 2, 3), (1, 2)), ((1, 2, 1, 3), (1, 3)), ((2, 3, 4), (2, 1, 0)),
+      ((2, 3, 4), ("x", 2, 1, 0, "x")), ((1, 4, 3, 2, 1), (3, 2, 1)), ((1, 1, 4), (1, 2)),
+      ((1, 1, 1), ()), ((1,), ("x", "x"))]
+for _i, (_xs, _pat) in enumerate(DS):
+    def _mk(xs=_xs, pat=_pat):
+        x = T("float64", xs, "x")
+        return [x], [x.dimshuffle(*pat), x.dimshuffle(*pat) * 2.0], [N(xs, seed=7)]
+    case(f"dimshuffle{_i}", exact=True)(_mk)
+
+
+@case("dimshuffle_int_T", exact=True)
+def _():
+    x = at.imatrix("x")
+    return [x], [x.T, x.T + 1], [I((37, 53), seed=3)]
+
+
+# ---------------------------------------------------------------------------------------
+# CAReduce (TestCAReduce cases)
+# ---------------------------------------------------------------------------------------
+RED = [((5, 6), None), ((5, 6), (0, 1)), ((5, 6), (0,)), ((5, 6), (1,)), ((5, 6), (-1,)),
+       ((5, 6), (-2,)), ((5, 6), ()), ((2, 3, 4, 5), (0, 1, 3)), ((2, 3, 4, 5), (-2, -3)),
+       ((5, 0), None), ((5, 0), (0,)), ((5, 0), (1,)), ((5, 0), ()), ((), None), ((), ())]
+for _i, (_xs, _ax) in enumerate(RED):
+    def _mk(xs=_xs, ax=_ax):
+        x = T("float64", xs, "x")
+        outs = [at.sum(x, axis=ax), at.prod(x, axis=ax)]
+        if 0 not in xs:
+            outs += [at.max(x, axis=ax), at.min(x, axis=ax)]
+        return [x], outs, [U(xs, seed=11, low=0.5, high=1.5)]
+    case(f"red{_i}_f64", rtol=1e-12, atol=1e-12)(_mk)
+
+    def _mk32(xs=_xs, ax=_ax):
+        x = T("float32", xs, "x")
+        return [x], [at.sum(x, axis=ax)], [U(xs, "float32", 11, 0.5, 1.5)]
+    case(f"red{_i}_f32", rtol=1e-6, atol=1e-6)(_mk32)
+
+    def _mki(xs=_xs, ax=_ax):
+        x = T("int32", xs, "x")
+        b = T("bool", xs, "b")
+        i8 = T("int8", xs, "i8")
+        outs = [at.sum(x, axis=ax), at.sum(i8, axis=ax), at.all(b, axis=ax), at.any(b, axis=ax)]
+        if 0 not in xs:
+            outs += [at.max(x, axis=ax), at.min(i8, axis=ax)]
+        return [x, b, i8], outs, [I(xs, seed=5, low=-100, high=100), B(xs, 6, 0.8),
+                                  I(xs, "int8", 7, -128, 128)]
+    case(f"red{_i}_int", exact=True)(_mki)
+
+
+@case("red_large_f32", rtol=2e-6, atol=1e-4)
+def _():
+    x = at.fmatrix("x")
+    return [x], [x.sum(axis=0), x.sum(axis=1), x.sum(), x.max(axis=0), x.min(axis=1)], \
+        [N((1500, 300), "float32", seed=21)]
+
+
+@case("red_large_3d", rtol=1e-11, atol=1e-11)
+def _():
+    x = at.dtensor3("x")
+    return [x], [x.sum(axis=(0, 2)), x.sum(axis=1), x.sum(axis=(1, 2)), x.max(axis=(0, 1))], \
+        [N((64, 3, 200), seed=22)]
+
+
+@case("red_tall_skinny", rtol=1e-6, atol=1e-3)
+def _():
+    x = at.fmatrix("x")
+    return [x], [x.sum(axis=0), x.mean(axis=0)], [N((20000, 8), "float32", seed=23)]
+
+
+@case("red_nan_propagation", exact=True)
+def _():
+    x = at.dmatrix("x")
+    y = at.switch(at.gt(x, 2.5), np.nan, x)
+    return [x], [at.max(y, axis=0), at.min(y, axis=1), at.max(y)], [N((40, 30), seed=24)]
+
+
+@case("red_fused_elemwise_axis", rtol=1e-12, atol=1e-12)
+def _():
+    x, y = at.dmatrix("x"), at.dvector("y")
+    e = at.exp(-(x - y) ** 2)
+    return [x, y], [e.sum(axis=0), e.sum(axis=1), (e * 2).sum(), e], \
+        [N((50, 70), seed=25), N((70,), seed=26)]
+
+
+# ---------------------------------------------------------------------------------------
+# BLAS (TestGemm.cmp / BaseGemv / TestBlasStrides / test_batched_dot)
+# ---------------------------------------------------------------------------------------
+def _gemm_case(name, dt, M, K, Nn, a, b, tx=False, ty=False, tz=False, rtol=None):
+    def mk():
+        z, x, y = (T(dt, (2, 2), n) for n in "zxy")
+        zs = N((M, Nn), dt, 1, view={"kind": "transpose"} if tz else None)
+        xs = N((M, K), dt, 2, view={"kind": "transpose"} if tx else None)
+        ys = N((K, Nn), dt, 3, view={"kind": "transpose"} if ty else None)
+        return [z, x, y], [b * z + a * at.dot(x, y)], [zs, xs, ys]
+    tol = rtol or (1e-12 if dt == "float64" else 2e-5)
+    case(name, rtol=tol, atol=tol * 10)(mk)
+
+
+_k = 0
+for _dt in ("float64", "float32"):
+    for (_M, _K, _N) in [(3, 4, 5), (4, 5, 1), (1, 7, 1), (130, 70, 250), (256, 256, 256)]:
+        for (_a, _b) in [(1.0, 0.0), (1.0, 1.0), (-1.0, 0.6), (0.6, -1.0), (0.0, 1.0)]:
+            if (_M, _K, _N) != (3, 4, 5) and (_a, _b) not in [(1.0, 0.0), (0.6, -1.0)]:
+                continue
+            _gemm_case(f"gemm{_k}_{_dt}", _dt, _M, _K, _N, _a, _b)
+            _k += 1
+    for (_tx, _ty, _tz) in [(1, 0, 0), (0, 1, 0), (1, 1, 0), (0, 0, 1), (1, 1, 1)]:
+        _gemm_case(f"gemm_T{_tx}{_ty}{_tz}_{_dt}", _dt, 132, 68, 200, 0.8, 0.4, _tx, _ty, _tz)
+    for (_M, _K, _N) in [(0, 4, 5), (3, 0, 5), (3, 4, 0)]:
+        _gemm_case(f"gemm_empty{_M}{_K}{_N}_{_dt}", _dt, _M, _K, _N, 0.5, 2.0)
+
+
+@case("dot22_f32", rtol=2e-5, atol=2e-4)
+def _():
+    x, y = at.fmatrix("x"), at.fmatrix("y")
+    return [x, y], [at.dot(x, y), at.dot(x, y) * np.float32(0.25)], \
+        [N((77, 129), "float32", 1), N((129, 65), "float32", 2)]
+
+
+@case("dot_vec_combos", rtol=1e-12, atol=1e-11)
+def _():
+    A, v, w = at.dmatrix("A"), at.dvector("v"), at.dvector("w")
+    return [A, v, w], [at.dot(A, v), at.dot(w, A), at.dot(w, at.dot(A, v))], \
+        [N((40, 60), seed=1), N((60,), seed=2), N((40,), seed=3)]
+
+
+def _gemv_case(name, dt, M, Nn, alpha, beta, tA=False, rtol=None):
+    def mk():
+        y, A, x = T(dt, (2,), "y"), T(dt, (2, 2), "A"), T(dt, (2,), "x")
+        return [y, A, x], [beta * y + alpha * at.dot(A, x)], \
+            [N((M,), dt, 1), N((M, Nn), dt, 2, view={"kind": "transpose"} if tA else None),
+             N((Nn,), dt, 3)]
+    tol = rtol or (1e-12 if dt == "float64" else 3e-5)
+    case(name, rtol=tol, atol=tol * 10)(mk)
+
+
+for _dt in ("float64", "float32"):
+    _gemv_case(f"gemv_small_{_dt}", _dt, 3, 5, 1.0, 0.0)
+    _gemv_case(f"gemv_beta_{_dt}", _dt, 200, 300, 0.5, -0.3)
+    _gemv_case(f"gemv_T_{_dt}", _dt, 256, 3000, 1.0, 0.0, tA=True)
+    _gemv_case(f"gemv_T_beta_{_dt}", _dt, 30, 50, 2.0, 1.0, tA=True)
+    _gemv_case(f"gemv_wide_{_dt}", _dt, 7, 4096, 1.0, 0.0)
+    _gemv_case(f"gemv_empty_{_dt}", _dt, 5, 0, 1.0, 1.0)
+
+
+@case("ger_f64", rtol=1e-12, atol=1e-12)
+def _():
+    A, x, y = at.dmatrix("A"), at.dvector("x"), at.dvector("y")
+    return [A, x, y], [A + 0.3 * at.outer(x, y)], [N((30, 40), seed=1), N((30,), seed=2),
+                                                   N((40,), seed=3)]
+
+
+# BatchedDot's C thunk references sgemm_/dgemm_ directly and cannot link without blas__ldflags
+# (tensor/blas.py:2241); the reference's own Python linker (perform :2224) is the oracle here.
+@case("batched_dot_f32", rtol=2e-5, atol=2e-4, ref_py=True)
+def _():
+    x, y = at.ftensor3("x"), at.ftensor3("y")
+    return [x, y], [at.batched_dot(x, y)], [N((7, 33, 40), "float32", 1),
+                                            N((7, 40, 21), "float32", 2)]
+
+
+@case("batched_dot_f64", rtol=1e-12, atol=1e-11, ref_py=True)
+def _():
+    x, y = at.dtensor3("x"), at.dtensor3("y")
+    return [x, y], [at.batched_dot(x, y)], [N((3, 130, 17), seed=1), N((3, 17, 140), seed=2)]
+
+
+# ---------------------------------------------------------------------------------------
+# Subtensor / IncSubtensor / AdvancedSubtensor1 / Alloc / Join (bit-exact)
+# ---------------------------------------------------------------------------------------
+@case("subtensor_basic", exact=True)
+def _():
+    x = at.imatrix("x")
+    i = at.lscalar("i")
+    return [x, i], [x[1:5], x[::-1], x[2], x[1:, ::2], x[i], x[-i:, 1], x[::-2, ::-1] + 0], \
+        [I((9, 11), seed=1), K(3, "int64")]
+
+
+@case("incsubtensor", exact=True)
+def _():
+    x, y, r = at.imatrix("x"), at.imatrix("y"), at.ivector("r")
+    return [x, y, r], [at.set_subtensor(x[1:3], y), at.inc_subtensor(x[::4, 1], r[:3]),
+                       at.inc_subtensor(x[2:4, :], y), at.set_subtensor(x[:, 0], 7)], \
+        [I((9, 11), seed=1), I((2, 11), seed=2), I((5,), seed=3)]
+
+
+@case("incsubtensor_f64", exact=True)
+def _():
+    x, y = at.dmatrix("x"), at.dvector("y")
+    return [x, y], [at.inc_subtensor(x[3], y), at.set_subtensor(x[::2, ::3], 1.5)], \
+        [N((8, 10), seed=1), N((10,), seed=2)]
+
+
+@case("advsub1", exact=True)
+def _():
+    x, idx, idx32 = at.imatrix("x"), at.lvector("idx"), at.ivector("idx32")
+    v = at.dvector("v")
+    return [x, idx, idx32, v], [x[idx], x[idx32], v[idx], x.T[idx32]], \
+        [I((13, 7), seed=1), I((20,), "int64", 2, -13, 13), I((5,), "int32", 3, -7, 7),
+         N((13,), seed=4)]
+
+
+# AdvancedIncSubtensor1's C thunk uses the NumPy-1 MapIter C-API (tensor/subtensor.py:2230) and does
+# not compile against NumPy 2; the reference's Python perform (:2267) is the oracle here.
+@case("advincsub1_int", exact=True, ref_py=True)
+def _():
+    x, y, idx = at.imatrix("x"), at.imatrix("y"), at.lvector("idx")
+    return [x, y, idx], [at.inc_subtensor(x[idx], y), at.inc_subtensor(x[idx], 2)], \
+        [I((13, 7), seed=1), I((20, 7), seed=2), I((20,), "int64", 3, -13, 13)]
+
+
+@case("advsetsub1_dups", exact=True, ref_py=True)
+def _():
+    x, y, idx = at.imatrix("x"), at.imatrix("y"), at.lvector("idx")
+    return [x, y, idx], [at.set_subtensor(x[idx], y)], \
+        [I((13, 7), seed=1), I((20, 7), seed=2), I((20,), "int64", 3, -13, 13)]
+
+
+@case("advincsub1_f32", rtol=1e-6, atol=1e-5, ref_py=True)
+def _():
+    x, y, idx = at.fmatrix("x"), at.fmatrix("y"), at.lvector("idx")
+    return [x, y, idx], [at.inc_subtensor(x[idx], y)], \
+        [N((50, 64), "float32", 1), N((300, 64), "float32", 2), I((300,), "int64", 3, 0, 50)]
+
+
+@case("alloc_join", exact=True)
+def _():
+    v, m = at.dvector("v"), at.dmatrix("m")
+    n = at.lscalar("n")
+    return [v, m, n], [at.alloc(v, n, v.shape[0]), at.zeros((n, 3)) + 1.0,
+                       at.concatenate([m, m * 2], axis=0), at.concatenate([m, m[:, :2]], axis=1),
+                       at.alloc(np.float64(2.5), 2, n), m.reshape((m.shape[1], m.shape[0])),
+                       m.T.reshape((-1,)), m.flatten()], \
+        [N((5,), seed=1), N((4, 5), seed=2), K(3, "int64")]
+
+
+# ---------------------------------------------------------------------------------------
+# Scan (tests/scan/test_basic.py style restatements)
+# ---------------------------------------------------------------------------------------
+@case("scan_cumsum", rtol=1e-12, atol=1e-12)
+def _():
+    x, s0 = at.dmatrix("x"), at.dvector("s0")
+    res, _ = ae.scan(lambda x_t, s: s + x_t, sequences=[x], outputs_info=[s0])
+    return [x, s0], [res, res[-1]], [N((20, 7), seed=1), N((7,), seed=2)]
+
+
+@case("scan_taps", rtol=1e-12, atol=1e-12)
+def _():
+    x, init, w = at.dvector("x"), at.dvector("init"), at.dscalar("w")
+    res, _ = ae.scan(lambda x_t, a, b, w: w * a + 0.5 * b + x_t, sequences=[x],
+                     outputs_info=[dict(initial=init, taps=[-2, -1])], non_sequences=[w])
+    return [x, init, w], [res], [N((15,), seed=1, scale=0.1), N((2,), seed=2), K(0.7, "float64")]
+
+
+@case("scan_nitsot_map", rtol=1e-12, atol=1e-12)
+def _():
+    x, W = at.dmatrix("x"), at.dmatrix("W")
+    res, _ = ae.scan(lambda x_t, W: at.tanh(at.dot(W, x_t)), sequences=[x], non_sequences=[W])
+    return [x, W], [res], [N((12, 6), seed=1), N((6, 6), seed=2)]
+
+
+@case("scan_two_outputs", rtol=1e-12, atol=1e-12)
+def _():
+    x, a0, b0 = at.dvector("x"), at.dscalar("a0"), at.dscalar("b0")
+    res, _ = ae.scan(lambda x_t, a, b: [a * 0.9 + x_t, b + a], sequences=[x],
+                     outputs_info=[a0, b0])
+    return [x, a0, b0], [res[0], res[1][-1]], [N((25,), seed=1), K(0.5, "float64"),
+                                              K(-1.0, "float64")]
+
+
+def _gru(dt, T_, H, B_, tol):
+    def mk():
+        x = T(dt, (2, 2) if B_ == 1 else (2, 2, 2), "x")
+        h0 = T(dt, (2,) if B_ == 1 else (2, 2), "h0")
+        Ws = [T(dt, (2, 2), n) for n in ("Wz", "Uz", "Wr", "Ur", "Wh", "Uh")]
+
+        def step(x_t, h, Wz, Uz, Wr, Ur, Wh, Uh):
+            z = at.sigmoid(at.dot(x_t, Wz) + at.dot(h, Uz))
+            r = at.sigmoid(at.dot(x_t, Wr) + at.dot(h, Ur))
+            hh = at.tanh(at.dot(x_t, Wh) + at.dot(r * h, Uh))
+            return (1 - z) * h + z * hh
+        hs, _ = ae.scan(step, sequences=[x], outputs_info=[h0], non_sequences=Ws)
+        xs = (T_, H) if B_ == 1 else (T_, B_, H)
+        hsz = (H,) if B_ == 1 else (B_, H)
+        return [x, h0] + Ws, [hs, hs[-1]], \
+            [N(xs, dt, 4, 0.1), K(0.0, dt, hsz)] + \
+            [N((H, H), dt, 5 + k, 1.0 / np.sqrt(H)) for k in range(6)]
+    return mk
+
+
+case("cfg4_gru_b1_f32", rtol=1e-5, atol=1e-5)(_gru("float32", 32, 64, 1, 1e-5))
+case("cfg4_gru_b8_f32", rtol=1e-5, atol=1e-5)(_gru("float32", 16, 64, 8, 1e-5))
+case("gru_b1_f64", rtol=1e-11, atol=1e-11)(_gru("float64", 10, 24, 1, 1e-11))
+
+
+# ---------------------------------------------------------------------------------------
+# BASELINE.json configs at reduced shapes
+# ---------------------------------------------------------------------------------------
+@case("cfg1a_scalar_add", exact=True)
+def _():
+    a, b = at.dscalar("a"), at.dscalar("b")
+    return [a, b], [a + b], [K(1.5, "float64"), K(2.5, "float64")]
+
+
+@case("cfg1b_matrix_add", exact=True)
+def _():
+    x, y = at.dmatrix("x"), at.dmatrix("y")
+    return [x, y], [x + y], [U((128, 96), seed=0), U((128, 96), seed=1)]
+
+
+@case("cfg2_gauss_sum", rtol=1e-12, atol=0)
+def _():
+    x, mu, sg = at.dmatrix("x"), at.dscalar("mu"), at.dscalar("sigma")
+    return [x, mu, sg], [at.exp(-(x - mu) ** 2 / (2 * sg ** 2)).sum()], \
+        [N((256, 192), seed=1), K(0.1, "float64"), K(1.3, "float64")]
+
+
+@case("cfg3a_gemv", rtol=1e-12, atol=1e-11)
+def _():
+    M, v, a = at.dmatrix("M"), at.dvector("v"), at.dscalar("a")
+    return [M, v, a], [a / a + at.dot(M + a, v), at.dot(M, v) + a], \
+        [N((200, 300), seed=2), N((300,), seed=3), K(2.0, "float64")]
+
+
+@case("cfg3b_gemm_update", rtol=2e-5, atol=2e-4)
+def _():
+    Cc, A, Bm = at.fmatrix("C"), at.fmatrix("A"), at.fmatrix("B")
+    return [Cc, A, Bm], [np.float32(0.4) * Cc + np.float32(0.8) * at.dot(A, Bm)], \
+        [N((256, 256), "float32", 1), N((256, 256), "float32", 3), N((256, 256), "float32", 4)]
+
+
+@case("cfg5_logistic", rtol=2e-5, atol=1e-3)
+def _():
+    X, w, b, y = at.fmatrix("X"), at.fvector("w"), at.fscalar("b"), at.fvector("y")
+    p = at.sigmoid(at.dot(X, w) + b)
+    logp = (y * at.log(p) + (1 - y) * at.log(1 - p)).sum()
+    gw, gb = ae.grad(logp, [w, b])
+    return [X, w, b, y], [logp, gw, gb], \
+        [N((4096, 256), "float32", 6), N((256,), "float32", 7, 1.0 / 16), K(0.1, "float32"),
+         B((4096,), 8, 0.5, "float32")]
+
+
+# ---------------------------------------------------------------------------------------
+def _close(a, b, exact, rtol, atol):
+    a, b = np.asarray(a), np.asarray(b)
+    if a.shape != b.shape or a.dtype != b.dtype:
+        return False, f"shape/dtype {a.shape}/{a.dtype} vs {b.shape}/{b.dtype}"
+    if exact:
+        ok = np.array_equal(a, b, equal_nan=True)
+        return ok, "exact mismatch" if not ok else ""
+    ok = np.allclose(a, b, rtol=rtol, atol=atol, equal_nan=True)
+    if not ok:
+        with np.errstate(all="ignore"):
+            err = np.nanmax(np.abs(a.astype("float64") - b.astype("float64")))
+        return False, f"max abs err {err}"
+    return True, ""
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="*")
+    args = ap.parse_args()
+    os.makedirs(GOLDEN, exist_ok=True)
+    cases_path = os.path.join(GOLDEN, "cases.json")
+    index = {}
+    if os.path.exists(cases_path) and args.only != "*":
+        with open(cases_path) as f:
+            index = {c["name"]: c for c in json.load(f)["cases"]}
+    n_ok = 0
+    for name, fn, exact, rtol, atol in CASES:
+        if not fnmatch.fnmatch(name, args.only):
+            continue
+        print(f"... {name}", flush=True)
+        ins, outs, specs = fn()
+        xs = [make_input(s) for s in specs]
+        # 2. reference's own linker (C thunks under the CVM)
+        f_ref = ae.function(ins, outs, mode=Mode("py", "fast_run") if name in REF_PY else REF_MODE,
+                            on_unused_input="ignore")
+        ref_out = [np.asarray(o) for o in f_ref(*xs)]
+        # 3. HIP lowering + oracle
+        linker = HipLinker(executor_factory=lambda plan: (lambda *a: interp.run_plan(plan, a)))
+        f_hip = ae.function(ins, outs, mode=Mode(linker, HIP_QUERY), on_unused_input="ignore")
+        plan = f_hip.maker.linker.plan
+        plan.name = name
+        ora = [np.asarray(o) for o in f_hip(*xs)]
+        is32 = any(o.dtype == np.float32 for o in ref_out)
+        rt = rtol if rtol is not None else (1e-5 if is32 else 1e-12)
+        atl = atol if atol is not None else (1e-6 if is32 else 1e-12)
+        for k, (r, o) in enumerate(zip(ref_out, ora)):
+            ok, msg = _close(o, r, exact, rt, atl)
+            if not ok:
+                raise SystemExit(f"ORACLE != REFERENCE for case {name} output {k}: {msg}\n"
+                                 f"{plan.pretty()}")
+        np.savez_compressed(os.path.join(GOLDEN, name + ".npz"),
+                            **{f"out{k}": r for k, r in enumerate(ref_out)})
+        index[name] = {"name": name, "ref_linker": "py" if name in REF_PY else "cvm", "plan": plan.to_json(), "inputs": specs, "exact": exact,
+                       "rtol": rt, "atol": atl, "n_out": len(ref_out)}
+        n_ok += 1
+        print(f"[ok] {name}: {len(plan.nodes)} nodes, {len(ref_out)} outputs")
+    with open(cases_path, "w") as f:
+        json.dump({"generator": "oracle/gen_golden.py", "reference": "aesara-devs/aesara@2024-10-08",
+                   "ref_mode": "Mode('cvm','fast_run')", "cases": list(index.values())}, f)
+    print(f"{n_ok} cases written to {GOLDEN}")
+
+
+if __name__ == "__main__":
+    main()

@@ -322,6 +322,9 @@ def run_plan(plan, inputs):
             # reference: tensor/basic.py:1427 Alloc.perform
             shape = tuple(int(np.asarray(s)) for s in a[1:])
             r = [np.array(np.broadcast_to(a[0], shape), dtype=ov[0].dtype)]
+        elif op == "BroadcastTo":
+            # reference: tensor/extra_ops.py BroadcastTo.perform (np.broadcast_to view)
+            r = [np.broadcast_to(a[0], tuple(int(np.asarray(s)) for s in a[1:]))]
         elif op == "AllocEmpty":
             shape = tuple(int(np.asarray(s)) for s in a)
             r = [np.zeros(shape, dtype=p["dtype"])]  # contents unspecified in the reference
