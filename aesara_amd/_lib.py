@@ -62,8 +62,9 @@ SIGNATURES = {
     "ahip_launch": (i32, [vp, u32, u32, u32, u32, u32, u32, u32, vp, sz, vp]),
     "ahip_elemwise": (i32, [vp, i32, p_i64, i32, p_vp, p_i64, i32, i32, vp]),
     "ahip_reduce_ws_bytes": (sz, []),
-    "ahip_elemwise_reduce_all": (i32, [vp, vp, i32, p_i64, i32, p_vp, p_i64, i32, i32, vp, vp,
-                                       sz, vp]),
+    "ahip_elemwise_reduce_all": (i32, [vp, i32, p_i64, i32, p_vp, p_i64, i32, i32, vp, vp, sz,
+                                       vp]),
+    "ahip_set_param": (i32, [C.c_char_p, i64]),
     "ahip_elemwise_reduce_axis": (i32, [vp, i32, i32, i32, p_i64, i32, p_vp, p_i64, i32, vp,
                                         i32, vp]),
     "ahip_gemm": (i32, [i32, i64, i64, i64, vp, vp, i64, i64, vp, i64, i64, vp, vp, i64, i64,
@@ -79,6 +80,16 @@ SIGNATURES = {
     "ahip_take_rows": (i32, [i32, vp, i64, i64, i64, vp, i32, i64, i64, vp, i64, vp, vp]),
     "ahip_scatter_rows": (i32, [i32, vp, i64, i64, i64, vp, i32, i64, i64, vp, i64, i32, vp,
                                 vp]),
+    "ahip_list_begin": (i32, []),
+    "ahip_list_end": (i32, [p_vp]),
+    "ahip_list_length": (i32, [vp]),
+    "ahip_list_run": (i32, [vp, vp]),
+    "ahip_list_destroy": (i32, [vp]),
+    "ahip_list_begin": (i32, []),
+    "ahip_list_end": (i32, [p_vp]),
+    "ahip_list_length": (i32, [vp]),
+    "ahip_list_run": (i32, [vp, vp]),
+    "ahip_list_destroy": (i32, [vp]),
     "ahip_graph_begin": (i32, [vp]),
     "ahip_graph_end": (i32, [vp, p_vp]),
     "ahip_graph_launch": (i32, [vp, vp]),

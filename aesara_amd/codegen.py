@@ -49,6 +49,20 @@ struct Args {
 };
 template <typename T, int N> struct alignas((sizeof(T) * N) >= 16 ? 16 : (sizeof(T) * N)) Pack { T v[N]; };
 
+template <typename T, int N> __device__ __forceinline__ Pack<T, N> nt_load(const Pack<T, N>* p) {
+  Pack<T, N> r;
+  if constexpr (sizeof(T) * N >= 16) {
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const u4* q = (const u4*)p;
+    u4* d = (u4*)&r;
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) * N / 16; ++i) d[i] = __builtin_nontemporal_load(q + i);
+  } else {
+    r = *p;
+  }
+  return r;
+}
+
 // ---- scalar helpers (reference: aesara/scalar/basic.py, scalar/math.py c_code) ----
 template <typename T> __device__ __forceinline__ T idiv_floor(T x, T y) {  // FloorDivide :2039
   if (y == 0) return 0;
@@ -92,6 +106,20 @@ template <typename T> __device__ __forceinline__ T fmax_nan(T x, T y) { return (
 template <typename T> __device__ __forceinline__ T fmin_nan(T x, T y) { return (y < x) ? y : ((x <= y) ? x : (T)NAN); }
 template <typename T> __device__ __forceinline__ T imax(T x, T y) { return x > y ? x : y; }
 template <typename T> __device__ __forceinline__ T imin(T x, T y) { return x < y ? x : y; }
+// x / c for a loop-invariant c with r = 1/c precomputed: Markstein refinement gives the correctly
+// rounded quotient whenever r is finite/non-zero and q does not overflow; otherwise fall back.
+__device__ __forceinline__ double fdiv_inv(double x, double c, double r) {
+  const double q = x * r;
+  const double e = fma(-q, c, x);
+  const double res = fma(e, r, q);
+  return (fabs(q) < INFINITY && fabs(r) < INFINITY && r != 0.0) ? res : x / c;
+}
+__device__ __forceinline__ float fdiv_inv(float x, float c, float r) {
+  const float q = x * r;
+  const float e = fmaf(-q, c, x);
+  const float res = fmaf(e, r, q);
+  return (fabsf(q) < INFINITY && fabsf(r) < INFINITY && r != 0.0f) ? res : x / c;
+}
 __device__ __forceinline__ float sigmoid_(float x) { return 1.0f / (1.0f + expf(-x)); }   // Sigmoid :1110
 __device__ __forceinline__ double sigmoid_(double x) { return 1.0 / (1.0 + exp(-x)); }
 __device__ __forceinline__ float softplus_(float x) {                                      // Softplus :1173
@@ -279,24 +307,54 @@ def scalar_node_expr(op, ins, in_dts, dt):
     raise NotImplementedError(f"HIP codegen: scalar op {op!r} for dtype {dt}")
 
 
-def emit_scalar_body(scalar, in_exprs, in_dts, indent="      ", suffix=""):
-    """Lines computing all temporaries of a plan scalar expression; returns (lines, out_exprs,
-    out_dtypes)."""
+def invariant_nodes(scalar, inv_inputs):
+    """Indices of scalar nodes that depend only on loop-invariant operands (scalar inputs with
+    all-zero strides, constants, other invariant nodes)."""
+    inv = set()
+
+    def is_inv(r):
+        return r[0] == "c" or (r[0] == "i" and inv_inputs[r[1]]) or (r[0] == "t" and r[1] in inv)
+
+    for k, n in enumerate(scalar["nodes"]):
+        if all(is_inv(r) for r in n["in"]) and n["op"] != "second":
+            inv.add(k)
+    return inv
+
+
+def emit_scalar_body(scalar, in_exprs, in_dts, indent="      ", suffix="", hoisted=None,
+                     only=None):
+    """Lines computing the temporaries of a plan scalar expression; returns (lines, out_exprs,
+    out_dtypes).  ``hoisted``: {node index: (name, recip_name | None)} of temporaries already
+    computed before the loop (loop-invariant sub-expressions); ``only``: restrict emission to
+    that set of nodes (used to emit the invariant prologue itself)."""
     lines = []
-    tdt = []
+    tdt = [n["dtype"] for n in scalar["nodes"]]
+    hoisted = hoisted or {}
 
     def ref(r):
         if r[0] == "i":
             return in_exprs[r[1]], in_dts[r[1]]
         if r[0] == "t":
+            if r[1] in hoisted:
+                return hoisted[r[1]][0], tdt[r[1]]
             return "t%d%s" % (r[1], suffix), tdt[r[1]]
         return _lit(r[1], r[2]), r[2]
 
     for k, n in enumerate(scalar["nodes"]):
+        if k in hoisted or (only is not None and k not in only):
+            continue
         refs = [ref(r) for r in n["in"]]
-        e = scalar_node_expr(n["op"], [x[0] for x in refs], [x[1] for x in refs], n["dtype"])
-        lines.append("%sconst %s t%d%s = %s;" % (indent, RTYPE[n["dtype"]], k, suffix, e))
-        tdt.append(n["dtype"])
+        dt = n["dtype"]
+        div = n["in"][1] if n["op"] == "true_div" else None
+        if (div is not None and _is_float(dt) and div[0] == "t" and div[1] in hoisted
+                and hoisted[div[1]][1] and refs[1][1] == dt):
+            # divisor is loop invariant: correctly-rounded division from its hoisted
+            # reciprocal (q = x*r; q += r*fma(-q, c, x)) instead of the full v_div_* sequence
+            e = "fdiv_inv(%s, %s, %s)" % (_cast(refs[0][0], refs[0][1], dt), refs[1][0],
+                                          hoisted[div[1]][1])
+        else:
+            e = scalar_node_expr(n["op"], [x[0] for x in refs], [x[1] for x in refs], dt)
+        lines.append("%sconst %s t%d%s = %s;" % (indent, RTYPE[dt], k, suffix, e))
     outs = [ref(r) for r in scalar["out"]]
     return lines, [o[0] for o in outs], [o[1] for o in outs]
 
@@ -350,7 +408,7 @@ class KernelSpec:
     """
 
     def __init__(self, scalar, in_dtypes, out_dtypes, out_refs, inner, nd, vec, block=256,
-                 idx64=False, reduce=None):
+                 idx64=False, reduce=None, unroll=1, nt=False, invariant=None):
         self.scalar = scalar
         self.in_dtypes = list(in_dtypes)
         self.out_dtypes = list(out_dtypes)
@@ -361,13 +419,18 @@ class KernelSpec:
         self.block = block
         self.idx64 = idx64
         self.reduce = reduce
+        self.unroll = unroll   # independent vectors in flight per lane (flat 1-d shape only)
+        self.nt = nt           # non-temporal (streaming) loads for read-once operands
+        # per-input flag: operand is a true scalar (all strides zero) -> loop invariant
+        self.invariant = list(invariant) if invariant else [False] * len(self.in_dtypes)
         assert len(self.inner) == len(self.in_dtypes) + len(self.out_dtypes)
         assert 1 <= nd <= AHIP_MAXD and len(self.inner) <= AHIP_MAXOPS
 
     def key(self):
         import json
         blob = json.dumps([self.scalar, self.in_dtypes, self.out_dtypes, self.out_refs,
-                           self.inner, self.nd, self.vec, self.block, self.idx64, self.reduce],
+                           self.inner, self.nd, self.vec, self.block, self.idx64, self.reduce,
+                           self.unroll, self.nt, self.invariant, "v7"],
                           sort_keys=True)
         return hashlib.sha256(blob.encode()).hexdigest()[:24]
 
@@ -398,11 +461,12 @@ def _offset_code(spec, nops, nd_lo, nd_hi, var, idx_t, inner_vecs=None):
 
 
 def generate(spec: KernelSpec):
-    """Return (source, kernel_names) for a spec.  kernel_names: ('k',) or ('k', 'k_fin')."""
+    """Return (source, kernel_names) for a spec (one kernel per spec)."""
     nin = len(spec.in_dtypes)
     nout = len(spec.out_dtypes)
     nops = nin + nout
     V = spec.vec
+    U = spec.unroll
     idx_t = "i64" if spec.idx64 else "int"
     red = spec.reduce
     name = "ew_" + spec.key()
@@ -424,41 +488,76 @@ def generate(spec: KernelSpec):
         acc_t = RTYPE[red["acc"]]
         L.append("  %s acc = %s;" % (acc_t, red_identity(red["op"], red["acc"])))
 
-    def body(elem_off_exprs):
-        """Load VEC elements per operand, evaluate, store/accumulate.  elem_off_exprs[k] is
-        the element offset expression of operand k at the start of the vector."""
+    # loop-invariant prologue: scalar operands are loaded once, sub-expressions that depend only
+    # on them are computed once per thread, and reciprocals of invariant divisors are hoisted
+    hoisted = {}
+    inv_in = {}
+    if any(spec.invariant):
+        for k in range(nin):
+            if spec.invariant[k]:
+                e = "xinv%d" % k
+                L.append("  const %s %s = p%d[0];" % (CTYPE[spec.in_dtypes[k]], e, k))
+                inv_in[k] = "(%s != 0)" % e if spec.in_dtypes[k] == "bool" else e
+        inv_nodes = invariant_nodes(spec.scalar, spec.invariant)
+        if inv_nodes:
+            ins0 = [inv_in.get(k, "0") for k in range(nin)]
+            lines, _, _ = emit_scalar_body(spec.scalar, ins0, spec.in_dtypes, indent="  ",
+                                           suffix="_inv", only=inv_nodes)
+            L.extend(lines)
+            divisors = {n["in"][1][1] for n in spec.scalar["nodes"]
+                        if n["op"] == "true_div" and n["in"][1][0] == "t"}
+            for k in sorted(inv_nodes):
+                dt = spec.scalar["nodes"][k]["dtype"]
+                rname = None
+                if k in divisors and _is_float(dt):
+                    rname = "r%d_inv" % k
+                    L.append("  const %s %s = (%s)1 / t%d_inv;" % (RTYPE[dt], rname, RTYPE[dt], k))
+                hoisted[k] = ("t%d_inv" % k, rname)
+
+    def loads(elem_off_exprs, sfx=""):
         B = []
-        # loads
         for k in range(nin):
             ct = CTYPE[spec.in_dtypes[k]]
             cls = spec.inner[k]
+            if k in inv_in:
+                continue
             if cls == "c" and V > 1:
-                B.append("      const Pack<%s, %d> x%d = *(const Pack<%s, %d>*)(p%d + %s);" %
-                         (ct, V, k, ct, V, k, elem_off_exprs[k]))
-            elif cls == "b" or V == 1:
-                B.append("      const %s x%d = p%d[%s];" % (ct, k, k, elem_off_exprs[k]))
+                ptr = "(const Pack<%s, %d>*)(p%d + %s)" % (ct, V, k, elem_off_exprs[k])
+                if spec.nt:
+                    B.append("      const Pack<%s, %d> x%d%s = nt_load(%s);" % (ct, V, k, sfx, ptr))
+                else:
+                    B.append("      const Pack<%s, %d> x%d%s = *%s;" % (ct, V, k, sfx, ptr))
+            else:
+                B.append("      const %s x%d%s = p%d[%s];" % (ct, k, sfx, k, elem_off_exprs[k]))
+        return B
+
+    def compute(elem_off_exprs, sfx=""):
+        B = []
         for k in range(nout):
             if V > 1:
-                B.append("      Pack<%s, %d> y%d;" % (CTYPE[spec.out_dtypes[k]], V, k))
+                B.append("      Pack<%s, %d> y%d%s;" % (CTYPE[spec.out_dtypes[k]], V, k, sfx))
         for v in range(V):
             ins = []
             for k in range(nin):
+                if k in inv_in:
+                    ins.append(inv_in[k])
+                    continue
                 if spec.inner[k] == "c" and V > 1:
-                    e = "x%d.v[%d]" % (k, v)
+                    e = "x%d%s.v[%d]" % (k, sfx, v)
                 else:
-                    e = "x%d" % k
+                    e = "x%d%s" % (k, sfx)
                 if spec.in_dtypes[k] == "bool":
                     e = "(%s != 0)" % e
                 ins.append(e)
             lines, outs, odts = emit_scalar_body(spec.scalar, ins, spec.in_dtypes,
-                                                 suffix="_%d" % v)
+                                                 suffix="_%d%s" % (v, sfx), hoisted=hoisted)
             B.extend(lines)
             for k, ri in enumerate(spec.out_refs):
                 val = _cast(outs[ri], odts[ri], spec.out_dtypes[k])
                 if spec.out_dtypes[k] == "bool":
                     val = "(unsigned char)(%s)" % val
                 if V > 1:
-                    B.append("      y%d.v[%d] = %s;" % (k, v, val))
+                    B.append("      y%d%s.v[%d] = %s;" % (k, sfx, v, val))
                 else:
                     B.append("      p%d[%s] = %s;" % (nin + k, elem_off_exprs[nin + k], val))
             if red is not None:
@@ -466,20 +565,20 @@ def generate(spec: KernelSpec):
                 B.append("      acc = %s;" % red_combine(red["op"], red["acc"], "acc", val))
         if V > 1:
             for k in range(nout):
-                B.append("      *(Pack<%s, %d>*)(p%d + %s) = y%d;" %
-                         (CTYPE[spec.out_dtypes[k]], V, nin + k, elem_off_exprs[nin + k], k))
+                B.append("      *(Pack<%s, %d>*)(p%d + %s) = y%d%s;" %
+                         (CTYPE[spec.out_dtypes[k]], V, nin + k, elem_off_exprs[nin + k], k, sfx))
         return B
 
-    def elem_offsets():
+    def elem_offsets(inner="inner", off_sfx=""):
         out = []
         for k in range(nops):
             cls = spec.inner[k]
             if cls == "c":
-                out.append("off%d + (i64)inner * %d" % (k, V))
+                out.append("off%d%s + (i64)%s * %d" % (k, off_sfx, inner, V))
             elif cls == "b":
-                out.append("off%d" % k)
+                out.append("off%d%s" % (k, off_sfx))
             else:
-                out.append("off%d + (i64)inner * is%d" % (k, k))
+                out.append("off%d%s + (i64)%s * is%d" % (k, off_sfx, inner, k))
         return out
 
     if red is None or red["kind"] == "all":
@@ -487,12 +586,27 @@ def generate(spec: KernelSpec):
         L.append("  const %s inner_vecs = (%s)(a.shape[%d] / %d);" % (idx_t, idx_t, nd - 1, V))
         L.append("  const %s items = (%s)(a.n / %d);" % (idx_t, idx_t, V))
         L.append("  const %s step = (%s)gridDim.x * %d;" % (idx_t, idx_t, spec.block))
-        L.append("  for (%s item = (%s)blockIdx.x * %d + threadIdx.x; item < items; item += step) {"
-                 % (idx_t, idx_t, spec.block))
+        L.append("  %s item = (%s)blockIdx.x * %d + threadIdx.x;" % (idx_t, idx_t, spec.block))
+        if nd == 1 and U > 1:
+            # flat streaming shape: U independent vectors in flight per lane, loads first
+            flat = []
+            for k in range(nops):
+                flat.append({"c": "(i64)%%s * %d" % V, "b": "0", "s": "(i64)%%s * is%d" % k}[spec.inner[k]])
+            L.append("  for (; item + %d * step < items; item += %d * step) {" % (U - 1, U))
+            for u in range(U):
+                it = "(item + %d * step)" % u
+                L.extend(loads([f % it if "%s" in f else f for f in flat], "_u%d" % u))
+            for u in range(U):
+                it = "(item + %d * step)" % u
+                L.extend(compute([f % it if "%s" in f else f for f in flat], "_u%d" % u))
+            L.append("  }")
+        L.append("  for (; item < items; item += step) {")
         L.append("      i64 " + ", ".join("off%d = 0" % k for k in range(nops)) + ";")
         L.append("      %s inner = 0;" % idx_t)
         L.extend(_offset_code(spec, nops, 0, nd, "item", idx_t, inner_vecs="inner_vecs"))
-        L.extend(body(elem_offsets()))
+        eo = elem_offsets()
+        L.extend(loads(eo))
+        L.extend(compute(eo))
         L.append("  }")
     else:
         nk, nr = red["nk"], red["nr"]
@@ -520,24 +634,88 @@ def generate(spec: KernelSpec):
             L.append("  for (i64 r0 = rbeg; r0 < rend; ++r0) {")
         L.append("      i64 " + ", ".join("off%d = base%d" % (k, k) for k in range(nops)) + ";")
         L.extend(_offset_code(spec, nops, nk, nk + nr, "r0", "i64"))
-        L.extend(body(["off%d" % k for k in range(nops)]))
+        eo = ["off%d" % k for k in range(nops)]
+        L.extend(loads(eo))
+        L.extend(compute(eo))
         L.append("  }")
 
     if red is not None:
         acc_t = RTYPE[red["acc"]]
+        sm_t = acc_t if acc_t != "bool" else "unsigned char"
         comb = lambda a_, b_: red_combine(red["op"], red["acc"], a_, b_)  # noqa: E731
         wave_red = ["  for (int m = 32; m > 0; m >>= 1) acc = %s;" %
                     comb("acc", "shfl_xor_<%s>(acc, m)" % acc_t)]
         if red["kind"] == "all":
+            # K2 single pass, two-level deterministic finalize (MI355X guide G16, "8-byte agent
+            # atomics on both sides"; no per-workgroup L2 write-back fence):
+            #   every workgroup publishes ONE 8-byte partial (write-through agent-scope store),
+            #   drains it, and takes a ticket on its shard's counter (8 shards = blockIdx & 7,
+            #   counters 256 B apart so the ~11 ns/atomic fan-in runs on 8 L2 channels);
+            #   the last arriver of a shard folds that shard's partials in index order (one load
+            #   per lane), publishes the shard sum and takes a ticket on the top counter;
+            #   the last shard folds the <= 8 shard sums in order and stores the result.
+            # Counters reset themselves, so the zero-initialised workspace is reusable.
             nw = spec.block // 64
-            L.extend(wave_red)
-            L.append("  __shared__ %s sm[%d];" % (acc_t if acc_t != "bool" else "unsigned char", nw))
-            L.append("  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;")
-            L.append("  __syncthreads();")
+            cta = CTYPE[red["acc"]]
+
+            def block_fold(dst):
+                out = list(wave_red)
+                out.append("  __syncthreads();")
+                out.append("  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;")
+                out.append("  __syncthreads();")
+                out.append("  %s %s = sm[0];" % (acc_t, dst))
+                out.append("  for (int w = 1; w < %d; ++w) %s = %s;" %
+                           (nw, dst, comb(dst, "(%s)sm[w]" % acc_t)))
+                return out
+
+            L.append("  __shared__ %s sm[%d];" % (sm_t, nw))
+            L.append("  __shared__ int flag;")
+            L.append("  unsigned long long* wsp = (unsigned long long*)a.ws;")
+            L.append("  unsigned long long* shard_sum = (unsigned long long*)((char*)a.ws + a.aux1);")
+            L.append("  unsigned* ticket = (unsigned*)((char*)a.ws + a.aux1 + 256);")
+            L.append("  const unsigned shard = blockIdx.x & 7u;")
+            L.append("  const unsigned nshard = (gridDim.x - shard + 7u) >> 3;")
+            L.extend(block_fold("part"))
             L.append("  if (threadIdx.x == 0) {")
-            L.append("    %s r = sm[0];" % acc_t)
-            L.append("    for (int w = 1; w < %d; ++w) r = %s;" % (nw, comb("r", "(%s)sm[w]" % acc_t)))
-            L.append("    ((%s*)a.ws)[blockIdx.x] = r;" % CTYPE[red["acc"]])
+            L.append("    union { unsigned long long u; %s v; } cv; cv.u = 0; cv.v = part;" % acc_t)
+            L.append("    __hip_atomic_store(wsp + blockIdx.x, cv.u, __ATOMIC_RELAXED, "
+                     "__HIP_MEMORY_SCOPE_AGENT);")
+            L.append('    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");')
+            L.append("    const unsigned t = __hip_atomic_fetch_add(ticket + 64 * (1 + shard), 1u, "
+                     "__ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);")
+            L.append("    flag = (t == nshard - 1);")
+            L.append("  }")
+            L.append("  __syncthreads();")
+            L.append("  if (!flag) return;")
+            # --- last workgroup of this shard: fold the shard's partials
+            L.append("  acc = %s;" % red_identity(red["op"], red["acc"]))
+            L.append("  for (unsigned i = shard + 8u * threadIdx.x; i < gridDim.x; i += 8u * %d) {"
+                     % spec.block)
+            L.append("    union { unsigned long long u; %s v; } cv;" % acc_t)
+            L.append("    cv.u = __hip_atomic_load(wsp + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);")
+            L.append("    acc = %s;" % comb("acc", "cv.v"))
+            L.append("  }")
+            L.extend(block_fold("ssum"))
+            L.append("  if (threadIdx.x == 0) {")
+            L.append("    union { unsigned long long u; %s v; } cv; cv.u = 0; cv.v = ssum;" % acc_t)
+            L.append("    __hip_atomic_store(shard_sum + shard, cv.u, __ATOMIC_RELAXED, "
+                     "__HIP_MEMORY_SCOPE_AGENT);")
+            L.append('    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");')
+            L.append("    __hip_atomic_store(ticket + 64 * (1 + shard), 0u, __ATOMIC_RELAXED, "
+                     "__HIP_MEMORY_SCOPE_AGENT);")
+            L.append("    const unsigned active = gridDim.x < 8u ? gridDim.x : 8u;")
+            L.append("    const unsigned t2 = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, "
+                     "__HIP_MEMORY_SCOPE_AGENT);")
+            L.append("    if (t2 == active - 1) {")
+            L.append("      %s r = %s;" % (acc_t, red_identity(red["op"], red["acc"])))
+            L.append("      for (unsigned k = 0; k < active; ++k) {")
+            L.append("        cv.u = __hip_atomic_load(shard_sum + k, __ATOMIC_RELAXED, "
+                     "__HIP_MEMORY_SCOPE_AGENT);")
+            L.append("        r = %s;" % comb("r", "cv.v"))
+            L.append("      }")
+            L.append("      *(%s*)a.out = %s;" % (CTYPE[red["out"]], _store_val("r", red["acc"], red["out"])))
+            L.append("      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);")
+            L.append("    }")
             L.append("  }")
         elif red["kind"] == "row":
             L.extend(wave_red)
@@ -548,31 +726,7 @@ def generate(spec: KernelSpec):
                      (CTYPE[red["out"]], _store_val("acc", red["acc"], red["out"])))
             L.append("  else ((%s*)a.out)[(i64)blockIdx.y * a.n + o] = acc;" % CTYPE[red["acc"]])
     L.append("}")
-
-    names = [name]
-    if red is not None and red["kind"] == "all":
-        acc_t = RTYPE[red["acc"]]
-        comb = lambda a_, b_: red_combine(red["op"], red["acc"], a_, b_)  # noqa: E731
-        fin = name + "_fin"
-        names.append(fin)
-        L.append('extern "C" __global__ __launch_bounds__(256) void %s(Args a) {' % fin)
-        L.append("  const %s* ws = (const %s*)a.ws;" % (CTYPE[red["acc"]], CTYPE[red["acc"]]))
-        L.append("  const int np = (int)a.aux0;")
-        L.append("  %s acc = %s;" % (acc_t, red_identity(red["op"], red["acc"])))
-        L.append("  for (int i = threadIdx.x; i < np; i += 256) acc = %s;" %
-                 comb("acc", "(%s)ws[i]" % acc_t))
-        L.append("  for (int m = 32; m > 0; m >>= 1) acc = %s;" %
-                 comb("acc", "shfl_xor_<%s>(acc, m)" % acc_t))
-        L.append("  __shared__ %s sm[4];" % (acc_t if acc_t != "bool" else "unsigned char"))
-        L.append("  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;")
-        L.append("  __syncthreads();")
-        L.append("  if (threadIdx.x == 0) {")
-        L.append("    %s r = sm[0];" % acc_t)
-        L.append("    for (int w = 1; w < 4; ++w) r = %s;" % comb("r", "(%s)sm[w]" % acc_t))
-        L.append("    *(%s*)a.out = %s;" % (CTYPE[red["out"]], _store_val("r", red["acc"], red["out"])))
-        L.append("  }")
-        L.append("}")
-    return "\n".join(L) + "\n", tuple(names)
+    return "\n".join(L) + "\n", (name,)
 
 
 def _store_val(expr, src_dt, dst_dt):

@@ -44,6 +44,21 @@ struct ahip_func_s { hipFunction_t fn; };
 
 int ahip_cu_count();  // cached after ahip_init / first use
 
+// Every kernel launch of the library goes through these two helpers so that a launch list
+// (ahip_list_*: the CVM analogue) can record the launches instead of executing them.
+int ahip_launch_static(const void* func, dim3 grid, dim3 block, size_t shmem, hipStream_t s,
+                       const void* arg, size_t arg_size);
+int ahip_launch_module(hipFunction_t f, dim3 grid, dim3 block, size_t shmem, hipStream_t s,
+                       const void* arg, size_t arg_size);
+
+// kernel must take exactly one (struct) argument, passed by value
+#define AHIP_LAUNCH(kernel, grid, block, shmem, stream, arg)                                   \
+  do {                                                                                         \
+    int _rc = ahip_launch_static((const void*)(kernel), grid, block, shmem, stream, &(arg),    \
+                                 sizeof(arg));                                                 \
+    if (_rc) return _rc;                                                                       \
+  } while (0)
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 // 8 XCDs on MI355X: workgroup b is dispatched to XCD b % 8 (speed hint only, never correctness).

@@ -57,9 +57,13 @@ __global__ __launch_bounds__(256) void copy_kernel(CopyArgs a) {
   }
 }
 
+struct FillArgs { void* dst; int64_t n; uint64_t bits; };
+
 template <typename T>
-__global__ __launch_bounds__(256) void fill_kernel(T* __restrict__ dst, int64_t n, T value) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+__global__ __launch_bounds__(256) void fill_kernel(FillArgs f) {
+  T* __restrict__ dst = static_cast<T*>(f.dst);
+  const T value = (T)f.bits;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < f.n;
        i += (int64_t)gridDim.x * blockDim.x)
     dst[i] = value;
 }
@@ -77,10 +81,9 @@ int launch_copy(CopyArgs& a, int vec, hipStream_t s) {
   unsigned grid = stream_grid(a.items);
   constexpr int MAXV = 16 / sizeof(T);
   if (vec == MAXV && MAXV > 1)
-    hipLaunchKernelGGL((copy_kernel<T, MAXV, ACC>), dim3(grid), dim3(256), 0, s, a);
+    AHIP_LAUNCH((copy_kernel<T, MAXV, ACC>), dim3(grid), dim3(256), 0, s, a);
   else
-    hipLaunchKernelGGL((copy_kernel<T, 1, ACC>), dim3(grid), dim3(256), 0, s, a);
-  AHIP_CHECK_HIP(hipGetLastError());
+    AHIP_LAUNCH((copy_kernel<T, 1, ACC>), dim3(grid), dim3(256), 0, s, a);
   return AHIP_OK;
 }
 
@@ -170,17 +173,14 @@ int ahip_fill(int dtype, const void* value, void* dst, int64_t n, void* stream) 
   AHIP_REQUIRE(dst != nullptr, "null dst");
   hipStream_t s = as_stream(stream);
   unsigned grid = stream_grid(n);
+  FillArgs f{dst, n, 0};
+  memcpy(&f.bits, value, (size_t)isz);  // little-endian: low bytes hold the value
   switch (isz) {
-    case 1: hipLaunchKernelGGL((fill_kernel<uint8_t>), dim3(grid), dim3(256), 0, s,
-                               static_cast<uint8_t*>(dst), n, *static_cast<const uint8_t*>(value)); break;
-    case 2: hipLaunchKernelGGL((fill_kernel<uint16_t>), dim3(grid), dim3(256), 0, s,
-                               static_cast<uint16_t*>(dst), n, *static_cast<const uint16_t*>(value)); break;
-    case 4: hipLaunchKernelGGL((fill_kernel<uint32_t>), dim3(grid), dim3(256), 0, s,
-                               static_cast<uint32_t*>(dst), n, *static_cast<const uint32_t*>(value)); break;
-    default: hipLaunchKernelGGL((fill_kernel<uint64_t>), dim3(grid), dim3(256), 0, s,
-                                static_cast<uint64_t*>(dst), n, *static_cast<const uint64_t*>(value)); break;
+    case 1: AHIP_LAUNCH((fill_kernel<uint8_t>), dim3(grid), dim3(256), 0, s, f); break;
+    case 2: AHIP_LAUNCH((fill_kernel<uint16_t>), dim3(grid), dim3(256), 0, s, f); break;
+    case 4: AHIP_LAUNCH((fill_kernel<uint32_t>), dim3(grid), dim3(256), 0, s, f); break;
+    default: AHIP_LAUNCH((fill_kernel<uint64_t>), dim3(grid), dim3(256), 0, s, f); break;
   }
-  AHIP_CHECK_HIP(hipGetLastError());
   return AHIP_OK;
 }
 

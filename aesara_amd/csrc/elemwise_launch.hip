@@ -31,19 +31,18 @@ static int pack_args(ahip_ew_args* a, int nd, const int64_t* shape, int nops, vo
 
 static int launch(ahip_fn_t k, uint32_t gx, uint32_t gy, uint32_t block, const ahip_ew_args* a,
                   void* stream) {
-  size_t sz = sizeof(*a);
-  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, const_cast<ahip_ew_args*>(a),
-                    HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-  AHIP_CHECK_HIP(hipModuleLaunchKernel(k->fn, gx, gy, 1, block, 1, 1, 0, as_stream(stream),
-                                       nullptr, config));
-  return AHIP_OK;
+  return ahip_launch_module(k->fn, dim3(gx, gy, 1), dim3(block, 1, 1), 0, as_stream(stream), a,
+                            sizeof(*a));
 }
 
 // Memory-bound streaming kernels: enough workgroups to fill 256 CUs x 8 resident blocks,
 // grid-stride over the rest (guide: Guideline 11).
+static int64_t g_stream_blocks_per_cu = 8;
+static int64_t g_reduce_blocks_per_cu = 8;
+
 static uint32_t stream_grid(int64_t items, int block) {
   int64_t want = (items + block - 1) / block;
-  int64_t cap = (int64_t)ahip_cu_count() * 8;
+  int64_t cap = (int64_t)ahip_cu_count() * g_stream_blocks_per_cu;
   if (want > cap) want = cap;
   if (want < 1) want = 1;
   return (uint32_t)want;
@@ -51,7 +50,15 @@ static uint32_t stream_grid(int64_t items, int block) {
 
 extern "C" {
 
-size_t ahip_reduce_ws_bytes(void) { return (size_t)AHIP_MAX_PARTIALS * 8; }
+size_t ahip_reduce_ws_bytes(void) { return (size_t)AHIP_MAX_PARTIALS * 8 + 4096; }
+
+int ahip_set_param(const char* name, int64_t value) {
+  AHIP_REQUIRE(name != nullptr && value > 0, "bad parameter");
+  if (!strcmp(name, "stream_blocks_per_cu")) g_stream_blocks_per_cu = value;
+  else if (!strcmp(name, "reduce_blocks_per_cu")) g_reduce_blocks_per_cu = value;
+  else { ahip_set_error("unknown parameter %s", name); return AHIP_EINVAL; }
+  return AHIP_OK;
+}
 
 int ahip_elemwise(ahip_fn_t k, int nd, const int64_t* shape, int nops, void* const* ptrs,
                   const int64_t* strides, int vec, int block, void* stream) {
@@ -67,10 +74,10 @@ int ahip_elemwise(ahip_fn_t k, int nd, const int64_t* shape, int nops, void* con
   return launch(k, stream_grid(items, block), 1, block, &a, stream);
 }
 
-int ahip_elemwise_reduce_all(ahip_fn_t k_main, ahip_fn_t k_fin, int nd, const int64_t* shape,
-                             int nops, void* const* ptrs, const int64_t* strides, int vec,
-                             int block, void* out, void* ws, size_t ws_bytes, void* stream) {
-  AHIP_REQUIRE(k_main && k_fin && out && ws, "null argument");
+int ahip_elemwise_reduce_all(ahip_fn_t k, int nd, const int64_t* shape, int nops,
+                             void* const* ptrs, const int64_t* strides, int vec, int block,
+                             void* out, void* ws, size_t ws_bytes, void* stream) {
+  AHIP_REQUIRE(k && out && ws, "null argument");
   AHIP_REQUIRE(ws_bytes >= ahip_reduce_ws_bytes(), "workspace too small");
   AHIP_REQUIRE(vec >= 1 && block >= 64 && block % 64 == 0, "bad vec/block");
   ahip_ew_args a;
@@ -78,22 +85,20 @@ int ahip_elemwise_reduce_all(ahip_fn_t k_main, ahip_fn_t k_fin, int nd, const in
   if (rc) return rc;
   a.ws = ws;
   a.out = out;
-  uint32_t grid = 0;
+  a.aux1 = (int64_t)AHIP_MAX_PARTIALS * 8;  // byte offset of the arrival ticket inside ws
+  int64_t want = 1;
   if (a.n > 0) {
     AHIP_REQUIRE(shape[nd - 1] % vec == 0, "inner extent not divisible by vec");
     int64_t items = a.n / vec;
-    // one partial per workgroup; 4 workgroups of 256 threads per CU keeps 16 waves/CU of
-    // 32-byte-per-lane loads in flight (HBM-bound) while the finalize stays tiny.
-    int64_t want = (items + block - 1) / block;
-    int64_t cap = (int64_t)ahip_cu_count() * 4;
+    // one partial per workgroup; a few workgroups of 256 threads per CU keep enough 16-byte
+    // loads in flight (HBM-bound) while the in-kernel finalize stays tiny.
+    want = (items + block - 1) / block;
+    int64_t cap = (int64_t)ahip_cu_count() * g_reduce_blocks_per_cu;
     if (cap > AHIP_MAX_PARTIALS) cap = AHIP_MAX_PARTIALS;
     if (want > cap) want = cap;
-    grid = (uint32_t)want;
-    rc = launch(k_main, grid, 1, block, &a, stream);
-    if (rc) return rc;
+    if (want < 1) want = 1;
   }
-  a.aux0 = grid;  // number of valid partials
-  return launch(k_fin, 1, 1, 256, &a, stream);
+  return launch(k, (uint32_t)want, 1, block, &a, stream);
 }
 
 int ahip_elemwise_reduce_axis(ahip_fn_t k, int mode, int nk, int nr, const int64_t* shape,

@@ -334,8 +334,7 @@ int launch_gemm(const GemmArgs& g, int64_t batch, hipStream_t s) {
     attr_set = true;
   }
   dim3 grid((unsigned)(g.tiles_m * g.tiles_n), 1, (unsigned)batch);
-  hipLaunchKernelGGL((gemm_kernel<T, AM, BMd>), grid, dim3(THREADS), lds, s, g);
-  AHIP_CHECK_HIP(hipGetLastError());
+  AHIP_LAUNCH((gemm_kernel<T, AM, BMd>), grid, dim3(THREADS), lds, s, g);
   return AHIP_OK;
 }
 
@@ -345,8 +344,7 @@ int gemm_dispatch(GemmArgs& g, int64_t batch, hipStream_t s) {
   if (g.K == 0 || g.alpha == 0.0) {
     int64_t n = g.M * g.N;
     unsigned blocks = (unsigned)(((n + 255) / 256) < 4096 ? ((n + 255) / 256) : 4096);
-    hipLaunchKernelGGL((scale_kernel<T>), dim3(blocks, 1, (unsigned)batch), dim3(256), 0, s, g);
-    AHIP_CHECK_HIP(hipGetLastError());
+    AHIP_LAUNCH((scale_kernel<T>), dim3(blocks, 1, (unsigned)batch), dim3(256), 0, s, g);
     return AHIP_OK;
   }
   g.tiles_m = (int)((g.M + BM - 1) / BM);

@@ -201,8 +201,7 @@ int gemv_dispatch(GemvArgs& g, size_t ws_bytes, hipStream_t s) {
   if (g.M == 0) return AHIP_OK;
   if (g.N == 0 || g.alpha == 0.0) {
     unsigned blocks = (unsigned)((g.M + 255) / 256 < 1024 ? (g.M + 255) / 256 : 1024);
-    hipLaunchKernelGGL((gemv_scale<T>), dim3(blocks), dim3(256), 0, s, g);
-    AHIP_CHECK_HIP(hipGetLastError());
+    AHIP_LAUNCH((gemv_scale<T>), dim3(blocks), dim3(256), 0, s, g);
     return AHIP_OK;
   }
   auto aligned = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
@@ -216,13 +215,11 @@ int gemv_dispatch(GemvArgs& g, size_t ws_bytes, hipStream_t s) {
     g.rows_per_slice = (g.N + g.nslice - 1) / g.nslice;
     int64_t gx = (g.M + (int64_t)g.tm * v - 1) / ((int64_t)g.tm * v);
     dim3 grid((unsigned)gx, (unsigned)g.nslice);
-    if (vec) hipLaunchKernelGGL((gemv_col_kernel<T, true>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((gemv_col_kernel<T, false>), grid, dim3(256), 0, s, g);
-    AHIP_CHECK_HIP(hipGetLastError());
+    if (vec) AHIP_LAUNCH((gemv_col_kernel<T, true>), grid, dim3(256), 0, s, g);
+    else AHIP_LAUNCH((gemv_col_kernel<T, false>), grid, dim3(256), 0, s, g);
     if (g.nslice > 1) {
       unsigned blocks = (unsigned)((g.M + 255) / 256 < 1024 ? (g.M + 255) / 256 : 1024);
-      hipLaunchKernelGGL((gemv_col_finalize<T>), dim3(blocks), dim3(256), 0, s, g);
-      AHIP_CHECK_HIP(hipGetLastError());
+      AHIP_LAUNCH((gemv_col_finalize<T>), dim3(blocks), dim3(256), 0, s, g);
     }
     return AHIP_OK;
   }
@@ -233,9 +230,8 @@ int gemv_dispatch(GemvArgs& g, size_t ws_bytes, hipStream_t s) {
   int64_t blocks = (waves_needed + 3) / 4;
   int64_t cap = (int64_t)ahip_cu_count() * 8;
   if (blocks > cap) blocks = cap;
-  if (vec) hipLaunchKernelGGL((gemv_row_kernel<T, true>), dim3((unsigned)blocks), dim3(256), 0, s, g);
-  else hipLaunchKernelGGL((gemv_row_kernel<T, false>), dim3((unsigned)blocks), dim3(256), 0, s, g);
-  AHIP_CHECK_HIP(hipGetLastError());
+  if (vec) AHIP_LAUNCH((gemv_row_kernel<T, true>), dim3((unsigned)blocks), dim3(256), 0, s, g);
+  else AHIP_LAUNCH((gemv_row_kernel<T, false>), dim3((unsigned)blocks), dim3(256), 0, s, g);
   return AHIP_OK;
 }
 
@@ -320,10 +316,9 @@ int ahip_ger(int dtype, int64_t M, int64_t N, const void* alpha, const void* x, 
   int64_t cap = (int64_t)ahip_cu_count() * 8;
   if (blocks > cap) blocks = cap;
   if (dtype == AHIP_F32)
-    hipLaunchKernelGGL((ger_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), g);
+    AHIP_LAUNCH((ger_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), g);
   else
-    hipLaunchKernelGGL((ger_kernel<double>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), g);
-  AHIP_CHECK_HIP(hipGetLastError());
+    AHIP_LAUNCH((ger_kernel<double>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), g);
   return AHIP_OK;
 }
 

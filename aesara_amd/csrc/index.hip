@@ -111,12 +111,11 @@ unsigned grid_for(int64_t items) {
 template <typename T, typename I>
 int run(int which, IdxArgs& a, hipStream_t s) {
   if (which == 0)
-    hipLaunchKernelGGL((take_rows_kernel<T, I>), dim3(grid_for(a.nidx * a.row_elems)), dim3(256), 0, s, a);
+    AHIP_LAUNCH((take_rows_kernel<T, I>), dim3(grid_for(a.nidx * a.row_elems)), dim3(256), 0, s, a);
   else if (which == 1)
-    hipLaunchKernelGGL((scatter_add_kernel<T, I>), dim3(grid_for(a.nidx * a.row_elems)), dim3(256), 0, s, a);
+    AHIP_LAUNCH((scatter_add_kernel<T, I>), dim3(grid_for(a.nidx * a.row_elems)), dim3(256), 0, s, a);
   else
-    hipLaunchKernelGGL((scatter_set_kernel<T, I>), dim3(grid_for(a.row_elems)), dim3(256), 0, s, a);
-  AHIP_CHECK_HIP(hipGetLastError());
+    AHIP_LAUNCH((scatter_set_kernel<T, I>), dim3(grid_for(a.row_elems)), dim3(256), 0, s, a);
   return AHIP_OK;
 }
 

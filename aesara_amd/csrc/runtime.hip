@@ -31,6 +31,65 @@ int ahip_cu_count() {
 }
 
 struct ahip_graph_s { hipGraph_t graph; hipGraphExec_t exec; };
+
+// ---- launch lists --------------------------------------------------------------------------
+struct LaunchRec {
+  const void* func;      // static kernel (hipLaunchKernel) or nullptr
+  hipFunction_t mfunc;   // module kernel (hipModuleLaunchKernel) or nullptr
+  dim3 grid, block;
+  unsigned shmem;
+  std::vector<char> arg; // by-value argument block
+};
+struct ahip_list_s { std::vector<LaunchRec> recs; };
+static thread_local ahip_list_s* g_recording = nullptr;
+
+static int issue(const LaunchRec& r, hipStream_t s) {
+  if (r.func) {
+    void* args[] = {const_cast<char*>(r.arg.data())};
+    AHIP_CHECK_HIP(hipLaunchKernel(r.func, r.grid, r.block, args, r.shmem, s));
+  } else {
+    size_t sz = r.arg.size();
+    void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, const_cast<char*>(r.arg.data()),
+                      HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+    AHIP_CHECK_HIP(hipModuleLaunchKernel(r.mfunc, r.grid.x, r.grid.y, r.grid.z, r.block.x,
+                                         r.block.y, r.block.z, r.shmem, s, nullptr, config));
+  }
+  return AHIP_OK;
+}
+
+static int launch_or_record(const void* func, hipFunction_t mfunc, dim3 grid, dim3 block,
+                            size_t shmem, hipStream_t s, const void* arg, size_t arg_size) {
+  if (grid.x == 0 || grid.y == 0 || grid.z == 0) {
+    ahip_set_error("empty launch grid");
+    return AHIP_EINVAL;
+  }
+  if (g_recording) {
+    LaunchRec r{func, mfunc, grid, block, (unsigned)shmem, {}};
+    r.arg.assign(static_cast<const char*>(arg), static_cast<const char*>(arg) + arg_size);
+    g_recording->recs.push_back(std::move(r));
+    return AHIP_OK;
+  }
+  if (func) {
+    void* args[] = {const_cast<void*>(arg)};
+    AHIP_CHECK_HIP(hipLaunchKernel(func, grid, block, args, shmem, s));
+  } else {
+    size_t sz = arg_size;
+    void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, const_cast<void*>(arg),
+                      HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+    AHIP_CHECK_HIP(hipModuleLaunchKernel(mfunc, grid.x, grid.y, grid.z, block.x, block.y, block.z,
+                                         shmem, s, nullptr, config));
+  }
+  return AHIP_OK;
+}
+
+int ahip_launch_static(const void* func, dim3 grid, dim3 block, size_t shmem, hipStream_t s,
+                       const void* arg, size_t arg_size) {
+  return launch_or_record(func, nullptr, grid, block, shmem, s, arg, arg_size);
+}
+int ahip_launch_module(hipFunction_t f, dim3 grid, dim3 block, size_t shmem, hipStream_t s,
+                       const void* arg, size_t arg_size) {
+  return launch_or_record(nullptr, f, grid, block, shmem, s, arg, arg_size);
+}
 struct ahip_event_s { hipEvent_t ev; };
 
 extern "C" {
@@ -152,12 +211,8 @@ int ahip_launch(ahip_fn_t f, uint32_t gx, uint32_t gy, uint32_t gz, uint32_t bx,
                 void* stream) {
   AHIP_REQUIRE(f != nullptr, "null kernel");
   AHIP_REQUIRE(gx > 0 && gy > 0 && gz > 0 && bx > 0, "empty launch");
-  size_t sz = kernarg_size;
-  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, const_cast<void*>(kernarg),
-                    HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-  AHIP_CHECK_HIP(hipModuleLaunchKernel(f->fn, gx, gy, gz, bx, by, bz, shmem_bytes,
-                                       as_stream(stream), nullptr, config));
-  return AHIP_OK;
+  return ahip_launch_module(f->fn, dim3(gx, gy, gz), dim3(bx, by, bz), shmem_bytes,
+                            as_stream(stream), kernarg, kernarg_size);
 }
 
 // ---- hipGraph capture / replay -----------------------------------------------------------
@@ -192,6 +247,43 @@ int ahip_graph_destroy(ahip_graph_t g) {
   hipGraphExecDestroy(g->exec);
   hipGraphDestroy(g->graph);
   delete g;
+  return AHIP_OK;
+}
+
+// ---- launch lists: record once, replay with one host call (H1, the CVM analogue) --------
+int ahip_list_begin(void) {
+  AHIP_REQUIRE(g_recording == nullptr, "a launch list is already being recorded on this thread");
+  g_recording = new ahip_list_s();
+  return AHIP_OK;
+}
+
+int ahip_list_end(ahip_list_t* out) {
+  AHIP_REQUIRE(g_recording != nullptr, "no launch list is being recorded");
+  ahip_list_s* l = g_recording;
+  g_recording = nullptr;
+  if (!out) {
+    delete l;
+    ahip_set_error("null out");
+    return AHIP_EINVAL;
+  }
+  *out = l;
+  return AHIP_OK;
+}
+
+int ahip_list_length(ahip_list_t l) { return l ? (int)l->recs.size() : -1; }
+
+int ahip_list_run(ahip_list_t l, void* stream) {
+  AHIP_REQUIRE(l != nullptr, "null list");
+  hipStream_t s = as_stream(stream);
+  for (const LaunchRec& r : l->recs) {
+    int rc = issue(r, s);
+    if (rc) return rc;
+  }
+  return AHIP_OK;
+}
+
+int ahip_list_destroy(ahip_list_t l) {
+  delete l;
   return AHIP_OK;
 }
 

@@ -50,6 +50,8 @@ typedef struct ahip_module_s* ahip_module_t;
 typedef struct ahip_func_s* ahip_fn_t;
 typedef struct ahip_graph_s* ahip_graph_t;
 typedef struct ahip_event_s* ahip_event_t;
+typedef struct ahip_list_s* ahip_list_t;
+typedef struct ahip_list_s* ahip_list_t;
 
 /* Kernel-argument block of every GENERATED fused Elemwise(+CAReduce) kernel
  *   extern "C" __global__ void k(ahip_ew_args a);
@@ -88,6 +90,8 @@ int ahip_init(int device_ordinal);
 const char* ahip_last_error(void);
 int ahip_get_device_info(ahip_device_info* out);
 int ahip_stream_synchronize(void* stream);
+/* launch-shape tunables: "stream_blocks_per_cu" (default 8), "reduce_blocks_per_cu" (default 8) */
+int ahip_set_param(const char* name, int64_t value);
 
 /* ---- runtime compilation of generated kernels ------------------------------------------
  * replaces: link/c/cmodule.py:2047 GCC_compiler.compile_str + :1240 ModuleCache.module_from_key
@@ -117,13 +121,15 @@ int ahip_elemwise(ahip_fn_t k, int nd, const int64_t* shape, int nops, void* con
 /* ---- K2: Elemwise fused into a full CAReduce (axis=None) --------------------------------
  * replaces: tensor/elemwise.py:1495 CAReduce.perform / :1522 _c_all (make_loop_careduce,
  * elemwise_cgen.py:502) applied to the output of the Elemwise above, without materialising
- * the intermediate.  Two generated kernels: `k_main` writes one partial per workgroup into
- * `ws` (>= ahip_reduce_ws_bytes()), `k_fin` folds the partials in a fixed order
- * (deterministic) and stores the cast result to `out`.                                       */
+ * the intermediate.  ONE generated kernel: every workgroup writes its partial into `ws`, takes
+ * an agent-scope arrival ticket, and the last workgroup to arrive folds the partials in index
+ * order (deterministic) and stores the cast result to `out`.  `ws` (>= ahip_reduce_ws_bytes())
+ * must be ZERO-INITIALISED once by the caller; the kernel leaves the ticket word zero again, so
+ * the same workspace serves every later launch on the same stream (graph replays included).  */
 size_t ahip_reduce_ws_bytes(void);
-int ahip_elemwise_reduce_all(ahip_fn_t k_main, ahip_fn_t k_fin, int nd, const int64_t* shape,
-                             int nops, void* const* ptrs, const int64_t* strides, int vec,
-                             int block, void* out, void* ws, size_t ws_bytes, void* stream);
+int ahip_elemwise_reduce_all(ahip_fn_t k, int nd, const int64_t* shape, int nops,
+                             void* const* ptrs, const int64_t* strides, int vec, int block,
+                             void* out, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- K2: axis CAReduce (optionally with a fused Elemwise producer) ----------------------
  * The iteration space is [kept dims (nk) | reduced dims (nr)], both already collapsed by the
@@ -199,6 +205,24 @@ int ahip_scatter_rows(int dtype, void* dst, int64_t nrows, int64_t dst_rs, int64
  * replaces: link/vm.py:388 Loop.__call__ / link/c/c_code/lazylinker_c.c:752 CLazyLinker_call and
  * the per-step VM entry of scan/scan_perform.pyx:418.  Everything launched on `stream` between
  * begin and end is recorded into one hipGraph; replay costs one host call per eval.            */
+/* Launch list: between begin and end, every kernel launch issued by ahip_* calls on THIS THREAD is
+ * recorded (kernel, grid, kernarg copy) instead of executed.  ahip_list_run re-issues them with
+ * plain launches from one host call (no per-node Python/ctypes cost, no graph-launch latency);
+ * run it inside ahip_graph_begin/end to turn the same list into a hipGraph for long lists.    */
+int ahip_list_begin(void);
+int ahip_list_end(ahip_list_t* out);
+int ahip_list_length(ahip_list_t l);
+int ahip_list_run(ahip_list_t l, void* stream);
+int ahip_list_destroy(ahip_list_t l);
+/* Launch list: between begin and end, every kernel launch issued by ahip_* calls on THIS THREAD is
+ * recorded (kernel, grid, kernarg copy) instead of executed.  ahip_list_run re-issues them with
+ * plain launches from one host call (no per-node Python/ctypes cost, no graph-launch latency);
+ * run it inside ahip_graph_begin/end to turn the same list into a hipGraph for long lists.    */
+int ahip_list_begin(void);
+int ahip_list_end(ahip_list_t* out);
+int ahip_list_length(ahip_list_t l);
+int ahip_list_run(ahip_list_t l, void* stream);
+int ahip_list_destroy(ahip_list_t l);
 int ahip_graph_begin(void* stream);
 int ahip_graph_end(void* stream, ahip_graph_t* out);
 int ahip_graph_launch(ahip_graph_t g, void* stream);

@@ -1,0 +1,163 @@
+#!/usr/bin/env python
+"""Per-config timing probe (MI355X): runs the BASELINE configs through the HIP linker at their
+full shapes and reports device time per eval (HIP events on the launch stream), evals/s and
+the roofline fraction of SURVEY §8(d).  Writes JSON lines; used to fill DESIGN.md's table."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+from golden_util import CASES, case_plan
+from aesara_amd._lib import check, lib
+from aesara_amd.executor import PlanExecutor
+
+
+def plan_of(name):
+    return case_plan(next(c for c in CASES if c["name"] == name))
+
+
+def timeit(fn, iters, warmup=5):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    check(lib.ahip_event_create(C.byref(e0)))
+    check(lib.ahip_event_create(C.byref(e1)))
+    t0 = time.perf_counter()
+    check(lib.ahip_event_record(e0, stream))
+    for _ in range(iters):
+        fn()
+    check(lib.ahip_event_record(e1, stream))
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / iters
+    ms = C.c_float()
+    check(lib.ahip_event_elapsed_ms(e0, e1, C.byref(ms)))
+    return ms.value / iters, wall * 1e3
+
+
+def randn(shape, dtype, seed):
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    return torch.randn(*shape, dtype=dtype, device="cuda", generator=g)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--out", default="gpurun_out/perf.jsonl")
+    ap.add_argument("--graph", type=int, default=1)
+    args = ap.parse_args()
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    rows = []
+
+    def report(name, dev_ms, wall_ms, work, unit, peak, **extra):
+        ach = work / (dev_ms * 1e-3) / 1e9 if unit == "GB/s" else work / (dev_ms * 1e-3) / 1e12
+        r = dict(tune={k: v for k, v in os.environ.items() if k.startswith("AESARA_HIP_")},
+                 config=name, dev_ms=dev_ms, wall_ms=wall_ms, evals_per_s=1e3 / max(wall_ms, dev_ms),
+                 achieved=ach, unit=unit, peak=peak, frac=ach / peak, **extra)
+        rows.append(r)
+        print(json.dumps(r), flush=True)
+
+    want = lambda n: (not args.only) or args.only in n  # noqa: E731
+    f64, f32 = torch.float64, torch.float32
+    G = bool(args.graph)
+
+    if want("cfg1b"):
+        ex = PlanExecutor(plan_of("cfg1b_matrix_add"), use_graph=G)
+        x, y = randn((4096, 4096), f64, 0), randn((4096, 4096), f64, 1)
+        d, w = timeit(lambda: ex(x, y), 200)
+        report("cfg1b add f64 4096^2", d, w, 3 * 4096 * 4096 * 8, "GB/s", 8000.0)
+
+    if want("cfg2"):
+        ex = PlanExecutor(plan_of("cfg2_gauss_sum"), use_graph=G)
+        x = randn((4096, 4096), f64, 1)
+        mu = torch.tensor(0.1, dtype=f64, device="cuda")
+        sg = torch.tensor(1.3, dtype=f64, device="cuda")
+        d, w = timeit(lambda: ex(x, mu, sg), 500)
+        report("cfg2 fused exp-sum f64 4096^2", d, w, 4096 * 4096 * 8, "GB/s", 8000.0)
+        exu = PlanExecutor(plan_of("cfg2_gauss_sum"), use_graph=G, fuse=False)
+        d, w = timeit(lambda: exu(x, mu, sg), 100)
+        report("cfg2 UNFUSED (reference node structure)", d, w, 4096 * 4096 * 8, "GB/s", 8000.0)
+
+    if want("redsum"):
+        from aesara_amd.plan import Node, Plan, Var
+        pl = Plan("redsum", {0: Var(0, "float64", [None, None]), 1: Var(1, "float64", [])}, [0], [1],
+                  [Node("CAReduce", [0], [1], {"scalar_op": "add", "axis": None,
+                                               "acc_dtype": "float64"})])
+        ex = PlanExecutor(pl, use_graph=G)
+        x = randn((4096, 4096), f64, 1)
+        d, w = timeit(lambda: ex(x), 500)
+        report("pure sum f64 4096^2 (streaming-read ceiling)", d, w, 4096 * 4096 * 8, "GB/s", 8000.0)
+
+    if want("cfg3a"):
+        ex = PlanExecutor(plan_of("gemv_small_float64"), use_graph=G)
+        M = randn((4096, 4096), f64, 2)
+        v = randn((4096,), f64, 3)
+        y = randn((4096,), f64, 4)
+        d, w = timeit(lambda: ex(y, M, v), 200)
+        report("cfg3a gemv f64 4096^2", d, w, 4096 * 4096 * 8 + 2 * 4096 * 8, "GB/s", 8000.0)
+        ext = PlanExecutor(plan_of("gemv_T_float64"), use_graph=G)
+        Mt = M.t()
+        d, w = timeit(lambda: ext(y, Mt, v), 200)
+        report("gemv f64 4096^2 (A.T view)", d, w, 4096 * 4096 * 8 + 2 * 4096 * 8, "GB/s", 8000.0)
+
+    if want("cfg3b"):
+        ex = PlanExecutor(plan_of("cfg3b_gemm_update"), use_graph=G)
+        Cm = torch.zeros(4096, 4096, dtype=f32, device="cuda")
+        A, B = randn((4096, 4096), f32, 3), randn((4096, 4096), f32, 4)
+        d, w = timeit(lambda: ex(Cm, A, B), 30)
+        report("cfg3b gemm f32 4096^3", d, w, 2 * 4096 ** 3, "TFLOP/s", 157.3)
+        for name, a, b in (("NT", A, B.t()), ("TN", A.t(), B), ("TT", A.t(), B.t())):
+            d, w = timeit(lambda: ex(Cm, a, b), 20)
+            report(f"gemm f32 4096^3 {name}", d, w, 2 * 4096 ** 3, "TFLOP/s", 157.3)
+        ex64 = PlanExecutor(plan_of("gemm_T000_float64") if any(
+            c["name"] == "gemm_T000_float64" for c in CASES) else plan_of("gemm1_float64"),
+            use_graph=G)
+        C64 = torch.zeros(4096, 4096, dtype=f64, device="cuda")
+        A64, B64 = randn((4096, 4096), f64, 3), randn((4096, 4096), f64, 4)
+        d, w = timeit(lambda: ex64(C64, A64, B64), 10)
+        report("gemm f64 4096^3", d, w, 2 * 4096 ** 3, "TFLOP/s", 78.6)
+
+    if want("cfg4"):
+        T, H = 512, 1024
+        ex = PlanExecutor(plan_of("cfg4_gru_b1_f32"), use_graph=G)
+        x = randn((T, H), f32, 4) * 0.1
+        h0 = torch.zeros(H, dtype=f32, device="cuda")
+        Ws = [randn((H, H), f32, 5 + k) / np.sqrt(H) for k in range(6)]
+        t0 = time.perf_counter()
+        ex(x, h0, *Ws)
+        torch.cuda.synchronize()
+        first = time.perf_counter() - t0
+        d, w = timeit(lambda: ex(x, h0, *Ws), 5, warmup=1)
+        report("cfg4 scan GRU T=512 H=1024 f32 B=1", d, w, T * 6 * H * H * 4, "GB/s", 8000.0,
+               us_per_step=d * 1e3 / T, first_call_s=first)
+
+    if want("cfg5"):
+        N, D = 1 << 22, 256
+        ex = PlanExecutor(plan_of("cfg5_logistic"), use_graph=G)
+        X = randn((N, D), f32, 6)
+        wv = randn((D,), f32, 7) / 16
+        b = torch.tensor(0.1, dtype=f32, device="cuda")
+        yv = (torch.rand(N, device="cuda") < 0.5).to(f32)
+        d, w = timeit(lambda: ex(X, wv, b, yv), 10, warmup=2)
+        report("cfg5 logistic logp+grad f32 N=2^22 D=256", d, w, N * D * 4 + N * 4, "GB/s", 8000.0,
+               note="algorithmic bytes = X once + y (reference graph reads X twice)")
+
+    with open(args.out, "a") as f:
+        for r in rows:
+            f.write(json.dumps(r) + "\n")
+
+
+if __name__ == "__main__":
+    main()
