@@ -5,7 +5,8 @@ Workload at N=1 = BASELINE.json configs[1]: the fused Elemwise chain
 ``exp(-(x-mu)**2 / (2*sigma**2)).sum()`` on a float64 4096x4096 matrix — the plan is the one the
 HIP linker lowers from the reference's FAST_RUN graph (tests/golden: cfg2_gauss_sum; shapes are
 dynamic, so the same plan runs at 4096x4096).  One "step" = one evaluation of the compiled
-function (one hipGraph replay: fused Elemwise+Sum kernel + finalize) with ``x`` resident in HBM.
+function: one launch-list replay (a single host call into libaesara_hip.so) that issues the ONE
+fused Elemwise+Sum kernel (in-kernel deterministic finalize), with ``x`` resident in HBM.
 
 N>1 (weak scaling): every rank evaluates its own 4096x4096 row block of a (N*4096)x4096 matrix;
 the CAReduce partial is summed over ranks with one RCCL all-reduce per eval (issued
@@ -71,10 +72,23 @@ def main():
     mu = torch.tensor(0.1, dtype=torch.float64, device="cuda")
     sigma = torch.tensor(1.3, dtype=torch.float64, device="cuda")
 
+    from aesara_amd.dist import ShardedFunction, plan_split_outputs
+
+    kinds = plan_split_outputs(plan, 0)           # ["allreduce"]: Sum over the split row axis
+    ring = [torch.zeros((), dtype=torch.float64, device="cuda") for _ in range(16)]
+    state = {"i": 0}
+    reducer = ShardedFunction(lambda slot: [slot], kinds)
+
     def step():
         (out,) = ex(x, mu, sigma)
         if world > 1:
-            return dist.all_reduce(out, async_op=True)
+            # the replayed executor reuses its output buffer: hand the partial to a ring slot
+            # before the asynchronous RCCL all-reduce so that consecutive evals can pipeline
+            slot = ring[state["i"] % len(ring)]
+            state["i"] += 1
+            slot.copy_(out)
+            _, hs = reducer(slot, async_op=True)
+            return hs[0]
         return None
 
     def barrier():
@@ -88,6 +102,7 @@ def main():
     rel = abs(out.item() - want.item()) / abs(want.item())
     assert rel < 1e-9, f"benchmark result mismatch: rel err {rel}"
 
+    h = None
     for _ in range(args.warmup):
         h = step()
     if h is not None:
@@ -139,12 +154,13 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: fused Elemwise exp(-(x-mu)^2/2sigma^2).sum(), "
-                                   "fp64 4096x4096 per GPU, inputs resident in HBM, hipGraph replay",
+                                   "fp64 4096x4096 per GPU, inputs resident in HBM, launch-list replay",
                        "rows_per_gpu": ROWS, "cols": COLS,
                        "parallelism": "row-sharded x%d, RCCL all-reduce of the CAReduce partial" % world
                                       if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": measured_traffic(),
                          "kernel_ms": dev_ms_per_eval, "algorithmic_bytes": ALGO_BYTES},
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -152,6 +168,18 @@ def main():
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
+
+
+def measured_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_bench_traffic.json: FETCH_SIZE doubled per the gfx950 correction of
+    MI355X_MICROARCH.md §HBM, + WRITE_SIZE); null when no profile has been committed."""
+    path = os.path.join(ROOT, "profiles", "r01_bench_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["hbm_bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def cpu_baseline(np):
