@@ -41,6 +41,21 @@ class DeviceInfo(C.Structure):
     ]
 
 
+AHIP_MAXDOTS = 8
+AHIP_GV_MAXOPS = 16
+
+
+class GvArgs(C.Structure):
+    _fields_ = [
+        ("M", C.c_int64),
+        ("A", C.c_void_p * AHIP_MAXDOTS), ("a_rs", C.c_int64 * AHIP_MAXDOTS),
+        ("a_cs", C.c_int64 * AHIP_MAXDOTS), ("K", C.c_int64 * AHIP_MAXDOTS),
+        ("x", C.c_void_p * AHIP_MAXDOTS), ("incx", C.c_int64 * AHIP_MAXDOTS),
+        ("ptr", C.c_void_p * AHIP_GV_MAXOPS), ("stride", C.c_int64 * AHIP_GV_MAXOPS),
+        ("ndots", C.c_int32), ("nops", C.c_int32),
+    ]
+
+
 vp, i64, i32, u32, sz = C.c_void_p, C.c_int64, C.c_int, C.c_uint32, C.c_size_t
 p_i64 = C.POINTER(C.c_int64)
 p_vp = C.POINTER(C.c_void_p)
@@ -74,6 +89,7 @@ SIGNATURES = {
     "ahip_gemv_ws_bytes": (sz, [i32, i64, i64]),
     "ahip_gemv": (i32, [i32, i64, i64, vp, vp, i64, i64, vp, i64, vp, vp, i64, vp, i64, vp, sz,
                         vp]),
+    "ahip_gemv_epilogue": (i32, [vp, C.POINTER(GvArgs), i32, vp]),
     "ahip_ger": (i32, [i32, i64, i64, vp, vp, i64, vp, i64, vp, i64, i64, vp, i64, i64, vp]),
     "ahip_copy_strided": (i32, [i32, i32, p_i64, vp, p_i64, vp, p_i64, i32, vp]),
     "ahip_fill": (i32, [i32, vp, vp, i64, vp]),

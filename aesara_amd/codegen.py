@@ -737,3 +737,117 @@ def _store_val(expr, src_dt, dst_dt):
 
 
 IDENTITY_SCALAR = {"n_in": 1, "nodes": [], "out": [["i", 0]]}
+
+
+# ----------------------------------------------------------------------------------------
+# fused GEMV-chain + Elemwise epilogue (ROW layout): one wavefront per output row
+# ----------------------------------------------------------------------------------------
+AHIP_MAXDOTS = 8
+AHIP_GV_MAXOPS = 16
+
+GV_STRUCT = r"""
+#define AHIP_MAXDOTS %d
+#define AHIP_GV_MAXOPS %d
+struct GvArgs {
+  i64 M;
+  const void* A[AHIP_MAXDOTS]; i64 a_rs[AHIP_MAXDOTS]; i64 a_cs[AHIP_MAXDOTS]; i64 K[AHIP_MAXDOTS];
+  const void* x[AHIP_MAXDOTS]; i64 incx[AHIP_MAXDOTS];
+  void* ptr[AHIP_GV_MAXOPS]; i64 stride[AHIP_GV_MAXOPS];
+  int ndots; int nops;
+};
+""" % (AHIP_MAXDOTS, AHIP_GV_MAXOPS)
+
+
+class GemvEpiSpec:
+    """y[m] = f(dot_0[m], ..., dot_{D-1}[m], operands[m]) with dot_d[m] = A_d[m, :] . x_d.
+
+    Replaces chains of ``Gemv`` nodes (tensor/blas.py:231; ``beta*y + alpha*A.x`` with y another
+    Gemv) and the ``Elemwise`` that consumes them — e.g. one GRU gate
+    ``sigmoid(W.T x + U.T h) * h`` of BASELINE config 4 — by a single HBM/L2-bound kernel: each
+    wavefront owns output rows, streams the D matrix rows with 16-byte loads, reduces with
+    cross-lane shuffles and evaluates the scalar epilogue in registers.
+
+    dtype     : float32 | float64 (all matrices / vectors of the dots)
+    dot_vec   : per dot, True when rows can be read with 16-byte vectors
+    scalar    : plan scalar expression; its first D inputs are the dot results
+    in_dtypes : dtypes of the non-dot epilogue operands; out_dtypes/out_refs as in KernelSpec
+    """
+
+    def __init__(self, dtype, dot_vec, scalar, in_dtypes, out_dtypes, out_refs, block=256):
+        self.dtype = dtype
+        self.dot_vec = list(dot_vec)
+        self.scalar = scalar
+        self.in_dtypes = list(in_dtypes)
+        self.out_dtypes = list(out_dtypes)
+        self.out_refs = list(out_refs)
+        self.block = block
+        assert 1 <= len(self.dot_vec) <= AHIP_MAXDOTS
+        assert len(self.in_dtypes) + len(self.out_dtypes) <= AHIP_GV_MAXOPS
+
+    def key(self):
+        import json
+        blob = json.dumps(["gv1", self.dtype, self.dot_vec, self.scalar, self.in_dtypes,
+                           self.out_dtypes, self.out_refs, self.block], sort_keys=True)
+        return hashlib.sha256(blob.encode()).hexdigest()[:24]
+
+
+def generate_gemv_epilogue(spec: GemvEpiSpec):
+    T = RTYPE[spec.dtype]
+    V = 4 if spec.dtype == "float32" else 2
+    D = len(spec.dot_vec)
+    nin, nout = len(spec.in_dtypes), len(spec.out_dtypes)
+    name = "gv_" + spec.key()
+    waves = spec.block // 64
+    L = [PRELUDE, GV_STRUCT]
+    L.append('extern "C" __global__ __launch_bounds__(%d) void %s(GvArgs a) {' % (spec.block, name))
+    L.append("  const int lane = threadIdx.x & 63;")
+    L.append("  const i64 nwaves = (i64)gridDim.x * %d;" % waves)
+    L.append("  for (i64 m = (i64)blockIdx.x * %d + (threadIdx.x >> 6); m < a.M; m += nwaves) {" % waves)
+    for d in range(D):
+        L.append("    %s d%d = 0;" % (T, d))
+        L.append("    {")
+        L.append("      const %s* __restrict__ row = (const %s*)a.A[%d] + m * a.a_rs[%d];" % (T, T, d, d))
+        L.append("      const %s* __restrict__ xv = (const %s*)a.x[%d];" % (T, T, d))
+        L.append("      const i64 K = a.K[%d];" % d)
+        if spec.dot_vec[d]:
+            L.append("      %s e0 = 0, e1 = 0;" % T)
+            L.append("      const i64 nv = K / %d;" % V)
+            L.append("      i64 v = lane;")
+            L.append("      for (; v + 64 < nv; v += 128) {")
+            L.append("        const Pack<%s, %d> a0 = *(const Pack<%s, %d>*)(row + v * %d);" % (T, V, T, V, V))
+            L.append("        const Pack<%s, %d> a1 = *(const Pack<%s, %d>*)(row + (v + 64) * %d);" % (T, V, T, V, V))
+            L.append("        const Pack<%s, %d> x0 = *(const Pack<%s, %d>*)(xv + v * %d);" % (T, V, T, V, V))
+            L.append("        const Pack<%s, %d> x1 = *(const Pack<%s, %d>*)(xv + (v + 64) * %d);" % (T, V, T, V, V))
+            for e in range(V):
+                L.append("        e0 += a0.v[%d] * x0.v[%d]; e1 += a1.v[%d] * x1.v[%d];" % (e, e, e, e))
+            L.append("      }")
+            L.append("      for (; v < nv; v += 64) {")
+            L.append("        const Pack<%s, %d> a0 = *(const Pack<%s, %d>*)(row + v * %d);" % (T, V, T, V, V))
+            L.append("        const Pack<%s, %d> x0 = *(const Pack<%s, %d>*)(xv + v * %d);" % (T, V, T, V, V))
+            for e in range(V):
+                L.append("        e0 += a0.v[%d] * x0.v[%d];" % (e, e))
+            L.append("      }")
+            L.append("      d%d = e0 + e1;" % d)
+        else:
+            L.append("      const i64 cs = a.a_cs[%d], ix = a.incx[%d];" % (d, d))
+            L.append("      for (i64 k = lane; k < K; k += 64) d%d += row[k * cs] * xv[k * ix];" % d)
+        L.append("      for (int s = 32; s > 0; s >>= 1) d%d += shfl_xor_<%s>(d%d, s);" % (d, T, d))
+        L.append("    }")
+    ins = ["d%d" % d for d in range(D)]
+    in_dts = [spec.dtype] * D
+    for k in range(nin):
+        ct = CTYPE[spec.in_dtypes[k]]
+        L.append("    const %s x%d = ((const %s*)a.ptr[%d])[m * a.stride[%d]];" % (ct, k, ct, k, k))
+        ins.append("(x%d != 0)" % k if spec.in_dtypes[k] == "bool" else "x%d" % k)
+        in_dts.append(spec.in_dtypes[k])
+    lines, outs, odts = emit_scalar_body(spec.scalar, ins, in_dts, indent="    ")
+    L.extend(lines)
+    L.append("    if (lane == 0) {")
+    for k, ri in enumerate(spec.out_refs):
+        val = _store_val(outs[ri], odts[ri], spec.out_dtypes[k])
+        L.append("      ((%s*)a.ptr[%d])[m * a.stride[%d]] = %s;" %
+                 (CTYPE[spec.out_dtypes[k]], nin + k, nin + k, val))
+    L.append("    }")
+    L.append("  }")
+    L.append("}")
+    return "\n".join(L) + "\n", (name,)

@@ -130,4 +130,18 @@ int ahip_elemwise_reduce_axis(ahip_fn_t k, int mode, int nk, int nr, const int64
   return launch(k, gx, gy, block, &a, stream);
 }
 
+int ahip_gemv_epilogue(ahip_fn_t k, const ahip_gv_args* args, int block, void* stream) {
+  AHIP_REQUIRE(k && args, "null argument");
+  AHIP_REQUIRE(block >= 64 && block % 64 == 0, "bad block");
+  AHIP_REQUIRE(args->ndots >= 1 && args->ndots <= AHIP_MAXDOTS, "bad ndots");
+  AHIP_REQUIRE(args->nops >= 1 && args->nops <= AHIP_GV_MAXOPS, "bad nops");
+  if (args->M <= 0) return AHIP_OK;
+  int waves = block / 64;
+  int64_t want = (args->M + waves - 1) / waves;
+  int64_t cap = (int64_t)ahip_cu_count() * 8;
+  if (want > cap) want = cap;
+  return ahip_launch_module(k->fn, dim3((unsigned)want, 1, 1), dim3(block, 1, 1), 0,
+                            as_stream(stream), args, sizeof(*args));
+}
+
 }  // extern "C"

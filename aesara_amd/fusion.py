@@ -12,7 +12,15 @@ Produces a list of :class:`Step`:
 
 * ``kind == "elemwise"`` — one generated kernel: ``scalar`` over ``inputs`` -> ``outputs``
 * ``kind == "reduce"``   — Elemwise producer (possibly identity) + CAReduce in one kernel
+* ``kind == "rowdot"``   — D = A . x (a Gemv stripped of its alpha/beta epilogue)
+* ``kind == "gemv_epi"`` — chain of row dots + the Elemwise that consumes them, one kernel
 * ``kind == "node"``     — any other plan node, executed by its handler
+
+``Gemv(y, alpha, A, x, beta)`` (tensor/blas.py:231) is split into ``D = rowdot(A, x)`` and the
+elementwise ``beta*y + alpha*D`` so that the ordinary Elemwise fusion merges Gemv chains
+(``y`` itself a Gemv) and neighbouring Composites around the dot products; whatever elementwise
+step finally consumes the dots becomes one ``gemv_epi`` kernel (one GRU gate of BASELINE
+config 4 = 1 launch instead of 5).
 """
 from __future__ import annotations
 
@@ -36,6 +44,8 @@ class Step:
     reduce: Optional[Dict[str, Any]] = None            # scalar_op, axis, acc_dtype, out, ref
     node: Optional[Node] = None
     alive: bool = True
+    dots: List[List[int]] = field(default_factory=list)  # gemv_epi: [A var, x var] per dot;
+    #                               the scalar's first len(dots) inputs are the dot results
 
 
 def _inline_constants(step: Step, plan: Plan):
@@ -99,10 +109,14 @@ def build_steps(plan: Plan, fuse: bool = True) -> List[Step]:
     producer: Dict[int, Step] = {}
 
     for ni, node in enumerate(plan.nodes):
-        if node.op == "Elemwise":
-            sc = copy.deepcopy(node.params["scalar"])
-            st = Step("elemwise", list(node.inputs), list(node.outputs), sc,
-                      out_refs=list(range(len(node.outputs))))
+        gemv_split = fuse and node.op == "Gemv" and _gemv_splittable(plan, node)
+        if node.op == "Elemwise" or gemv_split:
+            if gemv_split:
+                st = _split_gemv(plan, node, steps, producer)
+            else:
+                sc = copy.deepcopy(node.params["scalar"])
+                st = Step("elemwise", list(node.inputs), list(node.outputs), sc,
+                          out_refs=list(range(len(node.outputs))))
             _inline_constants(st, plan)
             if fuse:
                 changed = True
@@ -153,4 +167,124 @@ def build_steps(plan: Plan, fuse: bool = True) -> List[Step]:
             steps.append(st)
             for o in node.outputs:
                 producer[o] = st
+    steps = [s for s in steps if s.alive]
+    if fuse:
+        steps = _drop_dead(plan, _fuse_dots(plan, steps))
+    return steps
+
+
+_PURE_NODES = {"AllocEmpty", "Alloc", "DimShuffle", "Shape_i", "Shape", "ViewOp", "SpecifyShape",
+               "Subtensor", "Reshape", "ScalarFromTensor", "TensorFromScalar", "MakeVector",
+               "BroadcastTo", "DeepCopyOp"}
+
+
+def _drop_dead(plan: Plan, steps: List[Step]) -> List[Step]:
+    """Remove side-effect-free steps whose outputs nobody reads any more (e.g. the AllocEmpty
+    that only fed the ignored ``y`` of a ``beta == 0`` Gemv)."""
+    live = set(plan.outputs)
+    keep = []
+    for s in reversed(steps):
+        outs = list(s.outputs) + ([s.reduce["out"]] if s.reduce else [])
+        pure = s.kind in ("elemwise", "rowdot", "gemv_epi") or \
+            (s.kind == "node" and s.node.op in _PURE_NODES)
+        if pure and not any(o in live for o in outs):
+            continue
+        keep.append(s)
+        live.update(s.inputs)
+        for d in s.dots:
+            live.update(d)
+    return list(reversed(keep))
+
+
+def _gemv_splittable(plan: Plan, node: Node) -> bool:
+    y, alpha, A, x, beta = (plan.vars[i] for i in node.inputs)
+    return (A.ndim == 2 and x.ndim == 1 and A.dtype in ("float32", "float64")
+            and A.dtype == x.dtype == y.dtype)
+
+
+def _split_gemv(plan: Plan, node: Node, steps, producer) -> Step:
+    """Gemv(y, alpha, A, x, beta) -> rowdot step + elementwise step beta*y + alpha*D."""
+    yv, av, Av, xv, bv = node.inputs
+    dt = plan.vars[node.outputs[0]].dtype
+    d_var = plan.new_var(dt, [None], name="rowdot")
+    dot = Step("rowdot", [Av, xv], [d_var])
+    steps.append(dot)
+    producer[d_var] = dot
+    beta = plan.vars[bv]
+    beta_zero = beta.const is not None and len(beta.const["data"]) == 1 and \
+        float(beta.const["data"][0]) == 0.0
+    if beta_zero:
+        # BLAS semantics: beta == 0 never reads y (it is usually an uninitialised AllocEmpty)
+        sc = {"n_in": 2, "nodes": [{"op": "mul", "in": [["i", 0], ["i", 1]], "dtype": dt}],
+              "out": [["t", 0]]}
+        return Step("elemwise", [av, d_var], list(node.outputs), sc, out_refs=[0])
+    sc = {"n_in": 4, "nodes": [{"op": "mul", "in": [["i", 3], ["i", 0]], "dtype": dt},
+                               {"op": "mul", "in": [["i", 1], ["i", 2]], "dtype": dt},
+                               {"op": "add", "in": [["t", 0], ["t", 1]], "dtype": dt}],
+          "out": [["t", 2]]}
+    return Step("elemwise", [yv, av, d_var, bv], list(node.outputs), sc, out_refs=[0])
+
+
+def _fuse_dots(plan: Plan, steps: List[Step]) -> List[Step]:
+    """Absorb rowdot steps into the elementwise step that consumes them (kind gemv_epi)."""
+    from .codegen import AHIP_GV_MAXOPS, AHIP_MAXDOTS
+
+    dot_of = {s.outputs[0]: s for s in steps if s.kind == "rowdot"}
+    if not dot_of:
+        return steps
+    users: Dict[int, List[Step]] = {}
+    for s in steps:
+        for v in set(s.inputs):
+            users.setdefault(v, []).append(s)
+    outs = set(plan.outputs)
+    for s in steps:
+        if s.kind != "elemwise":
+            continue
+        dvars = [v for v in s.inputs if v in dot_of and len(users[v]) == 1 and v not in outs]
+        if not dvars or len(dvars) > AHIP_MAXDOTS:
+            continue
+        others = [v for v in s.inputs if v not in dvars]
+        if len(others) + len(s.outputs) > AHIP_GV_MAXOPS:
+            continue
+        # reorder the scalar inputs: dot results first, then the other operands
+        order = dvars + others
+        remap = {pos: ["i", order.index(v)] for pos, v in enumerate(s.inputs)}
+        s.scalar = _remap_inputs(s.scalar, remap, len(order))
+        s.inputs = others
+        s.dots = [list(dot_of[v].inputs) for v in dvars]
+        s.kind = "gemv_epi"
+        for v in dvars:
+            dot_of[v].alive = False
     return [s for s in steps if s.alive]
+
+
+def split_invariant(plan: Plan, invariant_inputs: List[int]):
+    """Hoist loop-invariant nodes out of a Scan inner plan.
+
+    ``invariant_inputs``: ids of the inner inputs that do not change across steps (the
+    non-sequences).  Returns ``(pre_plan, loop_plan, hoisted)``: ``pre_plan`` maps the
+    invariant inputs to the hoisted values (run once per Scan call), ``loop_plan`` takes the
+    original inputs followed by the hoisted values.  Only view/shape ops are hoisted (they are
+    free to recompute but hide loop-invariant *layouts* — e.g. the ``W.T`` DimShuffles feeding
+    every Gemv of a GRU step — from the executor, which materialises them once)."""
+    hoistable = {"DimShuffle", "Shape_i", "Shape", "ViewOp", "SpecifyShape", "Subtensor",
+                 "Reshape", "ScalarFromTensor", "TensorFromScalar", "MakeVector"}
+    inv = set(invariant_inputs)
+    const_ids = {vid for vid, v in plan.vars.items() if v.const is not None}
+    pre_nodes, loop_nodes = [], []
+    for n in plan.nodes:
+        if n.op in hoistable and all(i in inv or i in const_ids for i in n.inputs):
+            pre_nodes.append(n)
+            inv.update(n.outputs)
+        else:
+            loop_nodes.append(n)
+    hoisted = []
+    used = {i for n in loop_nodes for i in n.inputs} | set(plan.outputs)
+    for n in pre_nodes:
+        hoisted.extend(o for o in n.outputs if o in used)
+    if not hoisted:
+        return None, plan, []
+    pre = Plan(plan.name + "_invariant", plan.vars, list(invariant_inputs), hoisted, pre_nodes)
+    loop = Plan(plan.name + "_loop", plan.vars, list(plan.inputs) + hoisted, list(plan.outputs),
+                loop_nodes)
+    return pre, loop, hoisted

@@ -69,6 +69,21 @@ typedef struct ahip_ew_args {
   int32_t nops;
 } ahip_ew_args;
 
+/* Kernel-argument block of the GENERATED fused GEMV-chain + Elemwise epilogue kernels
+ *   extern "C" __global__ void k(ahip_gv_args a);       (codegen.generate_gemv_epilogue)
+ * y[m] = f(dot_0[m], .., dot_{D-1}[m], operands[m]),  dot_d[m] = sum_k A_d[m*a_rs + k*a_cs] * x_d[k*incx] */
+#define AHIP_MAXDOTS 8
+#define AHIP_GV_MAXOPS 16
+typedef struct ahip_gv_args {
+  int64_t M;
+  const void* A[AHIP_MAXDOTS]; int64_t a_rs[AHIP_MAXDOTS]; int64_t a_cs[AHIP_MAXDOTS];
+  int64_t K[AHIP_MAXDOTS];
+  const void* x[AHIP_MAXDOTS]; int64_t incx[AHIP_MAXDOTS];
+  void* ptr[AHIP_GV_MAXOPS];      /* epilogue operands: inputs then outputs               */
+  int64_t stride[AHIP_GV_MAXOPS]; /* element stride along m (0 = broadcast)               */
+  int32_t ndots; int32_t nops;
+} ahip_gv_args;
+
 typedef struct ahip_device_info {
   int32_t device;
   int32_t cu_count;
@@ -170,6 +185,11 @@ int ahip_gemv(int dtype, int64_t M, int64_t N, const void* alpha, const void* A,
               int64_t a_cs, const void* x, int64_t incx, const void* beta, const void* y_in,
               int64_t incy_in, void* y_out, int64_t incy_out, void* ws, size_t ws_bytes,
               void* stream);
+/* Fused GEMV chain + Elemwise epilogue (generated kernel `k`, one wavefront per output row):
+ * replaces a chain of Gemv nodes (beta*y + alpha*A.x with y itself a Gemv, tensor/blas.py:231)
+ * and the Elemwise consuming them (tensor/elemwise.py:304) — e.g. one GRU gate of the Scan
+ * inner graph (scan/op.py:637) — without materialising the intermediate vectors.            */
+int ahip_gemv_epilogue(ahip_fn_t k, const ahip_gv_args* args, int block, void* stream);
 /* A_out[M,N] = A_in + alpha * x[M] y[N]^T */
 int ahip_ger(int dtype, int64_t M, int64_t N, const void* alpha, const void* x, int64_t incx,
              const void* y, int64_t incy, const void* A_in, int64_t ai_rs, int64_t ai_cs,
