@@ -21,6 +21,8 @@
 //     buffers, one barrier per slab.
 //   * workgroup ids are remapped so the 8 XCDs (private L2s) each walk a contiguous band of
 //     tiles (speed only, placement-independent).
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -70,7 +72,17 @@ struct Stager {
   // ks = stride along k.  rows/kmax are the remaining extents for predication.
   __device__ __forceinline__ void load(const T* __restrict__ base, int64_t rs, int64_t ks,
                                        int64_t k0, int rows, int64_t K, int tid) {
+    // interior slab (wave-uniform test): unconditional loads, no per-vector branches
+    const bool full = (rows >= 128) && (k0 + BK <= K);
     if constexpr (MODE == 0) {
+      if (full) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+          int v = tid + THREADS * j;
+          r[j] = *reinterpret_cast<const vec_t*>(base + (v >> 3) * rs + k0 + (v & 7) * VEC);
+        }
+        return;
+      }
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
         int v = tid + THREADS * j;
@@ -81,12 +93,27 @@ struct Stager {
         r[j] = val;
       }
     } else if constexpr (MODE == 1) {
-      // micro-block = VEC k-rows x VEC contiguous rows; NV/VEC micro-blocks per thread
-      constexpr int NQ = 128 / VEC;  // micro-block columns per slab
+      // micro-block = VEC k-rows x VEC contiguous rows; NV/VEC micro-blocks per thread.
+      // Lane -> micro-block map: 8 consecutive lanes walk k (kq = 0..7) at the same row group, so
+      // each global row is still read in full 128-byte lines AND the transposed ds_write_b128 of
+      // an 8-lane group lands in ONE 128-byte LDS row segment (the n-fastest map measured 52 %
+      // of LDS cycles lost to 4-way bank conflicts, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).
+      if (full) {
+#pragma unroll
+        for (int b = 0; b < NV / VEC; ++b) {
+          int mb = tid + THREADS * b;
+          int kq = mb & 7, nq = mb >> 3;  // 8 lanes share a row: conflict-free ds_write_b128
+#pragma unroll
+          for (int i = 0; i < VEC; ++i)
+            r[b * VEC + i] = *reinterpret_cast<const vec_t*>(base + (k0 + kq * VEC + i) * ks +
+                                                             nq * VEC);
+        }
+        return;
+      }
 #pragma unroll
       for (int b = 0; b < NV / VEC; ++b) {
         int mb = tid + THREADS * b;
-        int nq = mb % NQ, kq = mb / NQ;
+        int kq = mb & 7, nq = mb >> 3;  // 8 lanes share a row: conflict-free ds_write_b128
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
           int64_t k = k0 + kq * VEC + i;
@@ -114,11 +141,10 @@ struct Stager {
 
   __device__ __forceinline__ void store(char* lds, int tid) const {
     if constexpr (MODE == 1) {
-      constexpr int NQ = 128 / VEC;
 #pragma unroll
       for (int b = 0; b < NV / VEC; ++b) {
         int mb = tid + THREADS * b;
-        int nq = mb % NQ, kq = mb / NQ;
+        int kq = mb & 7, nq = mb >> 3;  // 8 lanes share a row: conflict-free ds_write_b128
 #pragma unroll
         for (int jj = 0; jj < VEC; ++jj) {
           vec_t t;
@@ -223,45 +249,53 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_kernel(GemmArgs g) {
       sa.load(A, g.a_rs, g.a_cs, (int64_t)(t + 1) * BK, rows_a, g.K, tid);
       sb.load(B, g.b_cs, g.b_rs, (int64_t)(t + 1) * BK, rows_b, g.K, tid);
     }
+    {
+      // LDS fragments are double-buffered in registers: the ds_read_b64s of k-step ks+1 are
+      // issued before the MFMAs of k-step ks, so the matrix pipe never waits on LDS latency
+      using frag_t = typename std::conditional<sizeof(T) == 4,
+                                               float __attribute__((ext_vector_type(2))), double>::type;
+      constexpr int NB = sizeof(T) == 4 ? 2 : 1;  // fp64: 128 accumulator VGPRs leave no room
+      frag_t fa[NB][4], fb[NB][4];
+      const char* pa = bufA + wm * 64 * ROW_BYTES + frag_off;
+      const char* pb = bufB + wn * 64 * ROW_BYTES + frag_off;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      if constexpr (sizeof(T) == 4) {
-        using f2 = float __attribute__((ext_vector_type(2)));
-        f2 fa[4], fb[4];
+      for (int i = 0; i < 4; ++i) {
+        fa[0][i] = *reinterpret_cast<const frag_t*>(pa + i * 16 * ROW_BYTES);
+        fb[0][i] = *reinterpret_cast<const frag_t*>(pb + i * 16 * ROW_BYTES);
+      }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          fa[i] = *reinterpret_cast<const f2*>(bufA + (wm * 64 + i * 16) * ROW_BYTES + ks * 32 +
-                                               frag_off);
+      for (int ks = 0; ks < 4; ++ks) {
+        const int cur = (NB == 2) ? (ks & 1) : 0, nxt = cur ^ 1;
+        if constexpr (NB == 1) {
+          if (ks > 0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          fb[j] = *reinterpret_cast<const f2*>(bufB + (wn * 64 + j * 16) * ROW_BYTES + ks * 32 +
-                                               frag_off);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            mma(acc[i][j], fa[i].x, fb[j].x);
+            for (int i = 0; i < 4; ++i) {
+              fa[0][i] = *reinterpret_cast<const frag_t*>(pa + i * 16 * ROW_BYTES + ks * 32);
+              fb[0][i] = *reinterpret_cast<const frag_t*>(pb + i * 16 * ROW_BYTES + ks * 32);
+            }
           }
+        } else if (ks + 1 < 4) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            mma(acc[i][j], fa[i].y, fb[j].y);
+          for (int i = 0; i < 4; ++i) {
+            fa[nxt][i] = *reinterpret_cast<const frag_t*>(pa + i * 16 * ROW_BYTES + (ks + 1) * 32);
+            fb[nxt][i] = *reinterpret_cast<const frag_t*>(pb + i * 16 * ROW_BYTES + (ks + 1) * 32);
           }
-      } else {
-        double fa[4], fb[4];
+        }
+        if constexpr (sizeof(T) == 4) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          fa[i] = *reinterpret_cast<const double*>(bufA + (wm * 64 + i * 16) * ROW_BYTES +
-                                                   ks * 32 + frag_off);
+          for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          fb[j] = *reinterpret_cast<const double*>(bufB + (wn * 64 + j * 16) * ROW_BYTES +
-                                                   ks * 32 + frag_off);
+            for (int j = 0; j < 4; ++j) mma(acc[i][j], fa[cur][i].x, fb[cur][j].x);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+          for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) mma(acc[i][j], fa[i], fb[j]);
+            for (int j = 0; j < 4; ++j) mma(acc[i][j], fa[cur][i].y, fb[cur][j].y);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mma(acc[i][j], fa[cur][i], fb[cur][j]);
+        }
       }
     }
     if (more) {
