@@ -1,0 +1,106 @@
+"""Error behaviour and edge cases of the HIP path on a real device (mirrors the reference's
+exception contract, SURVEY §8b: shape errors are ValueError, index errors IndexError, dtype
+errors TypeError) and empty / ragged inputs."""
+import numpy as np
+import pytest
+
+from golden_util import CASES, case_plan
+
+pytestmark = pytest.mark.gpu
+
+
+def _ex(name, **kw):
+    from aesara_amd.executor import PlanExecutor
+    return PlanExecutor(case_plan(next(c for c in CASES if c["name"] == name)), **kw)
+
+
+def _t(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_elemwise_shape_mismatch_is_value_error():
+    ex = _ex("ew_bcast0_float64")
+    with pytest.raises(ValueError, match="Shapes on dimension 1 do not match"):
+        ex(_t(np.zeros((3, 5))), _t(np.zeros((3, 4))))
+
+
+def test_dtype_mismatch_is_type_error():
+    ex = _ex("cfg1b_matrix_add")
+    with pytest.raises(TypeError):
+        ex(_t(np.zeros((3, 5), "float32")), _t(np.zeros((3, 5))))
+
+
+def test_out_of_bounds_advanced_index_is_index_error():
+    ex = _ex("advsub1")
+    x = _t(np.arange(13 * 7, dtype="int32").reshape(13, 7))
+    good = _t(np.array([0, -13, 12], dtype="int64"))
+    bad = _t(np.array([0, 13, 1], dtype="int64"))
+    i32 = _t(np.array([0, 1], dtype="int32"))
+    v = _t(np.zeros(13))
+    ex(x, good, i32, v)
+    with pytest.raises(IndexError):
+        ex(x, bad, i32, v)
+    ex(x, good, i32, v)  # the flag is cleared after raising
+
+
+def test_basic_index_out_of_bounds_is_index_error():
+    ex = _ex("subtensor_basic")
+    with pytest.raises(IndexError):
+        ex(_t(np.zeros((9, 11), "int32")), np.int64(9))
+
+
+def test_gemm_inner_dimension_mismatch():
+    ex = _ex("gemm13_float32")
+    with pytest.raises(ValueError):
+        ex(_t(np.zeros((3, 5), "float32")), _t(np.zeros((3, 4), "float32")),
+           _t(np.zeros((5, 5), "float32")))
+
+
+def test_empty_reduction_of_max_raises_and_sum_is_identity():
+    ex = _ex("red9_f32")  # sum over a (5, 0) matrix, axis=None
+    (s,) = ex(_t(np.zeros((5, 0), "float32")))
+    assert s.item() == 0.0
+    exm = _ex("red0_f64")  # sum, prod, max, min of a matrix
+    with pytest.raises(ValueError, match="zero-size"):
+        exm(_t(np.zeros((0, 6))))
+
+
+def test_ragged_sizes_elemwise_and_reduce():
+    """Sizes that defeat every vector width / tile multiple (tail handling)."""
+    import torch
+    ex = _ex("red_fused_elemwise_axis")  # outputs: sum0, sum1, (e*2).sum(), e
+    for shape in ((1, 1), (7, 13), (129, 255), (1023, 3), (1, 4097)):
+        x = torch.randn(*shape, dtype=torch.float64, device="cuda")
+        y = torch.randn(shape[1], dtype=torch.float64, device="cuda")
+        e = torch.exp(-(x - y) ** 2)
+        s0, s1, tot, em = ex(x, y)
+        assert torch.allclose(em, e, rtol=1e-13, atol=0)
+        assert torch.allclose(s0, e.sum(0), rtol=1e-12, atol=1e-13)
+        assert torch.allclose(s1, e.sum(1), rtol=1e-12, atol=1e-13)
+        assert abs(tot.item() - 2 * e.sum().item()) <= 1e-12 * abs(tot.item()) + 1e-13
+
+
+def test_ragged_gemm_sizes_and_offsets():
+    import torch
+    ex = _ex("gemm0_float64")  # b*z + a*dot(x, y) with a=1, b=0
+    for (M, K, N) in ((1, 1, 1), (5, 3, 2), (127, 129, 131), (128, 17, 256), (257, 64, 1)):
+        x = torch.randn(M, K, dtype=torch.float64, device="cuda")
+        y = torch.randn(K, N, dtype=torch.float64, device="cuda")
+        z = torch.zeros(M, N, dtype=torch.float64, device="cuda")
+        (out,) = ex(z, x, y)
+        assert torch.allclose(out, x @ y, rtol=1e-12, atol=1e-12)
+    # misaligned (odd element offset) views force the scalar staging path
+    big = torch.randn(130, 131, dtype=torch.float64, device="cuda")
+    x, y = big[1:129, 1:130], big[:129, 2:131]
+    (out,) = ex(torch.zeros(128, 129, dtype=torch.float64, device="cuda"), x, y)
+    assert torch.allclose(out, x @ y, rtol=1e-12, atol=1e-12)
+
+
+def test_scan_zero_steps_and_one_step():
+    import torch
+    ex = _ex("scan_cumsum")  # outputs: res, res[-1]  -> res[-1] invalid for 0 steps, so 1 step
+    x = torch.randn(1, 7, dtype=torch.float64, device="cuda")
+    s0 = torch.randn(7, dtype=torch.float64, device="cuda")
+    res, last = ex(x, s0)
+    assert torch.allclose(res[0], s0 + x[0]) and torch.allclose(last, s0 + x[0])
