@@ -773,7 +773,9 @@ class GemvEpiSpec:
     in_dtypes : dtypes of the non-dot epilogue operands; out_dtypes/out_refs as in KernelSpec
     """
 
-    def __init__(self, dtype, dot_vec, scalar, in_dtypes, out_dtypes, out_refs, block=256):
+    def __init__(self, dtype, dot_vec, scalar, in_dtypes, out_dtypes, out_refs, block=256,
+                 rpw=1):
+        self.rpw = rpw  # rows per wavefront iteration (4 for short rows, 1 for long rows)
         self.dtype = dtype
         self.dot_vec = list(dot_vec)
         self.scalar = scalar
@@ -786,8 +788,8 @@ class GemvEpiSpec:
 
     def key(self):
         import json
-        blob = json.dumps(["gv1", self.dtype, self.dot_vec, self.scalar, self.in_dtypes,
-                           self.out_dtypes, self.out_refs, self.block], sort_keys=True)
+        blob = json.dumps(["gv2", self.dtype, self.dot_vec, self.scalar, self.in_dtypes,
+                           self.out_dtypes, self.out_refs, self.block, self.rpw], sort_keys=True)
         return hashlib.sha256(blob.encode()).hexdigest()[:24]
 
 
@@ -795,6 +797,7 @@ def generate_gemv_epilogue(spec: GemvEpiSpec):
     T = RTYPE[spec.dtype]
     V = 4 if spec.dtype == "float32" else 2
     D = len(spec.dot_vec)
+    R = spec.rpw
     nin, nout = len(spec.in_dtypes), len(spec.out_dtypes)
     name = "gv_" + spec.key()
     waves = spec.block // 64
@@ -802,52 +805,80 @@ def generate_gemv_epilogue(spec: GemvEpiSpec):
     L.append('extern "C" __global__ __launch_bounds__(%d) void %s(GvArgs a) {' % (spec.block, name))
     L.append("  const int lane = threadIdx.x & 63;")
     L.append("  const i64 nwaves = (i64)gridDim.x * %d;" % waves)
-    L.append("  for (i64 m = (i64)blockIdx.x * %d + (threadIdx.x >> 6); m < a.M; m += nwaves) {" % waves)
+    # each wavefront owns R consecutive output rows per iteration: for short rows (K*itemsize of
+    # a few KB) this keeps R independent 16-byte loads in flight per lane instead of one
+    L.append("  for (i64 m0 = ((i64)blockIdx.x * %d + (threadIdx.x >> 6)) * %d; m0 < a.M; "
+             "m0 += nwaves * %d) {" % (waves, R, R))
     for d in range(D):
-        L.append("    %s d%d = 0;" % (T, d))
+        for r in range(R):
+            L.append("    %s d%d_%d = 0;" % (T, d, r))
         L.append("    {")
-        L.append("      const %s* __restrict__ row = (const %s*)a.A[%d] + m * a.a_rs[%d];" % (T, T, d, d))
         L.append("      const %s* __restrict__ xv = (const %s*)a.x[%d];" % (T, T, d))
         L.append("      const i64 K = a.K[%d];" % d)
+        for r in range(R):
+            # rows past M are clamped to the last row (their results are never stored)
+            L.append("      const %s* __restrict__ row%d = (const %s*)a.A[%d] + "
+                     "((m0 + %d < a.M) ? (m0 + %d) : (a.M - 1)) * a.a_rs[%d];" % (T, r, T, d, r, r, d))
         if spec.dot_vec[d]:
-            L.append("      %s e0 = 0, e1 = 0;" % T)
             L.append("      const i64 nv = K / %d;" % V)
-            L.append("      i64 v = lane;")
-            L.append("      for (; v + 64 < nv; v += 128) {")
-            L.append("        const Pack<%s, %d> a0 = *(const Pack<%s, %d>*)(row + v * %d);" % (T, V, T, V, V))
-            L.append("        const Pack<%s, %d> a1 = *(const Pack<%s, %d>*)(row + (v + 64) * %d);" % (T, V, T, V, V))
-            L.append("        const Pack<%s, %d> x0 = *(const Pack<%s, %d>*)(xv + v * %d);" % (T, V, T, V, V))
-            L.append("        const Pack<%s, %d> x1 = *(const Pack<%s, %d>*)(xv + (v + 64) * %d);" % (T, V, T, V, V))
-            for e in range(V):
-                L.append("        e0 += a0.v[%d] * x0.v[%d]; e1 += a1.v[%d] * x1.v[%d];" % (e, e, e, e))
-            L.append("      }")
-            L.append("      for (; v < nv; v += 64) {")
-            L.append("        const Pack<%s, %d> a0 = *(const Pack<%s, %d>*)(row + v * %d);" % (T, V, T, V, V))
-            L.append("        const Pack<%s, %d> x0 = *(const Pack<%s, %d>*)(xv + v * %d);" % (T, V, T, V, V))
-            for e in range(V):
-                L.append("        e0 += a0.v[%d] * x0.v[%d];" % (e, e))
-            L.append("      }")
-            L.append("      d%d = e0 + e1;" % d)
+            if R == 1:
+                L.append("      %s e0 = 0, e1 = 0;" % T)
+                L.append("      i64 v = lane;")
+                L.append("      for (; v + 64 < nv; v += 128) {")
+                L.append("        const Pack<%s, %d> a0 = *(const Pack<%s, %d>*)(row0 + v * %d);" % (T, V, T, V, V))
+                L.append("        const Pack<%s, %d> a1 = *(const Pack<%s, %d>*)(row0 + (v + 64) * %d);" % (T, V, T, V, V))
+                L.append("        const Pack<%s, %d> x0 = *(const Pack<%s, %d>*)(xv + v * %d);" % (T, V, T, V, V))
+                L.append("        const Pack<%s, %d> x1 = *(const Pack<%s, %d>*)(xv + (v + 64) * %d);" % (T, V, T, V, V))
+                for e in range(V):
+                    L.append("        e0 += a0.v[%d] * x0.v[%d]; e1 += a1.v[%d] * x1.v[%d];" % (e, e, e, e))
+                L.append("      }")
+                L.append("      for (; v < nv; v += 64) {")
+                L.append("        const Pack<%s, %d> a0 = *(const Pack<%s, %d>*)(row0 + v * %d);" % (T, V, T, V, V))
+                L.append("        const Pack<%s, %d> x0 = *(const Pack<%s, %d>*)(xv + v * %d);" % (T, V, T, V, V))
+                for e in range(V):
+                    L.append("        e0 += a0.v[%d] * x0.v[%d];" % (e, e))
+                L.append("      }")
+                L.append("      d%d_0 = e0 + e1;" % d)
+            else:
+                L.append("      for (i64 v = lane; v < nv; v += 64) {")
+                L.append("        const Pack<%s, %d> x0 = *(const Pack<%s, %d>*)(xv + v * %d);" % (T, V, T, V, V))
+                for r in range(R):
+                    L.append("        const Pack<%s, %d> a%d = *(const Pack<%s, %d>*)(row%d + v * %d);"
+                             % (T, V, r, T, V, r, V))
+                for r in range(R):
+                    for e in range(V):
+                        L.append("        d%d_%d += a%d.v[%d] * x0.v[%d];" % (d, r, r, e, e))
+                L.append("      }")
         else:
             L.append("      const i64 cs = a.a_cs[%d], ix = a.incx[%d];" % (d, d))
-            L.append("      for (i64 k = lane; k < K; k += 64) d%d += row[k * cs] * xv[k * ix];" % d)
-        L.append("      for (int s = 32; s > 0; s >>= 1) d%d += shfl_xor_<%s>(d%d, s);" % (d, T, d))
+            L.append("      for (i64 k = lane; k < K; k += 64) {")
+            L.append("        const %s xk = xv[k * ix];" % T)
+            for r in range(R):
+                L.append("        d%d_%d += row%d[k * cs] * xk;" % (d, r, r))
+            L.append("      }")
+        for r in range(R):
+            L.append("      for (int s = 32; s > 0; s >>= 1) d%d_%d += shfl_xor_<%s>(d%d_%d, s);"
+                     % (d, r, T, d, r))
         L.append("    }")
-    ins = ["d%d" % d for d in range(D)]
-    in_dts = [spec.dtype] * D
-    for k in range(nin):
-        ct = CTYPE[spec.in_dtypes[k]]
-        L.append("    const %s x%d = ((const %s*)a.ptr[%d])[m * a.stride[%d]];" % (ct, k, ct, k, k))
-        ins.append("(x%d != 0)" % k if spec.in_dtypes[k] == "bool" else "x%d" % k)
-        in_dts.append(spec.in_dtypes[k])
-    lines, outs, odts = emit_scalar_body(spec.scalar, ins, in_dts, indent="    ")
-    L.extend(lines)
-    L.append("    if (lane == 0) {")
-    for k, ri in enumerate(spec.out_refs):
-        val = _store_val(outs[ri], odts[ri], spec.out_dtypes[k])
-        L.append("      ((%s*)a.ptr[%d])[m * a.stride[%d]] = %s;" %
-                 (CTYPE[spec.out_dtypes[k]], nin + k, nin + k, val))
-    L.append("    }")
+    for r in range(R):
+        L.append("    if (m0 + %d < a.M) {" % r)
+        L.append("      const i64 m = m0 + %d;" % r)
+        ins = ["d%d_%d" % (d, r) for d in range(D)]
+        in_dts = [spec.dtype] * D
+        for k in range(nin):
+            ct = CTYPE[spec.in_dtypes[k]]
+            L.append("      const %s x%d = ((const %s*)a.ptr[%d])[m * a.stride[%d]];" % (ct, k, ct, k, k))
+            ins.append("(x%d != 0)" % k if spec.in_dtypes[k] == "bool" else "x%d" % k)
+            in_dts.append(spec.in_dtypes[k])
+        lines, outs, odts = emit_scalar_body(spec.scalar, ins, in_dts, indent="      ")
+        L.extend(lines)
+        L.append("      if (lane == 0) {")
+        for k, ri in enumerate(spec.out_refs):
+            val = _store_val(outs[ri], odts[ri], spec.out_dtypes[k])
+            L.append("        ((%s*)a.ptr[%d])[m * a.stride[%d]] = %s;" %
+                     (CTYPE[spec.out_dtypes[k]], nin + k, nin + k, val))
+        L.append("      }")
+        L.append("    }")
     L.append("  }")
     L.append("}")
     return "\n".join(L) + "\n", (name,)

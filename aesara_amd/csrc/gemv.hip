@@ -150,16 +150,23 @@ __global__ __launch_bounds__(256) void gemv_col_kernel(GemvArgs g) {
   }
 }
 
+// second pass of the COL layout: one wavefront per output element folds the [nslice][M]
+// partials (lanes stride over slices, fixed shuffle tree: deterministic), then alpha/beta.
 template <typename T>
-__global__ void gemv_col_finalize(GemvArgs g) {
+__global__ __launch_bounds__(256) void gemv_col_finalize(GemvArgs g) {
   const T* ws = static_cast<const T*>(g.ws);
-  for (int64_t m = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; m < g.M;
-       m += (int64_t)gridDim.x * blockDim.x) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t m = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); m < g.M;
+       m += nwaves) {
     T s = 0;
-    for (int k = 0; k < g.nslice; ++k) s += ws[(int64_t)k * g.M + m];
-    T v = (T)g.alpha * s;
-    if (g.beta != 0.0) v += (T)g.beta * static_cast<const T*>(g.y_in)[m * g.incy_in];
-    static_cast<T*>(g.y_out)[m * g.incy_out] = v;
+    for (int k = lane; k < g.nslice; k += 64) s += ws[(int64_t)k * g.M + m];
+    s = wave_sum(s);
+    if (lane == 0) {
+      T v = (T)g.alpha * s;
+      if (g.beta != 0.0) v += (T)g.beta * static_cast<const T*>(g.y_in)[m * g.incy_in];
+      static_cast<T*>(g.y_out)[m * g.incy_out] = v;
+    }
   }
 }
 
@@ -218,7 +225,7 @@ int gemv_dispatch(GemvArgs& g, size_t ws_bytes, hipStream_t s) {
     if (vec) AHIP_LAUNCH((gemv_col_kernel<T, true>), grid, dim3(256), 0, s, g);
     else AHIP_LAUNCH((gemv_col_kernel<T, false>), grid, dim3(256), 0, s, g);
     if (g.nslice > 1) {
-      unsigned blocks = (unsigned)((g.M + 255) / 256 < 1024 ? (g.M + 255) / 256 : 1024);
+      unsigned blocks = (unsigned)((g.M + 3) / 4 < 2048 ? (g.M + 3) / 4 : 2048);
       AHIP_LAUNCH((gemv_col_finalize<T>), dim3(blocks), dim3(256), 0, s, g);
     }
     return AHIP_OK;
