@@ -8,17 +8,23 @@
 //   * exact-precision MFMA: v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64 (f32/f64 in, same
 //     accumulate) — results are an ordinary k-ordered fma chain, so parity with a CPU BLAS is
 //     roundoff-level; there is no TF32-like shortcut on gfx950.
-//   * 128x128 workgroup tile, 4 wavefronts (2x2), each wave owns a 64x64 sub-tile as 4x4 MFMA
-//     fragments (64 accumulator VGPRs); K is consumed in 128-byte slabs (BK = 32 f32 / 16 f64).
+//   * 128x128 workgroup tile, 8 wavefronts (2x4), each wave owns a 64x32 sub-tile as 4x2 MFMA
+//     fragments; K is consumed in 128-byte slabs (BK = 32 f32 / 16 f64).  <= 128 VGPRs per
+//     wave -> two workgroups = 16 waves per CU (4 per SIMD).  Measured on the 4-wave / 64x64
+//     predecessor: 1/8 of the slab loads miss the 4 MiB XCD L2 by construction (8x8 concurrent
+//     tiles per XCD), their latency exceeded one slab of MFMA time and the matrix pipe idled
+//     26 % (SQ_WAIT_ANY ~1900 of ~5500 cycles per wave-slab).  Four waves per SIMD plus a
+//     two-slab-deep register prefetch cover that latency.
 //   * both operands are staged through LDS in a [row][k] image with 144-byte rows (128 B + 16 B
-//     pad): fragments are fetched with one conflict-free ds_read_b64 per lane.  Operands whose
-//     contiguous axis is k are staged with 16-byte loads straight into that image; operands
+//     pad): fragments are fetched with one conflict-free ds_read_b64 per lane.  Waves 0-3 stage
+//     A, waves 4-7 stage B (4 x 16-byte vectors per thread per slab) through per-thread 32-bit
+//     offsets from a wave-uniform base (SGPR base + VGPR offset addressing: no per-slab address
+//     arithmetic).  Operands whose contiguous axis is k go straight into the image; operands
 //     whose contiguous axis is m/n (the "N" layout of B, transposed views of A) are loaded with
 //     coalesced 16-byte vectors and transposed VECxVEC in registers before the ds_write_b128 —
 //     all 8 unit-stride layouts of the reference (blas.py:719 encode_strides_in_unit) run
-//     without a copy; arbitrary strides / ragged sizes take the scalar-staging instantiation.
-//   * global->register prefetch of slab t+1 is issued before the MFMAs of slab t; two LDS
-//     buffers, one barrier per slab.
+//     without a copy; ragged sizes take the predicated (EDGE) instantiation, arbitrary strides
+//     the scalar-staging one.
 //   * workgroup ids are remapped so the 8 XCDs (private L2s) each walk a contiguous band of
 //     tiles (speed only, placement-independent).
 #include <type_traits>
@@ -33,17 +39,21 @@ template <> struct Traits<float> {
   static constexpr int BK = 32;    // k extent of one LDS slab (128 bytes)
   using vec_t = float __attribute__((ext_vector_type(4)));
   using acc_t = float __attribute__((ext_vector_type(4)));
+  using frag_t = float __attribute__((ext_vector_type(2)));
 };
 template <> struct Traits<double> {
   static constexpr int VEC = 2;
   static constexpr int BK = 16;
   using vec_t = double __attribute__((ext_vector_type(2)));
   using acc_t = double __attribute__((ext_vector_type(4)));
+  using frag_t = double;
 };
 
 constexpr int BM = 128, BN = 128;
 constexpr int ROW_BYTES = 144;  // 128 B of k + 16 B pad -> conflict-free ds_read_b64 fragments
-constexpr int THREADS = 256;
+constexpr int THREADS = 512;    // 8 wavefronts
+constexpr int STG = 256;        // threads staging one operand (waves 0-3: A, waves 4-7: B)
+constexpr int NV = 4;           // 16-byte vectors per staging thread per slab (128*8/256)
 
 struct GemmArgs {
   int64_t M, N, K;
@@ -58,93 +68,93 @@ struct GemmArgs {
 // ---- staging ---------------------------------------------------------------------------
 // MODE 0: k is the contiguous axis (unit stride along k, vectorisable)
 // MODE 1: the row axis (m for A, n for B) is contiguous (register transpose)
-// MODE 2: arbitrary strides / ragged extents (scalar loads, zero fill)
+// MODE 2: arbitrary strides (scalar loads, zero fill; always predicated)
+//
+// `rs` = element stride between rows of the operand (m for A, n for B), `ks` = stride along k.
+// A staging thread (stid in [0,256)) owns NV vectors per slab; their byte offsets from the
+// wave-uniform slab base are loop invariant and kept as 32-bit VGPRs.
 template <typename T, int MODE>
-struct Stager {
+struct Stage {
   using Tr = Traits<T>;
   using vec_t = typename Tr::vec_t;
   static constexpr int VEC = Tr::VEC;
-  static constexpr int BK = Tr::BK;
-  static constexpr int NV = 4;  // 16-byte vectors per thread per slab (128 rows * 8 vec / 256)
-  vec_t r[NV];
 
-  // base points at element (row0, 0) of the operand; rs = stride between rows (m or n),
-  // ks = stride along k.  rows/kmax are the remaining extents for predication.
-  __device__ __forceinline__ void load(const T* __restrict__ base, int64_t rs, int64_t ks,
-                                       int64_t k0, int rows, int64_t K, int tid) {
-    // interior slab (wave-uniform test): unconditional loads, no per-vector branches
-    const bool full = (rows >= 128) && (k0 + BK <= K);
-    if constexpr (MODE == 0) {
-      if (full) {
+  // vector j of thread stid: (row, k) inside the 128 x BK slab
+  static __device__ __forceinline__ void coords(int stid, int j, int& row, int& k) {
+    if constexpr (MODE == 1) {
+      // micro-block = VEC k-rows x VEC contiguous rows, NV/VEC micro-blocks per thread; 8
+      // consecutive lanes walk k (kq) at the same row group: global rows are read in full
+      // 128-byte lines and the transposed ds_write_b128 of an 8-lane group lands in ONE
+      // 128-byte LDS row segment (conflict-free)
+      int mb = stid + STG * (j / VEC);
+      int kq = mb & 7, nq = mb >> 3;
+      row = nq * VEC;
+      k = kq * VEC + (j % VEC);
+    } else {
+      int v = stid + STG * j;
+      row = v >> 3;
+      k = (v & 7) * VEC;
+    }
+  }
+
+  static __device__ __forceinline__ void offsets(unsigned (&off)[NV], int stid, int64_t rs,
+                                                 int64_t ks) {
 #pragma unroll
-        for (int j = 0; j < NV; ++j) {
-          int v = tid + THREADS * j;
-          r[j] = *reinterpret_cast<const vec_t*>(base + (v >> 3) * rs + k0 + (v & 7) * VEC);
-        }
-        return;
-      }
+    for (int j = 0; j < NV; ++j) {
+      int row, k;
+      coords(stid, j, row, k);
+      off[j] = (unsigned)(((int64_t)row * rs + (int64_t)k * ks) * (int64_t)sizeof(T));
+    }
+  }
+
+  // 16-byte load through a buffer resource: SGPR descriptor (wave-uniform base) + 32-bit VGPR
+  // byte offset (guide T8) — no 64-bit per-lane addresses to compute, keep or spill
+  static __device__ __forceinline__ vec_t bload(const char* base, unsigned off) {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, 0x7FFFFFFF, 0x00020000);
+    u4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+    return __builtin_bit_cast(vec_t, v);
+  }
+
+  // base = byte address of element (row0, k0) of the operand (wave uniform)
+  template <bool EDGE>
+  static __device__ __forceinline__ void load(vec_t (&r)[NV], const char* __restrict__ base,
+                                              const unsigned (&off)[NV], int stid, int64_t rs,
+                                              int64_t ks, int rows, int64_t krem) {
+    if constexpr (MODE == 2) {
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
-        int v = tid + THREADS * j;
-        int row = v >> 3, kv = v & 7;
-        int64_t k = k0 + kv * VEC;
+        int row, k;
+        coords(stid, j, row, k);
         vec_t val = 0;
-        if (row < rows && k < K) val = *reinterpret_cast<const vec_t*>(base + row * rs + k);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          if (row < rows && k + e < krem)
+            val[e] = reinterpret_cast<const T*>(base)[(int64_t)row * rs + (int64_t)(k + e) * ks];
         r[j] = val;
       }
-    } else if constexpr (MODE == 1) {
-      // micro-block = VEC k-rows x VEC contiguous rows; NV/VEC micro-blocks per thread.
-      // Lane -> micro-block map: 8 consecutive lanes walk k (kq = 0..7) at the same row group, so
-      // each global row is still read in full 128-byte lines AND the transposed ds_write_b128 of
-      // an 8-lane group lands in ONE 128-byte LDS row segment (the n-fastest map measured 52 %
-      // of LDS cycles lost to 4-way bank conflicts, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).
-      if (full) {
+    } else if constexpr (!EDGE) {
 #pragma unroll
-        for (int b = 0; b < NV / VEC; ++b) {
-          int mb = tid + THREADS * b;
-          int kq = mb & 7, nq = mb >> 3;  // 8 lanes share a row: conflict-free ds_write_b128
-#pragma unroll
-          for (int i = 0; i < VEC; ++i)
-            r[b * VEC + i] = *reinterpret_cast<const vec_t*>(base + (k0 + kq * VEC + i) * ks +
-                                                             nq * VEC);
-        }
-        return;
-      }
-#pragma unroll
-      for (int b = 0; b < NV / VEC; ++b) {
-        int mb = tid + THREADS * b;
-        int kq = mb & 7, nq = mb >> 3;  // 8 lanes share a row: conflict-free ds_write_b128
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-          int64_t k = k0 + kq * VEC + i;
-          int row = nq * VEC;
-          vec_t val = 0;
-          if (row < rows && k < K) val = *reinterpret_cast<const vec_t*>(base + k * ks + row);
-          r[b * VEC + i] = val;
-        }
-      }
+      for (int j = 0; j < NV; ++j) r[j] = bload(base, off[j]);
     } else {
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
-        int v = tid + THREADS * j;
-        int row = v >> 3, kv = v & 7;
+        int row, k;
+        coords(stid, j, row, k);
         vec_t val = 0;
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-          int64_t k = k0 + kv * VEC + e;
-          if (row < rows && k < K) val[e] = base[row * rs + k * ks];
-        }
+        if (row < rows && k < krem) val = bload(base, off[j]);
         r[j] = val;
       }
     }
   }
 
-  __device__ __forceinline__ void store(char* lds, int tid) const {
+  static __device__ __forceinline__ void store(const vec_t (&r)[NV], char* lds, int stid) {
     if constexpr (MODE == 1) {
 #pragma unroll
       for (int b = 0; b < NV / VEC; ++b) {
-        int mb = tid + THREADS * b;
-        int kq = mb & 7, nq = mb >> 3;  // 8 lanes share a row: conflict-free ds_write_b128
+        int mb = stid + STG * b;
+        int kq = mb & 7, nq = mb >> 3;
 #pragma unroll
         for (int jj = 0; jj < VEC; ++jj) {
           vec_t t;
@@ -156,9 +166,8 @@ struct Stager {
     } else {
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
-        int v = tid + THREADS * j;
-        int row = v >> 3, kv = v & 7;
-        *reinterpret_cast<vec_t*>(lds + row * ROW_BYTES + kv * 16) = r[j];
+        int v = stid + STG * j;
+        *reinterpret_cast<vec_t*>(lds + (v >> 3) * ROW_BYTES + (v & 7) * 16) = r[j];
       }
     }
   }
@@ -181,18 +190,22 @@ template <> __device__ __forceinline__ int frag_row<double>(int lane, int r) {
   return (lane >> 4) + 4 * r;
 }
 
-template <typename T, int AMODE, int BMODE>
-__global__ __launch_bounds__(THREADS, 2) void gemm_kernel(GemmArgs g) {
+template <typename T, int AMODE, int BMODE, bool EDGE>
+__global__ __launch_bounds__(THREADS, 4) void gemm_kernel(GemmArgs g) {
   using Tr = Traits<T>;
   using acc_t = typename Tr::acc_t;
+  using vec_t = typename Tr::vec_t;
+  using frag_t = typename Tr::frag_t;
   constexpr int BK = Tr::BK;
   constexpr int SLAB = (BM + BN) * ROW_BYTES;  // bytes per LDS buffer (A rows then B rows)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;  // 2x2 waves, 64x64 each
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;  // 2x4 waves, 64x32 each
+  const bool stage_a = wave < 4;            // wave-uniform: which operand this wave stages
+  const int stid = tid & (STG - 1);
 
   // XCD-aware bijective remap of the linear workgroup id (speed only), then a grouped
   // row-major walk (8 tile-rows per group) for L2 reuse of the B panels.
@@ -214,150 +227,152 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_kernel(GemmArgs g) {
 
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
   const int64_t z = blockIdx.z;
-  const T* A = static_cast<const T*>(g.A) + z * g.a_bs + m0 * g.a_rs;
-  const T* B = static_cast<const T*>(g.B) + z * g.b_bs + n0 * g.b_cs;
   const int rows_a = (int)((g.M - m0) < BM ? (g.M - m0) : BM);
   const int rows_b = (int)((g.N - n0) < BN ? (g.N - n0) : BN);
 
-  acc_t acc[4][4];
+  // this wave's staging operand: base of its tile rows, strides, slab step in bytes
+  const char* sbase = stage_a
+      ? reinterpret_cast<const char*>(static_cast<const T*>(g.A) + z * g.a_bs + m0 * g.a_rs)
+      : reinterpret_cast<const char*>(static_cast<const T*>(g.B) + z * g.b_bs + n0 * g.b_cs);
+  const int64_t s_rs = stage_a ? g.a_rs : g.b_cs;  // stride between tile rows (m / n)
+  const int64_t s_ks = stage_a ? g.a_cs : g.b_rs;  // stride along k
+  const int s_rows = stage_a ? rows_a : rows_b;
+  const int64_t slab_bytes = (int64_t)BK * s_ks * (int64_t)sizeof(T);
+  unsigned off[NV];
+  if (stage_a) Stage<T, AMODE>::offsets(off, stid, s_rs, s_ks);
+  else Stage<T, BMODE>::offsets(off, stid, s_rs, s_ks);
+
+  acc_t acc[4][2];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0;
+    for (int j = 0; j < 2; ++j) acc[i][j] = 0;
 
-  Stager<T, AMODE> sa;
-  Stager<T, BMODE> sb;
+  // two register staging sets (slab parity): loads of slab t+2 are issued at the start of slab
+  // t and stored to LDS at the end of slab t+1 (load-to-use distance: two slabs)
+  vec_t r0[NV], r1[NV];
   const int nslab = (int)((g.K + BK - 1) / BK);
 
+  auto gload = [&](vec_t (&r)[NV], int t) {
+    const char* base = sbase + (int64_t)t * slab_bytes;
+    const int64_t krem = g.K - (int64_t)t * BK;
+    if (stage_a) Stage<T, AMODE>::template load<EDGE>(r, base, off, stid, s_rs, s_ks, s_rows, krem);
+    else Stage<T, BMODE>::template load<EDGE>(r, base, off, stid, s_rs, s_ks, s_rows, krem);
+  };
+  auto lstore = [&](const vec_t (&r)[NV], int t) {
+    char* nb = smem + (t & 1) * SLAB;
+    // the LDS addresses are a few shifts of stid: recompute them per slab instead of letting
+    // LICM park 4-8 loop-invariant address VGPRs (the kernel sits at the 128-VGPR budget that
+    // buys 4 waves per SIMD; a spilled address is a scratch reload whose s_waitcnt vmcnt also
+    // drains the two-slab-deep prefetch)
+    int s2 = stid;
+    asm volatile("" : "+v"(s2));
+    if (stage_a) Stage<T, AMODE>::store(r, nb, s2);
+    else Stage<T, BMODE>::store(r, nb + BM * ROW_BYTES, s2);
+  };
+
   if (nslab > 0) {
-    sa.load(A, g.a_rs, g.a_cs, 0, rows_a, g.K, tid);
-    sb.load(B, g.b_cs, g.b_rs, 0, rows_b, g.K, tid);
-    sa.store(smem, tid);
-    sb.store(smem + BM * ROW_BYTES, tid);
+    gload(r0, 0);
+    if (nslab > 1) gload(r1, 1);
+    lstore(r0, 0);
   }
   __syncthreads();
 
   // per-lane fragment addressing: lane (i = l & 15, kg = l >> 4) reads 8 bytes at
   // row*144 + kstep*32 + kg*8  (f32: k = 8*kstep + 2*kg + {0,1}; f64: k = 4*kstep + kg)
   const int frag_off = (lane & 15) * ROW_BYTES + (lane >> 4) * 8;
+  const int pa_off = wm * 64 * ROW_BYTES + frag_off;
+  const int pb_off = BM * ROW_BYTES + wn * 32 * ROW_BYTES + frag_off;
 
-  // fp32 only: two-level summation.  Every FLUSH slabs (256 k) the MFMA accumulators are added
-  // into a second accumulator set and cleared, so rounding error grows like
-  // sqrt(256) + sqrt(K/256) instead of sqrt(K): at K = 4096 the Frobenius error vs an fp64
-  // product drops from 1.15e-6 to the blocked-BLAS class (the reference's OpenBLAS sgemm also
-  // sums in blocks), keeping parity inside the 1e-6 bar.  fp64 needs no such help.
-  constexpr bool TWO_LEVEL = (sizeof(T) == 4);
-  constexpr int FLUSH = 8;
-  acc_t acc2[TWO_LEVEL ? 4 : 1][TWO_LEVEL ? 4 : 1];
-  if constexpr (TWO_LEVEL) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc2[i][j] = 0;
-  }
+  // fp32 only: chunked summation.  A 4096-long fp32 fma chain has a Frobenius error of 1.15e-6
+  // against an fp64 product — outside the 1e-6 parity bar (the reference's OpenBLAS sgemm sums in
+  // blocks).  Instead of a second accumulator set (32 more VGPRs would cost the 4-waves-per-SIMD
+  // budget; scratch-resident sums measured -25 % throughput), every CHUNK slabs (2048 k) the
+  // accumulators are folded into the C tile in memory (each lane owns its C elements, so this is
+  // a private read-modify-write) and cleared: chains stay <= 2048 long (0.81e-6 at K = 4096) for
+  // one extra pass over C per 2048 k (+3 % at K = 4096).  fp64 needs no such help.
+  constexpr bool CHUNKED = (sizeof(T) == 4);
+  constexpr int CHUNK = 64;
+  bool flushed = false;
 
-  for (int t = 0; t < nslab; ++t) {
-    const char* bufA = smem + (t & 1) * SLAB;
-    const char* bufB = bufA + BM * ROW_BYTES;
-    const bool more = (t + 1 < nslab);
-    if (more) {
-      sa.load(A, g.a_rs, g.a_cs, (int64_t)(t + 1) * BK, rows_a, g.K, tid);
-      sb.load(B, g.b_cs, g.b_rs, (int64_t)(t + 1) * BK, rows_b, g.K, tid);
-    }
-    {
-      // LDS fragments are double-buffered in registers: the ds_read_b64s of k-step ks+1 are
-      // issued before the MFMAs of k-step ks, so the matrix pipe never waits on LDS latency
-      using frag_t = typename std::conditional<sizeof(T) == 4,
-                                               float __attribute__((ext_vector_type(2))), double>::type;
-      constexpr int NB = sizeof(T) == 4 ? 2 : 1;  // fp64: 128 accumulator VGPRs leave no room
-      frag_t fa[NB][4], fb[NB][4];
-      const char* pa = bufA + wm * 64 * ROW_BYTES + frag_off;
-      const char* pb = bufB + wn * 64 * ROW_BYTES + frag_off;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        fa[0][i] = *reinterpret_cast<const frag_t*>(pa + i * 16 * ROW_BYTES);
-        fb[0][i] = *reinterpret_cast<const frag_t*>(pb + i * 16 * ROW_BYTES);
-      }
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int cur = (NB == 2) ? (ks & 1) : 0, nxt = cur ^ 1;
-        if constexpr (NB == 1) {
-          if (ks > 0) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              fa[0][i] = *reinterpret_cast<const frag_t*>(pa + i * 16 * ROW_BYTES + ks * 32);
-              fb[0][i] = *reinterpret_cast<const frag_t*>(pb + i * 16 * ROW_BYTES + ks * 32);
-            }
-          }
-        } else if (ks + 1 < 4) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            fa[nxt][i] = *reinterpret_cast<const frag_t*>(pa + i * 16 * ROW_BYTES + (ks + 1) * 32);
-            fb[nxt][i] = *reinterpret_cast<const frag_t*>(pb + i * 16 * ROW_BYTES + (ks + 1) * 32);
-          }
-        }
-        if constexpr (sizeof(T) == 4) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) mma(acc[i][j], fa[cur][i].x, fb[cur][j].x);
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) mma(acc[i][j], fa[cur][i].y, fb[cur][j].y);
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) mma(acc[i][j], fa[cur][i], fb[cur][j]);
-        }
-      }
-    }
-    if (more) {
-      char* nb = smem + ((t + 1) & 1) * SLAB;
-      sa.store(nb, tid);
-      sb.store(nb + BM * ROW_BYTES, tid);
-    }
-    __syncthreads();
-    if constexpr (TWO_LEVEL) {
-      if ((t % FLUSH) == FLUSH - 1 && nslab > FLUSH) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            acc2[i][j] += acc[i][j];
-            acc[i][j] = 0;
-          }
-      }
-    }
-  }
-  if constexpr (TWO_LEVEL) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] += acc2[i][j];
-  }
-
-  // ---- epilogue: C = alpha*acc + beta*Cin ----------------------------------------------
   const T alpha = (T)g.alpha, beta = (T)g.beta;
   T* C = static_cast<T*>(g.C) + z * g.c_bs;
   const T* Cin = static_cast<const T*>(g.Cin) + z * g.ci_bs;
   const bool use_cin = (g.beta != 0.0);
+  // C = alpha*acc + (first fold: beta*Cin, later folds: the partial already in C)
+  auto fold = [&](bool first) {
+    // launder the lane id: the 32 element addresses must be recomputed HERE, not hoisted out of
+    // the slab loop as loop invariants (that cost 64+ VGPRs and 111 spills)
+    int l2 = lane;
+    asm volatile("" : "+v"(l2));
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t col = n0 + wn * 64 + j * 16 + (lane & 15);
+      for (int j = 0; j < 2; ++j) {
+        const int64_t col = n0 + wn * 32 + j * 16 + (l2 & 15);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int64_t row = m0 + wm * 64 + i * 16 + frag_row<T>(lane, r);
-        if (row < g.M && col < g.N) {
-          T v = alpha * acc[i][j][r];
-          if (use_cin) v += beta * Cin[row * g.ci_rs + col * g.ci_cs];
-          C[row * g.c_rs + col * g.c_cs] = v;
+        for (int r = 0; r < 4; ++r) {
+          const int64_t row = m0 + wm * 64 + i * 16 + frag_row<T>(l2, r);
+          if (!EDGE || (row < g.M && col < g.N)) {
+            T v = alpha * acc[i][j][r];
+            if (first) {
+              if (use_cin) v += beta * Cin[row * g.ci_rs + col * g.ci_cs];
+            } else {
+              v += C[row * g.c_rs + col * g.c_cs];
+            }
+            C[row * g.c_rs + col * g.c_cs] = v;
+          }
+          acc[i][j][r] = 0;
         }
       }
+  };
+
+  // one slab: prefetch slab t+2 into lr, MFMAs on LDS buffer t&1, stage slab t+1 from ur into
+  // the other LDS buffer, one barrier
+  auto slab = [&](int t, vec_t (&lr)[NV], const vec_t (&ur)[NV]) {
+    const char* buf = smem + (t & 1) * SLAB;
+    if (t + 2 < nslab) gload(lr, t + 2);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      frag_t fa[4], fb[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        fa[i] = *reinterpret_cast<const frag_t*>(buf + pa_off + i * 16 * ROW_BYTES + ks * 32);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        fb[j] = *reinterpret_cast<const frag_t*>(buf + pb_off + j * 16 * ROW_BYTES + ks * 32);
+      if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) mma(acc[i][j], fa[i].x, fb[j].x);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) mma(acc[i][j], fa[i].y, fb[j].y);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) mma(acc[i][j], fa[i], fb[j]);
+      }
     }
+    if (t + 1 < nslab) lstore(ur, t + 1);
+    __syncthreads();
+    if constexpr (CHUNKED) {
+      if ((t % CHUNK) == CHUNK - 1 && t + 1 < nslab) {
+        fold(!flushed);
+        flushed = true;
+      }
+    }
+  };
+
+  for (int t = 0; t < nslab; t += 2) {
+    slab(t, r0, r1);                         // loads slab t+2 (even set), stages t+1
+    if (t + 1 < nslab) slab(t + 1, r1, r0);  // loads slab t+3 (odd set), stages t+2
+  }
+  // ---- epilogue: C = alpha*acc + beta*Cin (or + the partial already folded into C) --------
+  fold(!flushed);
 }
 
 // K == 0 or degenerate: C = beta*Cin
@@ -376,23 +391,30 @@ __global__ void scale_kernel(GemmArgs g) {
   }
 }
 
+// staging mode of one operand (rs = stride between its tile rows, ks = stride along k) and
+// whether 32-bit byte offsets inside a tile are safe
 template <typename T>
 int operand_mode(const void* p, int64_t rs, int64_t ks, int64_t rows, int64_t K, int64_t bs,
                  int64_t batch) {
   constexpr int VEC = Traits<T>::VEC;
+  constexpr int BK = Traits<T>::BK;
   bool aligned = (reinterpret_cast<uintptr_t>(p) % 16 == 0) && (batch <= 1 || bs % VEC == 0);
-  if (ks == 1 && aligned && rs % VEC == 0 && K % VEC == 0) return 0;
-  if (rs == 1 && aligned && ks % VEC == 0 && rows % VEC == 0) return 1;
+  auto fits32 = [&](int64_t span) { return span >= 0 && span * (int64_t)sizeof(T) < (1LL << 31); };
+  if (ks == 1 && aligned && rs % VEC == 0 && K % VEC == 0 && rs >= 0 && fits32(128 * rs + BK))
+    return 0;
+  if (rs == 1 && aligned && ks % VEC == 0 && rows % VEC == 0 && ks >= 0 && fits32(BK * ks + 128))
+    return 1;
   return 2;
 }
 
-template <typename T, int AM, int BMd>
+template <typename T, int AM, int BMd, bool EDGE>
 int launch_gemm(const GemmArgs& g, int64_t batch, hipStream_t s) {
   constexpr size_t lds = 2 * (BM + BN) * ROW_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, AM, BMd>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(gemm_kernel<T, AM, BMd, EDGE>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       ahip_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
       return AHIP_EHIP;
@@ -400,8 +422,27 @@ int launch_gemm(const GemmArgs& g, int64_t batch, hipStream_t s) {
     attr_set = true;
   }
   dim3 grid((unsigned)(g.tiles_m * g.tiles_n), 1, (unsigned)batch);
-  AHIP_LAUNCH((gemm_kernel<T, AM, BMd>), grid, dim3(THREADS), lds, s, g);
+  AHIP_LAUNCH((gemm_kernel<T, AM, BMd, EDGE>), grid, dim3(THREADS), lds, s, g);
   return AHIP_OK;
+}
+
+template <typename T, bool EDGE>
+int dispatch_modes(const GemmArgs& g, int am, int bm, int64_t batch, hipStream_t s) {
+  switch (am * 3 + bm) {
+    case 0: return launch_gemm<T, 0, 0, EDGE>(g, batch, s);
+    case 1: return launch_gemm<T, 0, 1, EDGE>(g, batch, s);
+    case 3: return launch_gemm<T, 1, 0, EDGE>(g, batch, s);
+    case 4: return launch_gemm<T, 1, 1, EDGE>(g, batch, s);
+    default: break;
+  }
+  // any scalar-staged operand: always the predicated instantiation
+  switch (am * 3 + bm) {
+    case 2: return launch_gemm<T, 0, 2, true>(g, batch, s);
+    case 5: return launch_gemm<T, 1, 2, true>(g, batch, s);
+    case 6: return launch_gemm<T, 2, 0, true>(g, batch, s);
+    case 7: return launch_gemm<T, 2, 1, true>(g, batch, s);
+    default: return launch_gemm<T, 2, 2, true>(g, batch, s);
+  }
 }
 
 template <typename T>
@@ -418,17 +459,9 @@ int gemm_dispatch(GemmArgs& g, int64_t batch, hipStream_t s) {
   AHIP_REQUIRE((int64_t)g.tiles_m * g.tiles_n < (1LL << 31), "too many tiles");
   int am = operand_mode<T>(g.A, g.a_rs, g.a_cs, g.M, g.K, g.a_bs, batch);
   int bm = operand_mode<T>(g.B, g.b_cs, g.b_rs, g.N, g.K, g.b_bs, batch);
-  switch (am * 3 + bm) {
-    case 0: return launch_gemm<T, 0, 0>(g, batch, s);
-    case 1: return launch_gemm<T, 0, 1>(g, batch, s);
-    case 2: return launch_gemm<T, 0, 2>(g, batch, s);
-    case 3: return launch_gemm<T, 1, 0>(g, batch, s);
-    case 4: return launch_gemm<T, 1, 1>(g, batch, s);
-    case 5: return launch_gemm<T, 1, 2>(g, batch, s);
-    case 6: return launch_gemm<T, 2, 0>(g, batch, s);
-    case 7: return launch_gemm<T, 2, 1>(g, batch, s);
-    default: return launch_gemm<T, 2, 2>(g, batch, s);
-  }
+  const bool interior = (g.M % BM == 0) && (g.N % BN == 0) && (g.K % Traits<T>::BK == 0);
+  return interior ? dispatch_modes<T, false>(g, am, bm, batch, s)
+                  : dispatch_modes<T, true>(g, am, bm, batch, s);
 }
 
 double host_scalar(int dtype, const void* p) {

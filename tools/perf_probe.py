@@ -112,6 +112,16 @@ def main():
         d, w = timeit(lambda: ext(y, Mt, v), 200)
         report("gemv f64 4096^2 (A.T view)", d, w, 4096 * 4096 * 8 + 2 * 4096 * 8, "GB/s", 8000.0)
 
+    if args.only == "nn32":
+        ex = PlanExecutor(plan_of("cfg3b_gemm_update"), use_graph=G)
+        Cm = torch.zeros(4096, 4096, dtype=f32, device="cuda")
+        A, B = randn((4096, 4096), f32, 3), randn((4096, 4096), f32, 4)
+        d, w = timeit(lambda: ex(Cm, A, B), 30)
+        report("cfg3b gemm f32 4096^3", d, w, 2 * 4096 ** 3, "TFLOP/s", 157.3)
+        At, Bt = A.t().contiguous().t(), B.t().contiguous().t()
+        d, w = timeit(lambda: ex(Cm, A, Bt), 30)
+        report("gemm f32 4096^3 NT(B k-contig)", d, w, 2 * 4096 ** 3, "TFLOP/s", 157.3)
+
     if want("cfg3b"):
         ex = PlanExecutor(plan_of("cfg3b_gemm_update"), use_graph=G)
         Cm = torch.zeros(4096, 4096, dtype=f32, device="cuda")
