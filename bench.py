@@ -52,11 +52,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # test hooks (single-GPU boxes): AESARA_BENCH_BACKEND=gloo + AESARA_BENCH_ONE_DEVICE=1 run
+    # the N>1 control flow (ring slots, bucketed async all-reduce) with every rank on cuda:0
+    backend = os.environ.get("AESARA_BENCH_BACKEND", "nccl")
+    if os.environ.get("AESARA_BENCH_ONE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from golden_util import CASES, case_plan
     from aesara_amd._lib import check, lib
