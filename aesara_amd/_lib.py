@@ -56,6 +56,19 @@ class GvArgs(C.Structure):
     ]
 
 
+AHIP_RP_MAXOPS = 16
+
+
+class RpArgs(C.Structure):
+    _fields_ = [
+        ("N", C.c_int64), ("K", C.c_int64), ("X", C.c_void_p), ("x_rs", C.c_int64),
+        ("w", C.c_void_p),
+        ("ptr", C.c_void_p * AHIP_RP_MAXOPS), ("stride", C.c_int64 * AHIP_RP_MAXOPS),
+        ("col_ws", C.c_void_p), ("red_ws", C.c_void_p),
+        ("nops", C.c_int32), ("nred", C.c_int32),
+    ]
+
+
 vp, i64, i32, u32, sz = C.c_void_p, C.c_int64, C.c_int, C.c_uint32, C.c_size_t
 p_i64 = C.POINTER(C.c_int64)
 p_vp = C.POINTER(C.c_void_p)
@@ -90,6 +103,8 @@ SIGNATURES = {
     "ahip_gemv": (i32, [i32, i64, i64, vp, vp, i64, i64, vp, i64, vp, vp, i64, vp, i64, vp, sz,
                         vp]),
     "ahip_gemv_epilogue": (i32, [vp, C.POINTER(GvArgs), i32, vp]),
+    "ahip_rowpass_grid": (i32, [i64, i32, i32]),
+    "ahip_rowpass": (i32, [vp, C.POINTER(RpArgs), i32, i32, sz, vp]),
     "ahip_ger": (i32, [i32, i64, i64, vp, vp, i64, vp, i64, vp, i64, i64, vp, i64, i64, vp]),
     "ahip_copy_strided": (i32, [i32, i32, p_i64, vp, p_i64, vp, p_i64, i32, vp]),
     "ahip_fill": (i32, [i32, vp, vp, i64, vp]),

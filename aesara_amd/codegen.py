@@ -882,3 +882,181 @@ def generate_gemv_epilogue(spec: GemvEpiSpec):
     L.append("  }")
     L.append("}")
     return "\n".join(L) + "\n", (name,)
+
+
+# ----------------------------------------------------------------------------------------
+# single-pass "row program": y = X.w -> row-wise Elemwise / Sum -> X.T.r, X read ONCE
+# ----------------------------------------------------------------------------------------
+RP_MAXOPS = 16
+RP_MAXRED = 8
+
+RP_STRUCT = r"""
+#define RP_MAXOPS %d
+struct RpArgs {
+  i64 N; i64 K; const void* X; i64 x_rs; const void* w;
+  void* ptr[RP_MAXOPS]; i64 stride[RP_MAXOPS];
+  void* col_ws; void* red_ws;
+  int nops; int nred;
+};
+""" % RP_MAXOPS
+
+
+class RowPassSpec:
+    """One pass over a row-major matrix X (N x K) computing, per row m:
+    ``d = X[m,:] . w``; a scalar program over ``d`` and row-wise operands; full ``Sum``
+    reductions of some of its values (accumulator dtype per CAReduce._acc_dtype); materialised
+    row-wise outputs; and the column accumulation ``g[k] += X[m,k] * r[m]`` (the ``X.T @ r`` of
+    the gradient) while the row is still in registers.
+
+    Replaces, for GLM-shaped graphs such as BASELINE config 5 (logistic logp + grad), the
+    reference's two BLAS2 passes over X (tensor/blas.py:231 Gemv on X and on X.T) plus the
+    Elemwise/Sum nodes between them (X is read twice, 2 x 16 GiB at N = 16M).
+
+    kv        : 16-byte vectors of a row held per lane (K = 64 * VEC * kv)
+    scalar    : merged scalar program; input 0 is the dot result, then the row operands
+    reds      : [(scalar out index, acc dtype)] — Sum reductions
+    col_ref   : scalar out index of r (the column-accumulation weight), or None
+    """
+
+    def __init__(self, dtype, kv, scalar, in_dtypes, out_dtypes, out_refs, reds, col_ref,
+                 rpw=2, block=256):
+        self.dtype, self.kv, self.scalar = dtype, kv, scalar
+        self.in_dtypes, self.out_dtypes, self.out_refs = list(in_dtypes), list(out_dtypes), list(out_refs)
+        self.reds, self.col_ref, self.rpw, self.block = [list(r) for r in reds], col_ref, rpw, block
+        assert len(self.in_dtypes) + len(self.out_dtypes) <= RP_MAXOPS and len(self.reds) <= RP_MAXRED
+
+    def key(self):
+        import json
+        blob = json.dumps(["rp2", self.dtype, self.kv, self.scalar, self.in_dtypes, self.out_dtypes,
+                           self.out_refs, self.reds, self.col_ref, self.rpw, self.block],
+                          sort_keys=True)
+        return hashlib.sha256(blob.encode()).hexdigest()[:24]
+
+
+def generate_rowpass(spec: RowPassSpec):
+    """Wave-level schedule: a wavefront takes R = rpw consecutive rows per iteration (R a power
+    of two <= 16), keeps them in registers, forms R per-lane partial dots, and REDUCE-SCATTERS
+    them across the wave (log2 R halving steps + an all-reduce over the remaining lane bits) so
+    that lane l ends up with the full dot of row (l >> (6 - log2 R)).  Each lane then runs the
+    scalar program for ITS row only (not 64 redundant copies), leaders store/accumulate, and the
+    R column-accumulation weights are broadcast back with v_readlane."""
+    T = RTYPE[spec.dtype]
+    V = 4 if spec.dtype == "float32" else 2
+    KV, R = spec.kv, spec.rpw
+    P = R.bit_length() - 1
+    assert 1 << P == R and P <= 4
+    SH = 6 - P                     # lanes per row group = 1 << SH
+    nin, nout = len(spec.in_dtypes), len(spec.out_dtypes)
+    waves = spec.block // 64
+    name = "rp_" + spec.key()
+    L = [PRELUDE, RP_STRUCT]
+    L.append('extern "C" __global__ __launch_bounds__(%d) void %s(RpArgs a) {' % (spec.block, name))
+    L.append("  const int lane = threadIdx.x & 63;")
+    L.append("  const int wave = threadIdx.x >> 6;")
+    L.append("  const i64 nwaves = (i64)gridDim.x * %d;" % waves)
+    L.append("  const bool leader = (lane & %d) == 0;" % ((1 << SH) - 1))
+    L.append("  const %s* __restrict__ X = (const %s*)a.X;" % (T, T))
+    for v in range(KV):
+        L.append("  const Pack<%s, %d> w%d = *(const Pack<%s, %d>*)((const %s*)a.w + (%d * 64 + lane) * %d);"
+                 % (T, V, v, T, V, T, v, V))
+    if spec.col_ref is not None:
+        for v in range(KV):
+            for e in range(V):
+                L.append("  %s g%d_%d = 0;" % (T, v, e))
+    for j, (_, acc) in enumerate(spec.reds):
+        L.append("  %s racc%d = 0;" % (RTYPE[acc], j))
+    L.append("  for (i64 m0 = ((i64)blockIdx.x * %d + wave) * %d; m0 < a.N; m0 += nwaves * %d) {"
+             % (waves, R, R))
+    for r in range(R):
+        L.append("    const %s* __restrict__ row%d = X + ((m0 + %d < a.N) ? (m0 + %d) : (a.N - 1)) * a.x_rs;"
+                 % (T, r, r, r))
+        for v in range(KV):
+            L.append("    const Pack<%s, %d> x%d_%d = *(const Pack<%s, %d>*)(row%d + (%d * 64 + lane) * %d);"
+                     % (T, V, r, v, T, V, r, v, V))
+    for r in range(R):
+        terms = " + ".join("x%d_%d.v[%d] * w%d.v[%d]" % (r, v, e, v, e)
+                           for v in range(KV) for e in range(V))
+        L.append("    %s p%d = %s;" % (T, r, terms))
+    # reduce-scatter over the top P lane bits
+    cur = ["p%d" % r for r in range(R)]
+    for step in range(P):
+        mask = 32 >> step
+        half = len(cur) // 2
+        L.append("    const bool up%d = (lane & %d) != 0;" % (step, mask))
+        nxt = []
+        for i in range(half):
+            nm = "q%d_%d" % (step, i)
+            L.append("    const %s %s = (up%d ? %s : %s) + shfl_xor_<%s>(up%d ? %s : %s, %d);"
+                     % (T, nm, step, cur[i + half], cur[i], T, step, cur[i], cur[i + half], mask))
+            nxt.append(nm)
+        cur = nxt
+    L.append("    %s d = %s;" % (T, cur[0]))
+    for step in range(P, 6):
+        mask = 32 >> step
+        L.append("    d += shfl_xor_<%s>(d, %d);" % (T, mask))
+    # lane-local epilogue for row (lane >> SH)
+    L.append("    const i64 m = m0 + (lane >> %d);" % SH)
+    L.append("    const bool valid = m < a.N;")
+    L.append("    const i64 mc = valid ? m : (a.N - 1);")
+    ins, in_dts = ["d"], [spec.dtype]
+    for k in range(nin):
+        ct = CTYPE[spec.in_dtypes[k]]
+        L.append("    const %s o%d = ((const %s*)a.ptr[%d])[mc * a.stride[%d]];" % (ct, k, ct, k, k))
+        ins.append("(o%d != 0)" % k if spec.in_dtypes[k] == "bool" else "o%d" % k)
+        in_dts.append(spec.in_dtypes[k])
+    lines, outs, odts = emit_scalar_body(spec.scalar, ins, in_dts, indent="    ")
+    L.extend(lines)
+    if nout:
+        L.append("    if (leader && valid) {")
+        for k, ri in enumerate(spec.out_refs):
+            L.append("      ((%s*)a.ptr[%d])[m * a.stride[%d]] = %s;" %
+                     (CTYPE[spec.out_dtypes[k]], nin + k, nin + k,
+                      _store_val(outs[ri], odts[ri], spec.out_dtypes[k])))
+        L.append("    }")
+    for j, (ri, acc) in enumerate(spec.reds):
+        L.append("    if (leader && valid) racc%d += %s;" % (j, _cast(outs[ri], odts[ri], acc)))
+    if spec.col_ref is not None:
+        L.append("    const %s rmine = %s;" % (T, _cast(outs[spec.col_ref], odts[spec.col_ref], spec.dtype)))
+        for r in range(R):
+            src = r << SH
+            if spec.dtype == "float32":
+                L.append("    const float rr%d = __builtin_bit_cast(float, __builtin_amdgcn_readlane("
+                         "__builtin_bit_cast(int, rmine), %d));" % (r, src))
+            else:
+                L.append("    double rr%d; { union { double dd; int ii[2]; } u; u.dd = rmine; "
+                         "u.ii[0] = __builtin_amdgcn_readlane(u.ii[0], %d); "
+                         "u.ii[1] = __builtin_amdgcn_readlane(u.ii[1], %d); rr%d = u.dd; }"
+                         % (r, src, src, r))
+            L.append("    if (m0 + %d < a.N) {" % r)
+            for v in range(KV):
+                for e in range(V):
+                    L.append("      g%d_%d += x%d_%d.v[%d] * rr%d;" % (v, e, r, v, e, r))
+            L.append("    }")
+    L.append("  }")
+    # ---- fold the waves of the workgroup (fixed order), one partial per workgroup ----
+    L.append("  extern __shared__ __attribute__((aligned(16))) char smem[];")
+    if spec.col_ref is not None:
+        L.append("  %s* sg = (%s*)smem;" % (T, T))
+        for v in range(KV):
+            for e in range(V):
+                L.append("  sg[(i64)wave * a.K + (%d * 64 + lane) * %d + %d] = g%d_%d;" % (v, V, e, v, e))
+    L.append("  double* sr = (double*)(smem + %d * a.K * sizeof(%s));" % (waves, T))
+    for j, (_, acc) in enumerate(spec.reds):
+        L.append("  { double t = (double)racc%d; for (int s = 32; s > 0; s >>= 1) "
+                 "t += shfl_xor_<double>(t, s); if (lane == 0) sr[wave * %d + %d] = t; }"
+                 % (j, RP_MAXRED, j))
+    L.append("  __syncthreads();")
+    if spec.col_ref is not None:
+        L.append("  for (i64 k = threadIdx.x; k < a.K; k += %d) {" % spec.block)
+        L.append("    %s s = sg[k];" % T)
+        L.append("    for (int wv = 1; wv < %d; ++wv) s += sg[(i64)wv * a.K + k];" % waves)
+        L.append("    ((%s*)a.col_ws)[(i64)blockIdx.x * a.K + k] = s;" % T)
+        L.append("  }")
+    if spec.reds:
+        L.append("  if (threadIdx.x < %d) {" % len(spec.reds))
+        L.append("    double s = sr[threadIdx.x];")
+        L.append("    for (int wv = 1; wv < %d; ++wv) s += sr[wv * %d + threadIdx.x];" % (waves, RP_MAXRED))
+        L.append("    ((double*)a.red_ws)[(i64)blockIdx.x * %d + threadIdx.x] = s;" % len(spec.reds))
+        L.append("  }")
+    L.append("}")
+    return "\n".join(L) + "\n", (name,)

@@ -144,4 +144,24 @@ int ahip_gemv_epilogue(ahip_fn_t k, const ahip_gv_args* args, int block, void* s
                             as_stream(stream), args, sizeof(*args));
 }
 
+int ahip_rowpass_grid(int64_t N, int block, int rows_per_wave) {
+  if (N <= 0 || block < 64 || rows_per_wave < 1) return 0;
+  int waves = block / 64;
+  int64_t want = (N + (int64_t)waves * rows_per_wave - 1) / ((int64_t)waves * rows_per_wave);
+  int64_t cap = (int64_t)ahip_cu_count() * 8;
+  if (want > cap) want = cap;
+  return (int)want;
+}
+
+int ahip_rowpass(ahip_fn_t k, const ahip_rp_args* args, int block, int rows_per_wave,
+                 size_t shmem_bytes, void* stream) {
+  AHIP_REQUIRE(k && args, "null argument");
+  AHIP_REQUIRE(block >= 64 && block % 64 == 0, "bad block");
+  AHIP_REQUIRE(args->nops >= 0 && args->nops <= AHIP_RP_MAXOPS, "bad nops");
+  int grid = ahip_rowpass_grid(args->N, block, rows_per_wave);
+  if (grid <= 0) return AHIP_OK;
+  return ahip_launch_module(k->fn, dim3((unsigned)grid, 1, 1), dim3(block, 1, 1), shmem_bytes,
+                            as_stream(stream), args, sizeof(*args));
+}
+
 }  // extern "C"

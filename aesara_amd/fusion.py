@@ -46,6 +46,9 @@ class Step:
     alive: bool = True
     dots: List[List[int]] = field(default_factory=list)  # gemv_epi: [A var, x var] per dot;
     #                               the scalar's first len(dots) inputs are the dot results
+    extra: Dict[str, Any] = field(default_factory=dict)  # rowpass: reds, col_ref, ws vars
+    post: List["Step"] = field(default_factory=list)     # rowpass: fold steps run after it
+    fallback: List["Step"] = field(default_factory=list)  # rowpass: the unfused original steps
 
 
 def _inline_constants(step: Step, plan: Plan):
@@ -170,6 +173,7 @@ def build_steps(plan: Plan, fuse: bool = True) -> List[Step]:
     steps = [s for s in steps if s.alive]
     if fuse:
         steps = _drop_dead(plan, _fuse_dots(plan, steps))
+        steps = _fuse_rowpass(plan, steps)
     return steps
 
 
@@ -288,3 +292,136 @@ def split_invariant(plan: Plan, invariant_inputs: List[int]):
     loop = Plan(plan.name + "_loop", plan.vars, list(plan.inputs) + hoisted, list(plan.outputs),
                 loop_nodes)
     return pre, loop, hoisted
+
+
+def _fuse_rowpass(plan: Plan, steps: List[Step]) -> List[Step]:
+    """GLM pattern  z = X.w (+ epilogue) -> row-wise Elemwise / full Sum -> X.T.r  ==>  one
+    single-pass "rowpass" step (X read once) + deterministic folds of its per-workgroup partials.
+
+    The reference graph of BASELINE config 5 reads X twice (Gemv on X, Gemv on
+    X.T); whenever every step between the two is row-wise the linker can legally keep each row
+    in registers for both contractions."""
+    from .codegen import RP_MAXOPS, RP_MAXRED
+
+    producer_step = {}
+    for s in steps:
+        for o in list(s.outputs) + ([s.reduce["out"]] if s.reduce else []):
+            producer_step[o] = s
+    for i1, g1 in enumerate(steps):
+        if g1.kind != "gemv_epi" or len(g1.dots) != 1:
+            continue
+        xv, wv = g1.dots[0]
+        if plan.vars[xv].ndim != 2:
+            continue
+        # G2: a single dot over DimShuffle{1,0}(X)
+        for i2 in range(i1 + 1, len(steps)):
+            g2 = steps[i2]
+            if g2.kind not in ("gemv_epi", "rowdot"):
+                continue
+            d2 = g2.dots if g2.kind == "gemv_epi" else [list(g2.inputs)]
+            if len(d2) != 1:
+                continue
+            xt, rv = d2[0]
+            ds = producer_step.get(xt)
+            if not (ds is not None and ds.kind == "node" and ds.node.op == "DimShuffle"
+                    and ds.node.params["new_order"] == [1, 0] and ds.inputs == [xv]):
+                continue
+            fused = _build_rowpass(plan, steps, i1, i2, xv, wv, rv, RP_MAXOPS, RP_MAXRED)
+            if fused is not None:
+                return fused
+    return steps
+
+
+def _build_rowpass(plan, steps, i1, i2, xv, wv, rv, max_ops, max_red):
+    g1, g2 = steps[i1], steps[i2]
+    dt = plan.vars[xv].dtype
+    group, produced = [g1], set(g1.outputs)
+    outside = []
+    for s in steps[i1 + 1:i2]:
+        ins = set(s.inputs) | {v for d in s.dots for v in d}
+        if ins & produced:
+            ok = s.kind in ("elemwise", "reduce") and not s.dots and \
+                all(plan.vars[v].ndim <= 1 for v in s.inputs) and \
+                all(plan.vars[o].ndim == 1 for o in s.outputs)
+            if s.kind == "reduce":
+                r = s.reduce
+                ok = ok and r["scalar_op"] == "add" and (r["axis"] is None or r["axis"] == [0]) \
+                    and r["acc_dtype"] in ("float32", "float64")
+            if not ok:
+                return None
+            group.append(s)
+            produced |= set(s.outputs) | ({s.reduce["out"]} if s.reduce else set())
+        else:
+            outside.append(s)
+    if rv not in produced or plan.vars[rv].dtype != dt:
+        return None
+    # ---- merge the group's scalar programs: input 0 = the dot, then external row operands ----
+    ext, nodes, ref_of = [], [], {}
+
+    def slot(v):
+        if v not in ext:
+            ext.append(v)
+        return ["i", 1 + ext.index(v)]
+
+    def absorb(st, in_refs):
+        base = len(nodes)
+
+        def rr(r):
+            if r[0] == "i":
+                return list(in_refs[r[1]])
+            if r[0] == "t":
+                return ["t", r[1] + base]
+            return list(r)
+        for n in st.scalar["nodes"]:
+            nodes.append({"op": n["op"], "dtype": n["dtype"], "in": [rr(r) for r in n["in"]]})
+        return [rr(r) for r in st.scalar["out"]]
+
+    reds = []
+    for st in group:
+        in_refs = ([["i", 0]] if st is g1 else []) + \
+            [ref_of[v] if v in ref_of else slot(v) for v in st.inputs]
+        outs = absorb(st, in_refs)
+        for o, k in zip(st.outputs, st.out_refs):
+            ref_of[o] = outs[k]
+        if st.reduce:
+            reds.append((outs[st.reduce["ref"]], st.reduce["acc_dtype"], st.reduce["out"]))
+    if len(reds) > max_red:
+        return None
+    # which group-produced vectors must be materialised (consumers outside the fused group)
+    users = {}
+    for s in steps:
+        if s in group or s is g2:
+            continue
+        for v in list(s.inputs) + [v for d in s.dots for v in d]:
+            users.setdefault(v, []).append(s)
+    g2_other = set(g2.inputs) if g2.kind == "gemv_epi" else set()
+    mat = [v for st in group for v in st.outputs
+           if v in users or v in plan.outputs or v in g2_other]
+    if len(ext) + len(mat) > max_ops:
+        return None
+    scalar_out = [ref_of[v] for v in mat] + [r[0] for r in reds] + [ref_of[rv]]
+    scalar = {"n_in": 1 + len(ext), "nodes": nodes, "out": scalar_out}
+    n_mat = len(mat)
+    col_ws = plan.new_var(dt, [None, None], name="rowpass_col_ws")
+    d_var = plan.new_var(dt, [None], name="rowpass_xt_r")
+    red_ws = [plan.new_var("float64", [None], name="rowpass_red_ws") for _ in reds]
+    ident = {"n_in": 1, "nodes": [], "out": [["i", 0]]}
+    post = [Step("reduce", [col_ws], [], ident, out_refs=[],
+                 reduce={"scalar_op": "add", "axis": [0], "acc_dtype": "float64", "out": d_var,
+                         "ref": 0})]
+    if g2.kind == "gemv_epi":
+        post.append(Step("elemwise", [d_var] + list(g2.inputs), list(g2.outputs), g2.scalar,
+                         out_refs=list(g2.out_refs)))
+    else:
+        post.append(Step("elemwise", [d_var], list(g2.outputs), ident, out_refs=[0]))
+    for (ref, acc, out), wsv in zip(reds, red_ws):
+        post.append(Step("reduce", [wsv], [], ident, out_refs=[],
+                         reduce={"scalar_op": "add", "axis": None, "acc_dtype": "float64",
+                                 "out": out, "ref": 0}))
+    rp = Step("rowpass", list(ext), list(mat), scalar, out_refs=list(range(n_mat)),
+              dots=[[xv, wv]],
+              extra={"reds": [[n_mat + j, acc] for j, (_, acc, _) in enumerate(reds)],
+                     "col_ref": n_mat + len(reds), "col_ws": col_ws, "red_ws": red_ws,
+                     "dtype": dt},
+              post=post, fallback=group + [g2])
+    return steps[:i1] + outside + [rp] + steps[i2 + 1:]

@@ -84,6 +84,20 @@ typedef struct ahip_gv_args {
   int32_t ndots; int32_t nops;
 } ahip_gv_args;
 
+/* Kernel-argument block of the GENERATED single-pass "row program" kernels
+ *   extern "C" __global__ void k(ahip_rp_args a);       (codegen.generate_rowpass)
+ * per row m of the row-major N x K matrix X: d = X[m,:].w, a scalar program over d and the
+ * row-wise operands, Sum partials of some of its values, and the column accumulation
+ * g[k] += X[m,k] * r[m]; one partial per workgroup goes to col_ws [grid][K] / red_ws [grid][nred]. */
+#define AHIP_RP_MAXOPS 16
+typedef struct ahip_rp_args {
+  int64_t N; int64_t K; const void* X; int64_t x_rs; const void* w;
+  void* ptr[AHIP_RP_MAXOPS];      /* row-wise operands: inputs then materialised outputs   */
+  int64_t stride[AHIP_RP_MAXOPS]; /* element stride along the row index (0 = broadcast)    */
+  void* col_ws; void* red_ws;
+  int32_t nops; int32_t nred;
+} ahip_rp_args;
+
 typedef struct ahip_device_info {
   int32_t device;
   int32_t cu_count;
@@ -190,6 +204,14 @@ int ahip_gemv(int dtype, int64_t M, int64_t N, const void* alpha, const void* A,
  * and the Elemwise consuming them (tensor/elemwise.py:304) — e.g. one GRU gate of the Scan
  * inner graph (scan/op.py:637) — without materialising the intermediate vectors.            */
 int ahip_gemv_epilogue(ahip_fn_t k, const ahip_gv_args* args, int block, void* stream);
+/* Single-pass GLM row program (generated kernel `k`): replaces Gemv(X, w) -> Elemwise / Sum ->
+ * Gemv(X.T, r) (tensor/blas.py:231 twice + tensor/elemwise.py:304/1221 in between; BASELINE
+ * config 5) reading X once.  `grid` workgroups each leave one partial in col_ws / red_ws, folded
+ * afterwards by the ordinary reduction kernels (deterministic).  Returns the grid it will use
+ * for (N, block) when k == NULL (to size the workspaces).                                      */
+int ahip_rowpass_grid(int64_t N, int block, int rows_per_wave);
+int ahip_rowpass(ahip_fn_t k, const ahip_rp_args* args, int block, int rows_per_wave,
+                 size_t shmem_bytes, void* stream);
 /* A_out[M,N] = A_in + alpha * x[M] y[N]^T */
 int ahip_ger(int dtype, int64_t M, int64_t N, const void* alpha, const void* x, int64_t incx,
              const void* y, int64_t incy, const void* A_in, int64_t ai_rs, int64_t ai_cs,

@@ -40,11 +40,18 @@ def test_cfg2_fuses_to_one_kernel():
     assert ops == ["sqr", "sub", "sqr", "mul", "true_div", "exp"]
 
 
-def test_cfg5_reduce_fusion_keeps_shared_intermediate():
+def test_cfg5_fuses_to_single_pass_rowpass():
+    """BASELINE config 5 (14 reference nodes, X read twice): ONE row-program kernel that reads X
+    once + folds of its per-workgroup partials; the unfused steps are kept as the fallback."""
     steps = build_steps(case_plan(_case("cfg5_logistic")))
-    reds = [s for s in steps if s.kind == "reduce"]
-    assert len(reds) == 2
-    # r = y*(1-sigmoid(z)) - ... feeds both Gemv and Sum: it must stay materialised
+    rp = [s for s in steps if s.kind == "rowpass"]
+    assert len(rp) == 1 and not any(s.kind in ("gemv_epi", "reduce") for s in steps)
+    rp = rp[0]
+    assert rp.outputs == []                       # z and r never leave the kernel
+    assert len(rp.extra["reds"]) == 2             # logp and d/db partial sums (fp64)
+    assert [q.kind for q in rp.post] == ["reduce", "elemwise", "reduce", "reduce"]
+    reds = [s for s in rp.fallback if s.kind == "reduce"]
+    # in the unfused form r feeds both Gemv and Sum: it must stay materialised there
     assert sorted(len(s.outputs) for s in reds) == [0, 1]
 
 
