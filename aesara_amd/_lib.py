@@ -116,11 +116,6 @@ SIGNATURES = {
     "ahip_list_length": (i32, [vp]),
     "ahip_list_run": (i32, [vp, vp]),
     "ahip_list_destroy": (i32, [vp]),
-    "ahip_list_begin": (i32, []),
-    "ahip_list_end": (i32, [p_vp]),
-    "ahip_list_length": (i32, [vp]),
-    "ahip_list_run": (i32, [vp, vp]),
-    "ahip_list_destroy": (i32, [vp]),
     "ahip_graph_begin": (i32, [vp]),
     "ahip_graph_end": (i32, [vp, p_vp]),
     "ahip_graph_launch": (i32, [vp, vp]),

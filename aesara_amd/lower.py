@@ -341,11 +341,28 @@ def _register_handlers():
 
     @hip_lower.register(SpecifyShape)
     def _(op, node, ctx):
-        ctx.emit("SpecifyShape", node)
+        # reference: tensor/shape.py:376 SpecifyShape(x, *shape) (perform :439); unknown dims
+        # are NoneConst inputs and are dropped here ("dims" lists the checked positions)
+        from aesara.graph.basic import Constant
+        dims, ins = [], [node.inputs[0]]
+        for d, sv in enumerate(node.inputs[1:]):
+            if isinstance(sv, Constant) and sv.data is None:
+                continue
+            dims.append(d)
+            ins.append(sv)
+        ctx.emit("SpecifyShape", node, {"dims": dims, "ndim": len(node.inputs) - 1}, inputs=ins)
 
     @hip_lower.register(ViewOp)
     def _(op, node, ctx):
         ctx.emit("ViewOp", node)
+
+    from aesara.raise_op import CheckAndRaise
+
+    @hip_lower.register(CheckAndRaise)
+    def _(op, node, ctx):
+        # reference: raise_op.py:28 CheckAndRaise / Assert (perform :94): a view of its first
+        # input that raises ``exc_type(msg)`` unless every 0-d condition is true
+        ctx.emit("Assert", node, {"msg": str(op.msg), "exc_type": op.exc_type.__name__})
 
     @hip_lower.register(DeepCopyOp)
     def _(op, node, ctx):
@@ -397,19 +414,23 @@ def _register_handlers():
     @hip_lower.register(Scan)
     def _(op, node, ctx):
         # reference: scan/op.py:637 Scan; info layout scan/op.py:206 ScanInfo.  The inner
-        # fgraph is lowered recursively; the executor owns the step loop (K10).
+        # fgraph is lowered recursively; the executor owns the step loop (K10).  All output
+        # kinds are carried: mit-mot (gradient accumulators of Scan.L_op, op.py:2379), mit-sot,
+        # sit-sot, nit-sot, shared (scan updates) and the do-while condition (scan/utils.py until).
         info = op.info
-        if info.n_mit_mot or info.as_while or info.n_shared_outs:
-            raise UnsupportedOp("Scan with mit-mot / while / shared outputs (SURVEY §7 hard part 6)")
         inner_fg = op.fgraph.clone()
         if ctx.inner_rewriter is not None:
             ctx.inner_rewriter.rewrite(inner_fg)
         inner = lower_fgraph(inner_fg, name="scan_inner", inner_rewriter=ctx.inner_rewriter)
         ctx.emit("Scan", node, {
             "n_seqs": info.n_seqs,
+            "mit_mot_in_slices": [list(map(int, t)) for t in info.mit_mot_in_slices],
+            "mit_mot_out_slices": [list(map(int, t)) for t in info.mit_mot_out_slices],
             "mit_sot_in_slices": [list(map(int, t)) for t in info.mit_sot_in_slices],
             "sit_sot_in_slices": [list(map(int, t)) for t in info.sit_sot_in_slices],
             "n_nit_sot": info.n_nit_sot,
+            "n_shared_outs": info.n_shared_outs,
             "n_non_seqs": info.n_non_seqs,
+            "as_while": bool(info.as_while),
             "inner": inner,
         })

@@ -256,15 +256,6 @@ int ahip_list_end(ahip_list_t* out);
 int ahip_list_length(ahip_list_t l);
 int ahip_list_run(ahip_list_t l, void* stream);
 int ahip_list_destroy(ahip_list_t l);
-/* Launch list: between begin and end, every kernel launch issued by ahip_* calls on THIS THREAD is
- * recorded (kernel, grid, kernarg copy) instead of executed.  ahip_list_run re-issues them with
- * plain launches from one host call (no per-node Python/ctypes cost, no graph-launch latency);
- * run it inside ahip_graph_begin/end to turn the same list into a hipGraph for long lists.    */
-int ahip_list_begin(void);
-int ahip_list_end(ahip_list_t* out);
-int ahip_list_length(ahip_list_t l);
-int ahip_list_run(ahip_list_t l, void* stream);
-int ahip_list_destroy(ahip_list_t l);
 int ahip_graph_begin(void* stream);
 int ahip_graph_end(void* stream, ahip_graph_t* out);
 int ahip_graph_launch(ahip_graph_t g, void* stream);

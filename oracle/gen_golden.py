@@ -465,6 +465,83 @@ def _():
                                               K(-1.0, "float64")]
 
 
+# do-while scans (tests/scan/test_basic.py test_while0 / test_while1 / test_while_infershape)
+@case("scan_while_cumsum", rtol=1e-12, atol=1e-12)
+def _():
+    from aesara.scan.utils import until
+    x = at.dvector("x")
+    res, _ = ae.scan(lambda x_t, s: (s + x_t, until(s + x_t > 3.0)), sequences=[x],
+                     outputs_info=[at.as_tensor_variable(np.float64(0.0))])
+    return [x], [res, res[-1], res.shape[0]], [U((40,), seed=3, low=0.1, high=0.9)]
+
+
+@case("scan_while_never_stops", rtol=1e-12, atol=1e-12)
+def _():
+    from aesara.scan.utils import until
+    x = at.dvector("x")
+    res, _ = ae.scan(lambda x_t, s: (s + x_t, until(s + x_t > 1e9)), sequences=[x],
+                     outputs_info=[at.as_tensor_variable(np.float64(0.0))])
+    return [x], [res], [U((17,), seed=4)]
+
+
+@case("scan_while_nitsot_matrix", rtol=1e-12, atol=1e-12)
+def _():
+    from aesara.scan.utils import until
+    x, W, h0 = at.dmatrix("x"), at.dmatrix("W"), at.dvector("h0")
+
+    def step(x_t, h, W):
+        hn = at.tanh(at.dot(W, h) + x_t)
+        return [hn, (hn ** 2).sum()], until((hn ** 2).sum() > 2.5)
+    (hs, en), _ = ae.scan(step, sequences=[x], outputs_info=[h0, None], non_sequences=[W])
+    return [x, W, h0], [hs, en, hs.shape[0]], \
+        [N((30, 6), seed=1), N((6, 6), seed=2, scale=0.5), K(0.0, "float64", (6,))]
+
+
+# gradients through Scan: Scan.L_op (scan/op.py:2379) builds a reversed Scan with mit-mot
+# accumulators (tests/scan/test_basic.py test_grad_one_output / test_grad_multiple_outs_taps)
+@case("scan_grad_rnn", rtol=1e-11, atol=1e-11)
+def _():
+    x, h0, W = at.dmatrix("x"), at.dvector("h0"), at.dmatrix("W")
+    hs, _ = ae.scan(lambda x_t, h, W: at.tanh(at.dot(h, W) + x_t), sequences=[x],
+                    outputs_info=[h0], non_sequences=[W])
+    cost = (hs ** 2).sum()
+    return [x, h0, W], [cost] + list(ae.grad(cost, [W, h0, x])), \
+        [N((9, 5), seed=1), N((5,), seed=2), N((5, 5), seed=3, scale=0.4)]
+
+
+@case("scan_grad_taps", rtol=1e-11, atol=1e-11)
+def _():
+    x, init, w = at.dvector("x"), at.dvector("init"), at.dscalar("w")
+    res, _ = ae.scan(lambda x_t, a, b, w: at.tanh(w * a + 0.5 * b) + x_t, sequences=[x],
+                     outputs_info=[dict(initial=init, taps=[-2, -1])], non_sequences=[w])
+    cost = (res * res).sum()
+    return [x, init, w], [cost] + list(ae.grad(cost, [x, init, w])), \
+        [N((11,), seed=1, scale=0.3), N((2,), seed=2), K(0.7, "float64")]
+
+
+@case("scan_grad_last_state_f32", rtol=2e-5, atol=2e-5)
+def _():
+    x, h0, W, U_ = at.fmatrix("x"), at.fvector("h0"), at.fmatrix("W"), at.fmatrix("U")
+    hs, _ = ae.scan(lambda x_t, h, W, U_: at.tanh(at.dot(x_t, W) + at.dot(h, U_)),
+                    sequences=[x], outputs_info=[h0], non_sequences=[W, U_])
+    cost = hs[-1].sum()
+    return [x, h0, W, U_], [cost] + list(ae.grad(cost, [W, U_, h0])), \
+        [N((12, 8), "float32", 1), N((16,), "float32", 2), N((8, 16), "float32", 3, 0.3),
+         N((16, 16), "float32", 4, 0.25)]
+
+
+# CheckAndRaise / SpecifyShape views (raise_op.py:28, tensor/shape.py:376)
+@case("assert_specify_shape", exact=True)
+def _():
+    from aesara.raise_op import Assert
+    x, n = at.dmatrix("x"), at.lscalar("n")
+    a = Assert("n must be positive")(x, at.gt(n, 0))
+    b = at.specify_shape(x, (None, 5))
+    return [x, n], [a + 1.0, b * 2.0, at.specify_shape(x, (n, None)).sum(axis=0)], \
+        [N((4, 5), seed=1), K(4, "int64")]
+
+
+
 def _gru(dt, T_, H, B_, tol):
     def mk():
         x = T(dt, (2, 2) if B_ == 1 else (2, 2, 2), "x")

@@ -227,12 +227,18 @@ def _resolve_idx(idx_list, extra):
 
 
 def scan(p, inputs, run_inner):
-    """reference: scan/op.py:1673 Scan.perform / scan_perform.pyx:71 (sit-sot, mit-sot,
-    nit-sot, sequences, non-sequences; circular output buffers of length ``store_steps``)."""
+    """reference: scan/op.py:1673 Scan.perform / scan_perform.pyx:71 — sequences, mit-mot
+    (op.py:1954-1991), mit-sot / sit-sot with circular buffers of length ``store_steps``, nit-sot,
+    shared outputs (op.py:1833-1844, 2094-2100), non-sequences and the do-while condition
+    (op.py:1947-1949, truncation :2139-2159)."""
     n_seqs = p["n_seqs"]
+    mm_in = [list(t) for t in p.get("mit_mot_in_slices", [])]
+    mm_out = [list(t) for t in p.get("mit_mot_out_slices", [])]
     mit = p["mit_sot_in_slices"]
     sit = p["sit_sot_in_slices"]
     n_nit = p["n_nit_sot"]
+    n_sh = p.get("n_shared_outs", 0)
+    as_while = p.get("as_while", False)
     n_steps = int(np.asarray(inputs[0]))
     if n_steps < 0:
         raise IndexError(f"Scan was asked to run for negative number of step {n_steps}")
@@ -241,39 +247,76 @@ def scan(p, inputs, run_inner):
         if sq.shape[0] < n_steps:
             raise ValueError(f"Sequence {k} has shape {sq.shape} but the Scan's required "
                              f"number of steps is {n_steps}")
-    n_rec = len(mit) + len(sit)
-    rec_init = inputs[1 + n_seqs:1 + n_seqs + n_rec]
-    nit_len = [int(np.asarray(v)) for v in inputs[1 + n_seqs + n_rec:1 + n_seqs + n_rec + n_nit]]
-    non_seqs = inputs[1 + n_seqs + n_rec + n_nit:]
-    taps = [list(t) for t in mit] + [list(t) for t in sit]
+    n_mm = len(mm_in)
+    taps = mm_in + [list(t) for t in mit] + [list(t) for t in sit]
+    n_rec = len(taps)
+    o = 1 + n_seqs
+    rec_init = inputs[o:o + n_rec]
+    shared = list(inputs[o + n_rec:o + n_rec + n_sh])
+    o += n_rec + n_sh
+    nit_len = [int(np.asarray(v)) for v in inputs[o:o + n_nit]]
+    non_seqs = inputs[o + n_nit:]
     mintaps = [min(t) for t in taps] + [0] * n_nit
     outs = [np.array(v, copy=True) for v in rec_init] + [None] * n_nit
     store = [v.shape[0] for v in rec_init] + nit_len
     if n_steps == 0:
-        return outs[:n_rec] + [None] * n_nit
+        # op.py:1753-1762: nit-sot outputs are empty, shared outputs are left unset (None)
+        return outs[:n_rec] + [None] * n_nit + [None] * n_sh
     pos = [(-mintaps[k]) % store[k] for k in range(n_rec + n_nit)]
-    for i in range(n_steps):
+    n_mm_outs = sum(len(t) for t in mm_out)
+    i, cond = 0, True
+    while i < n_steps and cond:
         args = [sq[i] for sq in seqs]
         for k in range(n_rec):
             for t in taps[k]:
                 args.append(outs[k][(pos[k] + t) % store[k]].copy())
+        args.extend(shared)
         args.extend(non_seqs)
         res = run_inner(args)
-        for k in range(n_rec):
-            outs[k][pos[k]] = res[k]
+        if as_while:
+            cond = np.asarray(res[n_mm_outs + (n_rec - n_mm) + n_nit + n_sh]) == 0
+        ro = 0
+        for g in range(n_mm):
+            for sl in mm_out[g]:
+                outs[g][sl + pos[g]] = res[ro]
+                ro += 1
+        for k in range(n_mm, n_rec):
+            outs[k][pos[k]] = res[ro]
+            ro += 1
         for j in range(n_nit):
             k = n_rec + j
             if i == 0:
-                outs[k] = np.empty((store[k],) + np.shape(res[k]), dtype=np.asarray(res[k]).dtype)
-            outs[k][pos[k]] = res[k]
+                outs[k] = np.empty((store[k],) + np.shape(res[ro]), dtype=np.asarray(res[ro]).dtype)
+            outs[k][pos[k]] = res[ro]
+            ro += 1
+        shared = [np.asarray(r) for r in res[ro:ro + n_sh]]
         pos = [(pp + 1) % st for pp, st in zip(pos, store)]
-    # rotate circular buffers into chronological order (op.py:2115-2150)
-    for k in range(n_rec + n_nit):
-        if store[k] < n_steps - mintaps[k] and pos[k] < store[k]:
+        i += 1
+    # rotate circular buffers into chronological order (op.py:2105-2134); zero / truncate the
+    # part a do-while that stopped early (or truncated BPTT) never wrote (op.py:2139-2159)
+    for k in range(n_mm, n_rec + n_nit):
+        if store[k] < i - mintaps[k] and pos[k] < store[k]:
             outs[k] = np.concatenate([outs[k][pos[k]:], outs[k][:pos[k]]], axis=0)
-        elif store[k] > n_steps - mintaps[k]:
-            outs[k][n_steps - mintaps[k]:] = 0
-    return outs
+        elif store[k] > i - mintaps[k]:
+            outs[k][i - mintaps[k]:] = 0
+            if i < n_steps:
+                outs[k] = outs[k][:-(n_steps - i)]
+    return outs + shared
+
+
+def specify_shape_check(xshape, p, given):
+    """reference: tensor/shape.py:439-450; ``p["dims"]`` = positions whose size is given
+    (older plans carry no "dims": every given value is positional from 0)."""
+    dims = p.get("dims", list(range(len(given))))
+    ndim = p.get("ndim", len(xshape))
+    want = [None] * ndim
+    for d, s in zip(dims, given):
+        want[d] = s
+    if len(xshape) != ndim:
+        raise AssertionError(f"SpecifyShape: Got {len(xshape)} dimensions (shape {tuple(xshape)}), "
+                             f"expected {ndim} dimensions with shape {tuple(want)}.")
+    if not all(xs == s for xs, s in zip(xshape, want) if s is not None):
+        raise AssertionError(f"SpecifyShape: Got shape {tuple(xshape)}, expected {tuple(want)}.")
 
 
 def run_plan(plan, inputs):
@@ -333,7 +376,18 @@ def run_plan(plan, inputs):
         elif op == "Join":
             ax = int(np.asarray(a[0]))
             r = [np.concatenate(a[1:], axis=ax).astype(ov[0].dtype)]
-        elif op in ("ScalarFromTensor", "TensorFromScalar", "ViewOp", "SpecifyShape"):
+        elif op == "SpecifyShape":
+            # reference: tensor/shape.py:439 SpecifyShape.perform
+            specify_shape_check(np.shape(a[0]), p, [int(np.asarray(v)) for v in a[1:]])
+            r = [a[0]]
+        elif op in ("ScalarFromTensor", "TensorFromScalar", "ViewOp"):
+            r = [a[0]]
+        elif op == "Assert":
+            # reference: raise_op.py:94 CheckAndRaise.perform
+            if not np.all([np.asarray(c) for c in a[1:]]):
+                import builtins
+                exc = getattr(builtins, p.get("exc_type", "AssertionError"), AssertionError)
+                raise exc(p.get("msg", ""))
             r = [a[0]]
         elif op == "DeepCopyOp":
             r = [np.array(a[0], copy=True)]

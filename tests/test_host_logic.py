@@ -111,12 +111,16 @@ def test_dry_run_shapes_and_kernel_generation(c):
     """Full host path (fusion, broadcasting, views, dim collapsing, kernel specs, hiprtc
     cross-compilation of every generated kernel) with launches recorded instead of executed;
     output shapes/dtypes must equal the reference's."""
-    ex = PlanExecutor(case_plan(c), dry_run=True)
+    plan = case_plan(c)
+    ex = PlanExecutor(plan, dry_run=True)
     outs = ex(*case_inputs(c))
+    # a do-while Scan's trip count is data dependent: the dry run (no values) runs n_steps
+    data_dependent = any(n.op == "Scan" and n.params.get("as_while") for n in plan.nodes)
     for o, e in zip(outs, case_expected(c)):
         shape = o.shape if isinstance(o, DevArray) else np.shape(o)
         dtype = o.dtype if isinstance(o, DevArray) else np.asarray(o).dtype.name
-        assert tuple(shape) == e.shape and dtype == e.dtype.name
+        assert dtype == e.dtype.name and len(shape) == e.ndim
+        assert data_dependent or tuple(shape) == e.shape
     assert all(name.startswith("ahip_") for name in ex.trace)
 
 
