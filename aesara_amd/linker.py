@@ -58,6 +58,15 @@ class HipLinker(JITLinker):
         self.executor = ex
         return ex
 
+    def make_all(self, *args, **kwargs):
+        """``JITLinker.make_all`` (link/basic.py:684-747) plus one change: the input cells handed
+        to ``Function`` accept device tensors as they are (``sharedvar.DeviceContainer``), so an
+        ``updates=`` output is stored back into its shared variable without leaving HBM."""
+        from .sharedvar import DeviceContainer
+
+        fn, ins, outs, thunks, nodes = super().make_all(*args, **kwargs)
+        return fn, [DeviceContainer.adopt(c) for c in ins], outs, thunks, nodes
+
     def create_thunk_inputs(self, storage_map):
         return [storage_map[n] for n in self.fgraph.inputs]
 

@@ -67,6 +67,58 @@ def test_shared_variable_updates(ae):
     assert ops == ["Gemm"]
 
 
+def test_device_shared_variable_state_stays_on_device(ae):
+    """with ``hip_shared`` the check_blas update pattern never converts the
+    state to a host array: the storage cell holds a torch tensor before and after each call,
+    the thunk receives it as is, and the update output is stored back as is."""
+    import torch
+    import aesara.tensor as at
+    import interp
+    from aesara.compile.mode import Mode
+    from aesara.tensor.type import TensorType
+    from aesara_amd.linker import HIP_QUERY, HipLinker
+    from aesara_amd.sharedvar import hip_shared
+    seen = []
+
+    def factory(plan):
+        def run(*a):
+            seen.append([type(x) for x in a])
+            outs = interp.run_plan(plan, [x.numpy() if isinstance(x, torch.Tensor) else x
+                                          for x in a])
+            return [torch.from_numpy(np.ascontiguousarray(o)) for o in outs]
+        return run
+
+    rng = np.random.default_rng(0)
+    Av, Bv = (rng.standard_normal((8, 8)).astype("float32") for _ in range(2))
+    A, B = hip_shared(Av, device="cpu"), hip_shared(Bv, device="cpu")
+    C = hip_shared(np.zeros((8, 8), "float32"), name="C", device="cpu")
+    assert type(C.type) is TensorType and isinstance(C.container.value, torch.Tensor)
+    f = ae.function([], [], updates=[(C, np.float32(0.4) * C + np.float32(0.8) * at.dot(A, B))],
+                    mode=Mode(HipLinker(executor_factory=factory), HIP_QUERY))
+    want = np.zeros((8, 8), "float32")
+    for _ in range(3):
+        f()
+        want = np.float32(0.4) * want + np.float32(0.8) * (Av @ Bv)
+        assert isinstance(C.container.value, torch.Tensor)       # never became an ndarray
+    assert len(seen) == 3 and all(t is torch.Tensor for call in seen for t in call)
+    got = C.get_value()
+    assert isinstance(got, np.ndarray)
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
+    # host values are filtered by the reference's TensorType.filter, then uploaded
+    C.set_value(np.ones((8, 8), "float32"))
+    assert isinstance(C.get_value(borrow=True, return_internal_type=True), torch.Tensor)
+    with pytest.raises(TypeError):
+        C.set_value(torch.zeros(8, dtype=torch.float32))            # rank
+    with pytest.raises(TypeError):
+        C.set_value(torch.zeros((8, 8), dtype=torch.float64))       # dtype
+    # explicit inputs: device tensors pass with trust_input (reference types.py:851-856)
+    x = at.dvector("x")
+    g = ae.function([x], (x * 2.0).sum(),
+                    mode=Mode(HipLinker(executor_factory=factory), HIP_QUERY))
+    g.trust_input = True
+    assert float(g(torch.arange(5, dtype=torch.float64))) == 20.0
+
+
 def test_linker_clone_and_scan_inner_mode(ae):
     """Linker.clone(allow_gc=…) is used by Scan/Mode.clone (link/basic.py:190)."""
     from aesara_amd.linker import HipLinker
