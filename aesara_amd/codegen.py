@@ -107,18 +107,33 @@ template <typename T> __device__ __forceinline__ T fmin_nan(T x, T y) { return (
 template <typename T> __device__ __forceinline__ T imax(T x, T y) { return x > y ? x : y; }
 template <typename T> __device__ __forceinline__ T imin(T x, T y) { return x < y ? x : y; }
 // x / c for a loop-invariant c with r = 1/c precomputed: Markstein refinement gives the correctly
-// rounded quotient whenever r is finite/non-zero and q does not overflow; otherwise fall back.
-__device__ __forceinline__ double fdiv_inv(double x, double c, double r) {
-  const double q = x * r;
-  const double e = fma(-q, c, x);
-  const double res = fma(e, r, q);
-  return (fabs(q) < INFINITY && fabs(r) < INFINITY && r != 0.0) ? res : x / c;
+// rounded quotient when c and r are normal numbers (ok: hoisted, wave-uniform) and nothing
+// overflowed (a non-finite q or residual makes res non-finite); otherwise the full division.
+__device__ __forceinline__ bool recip_ok(double c, double r) {
+  return fabs(c) >= 2.2250738585072014e-308 && fabs(c) < INFINITY &&
+         fabs(r) >= 2.2250738585072014e-308 && fabs(r) < INFINITY;
 }
-__device__ __forceinline__ float fdiv_inv(float x, float c, float r) {
+__device__ __forceinline__ bool recip_ok(float c, float r) {
+  return fabsf(c) >= 1.17549435e-38f && fabsf(c) < INFINITY &&
+         fabsf(r) >= 1.17549435e-38f && fabsf(r) < INFINITY;
+}
+__device__ __forceinline__ double fdiv_inv(double x, double c, double r, bool ok) {
+  const double q = x * r;
+  double res = fma(fma(-q, c, x), r, q);
+  if (__builtin_expect(!(ok && fabs(res) < INFINITY), 0)) {
+    asm volatile("" ::: "memory");   // keep the full division out of line (no if-conversion)
+    res = x / c;
+  }
+  return res;
+}
+__device__ __forceinline__ float fdiv_inv(float x, float c, float r, bool ok) {
   const float q = x * r;
-  const float e = fmaf(-q, c, x);
-  const float res = fmaf(e, r, q);
-  return (fabsf(q) < INFINITY && fabsf(r) < INFINITY && r != 0.0f) ? res : x / c;
+  float res = fmaf(fmaf(-q, c, x), r, q);
+  if (__builtin_expect(!(ok && fabsf(res) < INFINITY), 0)) {
+    asm volatile("" ::: "memory");
+    res = x / c;
+  }
+  return res;
 }
 __device__ __forceinline__ float sigmoid_(float x) { return 1.0f / (1.0f + expf(-x)); }   // Sigmoid :1110
 __device__ __forceinline__ double sigmoid_(double x) { return 1.0 / (1.0 + exp(-x)); }
@@ -510,8 +525,9 @@ def generate(spec: KernelSpec):
                 dt = spec.scalar["nodes"][k]["dtype"]
                 rname = None
                 if k in divisors and _is_float(dt):
-                    rname = "r%d_inv" % k
-                    L.append("  const %s %s = (%s)1 / t%d_inv;" % (RTYPE[dt], rname, RTYPE[dt], k))
+                    rname = "r%d_inv, ok%d_inv" % (k, k)
+                    L.append("  const %s r%d_inv = (%s)1 / t%d_inv;" % (RTYPE[dt], k, RTYPE[dt], k))
+                    L.append("  const bool ok%d_inv = recip_ok(t%d_inv, r%d_inv);" % (k, k, k))
                 hoisted[k] = ("t%d_inv" % k, rname)
 
     def loads(elem_off_exprs, sfx=""):

@@ -69,7 +69,7 @@ def main():
         rows.append(r)
         print(json.dumps(r), flush=True)
 
-    want = lambda n: (not args.only) or args.only in n  # noqa: E731
+    want = lambda n: (not args.only) or any(t in n for t in args.only.split(","))  # noqa: E731
     f64, f32 = torch.float64, torch.float32
     G = bool(args.graph)
 
