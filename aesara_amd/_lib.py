@@ -111,6 +111,7 @@ SIGNATURES = {
     "ahip_take_rows": (i32, [i32, vp, i64, i64, i64, vp, i32, i64, i64, vp, i64, vp, vp]),
     "ahip_scatter_rows": (i32, [i32, vp, i64, i64, i64, vp, i32, i64, i64, vp, i64, i32, vp,
                                 vp]),
+    "ahip_argmax_rows": (i32, [i32, vp, i64, i64, i64, i64, vp, vp]),
     "ahip_list_begin": (i32, []),
     "ahip_list_end": (i32, [p_vp]),
     "ahip_list_length": (i32, [vp]),

@@ -159,6 +159,55 @@ int dispatch(int which, int dtype, int idx_dtype, IdxArgs& a, hipStream_t s) {
   }
 }
 
+// ---- row argmax (np.argmax semantics: first maximum; a NaN is the maximum; first NaN wins) ----
+template <typename T> __device__ __forceinline__ bool is_nan_(T) { return false; }
+template <> __device__ __forceinline__ bool is_nan_<float>(float v) { return v != v; }
+template <> __device__ __forceinline__ bool is_nan_<double>(double v) { return v != v; }
+
+// (a, ia) beats (b, ib): larger value, NaN above everything, ties -> lower index
+template <typename T>
+__device__ __forceinline__ bool beats(T a, int64_t ia, T b, int64_t ib) {
+  const bool na = is_nan_(a), nb = is_nan_(b);
+  if (na || nb) return na && (!nb || ia < ib);
+  return a > b || (a == b && ia < ib);
+}
+
+struct ArgmaxArgs { const void* x; int64_t* out; int64_t nrows, k, x_rs, x_cs; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void argmax_rows_kernel(ArgmaxArgs a) {
+  const T* __restrict__ x = static_cast<const T*>(a.x);
+  const int lane = threadIdx.x & 63;
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < a.nrows;
+       r += nwaves) {
+    const T* row = x + r * a.x_rs;
+    T best = row[0];
+    int64_t bi = 0;
+    for (int64_t j = lane; j < a.k; j += 64) {
+      const T v = row[j * a.x_cs];
+      if (beats(v, j, best, bi)) { best = v; bi = j; }
+    }
+    for (int m = 32; m > 0; m >>= 1) {
+      union { T t; int i[2]; } u; u.i[0] = u.i[1] = 0; u.t = best;
+      union { int64_t t; int i[2]; } w; w.t = bi;
+      u.i[0] = __shfl_xor(u.i[0], m, 64);
+      if (sizeof(T) == 8) u.i[1] = __shfl_xor(u.i[1], m, 64);
+      w.i[0] = __shfl_xor(w.i[0], m, 64); w.i[1] = __shfl_xor(w.i[1], m, 64);
+      if (beats(u.t, w.t, best, bi)) { best = u.t; bi = w.t; }
+    }
+    if (lane == 0) a.out[r] = bi;
+  }
+}
+
+template <typename T>
+int run_argmax(ArgmaxArgs& a, hipStream_t s) {
+  int64_t want = (a.nrows + 3) / 4, cap = (int64_t)ahip_cu_count() * 8;
+  if (want > cap) want = cap;
+  AHIP_LAUNCH((argmax_rows_kernel<T>), dim3((unsigned)want), dim3(256), 0, s, a);
+  return AHIP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -184,6 +233,29 @@ int ahip_scatter_rows(int dtype, void* dst, int64_t nrows, int64_t dst_rs, int64
   AHIP_REQUIRE(dst != nullptr || nrows == 0, "null dst");
   IdxArgs a{src, dst, idx, nrows, src_rs, dst_rs, row_elems, nidx, idx_stride, bad_index};
   return dispatch(accumulate ? 1 : 2, dtype, idx_dtype, a, as_stream(stream));
+}
+
+int ahip_argmax_rows(int dtype, const void* x, int64_t nrows, int64_t k, int64_t x_rs, int64_t x_cs,
+                     int64_t* out, void* stream) {
+  AHIP_REQUIRE(nrows >= 0 && k >= 0, "negative extent");
+  if (nrows == 0) return AHIP_OK;
+  AHIP_REQUIRE(k > 0, "attempt to get argmax of an empty sequence");
+  AHIP_REQUIRE(x && out, "null argument");
+  ArgmaxArgs a{x, out, nrows, k, x_rs, x_cs};
+  hipStream_t s = as_stream(stream);
+  switch (dtype) {
+    case AHIP_BOOL: case AHIP_U8: return run_argmax<uint8_t>(a, s);
+    case AHIP_I8: return run_argmax<int8_t>(a, s);
+    case AHIP_I16: return run_argmax<int16_t>(a, s);
+    case AHIP_I32: return run_argmax<int32_t>(a, s);
+    case AHIP_I64: return run_argmax<int64_t>(a, s);
+    case AHIP_U16: return run_argmax<uint16_t>(a, s);
+    case AHIP_U32: return run_argmax<uint32_t>(a, s);
+    case AHIP_U64: return run_argmax<uint64_t>(a, s);
+    case AHIP_F32: return run_argmax<float>(a, s);
+    case AHIP_F64: return run_argmax<double>(a, s);
+    default: ahip_set_error("bad dtype %d", dtype); return AHIP_EINVAL;
+  }
 }
 
 }  // extern "C"

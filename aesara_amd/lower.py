@@ -156,6 +156,12 @@ class _Ctx:
         self.vmap[v] = vid
         return vid
 
+    def raw(self, opname, in_vids, dtype, shape, params=None):
+        """Append a node on plan variables directly (decompositions); returns the output id."""
+        out = self.plan.new_var(dtype, list(shape), None)
+        self.plan.nodes.append(Node(opname, list(in_vids), [out], params or {}))
+        return out
+
     def emit(self, opname, node, params=None, inputs=None):
         ins = [self.vid(i) for i in (node.inputs if inputs is None else inputs)]
         outs = [self.new(o) for o in node.outputs]
@@ -410,6 +416,117 @@ def _register_handlers():
         # reference: tensor/subtensor.py:2128 AdvancedIncSubtensor1(x, y, ilist)
         ctx.emit("AdvancedIncSubtensor1", node, {
             "set_instead_of_inc": bool(op.set_instead_of_inc), "inplace": bool(op.inplace)})
+
+    # ---- Softmax family: decomposed into the plan's own primitives (max / exp-sum / normalise);
+    # the fusion pass merges them into row kernels.  Accumulation in fp64 for fp32 inputs like
+    # the reference's C loops (tensor/special.py:393 ``double sum_exp_dev``).
+    from aesara.tensor.special import LogSoftmax, Softmax, SoftmaxGrad
+
+    def _sx(n_in, nodes, out):
+        return {"n_in": n_in, "out": [out],
+                "nodes": [{"op": o, "dtype": d, "in": i} for o, d, i in nodes]}
+
+    def _row_axes(op, x):
+        nd = x.type.ndim
+        axes = list(range(nd)) if op.axis is None else [int(op.axis) % nd]
+        shape = _static_shape(x.type)
+        red = [sh for d, sh in enumerate(shape) if d not in axes]
+        keep_order, j = [], 0
+        for d in range(nd):
+            if d in axes:
+                keep_order.append("x")
+            else:
+                keep_order.append(j)
+                j += 1
+        kshape = [1 if d in axes else sh for d, sh in enumerate(shape)]
+        return axes, shape, red, kshape, keep_order
+
+    def _row_reduce(ctx, vid, sop, axes, red, kshape, order, dtype, acc):
+        r = ctx.raw("CAReduce", [vid], dtype, red,
+                    {"scalar_op": sop, "axis": axes, "acc_dtype": acc})
+        return ctx.raw("DimShuffle", [r], dtype, kshape, {"new_order": order})
+
+    def _float_only(op, x):
+        if x.type.dtype not in ("float32", "float64"):
+            raise UnsupportedOp(f"{type(op).__name__} on dtype {x.type.dtype}")
+        return x.type.dtype
+
+    @hip_lower.register(Softmax)
+    def _(op, node, ctx):
+        # reference: tensor/special.py:239 Softmax (perform :268 scipy.special.softmax; C :372-415)
+        x = node.inputs[0]
+        dt = _float_only(op, x)
+        axes, shape, red, kshape, order = _row_axes(op, x)
+        xv = ctx.vid(x)
+        m = _row_reduce(ctx, xv, "maximum", axes, red, kshape, order, dt, dt)
+        e = ctx.raw("Elemwise", [xv, m], dt, shape, {"scalar": _sx(
+            2, [("sub", dt, [["i", 0], ["i", 1]]), ("exp", dt, [["t", 0]])], ["t", 1])})
+        ssum = _row_reduce(ctx, e, "add", axes, red, kshape, order, "float64", "float64")
+        out = ctx.raw("Elemwise", [e, ssum], dt, shape, {"scalar": _sx(
+            2, [("reciprocal", "float64", [["i", 1]]), ("mul", "float64", [["i", 0], ["t", 0]]),
+                ("cast", dt, [["t", 1]])], ["t", 2])})
+        ctx.vmap[node.outputs[0]] = out
+
+    @hip_lower.register(LogSoftmax)
+    def _(op, node, ctx):
+        # reference: tensor/special.py:508 LogSoftmax (perform :537; C :640-740):
+        # xdev = x - max(x); out = xdev - log(sum(exp(xdev)))
+        x = node.inputs[0]
+        dt = _float_only(op, x)
+        axes, shape, red, kshape, order = _row_axes(op, x)
+        xv = ctx.vid(x)
+        m = _row_reduce(ctx, xv, "maximum", axes, red, kshape, order, dt, dt)
+        e = ctx.raw("Elemwise", [xv, m], dt, shape, {"scalar": _sx(
+            2, [("sub", dt, [["i", 0], ["i", 1]]), ("exp", dt, [["t", 0]])], ["t", 1])})
+        ssum = _row_reduce(ctx, e, "add", axes, red, kshape, order, "float64", "float64")
+        out = ctx.raw("Elemwise", [xv, m, ssum], dt, shape, {"scalar": _sx(
+            3, [("sub", dt, [["i", 0], ["i", 1]]), ("log", "float64", [["i", 2]]),
+                ("cast", dt, [["t", 1]]), ("sub", dt, [["t", 0], ["t", 2]])], ["t", 3])})
+        ctx.vmap[node.outputs[0]] = out
+
+    @hip_lower.register(SoftmaxGrad)
+    def _(op, node, ctx):
+        # reference: tensor/special.py:26 SoftmaxGrad (perform :39):
+        # dx = dy*sm - sum(dy*sm, axis, keepdims) * sm
+        dy, sm = node.inputs
+        dt = _float_only(op, node.outputs[0])
+        if dy.type.dtype != dt or sm.type.dtype != dt:
+            raise UnsupportedOp("SoftmaxGrad with mixed dtypes")
+        axes, shape, red, kshape, order = _row_axes(op, node.outputs[0])
+        dv, sv = ctx.vid(dy), ctx.vid(sm)
+        p = ctx.raw("Elemwise", [dv, sv], dt, shape, {"scalar": _sx(
+            2, [("mul", dt, [["i", 0], ["i", 1]])], ["t", 0])})
+        ssum = _row_reduce(ctx, p, "add", axes, red, kshape, order, "float64", "float64")
+        out = ctx.raw("Elemwise", [p, ssum, sv], dt, shape, {"scalar": _sx(
+            3, [("cast", dt, [["i", 1]]), ("mul", dt, [["t", 0], ["i", 2]]),
+                ("sub", dt, [["i", 0], ["t", 1]])], ["t", 2])})
+        ctx.vmap[node.outputs[0]] = out
+
+    from aesara.tensor.math import Argmax, MaxAndArgmax
+
+    def _argmax_axes(op, x):
+        nd = x.type.ndim
+        if op.axis is None:
+            return list(range(nd))
+        return sorted(int(a) % nd for a in op.axis)
+
+    @hip_lower.register(Argmax)
+    def _(op, node, ctx):
+        # reference: tensor/math.py:330 Argmax (perform :388)
+        ctx.emit("Argmax", node, {"axis": _argmax_axes(op, node.inputs[0])})
+
+    @hip_lower.register(MaxAndArgmax)
+    def _(op, node, ctx):
+        # reference: tensor/math.py:126 MaxAndArgmax (perform :163): both outputs of one pass
+        x = node.inputs[0]
+        axes = _argmax_axes(op, x)
+        xv = ctx.vid(x)
+        red = [sh for d, sh in enumerate(_static_shape(x.type)) if d not in axes]
+        mx = ctx.raw("CAReduce", [xv], x.type.dtype, red,
+                     {"scalar_op": "maximum", "axis": axes, "acc_dtype": x.type.dtype})
+        am = ctx.raw("Argmax", [xv], "int64", red, {"axis": axes})
+        ctx.vmap[node.outputs[0]] = mx
+        ctx.vmap[node.outputs[1]] = am
 
     @hip_lower.register(Scan)
     def _(op, node, ctx):

@@ -242,6 +242,11 @@ int ahip_scatter_rows(int dtype, void* dst, int64_t nrows, int64_t dst_rs, int64
                       const void* idx, int idx_dtype, int64_t nidx, int64_t idx_stride,
                       const void* src, int64_t src_rs, int accumulate, int64_t* bad_index,
                       void* stream);
+/* Row argmax, replaces tensor/math.py:330 Argmax (perform :388: np.argmax over the reduced axes
+ * moved last and flattened).  x is viewed as [nrows, k] with element strides x_rs / x_cs; out[r]
+ * = index of the first maximum of row r; a NaN counts as the maximum (first NaN wins).         */
+int ahip_argmax_rows(int dtype, const void* x, int64_t nrows, int64_t k, int64_t x_rs, int64_t x_cs,
+                     int64_t* out, void* stream);
 
 /* ---- H1/K10: launch-list capture & replay (the CVM analogue) --------------------------------
  * replaces: link/vm.py:388 Loop.__call__ / link/c/c_code/lazylinker_c.c:752 CLazyLinker_call and

@@ -568,6 +568,50 @@ case("gru_b1_f64", rtol=1e-11, atol=1e-11)(_gru("float64", 10, 24, 1, 1e-11))
 
 
 # ---------------------------------------------------------------------------------------
+# Softmax family and Argmax (tests/tensor/test_special.py TestSoftmax/TestLogSoftmax/
+# TestSoftmaxGrad; tests/tensor/test_math.py TestMaxAndArgmax)
+# ---------------------------------------------------------------------------------------
+for _dt, _tol in (("float64", 1e-12), ("float32", 3e-5)):
+    def _mk(dt=_dt):
+        from aesara.tensor.special import log_softmax, softmax
+        x, t3 = T(dt, (2, 2), "x"), T(dt, (2, 2, 2), "t3")
+        return [x, t3], [softmax(x, axis=-1), softmax(x, axis=0), softmax(t3, axis=1),
+                         log_softmax(x, axis=-1), log_softmax(t3, axis=0),
+                         at.log(softmax(x, axis=1))], \
+            [N((9, 40), dt, 1, 3.0), N((4, 5, 6), dt, 2, 2.0)]
+    case(f"softmax_family_{_dt}", rtol=_tol, atol=_tol)(_mk)
+
+    def _mkn(dt=_dt):
+        # axis=None: the reference's C code needs np.MAXDIMS (gone in NumPy 2) -> Python linker
+        from aesara.tensor.special import log_softmax, softmax
+        t3 = T(dt, (2, 2, 2), "t3")
+        return [t3], [softmax(t3, axis=None), log_softmax(t3, axis=None)], \
+            [N((4, 5, 6), dt, 2, 2.0)]
+    case(f"softmax_axis_none_{_dt}", rtol=_tol, atol=_tol, ref_py=True)(_mkn)
+
+    def _mkg(dt=_dt):
+        from aesara.tensor.special import log_softmax, softmax
+        x, w = T(dt, (2, 2), "x"), T(dt, (2, 2), "w")
+        c1 = (softmax(x, axis=-1) * w).sum()
+        c2 = (log_softmax(x, axis=0) * w).sum()
+        return [x, w], [ae.grad(c1, x), c1, ae.grad(c2, x)], \
+            [N((6, 17), dt, 3, 2.0), N((6, 17), dt, 4)]
+    case(f"softmax_grad_{_dt}", rtol=_tol * 3, atol=_tol * 3)(_mkg)
+
+
+@case("argmax_axes", exact=True)
+def _():
+    x, m, v = at.dtensor3("x"), at.imatrix("m"), at.dvector("v")
+    b = at.matrix("b", dtype="bool")
+    mx, am = at.max_and_argmax(m, axis=1)
+    return [x, m, v, b], [at.argmax(x, axis=None), at.argmax(x, axis=0), at.argmax(x, axis=2),
+                          at.argmax(x, axis=[0, 2]), at.argmax(x.dimshuffle(2, 0, 1), axis=1),
+                          mx, am, at.argmax(v), at.argmax(b, axis=0), at.argmax(m.T, axis=1)], \
+        [I((5, 6, 7), "float64", 1, -3, 3), I((9, 130), "int32", 2, -50, 50),
+         {"kind": "normal_with_nan", "shape": [301], "dtype": "float64", "seed": 7},
+         B((5, 9), 3, 0.3)]
+
+# ---------------------------------------------------------------------------------------
 # BASELINE.json configs at reduced shapes
 # ---------------------------------------------------------------------------------------
 @case("cfg1a_scalar_add", exact=True)

@@ -304,6 +304,17 @@ def scan(p, inputs, run_inner):
     return outs + shared
 
 
+def argmax(x, axes):
+    """reference: tensor/math.py:388 Argmax.perform — kept axes in front, reduced axes flattened
+    last, np.argmax over the last axis, int64 result."""
+    x = np.asarray(x)
+    keep = [i for i in range(x.ndim) if i not in axes]
+    t = np.transpose(x, keep + list(axes))
+    kept_shape = t.shape[:len(keep)]
+    flat = t.reshape(kept_shape + (int(np.prod(t.shape[len(keep):])),))
+    return np.asarray(np.argmax(flat, axis=-1), dtype="int64")
+
+
 def specify_shape_check(xshape, p, given):
     """reference: tensor/shape.py:439-450; ``p["dims"]`` = positions whose size is given
     (older plans carry no "dims": every given value is positional from 0)."""
@@ -389,6 +400,8 @@ def run_plan(plan, inputs):
                 exc = getattr(builtins, p.get("exc_type", "AssertionError"), AssertionError)
                 raise exc(p.get("msg", ""))
             r = [a[0]]
+        elif op == "Argmax":
+            r = [argmax(a[0], p["axis"])]
         elif op == "DeepCopyOp":
             r = [np.array(a[0], copy=True)]
         elif op == "Shape_i":

@@ -27,6 +27,11 @@ def make_input(spec):
         a = rng.integers(spec["low"], spec["high"], base_shape)
     elif kind == "bernoulli":
         a = rng.random(base_shape) < spec.get("p", 0.5)
+    elif kind == "normal_with_nan":
+        # a few NaNs and repeated maxima: argmax / max NaN and tie handling
+        a = np.round(rng.standard_normal(base_shape) * 2.0)
+        flat = a.reshape(-1)
+        flat[rng.integers(0, flat.size, 3) + flat.size // 2 - flat.size // 2] = np.nan
     elif kind == "const":
         a = np.full(base_shape, spec["value"])
     elif kind == "perm":
