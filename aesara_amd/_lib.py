@@ -69,6 +69,14 @@ class RpArgs(C.Structure):
     ]
 
 
+AHIP_RC_MAXOPS = 16
+
+
+class RcArgs(C.Structure):
+    _fields_ = [("N", C.c_int64), ("K", C.c_int64), ("ptr", C.c_void_p * AHIP_RC_MAXOPS),
+                ("rs", C.c_int64 * AHIP_RC_MAXOPS)]
+
+
 vp, i64, i32, u32, sz = C.c_void_p, C.c_int64, C.c_int, C.c_uint32, C.c_size_t
 p_i64 = C.POINTER(C.c_int64)
 p_vp = C.POINTER(C.c_void_p)
@@ -105,6 +113,7 @@ SIGNATURES = {
     "ahip_gemv_epilogue": (i32, [vp, C.POINTER(GvArgs), i32, vp]),
     "ahip_rowpass_grid": (i32, [i64, i32, i32]),
     "ahip_rowpass": (i32, [vp, C.POINTER(RpArgs), i32, i32, sz, vp]),
+    "ahip_rowchain": (i32, [vp, C.POINTER(RcArgs), i32, i32, vp]),
     "ahip_ger": (i32, [i32, i64, i64, vp, vp, i64, vp, i64, vp, i64, i64, vp, i64, i64, vp]),
     "ahip_copy_strided": (i32, [i32, i32, p_i64, vp, p_i64, vp, p_i64, i32, vp]),
     "ahip_fill": (i32, [i32, vp, vp, i64, vp]),

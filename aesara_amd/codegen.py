@@ -1076,3 +1076,168 @@ def generate_rowpass(spec: RowPassSpec):
         L.append("  }")
     L.append("}")
     return "\n".join(L) + "\n", (name,)
+
+
+# ----------------------------------------------------------------------------------------
+# row-chain kernels: a chain of last-axis reductions and the Elemwise steps between them
+# (softmax, log-softmax, softmax gradient, mean/variance normalisation ...) in ONE pass
+# ----------------------------------------------------------------------------------------
+RC_MAXOPS = 16
+
+RC_STRUCT = r"""
+#define RC_MAXOPS %d
+struct RcArgs { i64 N; i64 K; void* ptr[RC_MAXOPS]; i64 rs[RC_MAXOPS]; };
+""" % RC_MAXOPS
+
+
+class RowChainSpec:
+    """Rows of an [N, K] space (K = the last, contiguous axis) processed by sub-wave groups of
+    ``L`` lanes (L a power of two <= 64, 64 / L rows per wavefront); a lane keeps ``nch`` packs
+    of ``V`` consecutive elements of every full operand in registers, so each operand is read
+    from HBM exactly once and every intermediate between the reductions stays in registers.
+
+    Replaces the separate passes the reference makes for such chains — e.g. Softmax.c_code
+    (tensor/special.py:372-415: max pass, exp+sum pass, scale pass over the output) or the
+    CAReduce / DimShuffle / Elemwise node sequence a hand-written normalisation lowers to
+    (tensor/elemwise.py:1495, :222, :725).
+
+    ext      : [(dtype, cls)] external operands; cls "f" full [N, K], "r" per-row [N, 1],
+               "c" per-column [1, K], "s" scalar
+    members  : the chain in execution order; each {"scalar", "ins", "reduce", "stores"} with
+               ins[i] = ["e", k] | ["f", member, scalar-out index] | ["r", member];
+               reduce = None | {"op", "acc", "out", "ref", "slot"}; stores = [[out index, dtype,
+               slot]] (slots index RcArgs.ptr after the external operands)
+    """
+
+    def __init__(self, ext, members, L, V, nch, block=256):
+        self.ext = [list(e) for e in ext]
+        self.members, self.L, self.V, self.nch, self.block = members, L, V, nch, block
+        assert L in (1, 2, 4, 8, 16, 32, 64) and block % 64 == 0
+
+    def key(self):
+        import json
+        blob = json.dumps(["rc1", self.ext, self.members, self.L, self.V, self.nch, self.block],
+                          sort_keys=True)
+        return hashlib.sha256(blob.encode()).hexdigest()[:24]
+
+
+def generate_rowchain(spec: RowChainSpec):
+    L_, V, NCH = spec.L, spec.V, spec.nch
+    rpw = 64 // L_
+    waves = spec.block // 64
+    name = "rc_" + spec.key()
+    S = [PRELUDE, RC_STRUCT]
+    S.append('extern "C" __global__ __launch_bounds__(%d) void %s(RcArgs a) {' % (spec.block, name))
+    S.append("  const int lane = threadIdx.x & 63;")
+    S.append("  const int sub = lane & %d;" % (L_ - 1))
+    S.append("  const int grp = lane >> %d;" % (L_.bit_length() - 1))
+    S.append("  const i64 nwaves = (i64)gridDim.x * %d;" % waves)
+    for c in range(NCH):
+        S.append("  const i64 col%d = ((i64)%d + sub) * %d;" % (c, c * L_, V))
+        S.append("  const bool ok%d = col%d < a.K;" % (c, c))
+    for k, (dt, cls) in enumerate(spec.ext):
+        ct = CTYPE[dt]
+        if cls == "s":
+            S.append("  const %s sc%d = *(const %s*)a.ptr[%d];" % (ct, k, ct, k))
+        elif cls == "c":
+            for c in range(NCH):
+                S.append("  Pack<%s, %d> co%d_%d = {}; if (ok%d) co%d_%d = *(const Pack<%s, %d>*)"
+                         "((const %s*)a.ptr[%d] + col%d);" % (ct, V, k, c, c, k, c, ct, V, ct, k, c))
+    S.append("  for (i64 rb = ((i64)blockIdx.x * %d + (threadIdx.x >> 6)) * %d; rb < a.N; "
+             "rb += nwaves * %d) {" % (waves, rpw, rpw))
+    S.append("    const i64 row = rb + grp;")
+    S.append("    const bool rv = row < a.N;")
+    S.append("    const i64 rr = rv ? row : a.N - 1;")
+    for k, (dt, cls) in enumerate(spec.ext):
+        ct = CTYPE[dt]
+        if cls == "f":
+            S.append("    const %s* __restrict__ xp%d = (const %s*)a.ptr[%d] + rr * a.rs[%d];"
+                     % (ct, k, ct, k, k))
+            for c in range(NCH):
+                S.append("    Pack<%s, %d> x%d_%d = {}; if (ok%d) x%d_%d = *(const Pack<%s, %d>*)"
+                         "(xp%d + col%d);" % (ct, V, k, c, c, k, c, ct, V, k, c))
+        elif cls == "r":
+            S.append("    const %s ro%d = ((const %s*)a.ptr[%d])[rr * a.rs[%d]];" % (ct, k, ct, k, k))
+
+    def ext_expr(k, c, j):
+        dt, cls = spec.ext[k]
+        e = {"f": "x%d_%d.v[%d]" % (k, c, j), "r": "ro%d" % k, "c": "co%d_%d.v[%d]" % (k, c, j),
+             "s": "sc%d" % k}[cls]
+        return ("(%s != 0)" % e if dt == "bool" else e), dt
+
+    outs = []      # per member: {(c, j): ([expr], [dtype])}
+    rdt = {}       # member -> dtype of its row result
+    for mi, m in enumerate(spec.members):
+        red = m.get("reduce")
+        if red:
+            S.append("    %s acc%d = %s;" % (RTYPE[red["acc"]], mi, red_identity(red["op"], red["acc"])))
+        mouts = {}
+
+        def inputs_at(c, j):
+            in_exprs, in_dts = [], []
+            for r in m["ins"]:
+                if r[0] == "e":
+                    e, d = ext_expr(r[1], c, j)
+                elif r[0] == "f":
+                    es, ds = outs[r[1]][(c, j)]
+                    e, d = es[r[2]], ds[r[2]]
+                else:
+                    e, d = "r%d" % r[1], rdt[r[1]]
+                in_exprs.append(e)
+                in_dts.append(d)
+            return in_exprs, in_dts
+
+        if m.get("rowlike"):
+            # every input is per-row or scalar: one evaluation per row ([..., 1]-shaped values)
+            in_exprs, in_dts = inputs_at(0, 0)
+            lines, oe, od = emit_scalar_body(m["scalar"], in_exprs, in_dts, indent="    ",
+                                             suffix="_m%d_r" % mi)
+            S.extend(lines)
+            for c in range(NCH):
+                for j in range(V):
+                    mouts[(c, j)] = (oe, od)
+            outs.append(mouts)
+            for oref, odt, slot in m.get("stores", []):
+                S.append("    if (rv && sub == 0) ((%s*)a.ptr[%d])[row * a.rs[%d]] = %s;"
+                         % (CTYPE[odt], slot, slot, _store_val(oe[oref], od[oref], odt)))
+            continue
+        for c in range(NCH):
+            for j in range(V):
+                in_exprs, in_dts = inputs_at(c, j)
+                lines, oe, od = emit_scalar_body(m["scalar"], in_exprs, in_dts, indent="    ",
+                                                 suffix="_m%d_%d_%d" % (mi, c, j))
+                S.extend(lines)
+                mouts[(c, j)] = (oe, od)
+                if red:
+                    v = _cast(oe[red["ref"]], od[red["ref"]], red["acc"])
+                    S.append("    if (ok%d) acc%d = %s;" % (c, mi, red_combine(red["op"], red["acc"],
+                                                                               "acc%d" % mi, v)))
+        outs.append(mouts)
+        if red:
+            at_ = RTYPE[red["acc"]]
+            msk = L_ // 2
+            while msk >= 1:
+                S.append("    acc%d = %s;" % (mi, red_combine(
+                    red["op"], red["acc"], "acc%d" % mi, "shfl_xor_<%s>(acc%d, %d)" % (at_, mi, msk))))
+                msk //= 2
+            S.append("    const %s r%d = %s;" % (RTYPE[red["out"]], mi,
+                                                  _cast("acc%d" % mi, red["acc"], red["out"])))
+            rdt[mi] = red["out"]
+            if red.get("slot") is not None:
+                S.append("    if (rv && sub == 0) ((%s*)a.ptr[%d])[row * a.rs[%d]] = %s;"
+                         % (CTYPE[red["out"]], red["slot"], red["slot"],
+                            _store_val("r%d" % mi, red["out"], red["out"])))
+        for oref, odt, slot in m.get("stores", []):
+            ct = CTYPE[odt]
+            for c in range(NCH):
+                S.append("    if (rv && ok%d) {" % c)
+                S.append("      Pack<%s, %d> y;" % (ct, V))
+                for j in range(V):
+                    oe, od = mouts[(c, j)]
+                    S.append("      y.v[%d] = %s;" % (j, _store_val(oe[oref], od[oref], odt)))
+                S.append("      *(Pack<%s, %d>*)((%s*)a.ptr[%d] + row * a.rs[%d] + col%d) = y;"
+                         % (ct, V, ct, slot, slot, c))
+                S.append("    }")
+    S.append("  }")
+    S.append("}")
+    return "\n".join(S) + "\n", (name,)

@@ -164,4 +164,15 @@ int ahip_rowpass(ahip_fn_t k, const ahip_rp_args* args, int block, int rows_per_
                             as_stream(stream), args, sizeof(*args));
 }
 
+int ahip_rowchain(ahip_fn_t k, const ahip_rc_args* args, int block, int rows_per_wave,
+                  void* stream) {
+  AHIP_REQUIRE(k && args, "null argument");
+  AHIP_REQUIRE(block >= 64 && block % 64 == 0 && rows_per_wave >= 1 && rows_per_wave <= 64,
+               "bad block / rows_per_wave");
+  if (args->N <= 0 || args->K <= 0) return AHIP_OK;
+  int grid = ahip_rowpass_grid(args->N, block, rows_per_wave);
+  return ahip_launch_module(k->fn, dim3((unsigned)grid, 1, 1), dim3(block, 1, 1), 0,
+                            as_stream(stream), args, sizeof(*args));
+}
+
 }  // extern "C"

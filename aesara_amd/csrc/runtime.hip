@@ -228,7 +228,7 @@ int ahip_graph_end(void* stream, ahip_graph_t* out) {
   hipGraphExec_t e = nullptr;
   hipError_t err = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
   if (err != hipSuccess) {
-    hipGraphDestroy(g);
+    (void)hipGraphDestroy(g);
     ahip_set_error("hipGraphInstantiate failed: %s", hipGetErrorString(err));
     return AHIP_EHIP;
   }
@@ -244,8 +244,8 @@ int ahip_graph_launch(ahip_graph_t g, void* stream) {
 
 int ahip_graph_destroy(ahip_graph_t g) {
   if (!g) return AHIP_OK;
-  hipGraphExecDestroy(g->exec);
-  hipGraphDestroy(g->graph);
+  (void)hipGraphExecDestroy(g->exec);
+  (void)hipGraphDestroy(g->graph);
   delete g;
   return AHIP_OK;
 }
@@ -311,7 +311,7 @@ int ahip_event_elapsed_ms(ahip_event_t start, ahip_event_t stop, float* ms) {
 
 int ahip_event_destroy(ahip_event_t e) {
   if (!e) return AHIP_OK;
-  hipEventDestroy(e->ev);
+  (void)hipEventDestroy(e->ev);
   delete e;
   return AHIP_OK;
 }

@@ -174,6 +174,7 @@ def build_steps(plan: Plan, fuse: bool = True) -> List[Step]:
     if fuse:
         steps = _drop_dead(plan, _fuse_dots(plan, steps))
         steps = _fuse_rowpass(plan, steps)
+        steps = _fuse_rowchain(plan, steps)
     return steps
 
 
@@ -425,3 +426,117 @@ def _build_rowpass(plan, steps, i1, i2, xv, wv, rv, max_ops, max_red):
                      "dtype": dt},
               post=post, fallback=group + [g2])
     return steps[:i1] + outside + [rp] + steps[i2 + 1:]
+
+
+# ----------------------------------------------------------------------------------------
+# row chains: last-axis reductions + the Elemwise steps between them -> one kernel
+# ----------------------------------------------------------------------------------------
+def _step_reads(st: Step):
+    used = list(st.inputs) + [v for d in st.dots for v in d]
+    for q in st.fallback + st.post:
+        used += _step_reads(q)
+    return used
+
+
+def _fuse_rowchain(plan: Plan, steps: List[Step], max_ops: int = 16) -> List[Step]:
+    """A last-axis CAReduce whose (keepdims) result feeds Elemwise / further last-axis CAReduce
+    steps over the same [..., K] space (softmax = max -> exp-sum -> scale; log-softmax; softmax
+    gradient; mean/variance normalisation) becomes ONE "rowchain" step: every operand is read
+    once, every intermediate between the reductions lives in registers (codegen.RowChainSpec).
+    The reference runs such chains as separate passes (Softmax.c_code tensor/special.py:372-415)
+    or separate nodes.  Run-time layout checks are the executor's; the original steps are kept
+    as the fallback."""
+    while True:
+        fused = _fuse_one_rowchain(plan, steps, max_ops)
+        if fused is None:
+            return steps
+        steps = fused
+
+
+def _fuse_one_rowchain(plan: Plan, steps: List[Step], max_ops: int):
+    out_set = set(plan.outputs)
+    for i, seed in enumerate(steps):
+        if seed.kind != "reduce" or not seed.inputs:
+            continue
+        D = plan.vars[seed.inputs[0]].ndim
+        if D < 2 or seed.reduce["axis"] != [D - 1]:
+            continue
+        if any(plan.vars[v].ndim != D for v in seed.inputs):
+            continue
+        keep_order = list(range(D - 1)) + ["x"]
+        members, glue = [i], []
+        red_of = {seed.reduce["out"]: i}           # raw reduce result -> step index
+        row_vars: Dict[int, int] = {}              # keepdims var -> step index of its reduce
+        full_vars = {o: i for o in seed.outputs}   # [..., K] intermediates -> producing step
+        for j in range(i + 1, len(steps)):
+            t = steps[j]
+            if (t.kind == "node" and t.node.op == "DimShuffle" and t.inputs[0] in red_of
+                    and t.node.params["new_order"] == keep_order):
+                row_vars[t.outputs[0]] = red_of[t.inputs[0]]
+                glue.append(j)
+                continue
+            reads = _step_reads(t)
+            if not any(v in row_vars or v in full_vars or v in red_of for v in reads):
+                continue
+            ok = (t.kind in ("elemwise", "reduce") and t.inputs and not t.dots
+                  and all(plan.vars[v].ndim == D for v in t.inputs)
+                  and not any(v in red_of for v in t.inputs)
+                  and (t.kind != "reduce" or t.reduce["axis"] == [D - 1]))
+            if not ok:
+                break
+            members.append(j)
+            for o in t.outputs:
+                full_vars[o] = j
+            if t.kind == "reduce":
+                red_of[t.reduce["out"]] = j
+        if len(members) < 2:
+            continue
+        last = members[-1]
+        glue = [g for g in glue if g < last]
+        inside = set(members) | set(glue)
+        used_outside = set(out_set)
+        for j, t in enumerate(steps):
+            if j not in inside:
+                used_outside.update(_step_reads(t))
+        pos = {j: k for k, j in enumerate(members)}
+        ext: List[int] = []
+        mlist, stored, keep = [], [], {}
+        for j in members:
+            t = steps[j]
+            ins = []
+            for v in t.inputs:
+                if v in full_vars and full_vars[v] != j:
+                    p = steps[full_vars[v]]
+                    ins.append(["f", pos[full_vars[v]], p.out_refs[p.outputs.index(v)]])
+                elif v in row_vars:
+                    ins.append(["r", pos[row_vars[v]]])
+                else:
+                    if v not in ext:
+                        ext.append(v)
+                    ins.append(["e", ext.index(v)])
+            m = {"scalar": copy.deepcopy(t.scalar), "ins": ins, "reduce": None, "stores": []}
+            for o, ref in zip(t.outputs, t.out_refs):
+                if o in used_outside:
+                    m["stores"].append([ref, o])
+                    stored.append(o)
+            if t.kind == "reduce":
+                r = t.reduce
+                m["reduce"] = {"op": r["scalar_op"], "acc": r["acc_dtype"], "ref": r["ref"],
+                               "out": r["out"], "store": False}
+                need = r["out"] in used_outside
+                for g in glue:
+                    gk = steps[g]
+                    if gk.inputs[0] == r["out"] and gk.outputs[0] in used_outside:
+                        keep[gk.outputs[0]] = r["out"]
+                        need = True
+                if need:
+                    m["reduce"]["store"] = True
+                    stored.append(r["out"])
+            mlist.append(m)
+        if not stored or len(ext) + len(stored) > max_ops:
+            continue
+        fb = [steps[j] for j in sorted(inside)]
+        rc = Step("rowchain", ext, stored, extra={"members": mlist, "D": D, "keep": keep},
+                  fallback=fb)
+        return [rc if j == last else s for j, s in enumerate(steps) if j == last or j not in inside]
+    return None

@@ -98,6 +98,17 @@ typedef struct ahip_rp_args {
   int32_t nops; int32_t nred;
 } ahip_rp_args;
 
+/* Kernel-argument block of the GENERATED "row-chain" kernels
+ *   extern "C" __global__ void k(ahip_rc_args a);       (codegen.generate_rowchain)
+ * rows of an [N, K] space (K contiguous); ptr/rs: external operands then stored outputs, rs = element
+ * stride between rows (full and per-row operands / outputs; unused for per-column and scalars).  */
+#define AHIP_RC_MAXOPS 16
+typedef struct ahip_rc_args {
+  int64_t N; int64_t K;
+  void* ptr[AHIP_RC_MAXOPS];
+  int64_t rs[AHIP_RC_MAXOPS];
+} ahip_rc_args;
+
 typedef struct ahip_device_info {
   int32_t device;
   int32_t cu_count;
@@ -212,6 +223,11 @@ int ahip_gemv_epilogue(ahip_fn_t k, const ahip_gv_args* args, int block, void* s
 int ahip_rowpass_grid(int64_t N, int block, int rows_per_wave);
 int ahip_rowpass(ahip_fn_t k, const ahip_rp_args* args, int block, int rows_per_wave,
                  size_t shmem_bytes, void* stream);
+/* Row-chain kernel: a chain of last-axis CAReduce steps and the Elemwise steps between them in one
+ * pass (each operand read once; intermediates in registers).  replaces e.g. Softmax.c_code
+ * tensor/special.py:372-415 (three passes) / the CAReduce-DimShuffle-Elemwise node sequences of
+ * tensor/elemwise.py:1495/:222/:725.  rows_per_wave = 64 / lanes-per-row of the generated kernel. */
+int ahip_rowchain(ahip_fn_t k, const ahip_rc_args* args, int block, int rows_per_wave, void* stream);
 /* A_out[M,N] = A_in + alpha * x[M] y[N]^T */
 int ahip_ger(int dtype, int64_t M, int64_t N, const void* alpha, const void* x, int64_t incx,
              const void* y, int64_t incy, const void* A_in, int64_t ai_rs, int64_t ai_cs,

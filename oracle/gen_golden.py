@@ -599,6 +599,32 @@ for _dt, _tol in (("float64", 1e-12), ("float32", 3e-5)):
     case(f"softmax_grad_{_dt}", rtol=_tol * 3, atol=_tol * 3)(_mkg)
 
 
+@case("softmax_rows_f32", rtol=3e-5, atol=3e-6)
+def _():
+    from aesara.tensor.special import softmax
+    x = at.fmatrix("x")
+    return [x], [softmax(x, axis=-1)], [N((64, 1000), "float32", 1, 3.0)]
+
+
+@case("logsoftmax_rows_f64", rtol=1e-12, atol=1e-12)
+def _():
+    from aesara.tensor.special import log_softmax
+    x = at.dmatrix("x")
+    return [x], [log_softmax(x, axis=-1)], [N((33, 77), "float64", 2, 3.0)]
+
+
+for _dt, _tol in (("float64", 1e-11), ("float32", 5e-5)):
+    def _mkln(dt=_dt):
+        # a hand-written layer normalisation: CAReduce / DimShuffle / Elemwise nodes only
+        x, g, b = T(dt, (2, 2, 2), "x"), T(dt, (2,), "g"), T(dt, (2,), "b")
+        mu = x.mean(axis=-1, keepdims=True)
+        var = ((x - mu) ** 2).mean(axis=-1, keepdims=True)
+        y = (x - mu) / at.sqrt(var + np.asarray(1e-5, dt)) * g + b
+        return [x, g, b], [y, mu, var[..., 0]], \
+            [N((3, 7, 96), dt, 1, 2.0, 0.5), N((96,), dt, 2), N((96,), dt, 3)]
+    case(f"layernorm_{_dt}", rtol=_tol, atol=_tol)(_mkln)
+
+
 @case("argmax_axes", exact=True)
 def _():
     x, m, v = at.dtensor3("x"), at.imatrix("m"), at.dvector("v")

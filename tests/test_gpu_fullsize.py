@@ -154,6 +154,40 @@ def test_cfg5_logistic_large_batch_matches_fp64_restatement():
     assert torch.allclose(halves[0][1] + halves[1][1], gw, rtol=1e-4, atol=1e-2)
 
 
+def test_softmax_rowchain_large_rows_match_fp64_restatement():
+    """Row-chain kernel at 32768 x 1000 fp32 (ragged K: not a multiple of the 256-element chunk)
+    and 4096 x 4096: rows sum to 1, equal a torch fp64 softmax to fp32 round-off, and the
+    unfused three-pass path gives the same values."""
+    import torch
+    for shape in ((32768, 1000), (4096, 4096), (100000, 10)):
+        x = _randn(shape, torch.float32, 3, 4.0)
+        (y,) = _ex("softmax_rows_f32")(x)
+        ref = torch.softmax(x.double(), dim=-1)
+        assert y.shape == x.shape and torch.isfinite(y).all()
+        assert (y.double().sum(-1) - 1).abs().max().item() <= 2e-6
+        assert torch.allclose(y.double(), ref, rtol=3e-6, atol=1e-9)
+        (yu,) = _ex("softmax_rows_f32", fuse=False)(x)
+        assert torch.allclose(y, yu, rtol=2e-6, atol=1e-9)
+    # extreme logits: the max-shift keeps everything finite (tests/tensor/test_special.py)
+    x = torch.tensor([[1e4, 0.0, -1e4], [88.0, 89.0, 90.0]], dtype=torch.float32, device="cuda")
+    (y,) = _ex("softmax_rows_f32")(x)
+    assert torch.allclose(y.double(), torch.softmax(x.double(), -1), rtol=1e-6, atol=1e-12)
+
+
+def test_layernorm_rowchain_full_size():
+    import torch
+    x = _randn((64, 512, 1024), torch.float32, 5, 2.0) + 0.5
+    g, b = _randn((1024,), torch.float32, 6), _randn((1024,), torch.float32, 7)
+    y, mu, var = _ex("layernorm_float32")(x, g, b)
+    xd = x.double()
+    mud = xd.mean(-1, keepdim=True)
+    vard = ((xd - mud) ** 2).mean(-1, keepdim=True)
+    ref = (xd - mud) / torch.sqrt(vard + 1e-5) * g.double() + b.double()
+    assert torch.allclose(mu.double(), mud, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(var.double(), vard[..., 0], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(y.double(), ref, rtol=2e-5, atol=2e-5)
+
+
 def test_large_index_ops_bit_exact():
     """Row gather / scatter-add on 2^20 indices: bit-exact against torch integer ops."""
     import torch

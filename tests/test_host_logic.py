@@ -55,6 +55,22 @@ def test_cfg5_fuses_to_single_pass_rowpass():
     assert sorted(len(s.outputs) for s in reds) == [0, 1]
 
 
+def test_softmax_and_layernorm_fuse_to_one_rowchain():
+    """A last-axis reduction chain (Softmax: max -> exp-sum -> scale; a hand-written layer norm:
+    mean -> centred square mean -> normalise) becomes ONE row-chain step; nothing between the
+    reductions is materialised unless the graph asks for it."""
+    steps = build_steps(case_plan(_case("softmax_rows_f32")))
+    rc = [s for s in steps if s.kind == "rowchain"]
+    assert len(rc) == 1 and not any(s.kind in ("reduce", "elemwise") for s in steps)
+    assert [m["reduce"]["op"] if m["reduce"] else None for m in rc[0].extra["members"]] == \
+        ["maximum", "add", None]
+    assert len(rc[0].outputs) == 1 and len(rc[0].fallback) == 5
+    steps = build_steps(case_plan(_case("layernorm_float32")))
+    rc = [s for s in steps if s.kind == "rowchain"]
+    assert len(rc) == 1 and not any(s.kind == "reduce" for s in steps)
+    assert len(rc[0].outputs) == 3          # y, mu and var are graph outputs
+
+
 def test_unfused_steps_mirror_plan():
     p = case_plan(_case("cfg2_gauss_sum"))
     assert len(build_steps(p, fuse=False)) == len(p.nodes)

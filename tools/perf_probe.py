@@ -153,6 +153,29 @@ def main():
         report("cfg4 scan GRU T=512 H=1024 f32 B=1", d, w, T * 6 * H * H * 4, "GB/s", 8000.0,
                us_per_step=d * 1e3 / T, first_call_s=first)
 
+    if want("softmax"):
+        Nr, Kc = 1 << 16, 1024
+        x = randn((Nr, Kc), f32, 11) * 3
+        for label, kw in (("softmax rows f32 65536x1024 (row-chain kernel)", {}),
+                          ("softmax rows f32 65536x1024 UNFUSED (3 passes)", {"fuse": False})):
+            ex = PlanExecutor(plan_of("softmax_rows_f32"), use_graph=G, **kw)
+            d, w = timeit(lambda: ex(x), 20, warmup=3)
+            report(label, d, w, 2 * Nr * Kc * 4, "GB/s", 8000.0)
+        xs = randn((1 << 20, 64), f32, 12)
+        ex = PlanExecutor(plan_of("softmax_rows_f32"), use_graph=G)
+        d, w = timeit(lambda: ex(xs), 20, warmup=3)
+        report("softmax rows f32 1048576x64 (16 rows per wave)", d, w, 2 * (1 << 20) * 64 * 4,
+               "GB/s", 8000.0)
+
+    if want("layernorm"):
+        x = randn((64, 1024, 1024), f32, 13)
+        g, b = randn((1024,), f32, 14), randn((1024,), f32, 15)
+        for label, kw in (("layernorm f32 64x1024x1024 (row-chain kernel)", {}),
+                          ("layernorm f32 64x1024x1024 UNFUSED", {"fuse": False})):
+            ex = PlanExecutor(plan_of("layernorm_float32"), use_graph=G, **kw)
+            d, w = timeit(lambda: ex(x, g, b), 20, warmup=3)
+            report(label, d, w, 2 * x.numel() * 4, "GB/s", 8000.0)
+
     if want("cfg5"):
         N, D = 1 << 22, 256
         ex = PlanExecutor(plan_of("cfg5_logistic"), use_graph=G)
