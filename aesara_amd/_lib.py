@@ -70,11 +70,13 @@ class RpArgs(C.Structure):
 
 
 AHIP_RC_MAXOPS = 16
+AHIP_RC_MAXLEAD = 4
 
 
 class RcArgs(C.Structure):
-    _fields_ = [("N", C.c_int64), ("K", C.c_int64), ("ptr", C.c_void_p * AHIP_RC_MAXOPS),
-                ("rs", C.c_int64 * AHIP_RC_MAXOPS)]
+    _fields_ = [("N", C.c_int64), ("K", C.c_int64), ("lshape", C.c_int64 * AHIP_RC_MAXLEAD),
+                ("ptr", C.c_void_p * AHIP_RC_MAXOPS),
+                ("ls", (C.c_int64 * AHIP_RC_MAXLEAD) * AHIP_RC_MAXOPS)]
 
 
 vp, i64, i32, u32, sz = C.c_void_p, C.c_int64, C.c_int, C.c_uint32, C.c_size_t

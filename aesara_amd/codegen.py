@@ -1084,10 +1084,13 @@ def generate_rowpass(spec: RowPassSpec):
 # ----------------------------------------------------------------------------------------
 RC_MAXOPS = 16
 
+RC_MAXLEAD = 4
+
 RC_STRUCT = r"""
 #define RC_MAXOPS %d
-struct RcArgs { i64 N; i64 K; void* ptr[RC_MAXOPS]; i64 rs[RC_MAXOPS]; };
-""" % RC_MAXOPS
+#define RC_MAXLEAD %d
+struct RcArgs { i64 N; i64 K; i64 lshape[RC_MAXLEAD]; void* ptr[RC_MAXOPS]; i64 ls[RC_MAXOPS][RC_MAXLEAD]; };
+""" % (RC_MAXOPS, RC_MAXLEAD)
 
 
 class RowChainSpec:
@@ -1109,14 +1112,16 @@ class RowChainSpec:
                slot]] (slots index RcArgs.ptr after the external operands)
     """
 
-    def __init__(self, ext, members, L, V, nch, block=256):
+    def __init__(self, ext, members, L, V, nch, lnd=1, block=256):
         self.ext = [list(e) for e in ext]
         self.members, self.L, self.V, self.nch, self.block = members, L, V, nch, block
-        assert L in (1, 2, 4, 8, 16, 32, 64) and block % 64 == 0
+        self.lnd = lnd          # jointly-collapsed leading dims (row index -> coordinates)
+        assert L in (1, 2, 4, 8, 16, 32, 64) and block % 64 == 0 and 1 <= lnd <= RC_MAXLEAD
 
     def key(self):
         import json
-        blob = json.dumps(["rc1", self.ext, self.members, self.L, self.V, self.nch, self.block],
+        blob = json.dumps(["rc2", self.ext, self.members, self.L, self.V, self.nch, self.lnd,
+                           self.block],
                           sort_keys=True)
         return hashlib.sha256(blob.encode()).hexdigest()[:24]
 
@@ -1148,16 +1153,26 @@ def generate_rowchain(spec: RowChainSpec):
     S.append("    const i64 row = rb + grp;")
     S.append("    const bool rv = row < a.N;")
     S.append("    const i64 rr = rv ? row : a.N - 1;")
+    # row index -> coordinates over the collapsed leading dims (one div/mod per extra dim)
+    rem = "rr"
+    for d in range(spec.lnd - 1, 0, -1):
+        S.append("    const i64 q%d = %s / a.lshape[%d];" % (d, rem, d))
+        S.append("    const i64 lc%d = %s - q%d * a.lshape[%d];" % (d, rem, d, d))
+        rem = "q%d" % d
+    S.append("    const i64 lc0 = %s;" % rem)
+
+    def row_off(k):
+        return " + ".join("lc%d * a.ls[%d][%d]" % (d, k, d) for d in range(spec.lnd))
     for k, (dt, cls) in enumerate(spec.ext):
         ct = CTYPE[dt]
         if cls == "f":
-            S.append("    const %s* __restrict__ xp%d = (const %s*)a.ptr[%d] + rr * a.rs[%d];"
-                     % (ct, k, ct, k, k))
+            S.append("    const %s* __restrict__ xp%d = (const %s*)a.ptr[%d] + %s;"
+                     % (ct, k, ct, k, row_off(k)))
             for c in range(NCH):
                 S.append("    Pack<%s, %d> x%d_%d = {}; if (ok%d) x%d_%d = *(const Pack<%s, %d>*)"
                          "(xp%d + col%d);" % (ct, V, k, c, c, k, c, ct, V, k, c))
         elif cls == "r":
-            S.append("    const %s ro%d = ((const %s*)a.ptr[%d])[rr * a.rs[%d]];" % (ct, k, ct, k, k))
+            S.append("    const %s ro%d = ((const %s*)a.ptr[%d])[%s];" % (ct, k, ct, k, row_off(k)))
 
     def ext_expr(k, c, j):
         dt, cls = spec.ext[k]
@@ -1198,8 +1213,8 @@ def generate_rowchain(spec: RowChainSpec):
                     mouts[(c, j)] = (oe, od)
             outs.append(mouts)
             for oref, odt, slot in m.get("stores", []):
-                S.append("    if (rv && sub == 0) ((%s*)a.ptr[%d])[row * a.rs[%d]] = %s;"
-                         % (CTYPE[odt], slot, slot, _store_val(oe[oref], od[oref], odt)))
+                S.append("    if (rv && sub == 0) ((%s*)a.ptr[%d])[%s] = %s;"
+                         % (CTYPE[odt], slot, row_off(slot), _store_val(oe[oref], od[oref], odt)))
             continue
         for c in range(NCH):
             for j in range(V):
@@ -1224,8 +1239,8 @@ def generate_rowchain(spec: RowChainSpec):
                                                   _cast("acc%d" % mi, red["acc"], red["out"])))
             rdt[mi] = red["out"]
             if red.get("slot") is not None:
-                S.append("    if (rv && sub == 0) ((%s*)a.ptr[%d])[row * a.rs[%d]] = %s;"
-                         % (CTYPE[red["out"]], red["slot"], red["slot"],
+                S.append("    if (rv && sub == 0) ((%s*)a.ptr[%d])[%s] = %s;"
+                         % (CTYPE[red["out"]], red["slot"], row_off(red["slot"]),
                             _store_val("r%d" % mi, red["out"], red["out"])))
         for oref, odt, slot in m.get("stores", []):
             ct = CTYPE[odt]
@@ -1235,8 +1250,8 @@ def generate_rowchain(spec: RowChainSpec):
                 for j in range(V):
                     oe, od = mouts[(c, j)]
                     S.append("      y.v[%d] = %s;" % (j, _store_val(oe[oref], od[oref], odt)))
-                S.append("      *(Pack<%s, %d>*)((%s*)a.ptr[%d] + row * a.rs[%d] + col%d) = y;"
-                         % (ct, V, ct, slot, slot, c))
+                S.append("      *(Pack<%s, %d>*)((%s*)a.ptr[%d] + %s + col%d) = y;"
+                         % (ct, V, ct, slot, row_off(slot), c))
                 S.append("    }")
     S.append("  }")
     S.append("}")

@@ -491,6 +491,37 @@ def _fuse_one_rowchain(plan: Plan, steps: List[Step], max_ops: int):
                 red_of[t.reduce["out"]] = j
         if len(members) < 2:
             continue
+        # absorb Elemwise producers whose results only the chain reads (softmax(x / T + mask):
+        # the logits never go to memory)
+        readers: Dict[int, set] = {}
+        made_by: Dict[int, int] = {}
+        for j, t in enumerate(steps):
+            for v in _step_reads(t):
+                readers.setdefault(v, set()).add(j)
+            if t.kind == "elemwise" and not t.dots:
+                for o in t.outputs:
+                    made_by[o] = j
+        grown = True
+        while grown:
+            grown = False
+            for j in list(members):
+                for v in steps[j].inputs:
+                    pj = made_by.get(v)
+                    if pj is None or pj in members or pj > members[-1]:
+                        continue
+                    P = steps[pj]
+                    if not P.inputs or any(plan.vars[u].ndim != D for u in P.inputs):
+                        continue
+                    if any(o in out_set or not readers.get(o, set()) <= set(members)
+                           for o in P.outputs):
+                        continue
+                    members = sorted(members + [pj])
+                    for o in P.outputs:
+                        full_vars[o] = pj
+                    grown = True
+                    break
+                if grown:
+                    break
         last = members[-1]
         glue = [g for g in glue if g < last]
         inside = set(members) | set(glue)

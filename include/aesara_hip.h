@@ -100,13 +100,16 @@ typedef struct ahip_rp_args {
 
 /* Kernel-argument block of the GENERATED "row-chain" kernels
  *   extern "C" __global__ void k(ahip_rc_args a);       (codegen.generate_rowchain)
- * rows of an [N, K] space (K contiguous); ptr/rs: external operands then stored outputs, rs = element
- * stride between rows (full and per-row operands / outputs; unused for per-column and scalars).  */
+ * rows of a [lshape..., K] space (K contiguous, N = prod(lshape) rows, up to 4 jointly-collapsed
+ * leading dims); ptr: external operands then stored outputs; ls[k][d] = element stride of operand k
+ * along leading dim d (0 = broadcast).                                                          */
 #define AHIP_RC_MAXOPS 16
+#define AHIP_RC_MAXLEAD 4
 typedef struct ahip_rc_args {
   int64_t N; int64_t K;
+  int64_t lshape[AHIP_RC_MAXLEAD];
   void* ptr[AHIP_RC_MAXOPS];
-  int64_t rs[AHIP_RC_MAXOPS];
+  int64_t ls[AHIP_RC_MAXOPS][AHIP_RC_MAXLEAD];
 } ahip_rc_args;
 
 typedef struct ahip_device_info {

@@ -625,6 +625,17 @@ for _dt, _tol in (("float64", 1e-11), ("float32", 5e-5)):
     case(f"layernorm_{_dt}", rtol=_tol, atol=_tol)(_mkln)
 
 
+@case("softmax_masked_scaled_f32", rtol=3e-5, atol=3e-6)
+def _():
+    # attention-style: softmax(scores / temperature + mask) — the producer Elemwise joins the
+    # row chain, the scaled logits never reach memory
+    from aesara.tensor.special import softmax
+    sc, mask, tau = at.ftensor3("s"), at.fmatrix("mask"), at.fscalar("tau")
+    return [sc, mask, tau], [softmax(sc / tau + mask.dimshuffle("x", 0, 1), axis=-1)], \
+        [N((3, 17, 48), "float32", 1, 2.0), U((17, 48), "float32", 2, -4.0, 0.0),
+         K(0.7, "float32")]
+
+
 @case("argmax_axes", exact=True)
 def _():
     x, m, v = at.dtensor3("x"), at.imatrix("m"), at.dvector("v")

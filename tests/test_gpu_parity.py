@@ -41,7 +41,8 @@ def test_hip_matches_reference(c):
     assert_matches(c, _run(c), case_expected(c), "hip")
 
 
-@pytest.mark.parametrize("c", [c for c in CASES if c["name"].startswith(("cfg", "scan_", "gru"))],
+@pytest.mark.parametrize("c", [c for c in CASES if c["name"].startswith(
+    ("cfg", "scan_", "gru", "softmax", "logsoftmax", "layernorm", "argmax", "gemv_", "advsub1"))],
                          ids=lambda c: c["name"])
 def test_hip_graph_replay_matches_reference(c):
     """Same cases through hipGraph capture + replay (H1/K10 launch-list path)."""
@@ -54,7 +55,8 @@ def test_hip_graph_replay_matches_reference(c):
     assert_matches(c, got, case_expected(c), "hip-graph")
 
 
-@pytest.mark.parametrize("c", [c for c in CASES if c["name"].startswith(("cfg", "red_", "ew_t"))],
+@pytest.mark.parametrize("c", [c for c in CASES if c["name"].startswith(
+    ("cfg", "red_", "ew_t", "softmax", "logsoftmax", "layernorm"))],
                          ids=lambda c: c["name"])
 def test_unfused_matches_reference(c):
     """The linker-level fusion must not change results: run with fusion disabled too."""
