@@ -391,6 +391,83 @@ __global__ void scale_kernel(GemmArgs g) {
   }
 }
 
+
+// ---- small-output GEMM: 16x16 tile per workgroup, K split over its 4 wavefronts ----------------
+// When M*N is too small to give every CU a 128x128 tile (a batch-64 recurrent step is 64 x 1024:
+// 8 big tiles on 256 CUs) the big kernel leaves the chip idle and pays a full K loop per tile.
+// Here every 16x16 output block is its own workgroup (M=64, N=1024 -> 256 workgroups), each
+// wavefront runs the MFMA chain over a quarter of K straight from global memory (the operands are
+// L2-resident at these sizes; fragments are loaded in MFMA layout, no LDS staging), and the four
+// partial tiles are summed in wave order through LDS (deterministic).  Arbitrary strides.
+int64_t g_small_max_tiles = 64;    // use this kernel when the 128x128 tiling gives fewer tiles
+                                   // (measured: 512^3 = 16 tiles 45 -> 18 us; 1024^3 = 64 tiles: big wins)
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs g) {
+  using acc_t = typename Traits<T>::acc_t;
+  __shared__ T part[4][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, kg = lane >> 4;
+  const int64_t z = blockIdx.z;
+  const int64_t m0 = (int64_t)blockIdx.y * 16, n0 = (int64_t)blockIdx.x * 16;
+  const T* __restrict__ A = static_cast<const T*>(g.A) + z * g.a_bs;
+  const T* __restrict__ B = static_cast<const T*>(g.B) + z * g.b_bs;
+  // wave w owns k in [w*kq, min(K, (w+1)*kq)), kq a multiple of 4
+  const int64_t kq = ((g.K + 15) / 16) * 4;
+  const int64_t kbeg = wave * kq;
+  const int64_t kend = (kbeg + kq < g.K) ? kbeg + kq : g.K;
+  const bool mok = m0 + r < g.M, nok = n0 + r < g.N;
+  const T* ap = A + (mok ? m0 + r : 0) * g.a_rs;
+  const T* bp = B + (nok ? n0 + r : 0) * g.b_cs;
+  acc_t acc = {0, 0, 0, 0};
+  constexpr int U = 8;  // k-steps (of 4) per unrolled group: 16 loads in flight per lane
+  int64_t k = kbeg;
+  for (; k + 4 * U <= kend; k += 4 * U) {
+    T a[U], b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t kk = k + 4 * u + kg;
+      a[u] = mok ? ap[kk * g.a_cs] : (T)0;
+      b[u] = nok ? bp[kk * g.b_rs] : (T)0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) mma(acc, a[u], b[u]);
+  }
+  for (; k < kend; k += 4) {
+    const int64_t kk = k + kg;
+    const bool kok = kk < kend;
+    const T a = (mok && kok) ? ap[kk * g.a_cs] : (T)0;
+    const T b = (nok && kok) ? bp[kk * g.b_rs] : (T)0;
+    mma(acc, a, b);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) part[wave][frag_row<T>(lane, i) * 16 + r] = acc[i];
+  __syncthreads();
+  const int e = threadIdx.x, er = e >> 4, ec = e & 15;
+  if (m0 + er < g.M && n0 + ec < g.N) {
+    T sum = part[0][e];
+    sum += part[1][e];
+    sum += part[2][e];
+    sum += part[3][e];
+    T v = (T)g.alpha * sum;
+    if (g.beta != 0.0) {
+      const T* Cin = static_cast<const T*>(g.Cin) + z * g.ci_bs;
+      v += (T)g.beta * Cin[(m0 + er) * g.ci_rs + (n0 + ec) * g.ci_cs];
+    }
+    T* C = static_cast<T*>(g.C) + z * g.c_bs;
+    C[(m0 + er) * g.c_rs + (n0 + ec) * g.c_cs] = v;
+  }
+}
+
+template <typename T>
+int launch_small(const GemmArgs& g, int64_t batch, hipStream_t s) {
+  const int64_t gx = (g.N + 15) / 16, gy = (g.M + 15) / 16;
+  AHIP_REQUIRE(gy < 65536 && batch < 65536, "grid too large for the small-tile GEMM");
+  AHIP_LAUNCH((gemm_small_kernel<T>), dim3((unsigned)gx, (unsigned)gy, (unsigned)batch), dim3(256),
+              0, s, g);
+  return AHIP_OK;
+}
+
 // staging mode of one operand (rs = stride between its tile rows, ks = stride along k) and
 // whether 32-bit byte offsets inside a tile are safe
 template <typename T>
@@ -457,6 +534,9 @@ int gemm_dispatch(GemmArgs& g, int64_t batch, hipStream_t s) {
   g.tiles_m = (int)((g.M + BM - 1) / BM);
   g.tiles_n = (int)((g.N + BN - 1) / BN);
   AHIP_REQUIRE((int64_t)g.tiles_m * g.tiles_n < (1LL << 31), "too many tiles");
+  if ((int64_t)g.tiles_m * g.tiles_n * batch < g_small_max_tiles && (g.M + 15) / 16 < 65536 &&
+      batch < 65536)
+    return launch_small<T>(g, batch, s);
   int am = operand_mode<T>(g.A, g.a_rs, g.a_cs, g.M, g.K, g.a_bs, batch);
   int bm = operand_mode<T>(g.B, g.b_cs, g.b_rs, g.N, g.K, g.b_bs, batch);
   const bool interior = (g.M % BM == 0) && (g.N % BN == 0) && (g.K % Traits<T>::BK == 0);
@@ -470,6 +550,8 @@ double host_scalar(int dtype, const void* p) {
 }
 
 }  // namespace
+
+void ahip_gemm_set_small_max_tiles(int64_t v) { g_small_max_tiles = v; }
 
 extern "C" {
 

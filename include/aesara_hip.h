@@ -133,7 +133,9 @@ int ahip_init(int device_ordinal);
 const char* ahip_last_error(void);
 int ahip_get_device_info(ahip_device_info* out);
 int ahip_stream_synchronize(void* stream);
-/* launch-shape tunables: "stream_blocks_per_cu" (default 8), "reduce_blocks_per_cu" (default 8) */
+/* launch-shape tunables: "stream_blocks_per_cu" (default 8), "reduce_blocks_per_cu" (default 8),
+ * "gemm_small_max_tiles" (default 64: below that many 128x128 tiles ahip_gemm uses the
+ * 16x16-tile split-K kernel that gives every CU work on small outputs)                        */
 int ahip_set_param(const char* name, int64_t value);
 
 /* ---- runtime compilation of generated kernels ------------------------------------------

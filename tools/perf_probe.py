@@ -176,6 +176,33 @@ def main():
             d, w = timeit(lambda: ex(x, g, b), 20, warmup=3)
             report(label, d, w, 2 * x.numel() * 4, "GB/s", 8000.0)
 
+    if want("cfg4b64"):
+        T, H, B = 512, 1024, 64
+        ex = PlanExecutor(plan_of("cfg4_gru_b8_f32"), use_graph=G)
+        x = randn((T, B, H), f32, 4) * 0.1
+        h0 = torch.zeros((B, H), dtype=f32, device="cuda")
+        Ws = [randn((H, H), f32, 5 + k) / np.sqrt(H) for k in range(6)]
+        ex(x, h0, *Ws)
+        torch.cuda.synchronize()
+        d, w = timeit(lambda: ex(x, h0, *Ws), 3, warmup=1)
+        report("cfg4 scan GRU T=512 H=1024 f32 B=64 (matrix state)", d, w,
+               T * 6 * 2 * B * H * H, "TFLOP/s", 157.3, us_per_step=d * 1e3 / T)
+
+    if want("gemmsmall"):
+        from aesara_amd._lib import lib as _l
+        ex = PlanExecutor(plan_of("cfg3b_gemm_update"), use_graph=G)
+        for (M, N, K) in ((64, 1024, 1024), (8, 1024, 1024), (64, 4096, 4096), (512, 512, 512),
+                          (1024, 1024, 1024), (2048, 1024, 1024)):
+            Cm = torch.zeros((M, N), dtype=f32, device="cuda")
+            A, B = randn((M, K), f32, 3), randn((K, N), f32, 4)
+            for tiles in (1, 100000):
+                check(_l.ahip_set_param(b"gemm_small_max_tiles", tiles))
+                exx = PlanExecutor(plan_of("cfg3b_gemm_update"), use_graph=G)
+                d, w = timeit(lambda: exx(Cm, A, B), 20, warmup=3)
+                report("gemm f32 %dx%dx%d %s" % (M, N, K, "big-tile" if tiles == 1 else "small-tile"),
+                       d, w, 2 * M * N * K, "TFLOP/s", 157.3)
+        check(_l.ahip_set_param(b"gemm_small_max_tiles", 64))
+
     if want("cfg5"):
         N, D = 1 << 22, 256
         ex = PlanExecutor(plan_of("cfg5_logistic"), use_graph=G)
