@@ -57,6 +57,7 @@ int ahip_set_param(const char* name, int64_t value) {
   if (!strcmp(name, "stream_blocks_per_cu")) g_stream_blocks_per_cu = value;
   else if (!strcmp(name, "reduce_blocks_per_cu")) g_reduce_blocks_per_cu = value;
   else if (!strcmp(name, "gemm_small_max_tiles")) ahip_gemm_set_small_max_tiles(value);
+  else if (!strcmp(name, "gemm_skinny_nf")) ahip_gemm_set_skinny_nf(value);
   else { ahip_set_error("unknown parameter %s", name); return AHIP_EINVAL; }
   return AHIP_OK;
 }

@@ -399,8 +399,8 @@ __global__ void scale_kernel(GemmArgs g) {
 // wavefront runs the MFMA chain over a quarter of K straight from global memory (the operands are
 // L2-resident at these sizes; fragments are loaded in MFMA layout, no LDS staging), and the four
 // partial tiles are summed in wave order through LDS (deterministic).  Arbitrary strides.
-int64_t g_small_max_tiles = 64;    // use this kernel when the 128x128 tiling gives fewer tiles
-                                   // (measured: 512^3 = 16 tiles 45 -> 18 us; 1024^3 = 64 tiles: big wins)
+int64_t g_small_max_tiles = 64;    // scalar-load form: below this many 128x128 tiles (x4 for the
+                                   // vector-load form, see gemm_dispatch)
 
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs g) {
@@ -419,9 +419,9 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs g) {
   const bool mok = m0 + r < g.M, nok = n0 + r < g.N;
   const T* ap = A + (mok ? m0 + r : 0) * g.a_rs;
   const T* bp = B + (nok ? n0 + r : 0) * g.b_cs;
-  acc_t acc = {0, 0, 0, 0};
+  acc_t acc = {0, 0, 0, 0}, tot = {0, 0, 0, 0};
   constexpr int U = 8;  // k-steps (of 4) per unrolled group: 16 loads in flight per lane
-  int64_t k = kbeg;
+  int64_t k = kbeg, next_fold = kbeg + 512;   // two-level sum, see gemm_skinny_kernel
   for (; k + 4 * U <= kend; k += 4 * U) {
     T a[U], b[U];
 #pragma unroll
@@ -432,6 +432,11 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs g) {
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) mma(acc, a[u], b[u]);
+    if (k + 4 * U >= next_fold) {
+      tot += acc;
+      acc = acc_t{0, 0, 0, 0};
+      next_fold += 512;
+    }
   }
   for (; k < kend; k += 4) {
     const int64_t kk = k + kg;
@@ -441,7 +446,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs g) {
     mma(acc, a, b);
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) part[wave][frag_row<T>(lane, i) * 16 + r] = acc[i];
+  for (int i = 0; i < 4; ++i) part[wave][frag_row<T>(lane, i) * 16 + r] = tot[i] + acc[i];
   __syncthreads();
   const int e = threadIdx.x, er = e >> 4, ec = e & 15;
   if (m0 + er < g.M && n0 + ec < g.N) {
@@ -459,10 +464,151 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs g) {
   }
 }
 
+
+// Vector-load variant of the small-output kernel for the common layouts: A k-contiguous (row-major
+// x), B either n-contiguous (x @ W, BKC = false) or k-contiguous (x @ W.T, BKC = true).  Tile
+// 16 x (16*NF): a lane loads one 16-byte vector of A along k (VEC consecutive k = VEC MFMA steps)
+// and, per step, NF consecutive columns of B (BKC = false; the NF elements feed NF column
+// fragments, fragment f holding columns n0 + NF*r + f) or one k-vector per column fragment
+// (BKC = true, fragment f = columns n0 + 16 f + r).  Two-group software pipeline on the loads.
+int64_t g_skinny_nf = 0;           // 0 = choose by grid size; 1/2/4 forces the tile width
+
+template <typename T, int NF, bool BKC>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
+  using acc_t = typename Traits<T>::acc_t;
+  constexpr int VEC = Traits<T>::VEC;
+  constexpr int G = 4 * VEC;  // k extent of one vector group (4 lane groups x VEC)
+  struct alignas(sizeof(T) * VEC) KV { T v[VEC]; };
+  struct alignas(sizeof(T) * NF) NV_ { T v[NF]; };
+  __shared__ T part[4][256 * NF];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, kg = lane >> 4;
+  const int64_t z = blockIdx.z;
+  const int64_t m0 = (int64_t)blockIdx.y * 16, n0 = (int64_t)blockIdx.x * (16 * NF);
+  const T* __restrict__ A = static_cast<const T*>(g.A) + z * g.a_bs;
+  const T* __restrict__ B = static_cast<const T*>(g.B) + z * g.b_bs;
+  const int64_t kq = ((g.K + 4 * G - 1) / (4 * G)) * G;
+  const int64_t kbeg = wave * kq;
+  const int64_t kend = (kbeg + kq < g.K) ? kbeg + kq : g.K;
+  const bool mok = m0 + r < g.M;
+  const T* ap = A + (mok ? m0 + r : 0) * g.a_rs + VEC * kg;
+  acc_t acc[NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) acc[f] = acc_t{0, 0, 0, 0};
+
+  struct Frag { KV a; KV bk[NF]; NV_ bn[VEC]; };
+  auto load = [&](int64_t k0, Frag& fr) {
+    const bool kok = k0 + VEC * kg < kend;
+    fr.a = (mok && kok) ? *reinterpret_cast<const KV*>(ap + k0) : KV{};
+    if constexpr (BKC) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        const int64_t nn = n0 + 16 * f + r;
+        fr.bk[f] = (nn < g.N && kok)
+            ? *reinterpret_cast<const KV*>(B + nn * g.b_cs + k0 + VEC * kg) : KV{};
+      }
+    } else {
+      const int64_t nn = n0 + NF * r;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j)
+        fr.bn[j] = (nn < g.N && kok)
+            ? *reinterpret_cast<const NV_*>(B + (k0 + VEC * kg + j) * g.b_rs + nn) : NV_{};
+    }
+  };
+  auto compute = [&](const Frag& fr) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j)
+#pragma unroll
+      for (int f = 0; f < NF; ++f)
+        mma(acc[f], fr.a.v[j], BKC ? fr.bk[f].v[j] : fr.bn[j].v[f]);
+  };
+  // fp32: a long k-ordered FMA chain drifts past the 1e-6 Frobenius bar (1.15e-6 at 4096), so the
+  // running accumulators are folded into a second register set every FOLD k (two-level sum)
+  constexpr int64_t FOLD = 512;
+  acc_t tot[NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) tot[f] = acc_t{0, 0, 0, 0};
+  Frag f0, f1;
+  int64_t k0 = kbeg, next_fold = kbeg + FOLD;
+  if (k0 < kend) load(k0, f0);
+  for (; k0 < kend; k0 += 2 * G) {
+    if (k0 + G < kend) load(k0 + G, f1);
+    compute(f0);
+    if (k0 + G < kend) {
+      if (k0 + 2 * G < kend) load(k0 + 2 * G, f0);
+      compute(f1);
+    }
+    if (k0 + 2 * G >= next_fold) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f) { tot[f] += acc[f]; acc[f] = acc_t{0, 0, 0, 0}; }
+      next_fold += FOLD;
+    }
+  }
+#pragma unroll
+  for (int f = 0; f < NF; ++f)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      part[wave][(frag_row<T>(lane, i) * 16 + r) * NF + f] = tot[f][i] + acc[f][i];
+  __syncthreads();
+  const int e = threadIdx.x, er = e >> 4, ec = e & 15;
+  if (m0 + er < g.M) {
+    T* C = static_cast<T*>(g.C) + z * g.c_bs;
+    const T* Cin = static_cast<const T*>(g.Cin) + z * g.ci_bs;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const int64_t col = BKC ? n0 + 16 * f + ec : n0 + NF * ec + f;
+      if (col >= g.N) continue;
+      T sum = part[0][e * NF + f];
+      sum += part[1][e * NF + f];
+      sum += part[2][e * NF + f];
+      sum += part[3][e * NF + f];
+      T v = (T)g.alpha * sum;
+      if (g.beta != 0.0) v += (T)g.beta * Cin[(m0 + er) * g.ci_rs + col * g.ci_cs];
+      C[(m0 + er) * g.c_rs + col * g.c_cs] = v;
+    }
+  }
+}
+
+template <typename T, int NF, bool BKC>
+int launch_skinny(const GemmArgs& g, int64_t batch, hipStream_t s) {
+  const int64_t gx = (g.N + 16 * NF - 1) / (16 * NF), gy = (g.M + 15) / 16;
+  AHIP_LAUNCH((gemm_skinny_kernel<T, NF, BKC>), dim3((unsigned)gx, (unsigned)gy, (unsigned)batch),
+              dim3(256), 0, s, g);
+  return AHIP_OK;
+}
+
 template <typename T>
 int launch_small(const GemmArgs& g, int64_t batch, hipStream_t s) {
   const int64_t gx = (g.N + 15) / 16, gy = (g.M + 15) / 16;
   AHIP_REQUIRE(gy < 65536 && batch < 65536, "grid too large for the small-tile GEMM");
+  // vector-load variant when the layouts allow it
+  constexpr int VEC = Traits<T>::VEC;
+  auto al = [](const void* p, size_t b) { return reinterpret_cast<uintptr_t>(p) % b == 0; };
+  const bool a_ok = g.a_cs == 1 && al(g.A, 16) && g.a_rs % VEC == 0 && g.K % VEC == 0 &&
+                    (batch <= 1 || g.a_bs % VEC == 0);
+  if (a_ok) {
+    const bool bk_ok = g.b_rs == 1 && al(g.B, 16) && g.b_cs % VEC == 0 &&
+                       (batch <= 1 || g.b_bs % VEC == 0);
+    int nf = VEC;
+    if (g_skinny_nf > 0) nf = (int)(g_skinny_nf < VEC ? g_skinny_nf : VEC);
+    else
+      while (nf > 1 && gy * ((g.N + 16 * nf - 1) / (16 * nf)) * batch < ahip_cu_count()) nf /= 2;
+    auto bn_ok = [&](int f) {
+      return g.b_cs == 1 && al(g.B, sizeof(T) * f) && g.b_rs % f == 0 && g.N % f == 0 &&
+             (batch <= 1 || g.b_bs % f == 0);
+    };
+    if (bk_ok) {
+      if (nf >= 4 && VEC >= 4) return launch_skinny<T, (VEC >= 4 ? 4 : VEC), true>(g, batch, s);
+      if (nf >= 2) return launch_skinny<T, 2, true>(g, batch, s);
+      return launch_skinny<T, 1, true>(g, batch, s);
+    }
+    while (nf > 1 && !bn_ok(nf)) nf /= 2;
+    if (bn_ok(nf)) {
+      if (nf >= 4 && VEC >= 4) return launch_skinny<T, (VEC >= 4 ? 4 : VEC), false>(g, batch, s);
+      if (nf >= 2) return launch_skinny<T, 2, false>(g, batch, s);
+      return launch_skinny<T, 1, false>(g, batch, s);
+    }
+  }
   AHIP_LAUNCH((gemm_small_kernel<T>), dim3((unsigned)gx, (unsigned)gy, (unsigned)batch), dim3(256),
               0, s, g);
   return AHIP_OK;
@@ -534,9 +680,23 @@ int gemm_dispatch(GemmArgs& g, int64_t batch, hipStream_t s) {
   g.tiles_m = (int)((g.M + BM - 1) / BM);
   g.tiles_n = (int)((g.N + BN - 1) / BN);
   AHIP_REQUIRE((int64_t)g.tiles_m * g.tiles_n < (1LL << 31), "too many tiles");
-  if ((int64_t)g.tiles_m * g.tiles_n * batch < g_small_max_tiles && (g.M + 15) / 16 < 65536 &&
-      batch < 65536)
-    return launch_small<T>(g, batch, s);
+  // below one 128x128 tile per CU the 16-row kernels win when their vector-load form applies
+  // (measured fp32: 1024^3 = 64 tiles 86 -> 36 us, 2048x1024x1024 = 128 tiles 88 -> 65 us,
+  // 2048x2048x512 = 256 tiles: big 53 vs 64 us); the scalar-load form only below 64 tiles
+  {
+    constexpr int VEC = Traits<T>::VEC;
+    const bool a_vec = g.a_cs == 1 && reinterpret_cast<uintptr_t>(g.A) % 16 == 0 &&
+                       g.a_rs % VEC == 0 && g.K % VEC == 0 && (batch <= 1 || g.a_bs % VEC == 0);
+    const bool b_vec = reinterpret_cast<uintptr_t>(g.B) % 16 == 0 &&
+                       ((g.b_rs == 1 && g.b_cs % VEC == 0) ||
+                        (g.b_cs == 1 && g.b_rs % VEC == 0 && g.N % VEC == 0)) &&
+                       (batch <= 1 || g.b_bs % VEC == 0);
+    const int64_t limit = (a_vec && b_vec) ? (g_small_max_tiles < 64 ? g_small_max_tiles
+                                                                       : 4 * g_small_max_tiles)
+                                           : g_small_max_tiles;
+    if ((int64_t)g.tiles_m * g.tiles_n * batch < limit && (g.M + 15) / 16 < 65536 && batch < 65536)
+      return launch_small<T>(g, batch, s);
+  }
   int am = operand_mode<T>(g.A, g.a_rs, g.a_cs, g.M, g.K, g.a_bs, batch);
   int bm = operand_mode<T>(g.B, g.b_cs, g.b_rs, g.N, g.K, g.b_bs, batch);
   const bool interior = (g.M % BM == 0) && (g.N % BN == 0) && (g.K % Traits<T>::BK == 0);
@@ -552,6 +712,7 @@ double host_scalar(int dtype, const void* p) {
 }  // namespace
 
 void ahip_gemm_set_small_max_tiles(int64_t v) { g_small_max_tiles = v; }
+void ahip_gemm_set_skinny_nf(int64_t v) { g_skinny_nf = v; }
 
 extern "C" {
 

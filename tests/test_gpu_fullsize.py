@@ -94,6 +94,49 @@ def test_cfg3b_gemm_full_size_frobenius_and_associativity():
     assert (torch.linalg.norm(lhs - rhs) / torch.linalg.norm(rhs)).item() <= 1e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 1024, 1024), (8, 1024, 4096), (50, 1000, 1004),
+                                   (37, 333, 1003), (1024, 1024, 1024), (64, 256, 20480)])
+def test_small_output_gemm_kernels_all_layouts(M, N, K):
+    """Outputs too small for one 128x128 tile per CU take the 16-row split-K kernels (vector-load
+    form for k-/n-contiguous operands, scalar-load form otherwise): Frobenius error <= 1e-6
+    (fp32) / 1e-13 (fp64) against an fp64 restatement, all four operand layouts, beta != 0."""
+    import torch
+    ex = _ex("cfg3b_gemm_update")               # fp32: 0.4*C + 0.8*A@B
+    for dt, e, tol in ((torch.float32, ex, 1e-6), (torch.float64, None, 1e-13)):
+        Cm = _randn((M, N), dt, 1)
+        A, At = _randn((M, K), dt, 2), _randn((K, M), dt, 3).t()
+        B, Bt = _randn((K, N), dt, 4), _randn((N, K), dt, 5).t()
+        for a in (A, At):
+            for b in (B, Bt):
+                if dt == torch.float32:
+                    (out,) = e(Cm, a, b)
+                    ref = 0.4 * Cm.double() + 0.8 * (a.double() @ b.double())
+                else:
+                    out = _gemm64(Cm, a, b)
+                    ref = Cm + a @ b
+                rel = torch.linalg.norm(out.double() - ref) / torch.linalg.norm(ref)
+                assert rel.item() <= tol, (M, N, K, str(dt), rel.item())
+
+
+def _gemm64(Cm, a, b):
+    """C + A@B in fp64 through ahip_gemm (executor's Gemm path on a one-node plan)."""
+    from aesara_amd.executor import PlanExecutor
+    from aesara_amd.plan import Node, Plan
+    global _GEMM64
+    try:
+        ex = _GEMM64
+    except NameError:
+        p = Plan("gemm64", {}, [], [], [])
+        z, x, y = (p.new_var("float64", [None, None], n) for n in "zxy")
+        one = p.add_const(np.float64(1.0), dtype="float64")
+        o = p.new_var("float64", [None, None], "o")
+        p.inputs = [z, x, y]
+        p.nodes.append(Node("Gemm", [z, one, x, y, one], [o], {"inplace": False}))
+        p.outputs = [o]
+        ex = _GEMM64 = PlanExecutor(p)
+    return ex(Cm, a, b)[0]
+
+
 def test_cfg4_scan_full_size_chunk_consistency():
     """GRU scan T=512, H=1024 fp32: running steps [0,256) then [256,512) from the carried state
     equals one 512-step scan (recurrence semantics), within the fp32 recurrence tolerance, and the
