@@ -790,8 +790,14 @@ class GemvEpiSpec:
     """
 
     def __init__(self, dtype, dot_vec, scalar, in_dtypes, out_dtypes, out_refs, block=256,
-                 rpw=1):
+                 rpw=1, kvs=None):
         self.rpw = rpw  # rows per wavefront iteration (4 for short rows, 1 for long rows)
+        # kvs: per dot, 16-byte vectors per lane (K = 64 * VEC * kv) when every row length is
+        # such a multiple and small: the kernel is then specialised on the lengths and issues
+        # ALL row loads of ALL dots before the first FMA (one memory round trip per wavefront
+        # instead of one per loop iteration per dot — short kernels are latency-, not
+        # bandwidth-bound: BASELINE config 4 step kernels 4.5 -> see DESIGN §3.3)
+        self.kvs = list(kvs) if kvs else None
         self.dtype = dtype
         self.dot_vec = list(dot_vec)
         self.scalar = scalar
@@ -804,8 +810,9 @@ class GemvEpiSpec:
 
     def key(self):
         import json
-        blob = json.dumps(["gv2", self.dtype, self.dot_vec, self.scalar, self.in_dtypes,
-                           self.out_dtypes, self.out_refs, self.block, self.rpw], sort_keys=True)
+        blob = json.dumps(["gv3", self.dtype, self.dot_vec, self.scalar, self.in_dtypes,
+                           self.out_dtypes, self.out_refs, self.block, self.rpw, self.kvs],
+                          sort_keys=True)
         return hashlib.sha256(blob.encode()).hexdigest()[:24]
 
 
@@ -825,7 +832,34 @@ def generate_gemv_epilogue(spec: GemvEpiSpec):
     # a few KB) this keeps R independent 16-byte loads in flight per lane instead of one
     L.append("  for (i64 m0 = ((i64)blockIdx.x * %d + (threadIdx.x >> 6)) * %d; m0 < a.M; "
              "m0 += nwaves * %d) {" % (waves, R, R))
-    for d in range(D):
+    if spec.kvs:
+        # ---- fixed lengths: loads of every dot first, then FMAs, then interleaved reductions
+        for d in range(D):
+            L.append("    const %s* __restrict__ xv%d = (const %s*)a.x[%d];" % (T, d, T, d))
+            for r in range(R):
+                L.append("    const %s* __restrict__ row%d_%d = (const %s*)a.A[%d] + "
+                         "((m0 + %d < a.M) ? (m0 + %d) : (a.M - 1)) * a.a_rs[%d];"
+                         % (T, d, r, T, d, r, r, d))
+        for d in range(D):
+            for j in range(spec.kvs[d]):
+                for r in range(R):
+                    L.append("    const Pack<%s, %d> a%d_%d_%d = *(const Pack<%s, %d>*)"
+                             "(row%d_%d + (%d + lane) * %d);" % (T, V, d, r, j, T, V, d, r, j * 64, V))
+                L.append("    const Pack<%s, %d> x%d_%d = *(const Pack<%s, %d>*)(xv%d + (%d + lane) * %d);"
+                         % (T, V, d, j, T, V, d, j * 64, V))
+        for d in range(D):
+            for r in range(R):
+                terms = ["a%d_%d_%d.v[%d] * x%d_%d.v[%d]" % (d, r, j, e, d, j, e)
+                         for j in range(spec.kvs[d]) for e in range(V)]
+                # two interleaved accumulation chains per dot (as the generic loop does)
+                L.append("    %s d%d_%d = (%s) + (%s);" % (T, d, r, " + ".join(terms[0::2]),
+                                                          " + ".join(terms[1::2]) if terms[1::2] else "0"))
+        L.append("    for (int s = 32; s > 0; s >>= 1) {")
+        for d in range(D):
+            for r in range(R):
+                L.append("      d%d_%d += shfl_xor_<%s>(d%d_%d, s);" % (d, r, T, d, r))
+        L.append("    }")
+    for d in (range(D) if not spec.kvs else []):
         for r in range(R):
             L.append("    %s d%d_%d = 0;" % (T, d, r))
         L.append("    {")

@@ -92,6 +92,20 @@ int copy_typed(CopyArgs& a, int vec, int accumulate, hipStream_t s) {
   return accumulate ? launch_copy<T, true>(a, vec, s) : launch_copy<T, false>(a, vec, s);
 }
 
+// ---- ARange: out[i] = first + i * delta in the output dtype (np.arange's fill rule; the caller
+// passes first = dtype(start) and delta = dtype(start + step) - first) ----
+struct ArangeArgs { void* dst; int64_t n; double fstart, fdelta; int64_t istart, istep; };
+
+template <typename T, bool FLT>
+__global__ __launch_bounds__(256) void arange_kernel(ArangeArgs a) {
+  T* __restrict__ dst = static_cast<T*>(a.dst);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    if constexpr (FLT) dst[i] = (T)a.fstart + (T)i * (T)a.fdelta;
+    else dst[i] = (T)(a.istart + i * a.istep);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -180,6 +194,46 @@ int ahip_fill(int dtype, const void* value, void* dst, int64_t n, void* stream) 
     case 2: AHIP_LAUNCH((fill_kernel<uint16_t>), dim3(grid), dim3(256), 0, s, f); break;
     case 4: AHIP_LAUNCH((fill_kernel<uint32_t>), dim3(grid), dim3(256), 0, s, f); break;
     default: AHIP_LAUNCH((fill_kernel<uint64_t>), dim3(grid), dim3(256), 0, s, f); break;
+  }
+  return AHIP_OK;
+}
+
+int ahip_arange(int dtype, const void* first, const void* delta, int64_t n, void* dst, void* stream) {
+  const void* start = first; const void* step = delta;
+  AHIP_REQUIRE(start && step && n >= 0, "bad argument");
+  if (n == 0) return AHIP_OK;
+  AHIP_REQUIRE(dst != nullptr, "null dst");
+  hipStream_t s = as_stream(stream);
+  unsigned grid = stream_grid(n);
+  ArangeArgs a{dst, n, 0.0, 0.0, 0, 0};
+  auto ival = [&](const void* p) -> int64_t {
+    switch (dtype) {
+      case AHIP_BOOL: case AHIP_U8: return *static_cast<const uint8_t*>(p);
+      case AHIP_I8: return *static_cast<const int8_t*>(p);
+      case AHIP_I16: return *static_cast<const int16_t*>(p);
+      case AHIP_U16: return *static_cast<const uint16_t*>(p);
+      case AHIP_I32: return *static_cast<const int32_t*>(p);
+      case AHIP_U32: return *static_cast<const uint32_t*>(p);
+      default: return *static_cast<const int64_t*>(p);
+    }
+  };
+  if (dtype == AHIP_F32) {
+    const float st = *static_cast<const float*>(start), sp = *static_cast<const float*>(step);
+    a.fstart = st; a.fdelta = sp;
+    AHIP_LAUNCH((arange_kernel<float, true>), dim3(grid), dim3(256), 0, s, a);
+  } else if (dtype == AHIP_F64) {
+    const double st = *static_cast<const double*>(start), sp = *static_cast<const double*>(step);
+    a.fstart = st; a.fdelta = sp;
+    AHIP_LAUNCH((arange_kernel<double, true>), dim3(grid), dim3(256), 0, s, a);
+  } else {
+    a.istart = ival(start); a.istep = ival(step);
+    switch (ahip_itemsize(dtype)) {
+      case 1: AHIP_LAUNCH((arange_kernel<uint8_t, false>), dim3(grid), dim3(256), 0, s, a); break;
+      case 2: AHIP_LAUNCH((arange_kernel<uint16_t, false>), dim3(grid), dim3(256), 0, s, a); break;
+      case 4: AHIP_LAUNCH((arange_kernel<uint32_t, false>), dim3(grid), dim3(256), 0, s, a); break;
+      case 8: AHIP_LAUNCH((arange_kernel<uint64_t, false>), dim3(grid), dim3(256), 0, s, a); break;
+      default: ahip_set_error("bad dtype %d", dtype); return AHIP_EINVAL;
+    }
   }
   return AHIP_OK;
 }

@@ -208,6 +208,48 @@ int run_argmax(ArgmaxArgs& a, hipStream_t s) {
   return AHIP_OK;
 }
 
+// ---- N-d integer indexing: flat row index of x[i0[j], i1[j], ...] (NumPy advanced indexing with
+// only integer arrays: they address the leading dims; each index wraps once, like resolve()) ----
+constexpr int LIN_MAX = 8;
+struct LinArgs {
+  const void* idx[LIN_MAX]; int dtype[LIN_MAX]; int64_t stride[LIN_MAX];
+  int64_t dim[LIN_MAX]; int64_t mult[LIN_MAX];
+  int64_t n; int64_t* out; int64_t* bad; int nidx;
+};
+
+__device__ __forceinline__ int64_t load_index(const void* p, int dtype, int64_t i) {
+  switch (dtype) {
+    case AHIP_I8: return static_cast<const int8_t*>(p)[i];
+    case AHIP_I16: return static_cast<const int16_t*>(p)[i];
+    case AHIP_I32: return static_cast<const int32_t*>(p)[i];
+    case AHIP_I64: return static_cast<const int64_t*>(p)[i];
+    case AHIP_U8: return static_cast<const uint8_t*>(p)[i];
+    case AHIP_U16: return static_cast<const uint16_t*>(p)[i];
+    case AHIP_U32: return static_cast<const uint32_t*>(p)[i];
+    default: return (int64_t)static_cast<const uint64_t*>(p)[i];
+  }
+}
+
+__global__ __launch_bounds__(256) void linearize_kernel(LinArgs a) {
+  for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < a.n;
+       j += (int64_t)gridDim.x * blockDim.x) {
+    int64_t lin = 0;
+    bool ok = true;
+    for (int d = 0; d < a.nidx; ++d) {
+      const int64_t v = load_index(a.idx[d], a.dtype[d], j * a.stride[d]);
+      const int64_t w = v < 0 ? v + a.dim[d] : v;
+      if (w < 0 || w >= a.dim[d]) {
+        unsigned long long code = (unsigned long long)(v >= 0 ? v + 1 : v);
+        atomicCAS(reinterpret_cast<unsigned long long*>(a.bad), 0ULL, code);
+        ok = false;
+      } else {
+        lin += w * a.mult[d];
+      }
+    }
+    a.out[j] = ok ? lin : 0;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -256,6 +298,25 @@ int ahip_argmax_rows(int dtype, const void* x, int64_t nrows, int64_t k, int64_t
     case AHIP_F64: return run_argmax<double>(a, s);
     default: ahip_set_error("bad dtype %d", dtype); return AHIP_EINVAL;
   }
+}
+
+int ahip_linearize_indices(int nidx, const void* const* idx, const int* idx_dtypes,
+                           const int64_t* idx_strides, const int64_t* dims, const int64_t* mults,
+                           int64_t n, int64_t* out, int64_t* bad_index, void* stream) {
+  AHIP_REQUIRE(nidx >= 1 && nidx <= LIN_MAX, "1..8 index arrays");
+  AHIP_REQUIRE(n >= 0, "negative extent");
+  if (n == 0) return AHIP_OK;
+  AHIP_REQUIRE(idx && idx_dtypes && idx_strides && dims && mults && out && bad_index, "null argument");
+  LinArgs a{};
+  for (int d = 0; d < nidx; ++d) {
+    AHIP_REQUIRE(idx[d] != nullptr, "null index array");
+    AHIP_REQUIRE(idx_dtypes[d] >= AHIP_I8 && idx_dtypes[d] <= AHIP_U64, "index dtype must be an integer type");
+    a.idx[d] = idx[d]; a.dtype[d] = idx_dtypes[d]; a.stride[d] = idx_strides[d];
+    a.dim[d] = dims[d]; a.mult[d] = mults[d];
+  }
+  a.n = n; a.out = out; a.bad = bad_index; a.nidx = nidx;
+  AHIP_LAUNCH(linearize_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), a);
+  return AHIP_OK;
 }
 
 }  // extern "C"

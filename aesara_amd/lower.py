@@ -528,6 +528,38 @@ def _register_handlers():
         ctx.vmap[node.outputs[0]] = mx
         ctx.vmap[node.outputs[1]] = am
 
+    from aesara.tensor.basic import ARange
+    from aesara.tensor.subtensor import AdvancedIncSubtensor, AdvancedSubtensor
+
+    @hip_lower.register(ARange)
+    def _(op, node, ctx):
+        # reference: tensor/basic.py:2867 ARange(start, stop, step) (perform :2937)
+        ctx.emit("ARange", node, {"dtype": str(op.dtype)})
+
+    def _int_array_indices(op, idx_vars):
+        from aesara.tensor.type import TensorType
+        for v in idx_vars:
+            if not (isinstance(v.type, TensorType) and v.type.dtype.startswith(("int", "uint"))):
+                raise UnsupportedOp(f"{type(op).__name__} with a non-integer-array index "
+                                    f"({v.type}): slices / masks / newaxis are outside the path")
+        if not 1 <= len(idx_vars) <= 8:
+            raise UnsupportedOp("advanced indexing with more than 8 index arrays")
+
+    @hip_lower.register(AdvancedSubtensor)
+    def _(op, node, ctx):
+        # reference: tensor/subtensor.py:2543 AdvancedSubtensor (perform :2607), integer arrays
+        _int_array_indices(op, node.inputs[1:])
+        ctx.emit("AdvancedSubtensor", node)
+
+    @hip_lower.register(AdvancedIncSubtensor)
+    def _(op, node, ctx):
+        # reference: tensor/subtensor.py:2647 AdvancedIncSubtensor (perform :2688: np.add.at / set)
+        _int_array_indices(op, node.inputs[2:])
+        if getattr(op, "ignore_duplicates", False):
+            raise UnsupportedOp("AdvancedIncSubtensor(ignore_duplicates=True)")
+        ctx.emit("AdvancedIncSubtensor", node, {
+            "set_instead_of_inc": bool(op.set_instead_of_inc), "inplace": bool(op.inplace)})
+
     @hip_lower.register(Scan)
     def _(op, node, ctx):
         # reference: scan/op.py:637 Scan; info layout scan/op.py:206 ScanInfo.  The inner

@@ -248,6 +248,11 @@ int ahip_copy_strided(int dtype, int nd, const int64_t* shape, const void* src,
                       const int64_t* sstrides, void* dst, const int64_t* dstrides, int accumulate,
                       void* stream);
 int ahip_fill(int dtype, const void* value /* host scalar */, void* dst, int64_t n, void* stream);
+/* tensor/basic.py:2867 ARange (perform :2937, np.arange(start, stop, step, dtype)): dst[i] = first +
+ * i*delta evaluated in the output dtype — NumPy's fill rule with first = dtype(start), delta =
+ * dtype(start + step) - first, both host scalars of `dtype`; n = ceil((stop - start) / step) is the
+ * caller's.                                                                                     */
+int ahip_arange(int dtype, const void* first, const void* delta, int64_t n, void* dst, void* stream);
 
 /* ---- K9: integer row gather / scatter (bit-exact) ------------------------------------------
  * replaces: tensor/subtensor.py:1925 AdvancedSubtensor1 (perform :1953, x.take(idx, axis=0)) and
@@ -263,6 +268,13 @@ int ahip_scatter_rows(int dtype, void* dst, int64_t nrows, int64_t dst_rs, int64
                       const void* idx, int idx_dtype, int64_t nidx, int64_t idx_stride,
                       const void* src, int64_t src_rs, int accumulate, int64_t* bad_index,
                       void* stream);
+/* N-d integer-array indexing, tensor/subtensor.py:2543 AdvancedSubtensor / :2647 AdvancedIncSubtensor
+ * (perform :2607 / :2688) with integer index arrays only: out[j] = sum_d wrap(idx_d[j*stride_d]) * mults[d]
+ * is the flat row index consumed by ahip_take_rows / ahip_scatter_rows; each index wraps once
+ * (v + dims[d]); out-of-range values are reported through *bad_index (row 0 is used instead).       */
+int ahip_linearize_indices(int nidx, const void* const* idx, const int* idx_dtypes,
+                           const int64_t* idx_strides, const int64_t* dims, const int64_t* mults,
+                           int64_t n, int64_t* out, int64_t* bad_index, void* stream);
 /* Row argmax, replaces tensor/math.py:330 Argmax (perform :388: np.argmax over the reduced axes
  * moved last and flattened).  x is viewed as [nrows, k] with element strides x_rs / x_cs; out[r]
  * = index of the first maximum of row r; a NaN counts as the maximum (first NaN wins).         */

@@ -649,6 +649,60 @@ def _():
          B((5, 9), 3, 0.3)]
 
 # ---------------------------------------------------------------------------------------
+# ARange and N-d integer-array indexing (tests/tensor/test_subtensor.py TestAdvancedSubtensor,
+# test_basic.py TestARange); the NLL idiom log_softmax(x)[arange(n), y] and its gradient
+# ---------------------------------------------------------------------------------------
+@case("arange_variants", exact=True)
+def _():
+    n, a, b = at.lscalar("n"), at.lscalar("a"), at.lscalar("b")
+    return [n, a, b], [at.arange(n), at.arange(a, n, b), at.arange(n, a, -b),
+                       at.arange(n, dtype="int32") * 2, at.arange(a, a)], \
+        [K(11, "int64"), K(2, "int64"), K(3, "int64")]
+
+
+@case("arange_float", rtol=1e-6, atol=1e-6)
+def _():
+    s, e = at.dscalar("s"), at.dscalar("e")
+    return [s, e], [at.arange(s, e, 0.25), at.arange(s, e, 0.1, dtype="float32")], \
+        [K(-1.5, "float64"), K(3.2, "float64")]
+
+
+@case("advsub_nd", exact=True)
+def _():
+    x, t = at.imatrix("x"), at.tensor3("t", dtype="int32")
+    i, j = at.lvector("i"), at.ivector("j")
+    ci = at.lmatrix("ci")
+    return [x, t, i, j, ci], [x[i, j], x[at.arange(i.shape[0]), j], t[i, j], t[i, j, i],
+                              x[ci, j.dimshuffle("x", 0)], x.T[j, i]], \
+        [I((9, 7), "int32", 1, -99, 99), I((9, 7, 9), "int32", 2, -99, 99),
+         I((6,), "int64", 3, -9, 9), I((6,), "int32", 4, -7, 7), I((4, 1), "int64", 5, 0, 9)]
+
+
+@case("advincsub_nd", exact=True, ref_py=True)
+def _():
+    x, y = at.imatrix("x"), at.ivector("y")
+    i, j = at.lvector("i"), at.ivector("j")
+    from aesara.tensor.subtensor import inc_subtensor, set_subtensor
+    return [x, y, i, j], [inc_subtensor(x[i, j], y), inc_subtensor(x[i, j], 5),
+                          set_subtensor(x[i, i], y)], \
+        [I((9, 7), "int32", 1, -99, 99), I((6,), "int32", 2, -9, 9),
+         {"kind": "perm", "n": 7, "shape": [6], "dtype": "int64", "seed": 3},
+         I((6,), "int32", 4, -7, 7)]
+
+
+for _dt, _tol in (("float64", 1e-12), ("float32", 3e-5)):
+    def _mknll(dt=_dt):
+        from aesara.tensor.special import log_softmax
+        x, W, b, y = T(dt, (2, 2), "x"), T(dt, (2, 2), "W"), T(dt, (2,), "b"), at.lvector("y")
+        logits = at.dot(x, W) + b
+        nll = -log_softmax(logits, axis=-1)[at.arange(y.shape[0]), y].mean()
+        gW, gb = ae.grad(nll, [W, b])
+        return [x, W, b, y], [nll, gW, gb, at.argmax(logits, axis=1)], \
+            [N((48, 20), dt, 1), N((20, 10), dt, 2, 0.5), N((10,), dt, 3, 0.1),
+             I((48,), "int64", 4, 0, 10)]
+    case(f"nll_classifier_{_dt}", rtol=_tol, atol=_tol)(_mknll)
+
+# ---------------------------------------------------------------------------------------
 # BASELINE.json configs at reduced shapes
 # ---------------------------------------------------------------------------------------
 @case("cfg1a_scalar_add", exact=True)

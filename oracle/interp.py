@@ -400,6 +400,22 @@ def run_plan(plan, inputs):
                 exc = getattr(builtins, p.get("exc_type", "AssertionError"), AssertionError)
                 raise exc(p.get("msg", ""))
             r = [a[0]]
+        elif op == "ARange":
+            # reference: tensor/basic.py:2937 ARange.perform
+            st, sp, se = (np.asarray(v).item() for v in a)
+            r = [np.arange(st, sp, se, dtype=p["dtype"])]
+        elif op == "AdvancedSubtensor":
+            # reference: tensor/subtensor.py:2607 AdvancedSubtensor.perform
+            r = [np.asarray(a[0])[tuple(np.asarray(i) for i in a[1:])]]
+        elif op == "AdvancedIncSubtensor":
+            # reference: tensor/subtensor.py:2688 AdvancedIncSubtensor.perform
+            out = np.array(a[0], copy=True)
+            idx = tuple(np.asarray(i) for i in a[2:])
+            if p["set_instead_of_inc"]:
+                out[idx] = a[1]
+            else:
+                np.add.at(out, idx, a[1])
+            r = [out]
         elif op == "Argmax":
             r = [argmax(a[0], p["axis"])]
         elif op == "DeepCopyOp":

@@ -8,7 +8,7 @@ import csv, collections
 d = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open("$out/p_counter_collection.csv")):
     k = r["Kernel_Name"][:40]
-    if not k.startswith(("ew_", "void (anonymous")): continue
+    if not k.startswith(("ew_", "gv_", "rp_", "rc_", "void (anonymous")): continue
     d[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     d[k]["dur_ns"].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 for k, v in d.items():
