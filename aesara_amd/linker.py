@@ -47,6 +47,10 @@ class HipLinker(JITLinker):
                        storage_map=None, **kwargs):
         self.plan = lower_fgraph(fgraph, order=order, name=getattr(fgraph, "name", None)
                                  or "fgraph", inner_rewriter=hip_mode.optimizer)
+        # outputs that are ``updates=`` expressions go back into shared-variable cells
+        # (types.py:1060-1069), never to the caller: they stay device tensors
+        self._update_outputs = {fgraph.outputs[i]
+                                for i in getattr(fgraph, "update_mapping", None) or {}}
         return self.plan
 
     def jit_compile(self, plan):
@@ -71,7 +75,8 @@ class HipLinker(JITLinker):
         return [storage_map[n] for n in self.fgraph.inputs]
 
     def output_filter(self, var, out):
-        if self.return_numpy and hasattr(out, "detach"):
+        if self.return_numpy and hasattr(out, "detach") \
+                and var not in getattr(self, "_update_outputs", ()):
             return out.detach().cpu().numpy()
         return out
 

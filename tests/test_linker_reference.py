@@ -119,6 +119,53 @@ def test_device_shared_variable_state_stays_on_device(ae):
     assert float(g(torch.arange(5, dtype=torch.float64))) == 20.0
 
 
+def test_mlp_training_step_through_the_linker_matches_c_linker(ae):
+    """A whole SGD step of a 2-layer softmax classifier (Gemm, row-chain log-softmax, N-d
+    integer indexing for the NLL, its gradient scatter, Argmax, four shared-variable updates)
+    compiled with mode=HIP and run for several steps: losses, predictions and parameters follow
+    the reference's C linker; the parameters live in device-resident shared variables."""
+    import torch
+    import aesara.tensor as at
+    import interp
+    from aesara.compile.mode import Mode
+    from aesara.tensor.special import log_softmax
+    from aesara_amd.linker import HIP_QUERY, HipLinker
+    from aesara_amd.sharedvar import hip_shared
+
+    def factory(plan):
+        def run(*a):
+            outs = interp.run_plan(plan, [x.numpy() if isinstance(x, torch.Tensor) else x
+                                          for x in a])
+            return [torch.from_numpy(np.ascontiguousarray(o)) for o in outs]
+        return run
+
+    rng = np.random.default_rng(0)
+    init = [rng.standard_normal((20, 32)) * 0.3, np.zeros(32), rng.standard_normal((32, 10)) * 0.3,
+            np.zeros(10)]
+
+    def build(make_shared, mode):
+        x, y = at.dmatrix("x"), at.lvector("y")
+        W1, b1, W2, b2 = params = [make_shared(v.copy()) for v in init]
+        logits = at.dot(at.tanh(at.dot(x, W1) + b1), W2) + b2
+        loss = -log_softmax(logits, axis=-1)[at.arange(y.shape[0]), y].mean()
+        upd = [(p, p - 0.1 * g) for p, g in zip(params, ae.grad(loss, params))]
+        return ae.function([x, y], [loss, at.argmax(logits, axis=1)], updates=upd, mode=mode), params
+
+    f_hip, p_hip = build(lambda v: hip_shared(v, device="cpu"),
+                         Mode(HipLinker(executor_factory=factory, return_numpy=True), HIP_QUERY))
+    f_ref, p_ref = build(ae.shared, None)
+    for step in range(4):
+        xv = rng.standard_normal((64, 20))
+        yv = rng.integers(0, 10, 64)
+        l1, a1 = f_hip(xv, yv)
+        l2, a2 = f_ref(xv, yv)
+        np.testing.assert_allclose(l1, l2, rtol=1e-10)
+        np.testing.assert_array_equal(a1, a2)
+    for ph, pr in zip(p_hip, p_ref):
+        assert isinstance(ph.container.value, torch.Tensor)
+        np.testing.assert_allclose(ph.get_value(), pr.get_value(), rtol=1e-9, atol=1e-12)
+
+
 def test_linker_clone_and_scan_inner_mode(ae):
     """Linker.clone(allow_gc=…) is used by Scan/Mode.clone (link/basic.py:190)."""
     from aesara_amd.linker import HipLinker
