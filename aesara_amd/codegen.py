@@ -641,12 +641,16 @@ def generate(spec: KernelSpec):
         L.append("      " + " ".join("base%d = off%d;" % (k, k) for k in range(nops)))
         L.append("  }")
         L.append("  const i64 nred = a.aux0;")
+        # the loads of consecutive iterations are independent: unrolling keeps several in flight
+        # per lane (these loops are latency-, not issue-bound)
         if red["kind"] == "row":
+            L.append("#pragma unroll 4")
             L.append("  for (i64 r0 = lane; r0 < nred; r0 += 64) {")
         else:
             L.append("  const i64 per = (nred + a.aux1 - 1) / a.aux1;")
             L.append("  const i64 rbeg = (i64)blockIdx.y * per;")
             L.append("  const i64 rend = (rbeg + per < nred) ? rbeg + per : nred;")
+            L.append("#pragma unroll 4")
             L.append("  for (i64 r0 = rbeg; r0 < rend; ++r0) {")
         L.append("      i64 " + ", ".join("off%d = base%d" % (k, k) for k in range(nops)) + ";")
         L.extend(_offset_code(spec, nops, nk, nk + nr, "r0", "i64"))

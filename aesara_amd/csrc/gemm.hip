@@ -569,6 +569,117 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
   }
 }
 
+
+// Weight-gradient layout (A = X.T, m-contiguous; B n-contiguous): C[M,N] = sum_k A[k][m] B[k][n] with
+// few output tiles and a very long K (X.T @ dY of a classifier: 1024 x 1000 x 32768 is 64 big
+// tiles).  Tile (16 VEC) x (16 VEC) per workgroup, K split over its 4 wavefronts; per k-step a
+// lane loads ONE 16-byte vector of A (VEC consecutive rows = VEC row fragments, fragment e holding
+// rows m0 + VEC*i + e) and ONE of B (VEC column fragments): 2 loads feed VEC*VEC MFMAs.
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs g) {
+  using acc_t = typename Traits<T>::acc_t;
+  constexpr int VEC = Traits<T>::VEC;
+  constexpr int TILE = 16 * VEC;
+  constexpr int U = 4;  // k-steps per load group
+  struct alignas(sizeof(T) * VEC) PV { T v[VEC]; };
+  __shared__ T part[3][TILE * TILE];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, kg = lane >> 4;
+  const int64_t z = blockIdx.z;
+  const int64_t m0 = (int64_t)blockIdx.y * TILE, n0 = (int64_t)blockIdx.x * TILE;
+  const T* __restrict__ A = static_cast<const T*>(g.A) + z * g.a_bs;
+  const T* __restrict__ B = static_cast<const T*>(g.B) + z * g.b_bs;
+  const int64_t kq = ((g.K + 4 * 4 * U - 1) / (4 * 4 * U)) * (4 * U);
+  const int64_t kbeg = wave * kq;
+  const int64_t kend = (kbeg + kq < g.K) ? kbeg + kq : g.K;
+  const bool mok = m0 + VEC * r < g.M, nok = n0 + VEC * r < g.N;   // M % VEC == N % VEC == 0
+  const T* ap = A + (mok ? m0 + VEC * r : 0);       // a_rs == 1: rows contiguous
+  const T* bp = B + (nok ? n0 + VEC * r : 0);       // b_cs == 1: columns contiguous
+  acc_t acc[VEC][VEC], tot[VEC][VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e)
+#pragma unroll
+    for (int f = 0; f < VEC; ++f) { acc[e][f] = acc_t{0, 0, 0, 0}; tot[e][f] = acc_t{0, 0, 0, 0}; }
+  struct Grp { PV a[U], b[U]; };
+  auto load = [&](int64_t k0, Grp& gr) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t kk = k0 + 4 * u + kg;
+      const bool kok = kk < kend;
+      gr.a[u] = (mok && kok) ? *reinterpret_cast<const PV*>(ap + kk * g.a_cs) : PV{};
+      gr.b[u] = (nok && kok) ? *reinterpret_cast<const PV*>(bp + kk * g.b_rs) : PV{};
+    }
+  };
+  auto compute = [&](const Grp& gr) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e)
+#pragma unroll
+        for (int f = 0; f < VEC; ++f) mma(acc[e][f], gr.a[u].v[e], gr.b[u].v[f]);
+  };
+  constexpr int64_t GK = 4 * U;
+  Grp g0, g1;
+  int64_t k0 = kbeg, next_fold = kbeg + 512;
+  if (k0 < kend) load(k0, g0);
+  for (; k0 < kend; k0 += 2 * GK) {
+    if (k0 + GK < kend) load(k0 + GK, g1);
+    compute(g0);
+    if (k0 + GK < kend) {
+      if (k0 + 2 * GK < kend) load(k0 + 2 * GK, g0);
+      compute(g1);
+    }
+    if (k0 + 2 * GK >= next_fold) {   // two-level sum (see gemm_skinny_kernel)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e)
+#pragma unroll
+        for (int f = 0; f < VEC; ++f) { tot[e][f] += acc[e][f]; acc[e][f] = acc_t{0, 0, 0, 0}; }
+      next_fold += 512;
+    }
+  }
+  // element (row i, fragment e; column r, fragment f) -> tile position (VEC*i + e, VEC*r + f)
+  auto tpos = [&](int i, int e, int f) { return (VEC * frag_row<T>(lane, i) + e) * TILE + VEC * r + f; };
+  if (wave > 0) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e)
+#pragma unroll
+      for (int f = 0; f < VEC; ++f)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) part[wave - 1][tpos(i, e, f)] = tot[e][f][i] + acc[e][f][i];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    T* C = static_cast<T*>(g.C) + z * g.c_bs;
+    const T* Cin = static_cast<const T*>(g.Cin) + z * g.ci_bs;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e)
+#pragma unroll
+      for (int f = 0; f < VEC; ++f)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int p = tpos(i, e, f);
+          const int64_t row = m0 + p / TILE, col = n0 + p % TILE;
+          if (row >= g.M || col >= g.N) continue;
+          T sum = tot[e][f][i] + acc[e][f][i];
+          sum += part[0][p];
+          sum += part[1][p];
+          sum += part[2][p];
+          T v = (T)g.alpha * sum;
+          if (g.beta != 0.0) v += (T)g.beta * Cin[row * g.ci_rs + col * g.ci_cs];
+          C[row * g.c_rs + col * g.c_cs] = v;
+        }
+  }
+}
+
+template <typename T>
+int launch_tn(const GemmArgs& g, int64_t batch, hipStream_t s) {
+  constexpr int TILE = 16 * Traits<T>::VEC;
+  const int64_t gx = (g.N + TILE - 1) / TILE, gy = (g.M + TILE - 1) / TILE;
+  AHIP_LAUNCH((gemm_tn_kernel<T>), dim3((unsigned)gx, (unsigned)gy, (unsigned)batch), dim3(256), 0,
+              s, g);
+  return AHIP_OK;
+}
+
 template <typename T, int NF, bool BKC>
 int launch_skinny(const GemmArgs& g, int64_t batch, hipStream_t s) {
   const int64_t gx = (g.N + 16 * NF - 1) / (16 * NF), gy = (g.M + 15) / 16;
@@ -586,6 +697,11 @@ int launch_small(const GemmArgs& g, int64_t batch, hipStream_t s) {
   auto al = [](const void* p, size_t b) { return reinterpret_cast<uintptr_t>(p) % b == 0; };
   const bool a_ok = g.a_cs == 1 && al(g.A, 16) && g.a_rs % VEC == 0 && g.K % VEC == 0 &&
                     (batch <= 1 || g.a_bs % VEC == 0);
+  const bool a_mc = g.a_rs == 1 && al(g.A, 16) && g.a_cs % VEC == 0 && g.M % VEC == 0 &&
+                    (batch <= 1 || g.a_bs % VEC == 0);
+  const bool b_nc = g.b_cs == 1 && al(g.B, 16) && g.b_rs % VEC == 0 && g.N % VEC == 0 &&
+                    (batch <= 1 || g.b_bs % VEC == 0);
+  if (!a_ok && a_mc && b_nc) return launch_tn<T>(g, batch, s);
   if (a_ok) {
     const bool bk_ok = g.b_rs == 1 && al(g.B, 16) && g.b_cs % VEC == 0 &&
                        (batch <= 1 || g.b_bs % VEC == 0);
@@ -691,11 +807,50 @@ int gemm_dispatch(GemmArgs& g, int64_t batch, hipStream_t s) {
                        ((g.b_rs == 1 && g.b_cs % VEC == 0) ||
                         (g.b_cs == 1 && g.b_rs % VEC == 0 && g.N % VEC == 0)) &&
                        (batch <= 1 || g.b_bs % VEC == 0);
-    const int64_t limit = (a_vec && b_vec) ? (g_small_max_tiles < 64 ? g_small_max_tiles
+    const bool tn_vec = g.a_rs == 1 && reinterpret_cast<uintptr_t>(g.A) % 16 == 0 &&
+                        g.a_cs % VEC == 0 && g.M % VEC == 0 && g.b_cs == 1 && g.b_rs % VEC == 0 &&
+                        g.N % VEC == 0 && reinterpret_cast<uintptr_t>(g.B) % 16 == 0 &&
+                        (batch <= 1 || (g.a_bs % VEC == 0 && g.b_bs % VEC == 0));
+    const int64_t limit = ((a_vec && b_vec) || tn_vec) ? (g_small_max_tiles < 64 ? g_small_max_tiles
                                                                        : 4 * g_small_max_tiles)
                                            : g_small_max_tiles;
     if ((int64_t)g.tiles_m * g.tiles_n * batch < limit && (g.M + 15) / 16 < 65536 && batch < 65536)
       return launch_small<T>(g, batch, s);
+  }
+  // ragged M / N on a large problem: the tile-aligned block runs the unpredicated instantiation
+  // (118-123 vs ~100 TFLOP/s for the predicated one), the right / bottom strips are dispatched
+  // on their own (predicated big tiles or the small-output kernels)
+  {
+    const int64_t Mi = (g.M / BM) * BM, Ni = (g.N / BN) * BN;
+    if (g.K % Traits<T>::BK == 0 && Mi > 0 && Ni > 0 && (Mi < g.M || Ni < g.N) &&
+        (Mi / BM) * (Ni / BN) * batch >= 256) {
+      auto off = [](const void* p, int64_t e) {
+        return static_cast<const void*>(static_cast<const T*>(p) + e);
+      };
+      GemmArgs a = g;
+      a.M = Mi; a.N = Ni;
+      int rc = gemm_dispatch<T>(a, batch, s);
+      if (rc) return rc;
+      if (Ni < g.N) {                       // right strip: all rows, columns [Ni, N)
+        GemmArgs b = g;
+        b.N = g.N - Ni;
+        b.B = off(g.B, Ni * g.b_cs);
+        b.Cin = g.Cin ? off(g.Cin, Ni * g.ci_cs) : nullptr;
+        b.C = const_cast<void*>(off(g.C, Ni * g.c_cs));
+        rc = gemm_dispatch<T>(b, batch, s);
+        if (rc) return rc;
+      }
+      if (Mi < g.M) {                       // bottom strip: rows [Mi, M), columns [0, Ni)
+        GemmArgs c = g;
+        c.M = g.M - Mi; c.N = Ni;
+        c.A = off(g.A, Mi * g.a_rs);
+        c.Cin = g.Cin ? off(g.Cin, Mi * g.ci_rs) : nullptr;
+        c.C = const_cast<void*>(off(g.C, Mi * g.c_rs));
+        rc = gemm_dispatch<T>(c, batch, s);
+        if (rc) return rc;
+      }
+      return AHIP_OK;
+    }
   }
   int am = operand_mode<T>(g.A, g.a_rs, g.a_cs, g.M, g.K, g.a_bs, batch);
   int bm = operand_mode<T>(g.B, g.b_cs, g.b_rs, g.N, g.K, g.b_bs, batch);

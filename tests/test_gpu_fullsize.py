@@ -95,9 +95,11 @@ def test_cfg3b_gemm_full_size_frobenius_and_associativity():
 
 
 @pytest.mark.parametrize("M,N,K", [(64, 1024, 1024), (8, 1024, 4096), (50, 1000, 1004),
-                                   (37, 333, 1003), (1024, 1024, 1024), (64, 256, 20480)])
+                                   (37, 333, 1003), (1024, 1024, 1024), (64, 256, 20480),
+                                   (1024, 1000, 8192), (2100, 2500, 512)])
 def test_small_output_gemm_kernels_all_layouts(M, N, K):
-    """Outputs too small for one 128x128 tile per CU take the 16-row split-K kernels (vector-load
+    """(The last shape is a large ragged problem: aligned block unpredicated + edge strips.)
+    Outputs too small for one 128x128 tile per CU take the 16-row split-K kernels (vector-load
     form for k-/n-contiguous operands, scalar-load form otherwise): Frobenius error <= 1e-6
     (fp32) / 1e-13 (fp64) against an fp64 restatement, all four operand layouts, beta != 0."""
     import torch

@@ -202,6 +202,18 @@ def main():
                        d, w, 2 * M * N * K, "TFLOP/s", 157.3)
         check(_l.ahip_set_param(b"gemm_small_max_tiles", 64))
 
+    if want("nll"):
+        Nb, Dd, Cc = 32768, 1024, 1000
+        ex = PlanExecutor(plan_of("nll_classifier_float32"), use_graph=G)
+        x = randn((Nb, Dd), f32, 21)
+        W = randn((Dd, Cc), f32, 22) * 0.03
+        b = randn((Cc,), f32, 23) * 0.1
+        y = torch.randint(0, Cc, (Nb,), device="cuda")
+        d, w = timeit(lambda: ex(x, W, b, y), 10, warmup=2)
+        report("softmax-classifier NLL + grads f32 N=32768 D=1024 C=1000", d, w,
+               3 * 2 * Nb * Dd * Cc, "TFLOP/s", 157.3,
+               note="flops = forward GEMM + dW GEMM + dX-free; includes log-softmax, gather, scatter")
+
     if want("cfg5"):
         N, D = 1 << 22, 256
         ex = PlanExecutor(plan_of("cfg5_logistic"), use_graph=G)
