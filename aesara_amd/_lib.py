@@ -107,6 +107,9 @@ SIGNATURES = {
                                         i32, vp]),
     "ahip_gemm": (i32, [i32, i64, i64, i64, vp, vp, i64, i64, vp, i64, i64, vp, vp, i64, i64,
                         vp, i64, i64, vp]),
+    "ahip_gemm_ws_bytes": (sz, [i32, i64, i64, i64, i64]),
+    "ahip_gemm_splitk": (i32, [i32, i64, i64, i64, vp, vp, i64, i64, vp, i64, i64, vp, vp, i64, i64,
+                               vp, i64, i64, vp, sz, vp]),
     "ahip_gemm_batched": (i32, [i32, i64, i64, i64, i64, vp, vp, i64, i64, i64, vp, i64, i64,
                                 i64, vp, vp, i64, i64, i64, vp, i64, i64, i64, vp]),
     "ahip_gemv_ws_bytes": (sz, [i32, i64, i64]),

@@ -859,6 +859,63 @@ int gemm_dispatch(GemmArgs& g, int64_t batch, hipStream_t s) {
                   : dispatch_modes<T, true>(g, am, bm, batch, s);
 }
 
+
+// ---- split-K for few-tile / long-K problems (weight gradients) ---------------------------------
+// The K range is cut into S slices that run as S "batches" of the big 128x128 kernel into a
+// caller-provided workspace [S][M][N]; splitk_reduce_kernel sums the slices in order and applies
+// the alpha / beta epilogue (deterministic; no float atomics).
+struct SplitArgs { const void* ws; const void* Cin; void* C; int64_t M, N, S, ci_rs, ci_cs, c_rs, c_cs;
+                   double alpha, beta; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(SplitArgs a) {
+  const T* __restrict__ ws = static_cast<const T*>(a.ws);
+  const int64_t n = a.M * a.N;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    T sum = ws[i];
+    for (int64_t sidx = 1; sidx < a.S; ++sidx) sum += ws[sidx * n + i];
+    const int64_t r = i / a.N, c = i - r * a.N;
+    T v = (T)a.alpha * sum;
+    if (a.beta != 0.0) v += (T)a.beta * static_cast<const T*>(a.Cin)[r * a.ci_rs + c * a.ci_cs];
+    static_cast<T*>(a.C)[r * a.c_rs + c * a.c_cs] = v;
+  }
+}
+
+// number of K slices for (M, N, K), 0 = do not split
+int64_t splitk_slices(int64_t M, int64_t N, int64_t K, int64_t batch, int bk) {
+  if (batch != 1 || M < BM || N < BN || K < 8192) return 0;
+  const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  if (tiles >= 128) return 0;
+  int64_t S = 16;
+  while (S > 1 && (tiles * S > 512 || K % (S * bk) != 0 || K / S < 1024)) S /= 2;
+  return S > 1 ? S : 0;
+}
+
+template <typename T>
+int gemm_splitk(const GemmArgs& g, int64_t S, void* ws, hipStream_t s) {
+  GemmArgs p = g;
+  p.K = g.K / S;
+  p.a_bs = p.K * g.a_cs;
+  p.b_bs = p.K * g.b_rs;
+  p.C = ws; p.c_bs = g.M * g.N; p.c_rs = g.N; p.c_cs = 1;
+  p.Cin = ws; p.ci_bs = p.c_bs; p.ci_rs = g.N; p.ci_cs = 1;
+  p.alpha = 1.0; p.beta = 0.0;
+  p.tiles_m = (int)((g.M + BM - 1) / BM);
+  p.tiles_n = (int)((g.N + BN - 1) / BN);
+  int am = operand_mode<T>(p.A, p.a_rs, p.a_cs, p.M, p.K, p.a_bs, S);
+  int bm = operand_mode<T>(p.B, p.b_cs, p.b_rs, p.N, p.K, p.b_bs, S);
+  const bool interior = (p.M % BM == 0) && (p.N % BN == 0) && (p.K % Traits<T>::BK == 0);
+  int rc = interior ? dispatch_modes<T, false>(p, am, bm, S, s)
+                    : dispatch_modes<T, true>(p, am, bm, S, s);
+  if (rc) return rc;
+  SplitArgs r{ws, g.Cin, g.C, g.M, g.N, S, g.ci_rs, g.ci_cs, g.c_rs, g.c_cs, g.alpha, g.beta};
+  int64_t n = g.M * g.N;
+  unsigned blocks = (unsigned)(((n + 255) / 256) < 2048 ? ((n + 255) / 256) : 2048);
+  AHIP_LAUNCH((splitk_reduce_kernel<T>), dim3(blocks), dim3(256), 0, s, r);
+  return AHIP_OK;
+}
+
 double host_scalar(int dtype, const void* p) {
   return dtype == AHIP_F32 ? (double)*static_cast<const float*>(p)
                            : *static_cast<const double*>(p);
@@ -904,6 +961,38 @@ int ahip_gemm(int dtype, int64_t M, int64_t N, int64_t K, const void* alpha, con
               int64_t c_rs, int64_t c_cs, void* stream) {
   return ahip_gemm_batched(dtype, 1, M, N, K, alpha, A, 0, a_rs, a_cs, B, 0, b_rs, b_cs, beta,
                            Cin, 0, ci_rs, ci_cs, C, 0, c_rs, c_cs, stream);
+}
+
+size_t ahip_gemm_ws_bytes(int dtype, int64_t batch, int64_t M, int64_t N, int64_t K) {
+  if (dtype != AHIP_F32 && dtype != AHIP_F64) return 0;
+  const int bk = dtype == AHIP_F32 ? Traits<float>::BK : Traits<double>::BK;
+  const int64_t S = splitk_slices(M, N, K, batch, bk);
+  return (size_t)(S * M * N) * (dtype == AHIP_F32 ? 4 : 8);
+}
+
+int ahip_gemm_splitk(int dtype, int64_t M, int64_t N, int64_t K, const void* alpha, const void* A,
+                     int64_t a_rs, int64_t a_cs, const void* B, int64_t b_rs, int64_t b_cs,
+                     const void* beta, const void* Cin, int64_t ci_rs, int64_t ci_cs, void* C,
+                     int64_t c_rs, int64_t c_cs, void* ws, size_t ws_bytes, void* stream) {
+  const size_t need = ahip_gemm_ws_bytes(dtype, 1, M, N, K);
+  if (need == 0 || ws == nullptr || ws_bytes < need)
+    return ahip_gemm(dtype, M, N, K, alpha, A, a_rs, a_cs, B, b_rs, b_cs, beta, Cin, ci_rs, ci_cs,
+                     C, c_rs, c_cs, stream);
+  AHIP_REQUIRE(alpha && beta && A && B && C, "null argument");
+  GemmArgs g;
+  g.M = M; g.N = N; g.K = K;
+  g.A = A; g.a_bs = 0; g.a_rs = a_rs; g.a_cs = a_cs;
+  g.B = B; g.b_bs = 0; g.b_rs = b_rs; g.b_cs = b_cs;
+  g.alpha = host_scalar(dtype, alpha);
+  g.beta = host_scalar(dtype, beta);
+  AHIP_REQUIRE(g.beta == 0.0 || Cin != nullptr, "beta != 0 needs Cin");
+  g.Cin = (g.beta != 0.0) ? Cin : C; g.ci_bs = 0; g.ci_rs = ci_rs; g.ci_cs = ci_cs;
+  g.C = C; g.c_bs = 0; g.c_rs = c_rs; g.c_cs = c_cs;
+  g.tiles_m = g.tiles_n = 0;
+  const int bk = dtype == AHIP_F32 ? Traits<float>::BK : Traits<double>::BK;
+  const int64_t S = splitk_slices(M, N, K, 1, bk);
+  return dtype == AHIP_F32 ? gemm_splitk<float>(g, S, ws, as_stream(stream))
+                           : gemm_splitk<double>(g, S, ws, as_stream(stream));
 }
 
 }  // extern "C"

@@ -203,6 +203,16 @@ int ahip_gemm_batched(int dtype, int64_t batch, int64_t M, int64_t N, int64_t K,
                       const void* B, int64_t b_bs, int64_t b_rs, int64_t b_cs, const void* beta,
                       const void* Cin, int64_t ci_bs, int64_t ci_rs, int64_t ci_cs, void* C,
                       int64_t c_bs, int64_t c_rs, int64_t c_cs, void* stream);
+/* Split-K form for few output tiles and a very long K (weight gradients X.T @ dY): the K range runs
+ * as S slices of the 128x128 kernel into the caller-provided workspace [S][M][N], then one pass
+ * sums the slices in order and applies alpha / beta (deterministic).  ahip_gemm_ws_bytes returns
+ * the bytes it wants (0 = this shape is not split); with ws == NULL / too small / 0 wanted,
+ * ahip_gemm_splitk is exactly ahip_gemm.                                                         */
+size_t ahip_gemm_ws_bytes(int dtype, int64_t batch, int64_t M, int64_t N, int64_t K);
+int ahip_gemm_splitk(int dtype, int64_t M, int64_t N, int64_t K, const void* alpha, const void* A,
+                     int64_t a_rs, int64_t a_cs, const void* B, int64_t b_rs, int64_t b_cs,
+                     const void* beta, const void* Cin, int64_t ci_rs, int64_t ci_cs, void* C,
+                     int64_t c_rs, int64_t c_cs, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- K5: GEMV / GER (HBM-bound BLAS2) -----------------------------------------------------
  * replaces: tensor/blas.py:231 Gemv (perform :279), tensor/blas_c.py:611 CGemv (gemv_c_code
