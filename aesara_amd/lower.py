@@ -560,6 +560,20 @@ def _register_handlers():
         ctx.emit("AdvancedIncSubtensor", node, {
             "set_instead_of_inc": bool(op.set_instead_of_inc), "inplace": bool(op.inplace)})
 
+    from aesara.tensor.basic import Split
+    from aesara.tensor.extra_ops import CumOp
+
+    @hip_lower.register(Split)
+    def _(op, node, ctx):
+        # reference: tensor/basic.py:1882 Split(x, axis, splits) (perform :1929)
+        ctx.emit("Split", node, {"len_splits": int(op.len_splits)})
+
+    @hip_lower.register(CumOp)
+    def _(op, node, ctx):
+        # reference: tensor/extra_ops.py:283 CumOp (perform :311)
+        ctx.emit("CumOp", node, {"axis": None if op.axis is None else int(op.axis),
+                                 "mode": str(op.mode)})
+
     @hip_lower.register(Scan)
     def _(op, node, ctx):
         # reference: scan/op.py:637 Scan; info layout scan/op.py:206 ScanInfo.  The inner

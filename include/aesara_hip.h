@@ -285,6 +285,12 @@ int ahip_scatter_rows(int dtype, void* dst, int64_t nrows, int64_t dst_rs, int64
 int ahip_linearize_indices(int nidx, const void* const* idx, const int* idx_dtypes,
                            const int64_t* idx_strides, const int64_t* dims, const int64_t* mults,
                            int64_t n, int64_t* out, int64_t* bad_index, void* stream);
+/* ---- K12: cumulative sum / product along one axis --------------------------------------------
+ * replaces: tensor/extra_ops.py:283 CumOp (perform :311 np.cumsum / np.cumprod).  x is viewed as
+ * [outer, n, inner] with element strides (x_so, x_sn, x_si); out is C-contiguous [outer, n, inner].
+ * mul = 0: sum, 1: product.  Integers wrap in `dtype`.                                            */
+int ahip_cumulative(int dtype, int mul, const void* x, int64_t outer, int64_t n, int64_t inner,
+                    int64_t x_so, int64_t x_sn, int64_t x_si, void* out, void* stream);
 /* Row argmax, replaces tensor/math.py:330 Argmax (perform :388: np.argmax over the reduced axes
  * moved last and flattened).  x is viewed as [nrows, k] with element strides x_rs / x_cs; out[r]
  * = index of the first maximum of row r; a NaN counts as the maximum (first NaN wins).         */

@@ -636,6 +636,35 @@ def _():
          K(0.7, "float32")]
 
 
+@case("split_and_join_grad", rtol=1e-12, atol=1e-12)
+def _():
+    # Split itself, and the gradient of a concatenation (Join.grad emits Split)
+    x, y, sp = at.dmatrix("x"), at.dmatrix("y"), at.lvector("sp")
+    parts = at.split(x, sp, 3, axis=1)
+    c = at.concatenate([x, y], axis=1)
+    cost = (c ** 2 * at.arange(c.shape[1])).sum()
+    return [x, y, sp], [parts[0], parts[1] * 2.0, parts[2]] + list(ae.grad(cost, [x, y])), \
+        [N((5, 9), seed=1), N((5, 4), seed=2), {"kind": "const_list", "values": [2, 3, 4],
+                                                "shape": [3], "dtype": "int64"}]
+
+
+@case("cumop_int", exact=True, ref_py=True)
+def _():
+    # int64 only: for narrower ints the reference's Python perform returns NumPy's promoted int64
+    # although the Op declares the input dtype (its C code keeps it) — not a behaviour to pin
+    x, t = at.lmatrix("x"), at.tensor3("t", dtype="int64")
+    return [x, t], [at.cumsum(x, axis=0), at.cumsum(x, axis=1), at.cumsum(x), at.cumprod(x % 3 + 1, axis=1),
+                    at.cumsum(t, axis=1), at.cumsum(t.dimshuffle(2, 0, 1), axis=2)], \
+        [I((7, 150), "int64", 1, -9, 9), I((3, 70, 5), "int64", 2, -99, 99)]
+
+
+@case("cumop_float", rtol=1e-5, atol=1e-5, ref_py=True)
+def _():
+    x, v = at.fmatrix("x"), at.dvector("v")
+    return [x, v], [at.cumsum(x, axis=1), at.cumsum(x, axis=0), at.cumsum(v), at.cumprod(v * 0.1 + 1.0)], \
+        [N((6, 200), "float32", 1), N((300,), "float64", 2)]
+
+
 @case("argmax_axes", exact=True)
 def _():
     x, m, v = at.dtensor3("x"), at.imatrix("m"), at.dvector("v")

@@ -400,6 +400,25 @@ def run_plan(plan, inputs):
                 exc = getattr(builtins, p.get("exc_type", "AssertionError"), AssertionError)
                 raise exc(p.get("msg", ""))
             r = [a[0]]
+        elif op == "Split":
+            # reference: tensor/basic.py:1929 Split.perform
+            x, axis, splits = a[0], int(np.asarray(a[1])), [int(v) for v in np.asarray(a[2])]
+            if len(splits) != p["len_splits"]:
+                raise ValueError("Length of `splits` is not equal to `len_splits`")
+            if sum(splits) != x.shape[axis]:
+                raise ValueError(f"The splits sum to {sum(splits)}; expected {x.shape[axis]}")
+            if any(nb < 0 for nb in splits):
+                raise ValueError("Attempted to make an array with a negative number of elements")
+            r, lo = [], 0
+            key = [slice(None)] * x.ndim
+            for nb in splits:
+                key[axis] = slice(lo, lo + nb)
+                r.append(x[tuple(key)].copy())
+                lo += nb
+        elif op == "CumOp":
+            # reference: tensor/extra_ops.py:311 CumOp.perform (result in the output dtype)
+            fn = np.cumsum if p["mode"] == "add" else np.cumprod
+            r = [fn(a[0], axis=p["axis"], dtype=ov[0].dtype)]
         elif op == "ARange":
             # reference: tensor/basic.py:2937 ARange.perform
             st, sp, se = (np.asarray(v).item() for v in a)

@@ -35,6 +35,7 @@ for _name, _val in (
     ("unicode_", np.str_),
     ("Inf", np.inf),
     ("NaN", np.nan),
+    ("MAXDIMS", 32),   # NumPy 1.x value; only read as the "axis=None" sentinel of Op params
 ):
     if _name not in np.__dict__:
         try:

@@ -32,6 +32,8 @@ def make_input(spec):
         a = np.round(rng.standard_normal(base_shape) * 2.0)
         flat = a.reshape(-1)
         flat[rng.integers(0, flat.size, 3) + flat.size // 2 - flat.size // 2] = np.nan
+    elif kind == "const_list":
+        a = np.asarray(spec["values"]).reshape(base_shape)
     elif kind == "const":
         a = np.full(base_shape, spec["value"])
     elif kind == "perm":
