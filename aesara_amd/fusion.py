@@ -295,6 +295,50 @@ def split_invariant(plan: Plan, invariant_inputs: List[int]):
     return pre, loop, hoisted
 
 
+def hoist_sequence_dots(plan: Plan, seq_inputs: List[int], invariant: set):
+    """Matrix products of a Scan step that involve only a *sequence* row and loop-invariant
+    matrices (``x_t @ W`` of an RNN gate) do not depend on the recurrence: they are removed from
+    the step and computed for ALL steps by one GEMM before the loop (T x K @ K x M fills the
+    chip; T separate K x M GEMVs cannot), the step then reads row t of the result.  The
+    reference's ``scan_pushout`` rewrites (scan/rewriting.py) move Elemwise work on sequences out
+    of the loop the same way but leave the dots inside.
+
+    Returns ``(loop_plan, hoists)``; each hoist = {"kind": "gemv" | "dot", "seq": inner input id,
+    "mat": invariant id, "alpha": float, "out": var id (appended to the plan inputs)}."""
+    def const_value(vid):
+        v = plan.vars[vid]
+        if v.const is not None and len(v.const["data"]) == 1:
+            return float(v.const["data"][0])
+        return None
+
+    seqs = set(seq_inputs)
+    keep, hoists = [], []
+    for n in plan.nodes:
+        h = None
+        if n.op == "Gemv":
+            _y, alpha, A, x, beta = n.inputs
+            if A in invariant and x in seqs and const_value(beta) == 0.0 \
+                    and const_value(alpha) is not None:
+                h = {"kind": "gemv", "seq": x, "mat": A, "alpha": const_value(alpha)}
+        elif n.op in ("Dot22", "Dot"):
+            a, b = n.inputs
+            if a in seqs and b in invariant and plan.vars[b].ndim == 2:
+                h = {"kind": "dot", "seq": a, "mat": b, "alpha": 1.0}
+            elif (n.op == "Dot" and a in invariant and b in seqs and plan.vars[a].ndim == 2
+                  and plan.vars[b].ndim == 1):
+                h = {"kind": "gemv", "seq": b, "mat": a, "alpha": 1.0}
+        if h is not None and plan.vars[n.outputs[0]].dtype in ("float32", "float64"):
+            h["out"] = n.outputs[0]
+            hoists.append(h)
+        else:
+            keep.append(n)
+    if not hoists:
+        return plan, []
+    loop = Plan(plan.name + "_seqdots", plan.vars, list(plan.inputs) + [h["out"] for h in hoists],
+                list(plan.outputs), keep)
+    return loop, hoists
+
+
 def _fuse_rowpass(plan: Plan, steps: List[Step]) -> List[Step]:
     """GLM pattern  z = X.w (+ epilogue) -> row-wise Elemwise / full Sum -> X.T.r  ==>  one
     single-pass "rowpass" step (X read once) + deterministic folds of its per-workgroup partials.
