@@ -69,6 +69,19 @@ class RpArgs(C.Structure):
     ]
 
 
+AHIP_GE_MAXDOTS = 3
+AHIP_GE_MAXOPS = 12
+
+
+class GeArgs(C.Structure):
+    _fields_ = [("M", C.c_int64), ("N", C.c_int64), ("K", C.c_int64 * AHIP_GE_MAXDOTS),
+                ("A", C.c_void_p * AHIP_GE_MAXDOTS), ("a_rs", C.c_int64 * AHIP_GE_MAXDOTS),
+                ("B", C.c_void_p * AHIP_GE_MAXDOTS), ("b_rs", C.c_int64 * AHIP_GE_MAXDOTS),
+                ("b_cs", C.c_int64 * AHIP_GE_MAXDOTS),
+                ("ptr", C.c_void_p * AHIP_GE_MAXOPS), ("rs", C.c_int64 * AHIP_GE_MAXOPS),
+                ("cs", C.c_int64 * AHIP_GE_MAXOPS)]
+
+
 AHIP_RC_MAXOPS = 16
 AHIP_RC_MAXLEAD = 4
 
@@ -119,6 +132,7 @@ SIGNATURES = {
     "ahip_rowpass_grid": (i32, [i64, i32, i32]),
     "ahip_rowpass": (i32, [vp, C.POINTER(RpArgs), i32, i32, sz, vp]),
     "ahip_rowchain": (i32, [vp, C.POINTER(RcArgs), i32, i32, vp]),
+    "ahip_gemm_epilogue": (i32, [vp, C.POINTER(GeArgs), i32, vp]),
     "ahip_ger": (i32, [i32, i64, i64, vp, vp, i64, vp, i64, vp, i64, i64, vp, i64, i64, vp]),
     "ahip_copy_strided": (i32, [i32, i32, p_i64, vp, p_i64, vp, p_i64, i32, vp]),
     "ahip_fill": (i32, [i32, vp, vp, i64, vp]),

@@ -1294,3 +1294,190 @@ def generate_rowchain(spec: RowChainSpec):
     S.append("  }")
     S.append("}")
     return "\n".join(S) + "\n", (name,)
+
+
+# ----------------------------------------------------------------------------------------
+# small-M GEMM chain + Elemwise epilogue: f(A_0 @ B_0, A_1 @ B_1, ..., operands) in ONE kernel
+# ----------------------------------------------------------------------------------------
+GE_MAXDOTS = 3
+GE_MAXOPS = 12
+
+GE_PRELUDE = r"""
+#define GE_MAXDOTS %d
+#define GE_MAXOPS %d
+struct GeArgs {
+  i64 M; i64 N; i64 K[GE_MAXDOTS];
+  const void* A[GE_MAXDOTS]; i64 a_rs[GE_MAXDOTS];
+  const void* B[GE_MAXDOTS]; i64 b_rs[GE_MAXDOTS]; i64 b_cs[GE_MAXDOTS];
+  void* ptr[GE_MAXOPS]; i64 rs[GE_MAXOPS]; i64 cs[GE_MAXOPS];
+};
+template <typename T> struct MfmaT;
+template <> struct MfmaT<float> {
+  typedef float acc_t __attribute__((ext_vector_type(4)));
+  static constexpr int VEC = 4;
+  static __device__ __forceinline__ void mma(acc_t& c, float a, float b) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int frag_row(int lane, int i) { return (lane >> 4) * 4 + i; }
+};
+template <> struct MfmaT<double> {
+  typedef double acc_t __attribute__((ext_vector_type(4)));
+  static constexpr int VEC = 2;
+  static __device__ __forceinline__ void mma(acc_t& c, double a, double b) {
+    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int frag_row(int lane, int i) { return (lane >> 4) + 4 * i; }
+};
+
+// One wavefront's share (a quarter of K) of a 16 x (16*NF) tile of A @ B; same schedule as
+// gemm_skinny_kernel in csrc/gemm.hip (A k-contiguous, B n- or k-contiguous, vector loads in
+// MFMA layout, two-group software pipeline, accumulators folded every 512 k).
+template <typename T, int NF, bool BKC>
+__device__ __forceinline__ void skinny_dot(const T* __restrict__ A, i64 a_rs, const T* __restrict__ B,
+                                           i64 b_rs, i64 b_cs, i64 M, i64 N, i64 K, i64 m0, i64 n0,
+                                           int lane, int wave, typename MfmaT<T>::acc_t (&res)[NF]) {
+  typedef typename MfmaT<T>::acc_t acc_t;
+  constexpr int VEC = MfmaT<T>::VEC;
+  constexpr int G = 4 * VEC;
+  struct alignas(sizeof(T) * VEC) KV { T v[VEC]; };
+  struct alignas(sizeof(T) * NF) NV { T v[NF]; };
+  struct Frag { KV a; KV bk[NF]; NV bn[VEC]; };
+  const int r = lane & 15, kg = lane >> 4;
+  const i64 kq = ((K + 4 * G - 1) / (4 * G)) * G;
+  const i64 kbeg = wave * kq;
+  const i64 kend = (kbeg + kq < K) ? kbeg + kq : K;
+  const bool mok = m0 + r < M;
+  const T* ap = A + (mok ? m0 + r : 0) * a_rs + VEC * kg;
+  acc_t acc[NF], tot[NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) { acc[f] = acc_t{0, 0, 0, 0}; tot[f] = acc_t{0, 0, 0, 0}; }
+  auto load = [&](i64 k0, Frag& fr) {
+    const bool kok = k0 + VEC * kg < kend;
+    fr.a = (mok && kok) ? *reinterpret_cast<const KV*>(ap + k0) : KV{};
+    if constexpr (BKC) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        const i64 nn = n0 + 16 * f + r;
+        fr.bk[f] = (nn < N && kok) ? *reinterpret_cast<const KV*>(B + nn * b_cs + k0 + VEC * kg) : KV{};
+      }
+    } else {
+      const i64 nn = n0 + NF * r;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j)
+        fr.bn[j] = (nn < N && kok)
+            ? *reinterpret_cast<const NV*>(B + (k0 + VEC * kg + j) * b_rs + nn) : NV{};
+    }
+  };
+  auto compute = [&](const Frag& fr) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j)
+#pragma unroll
+      for (int f = 0; f < NF; ++f)
+        MfmaT<T>::mma(acc[f], fr.a.v[j], BKC ? fr.bk[f].v[j] : fr.bn[j].v[f]);
+  };
+  Frag f0, f1;
+  i64 k0 = kbeg, next_fold = kbeg + 512;
+  if (k0 < kend) load(k0, f0);
+  for (; k0 < kend; k0 += 2 * G) {
+    if (k0 + G < kend) load(k0 + G, f1);
+    compute(f0);
+    if (k0 + G < kend) {
+      if (k0 + 2 * G < kend) load(k0 + 2 * G, f0);
+      compute(f1);
+    }
+    if (k0 + 2 * G >= next_fold) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f) { tot[f] += acc[f]; acc[f] = acc_t{0, 0, 0, 0}; }
+      next_fold += 512;
+    }
+  }
+#pragma unroll
+  for (int f = 0; f < NF; ++f) res[f] = tot[f] + acc[f];
+}
+""" % (GE_MAXDOTS, GE_MAXOPS)
+
+
+class GemmEpiSpec:
+    """out[m, n] = f(dot_0[m, n], ..., dot_{D-1}[m, n], operands[m, n]) with dot_d = A_d @ B_d,
+    for outputs too small to fill the chip with 128x128 tiles (a recurrent step with a batch of
+    states, a small-batch MLP layer): the 16-row split-K MFMA schedule of csrc/gemm.hip with the
+    Elemwise consumer evaluated on the accumulators.
+
+    Replaces ``Gemm`` / ``Dot22`` nodes (tensor/blas.py:872 / :1659) followed by the ``Elemwise``
+    that consumes them — one GRU gate ``sigmoid(h @ U + V_t) * h`` = 1 launch instead of 2-3.
+
+    dtype : float32 | float64;  nf : column fragments per workgroup (1, 2, 4 <= VEC)
+    bkc   : per dot, True when B is k-contiguous (x @ W.T), False when n-contiguous (x @ W)
+    scalar: plan scalar expression; its first D inputs are the dot results
+    """
+
+    def __init__(self, dtype, nf, bkc, scalar, in_dtypes, out_dtypes, out_refs):
+        self.dtype, self.nf, self.bkc, self.scalar = dtype, nf, [bool(b) for b in bkc], scalar
+        self.in_dtypes, self.out_dtypes, self.out_refs = list(in_dtypes), list(out_dtypes), list(out_refs)
+        assert 1 <= len(self.bkc) <= GE_MAXDOTS
+        assert all(self.bkc) or not any(self.bkc) or nf == 1   # one column map per kernel
+        assert len(self.in_dtypes) + len(self.out_dtypes) <= GE_MAXOPS
+
+    def key(self):
+        import json
+        blob = json.dumps(["ge1", self.dtype, self.nf, self.bkc, self.scalar, self.in_dtypes,
+                           self.out_dtypes, self.out_refs], sort_keys=True)
+        return hashlib.sha256(blob.encode()).hexdigest()[:24]
+
+
+def generate_gemm_epilogue(spec: GemmEpiSpec):
+    T = RTYPE[spec.dtype]
+    NF, D = spec.nf, len(spec.bkc)
+    nin, nout = len(spec.in_dtypes), len(spec.out_dtypes)
+    name = "ge_" + spec.key()
+    S = [PRELUDE, GE_PRELUDE]
+    S.append('extern "C" __global__ __launch_bounds__(256) void %s(GeArgs a) {' % name)
+    S.append("  typedef MfmaT<%s>::acc_t acc_t;" % T)
+    S.append("  __shared__ %s part[4][%d][%d];" % (T, D, 256 * NF))
+    S.append("  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15;")
+    S.append("  const i64 m0 = (i64)blockIdx.y * 16, n0 = (i64)blockIdx.x * %d;" % (16 * NF))
+    for d in range(D):
+        S.append("  {")
+        S.append("    acc_t res[%d];" % NF)
+        S.append("    skinny_dot<%s, %d, %s>((const %s*)a.A[%d], a.a_rs[%d], (const %s*)a.B[%d], "
+                 "a.b_rs[%d], a.b_cs[%d], a.M, a.N, a.K[%d], m0, n0, lane, wave, res);"
+                 % (T, NF, "true" if spec.bkc[d] else "false", T, d, d, T, d, d, d, d))
+        S.append("    for (int f = 0; f < %d; ++f)" % NF)
+        S.append("      for (int i = 0; i < 4; ++i)")
+        S.append("        part[wave][%d][(MfmaT<%s>::frag_row(lane, i) * 16 + r) * %d + f] = res[f][i];"
+                 % (d, T, NF))
+        S.append("  }")
+    S.append("  __syncthreads();")
+    S.append("  const int e = threadIdx.x, er = e >> 4, ec = e & 15;")
+    S.append("  const i64 m = m0 + er;")
+    S.append("  if (m >= a.M) return;")
+    S.append("  for (int f = 0; f < %d; ++f) {" % NF)
+    # column of fragment f: BKC dots use n0 + 16 f + ec, the others n0 + NF ec + f.  All dots of
+    # one kernel must agree, which the executor guarantees by choosing NF = 1 for mixed layouts.
+    if all(spec.bkc):
+        S.append("    const i64 n = n0 + 16 * f + ec;")
+    else:
+        S.append("    const i64 n = n0 + %d * ec + f;" % NF)
+    S.append("    if (n >= a.N) continue;")
+    ins, in_dts = [], []
+    for d in range(D):
+        S.append("    const %s d%d = ((part[0][%d][e * %d + f] + part[1][%d][e * %d + f]) + "
+                 "part[2][%d][e * %d + f]) + part[3][%d][e * %d + f];"
+                 % (T, d, d, NF, d, NF, d, NF, d, NF))
+        ins.append("d%d" % d)
+        in_dts.append(spec.dtype)
+    for k in range(nin):
+        ct = CTYPE[spec.in_dtypes[k]]
+        S.append("    const %s x%d = ((const %s*)a.ptr[%d])[m * a.rs[%d] + n * a.cs[%d]];"
+                 % (ct, k, ct, k, k, k))
+        ins.append("(x%d != 0)" % k if spec.in_dtypes[k] == "bool" else "x%d" % k)
+        in_dts.append(spec.in_dtypes[k])
+    lines, outs, odts = emit_scalar_body(spec.scalar, ins, in_dts, indent="    ")
+    S.extend(lines)
+    for k, ri in enumerate(spec.out_refs):
+        S.append("    ((%s*)a.ptr[%d])[m * a.rs[%d] + n * a.cs[%d]] = %s;"
+                 % (CTYPE[spec.out_dtypes[k]], nin + k, nin + k, nin + k,
+                    _store_val(outs[ri], odts[ri], spec.out_dtypes[k])))
+    S.append("  }")
+    S.append("}")
+    return "\n".join(S) + "\n", (name,)

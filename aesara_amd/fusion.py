@@ -175,6 +175,7 @@ def build_steps(plan: Plan, fuse: bool = True) -> List[Step]:
         steps = _drop_dead(plan, _fuse_dots(plan, steps))
         steps = _fuse_rowpass(plan, steps)
         steps = _fuse_rowchain(plan, steps)
+        steps = _fuse_gemm_epi(plan, steps)
     return steps
 
 
@@ -615,3 +616,94 @@ def _fuse_one_rowchain(plan: Plan, steps: List[Step], max_ops: int):
                   fallback=fb)
         return [rc if j == last else s for j, s in enumerate(steps) if j == last or j not in inside]
     return None
+
+
+# ----------------------------------------------------------------------------------------
+# small-M GEMM chain + Elemwise consumer -> one kernel (kind "gemm_epi")
+# ----------------------------------------------------------------------------------------
+def _fuse_gemm_epi(plan: Plan, steps: List[Step], max_dots: int = 3, max_ops: int = 12) -> List[Step]:
+    """``Gemm`` / ``Dot22`` nodes whose only reader is one Elemwise step (a recurrent gate
+    ``sigmoid(h @ U + V_t) * h``, an MLP layer ``tanh(x @ W + b)``) become one "gemm_epi" step: the
+    products are accumulated by the 16-row split-K MFMA schedule and the Elemwise runs on the
+    accumulators.  Only worth it (and only generated) for outputs too small to fill the chip with
+    128x128 tiles — the executor decides from the run-time shapes and otherwise runs the original
+    steps, which are kept as the fallback (the big GEMM has its own alpha/beta epilogue)."""
+    out_set = set(plan.outputs)
+    readers: Dict[int, List[int]] = {}
+    for j, t in enumerate(steps):
+        for v in set(_step_reads(t)):
+            readers.setdefault(v, []).append(j)
+
+    def const1(vid):
+        v = plan.vars[vid]
+        return v.const is not None and len(v.const["data"]) == 1
+
+    producer = {}
+    for j, t in enumerate(steps):
+        if t.kind == "node" and t.node.op in ("Gemm", "Dot22", "Dot22Scalar"):
+            producer[t.outputs[0]] = j
+    if not producer:
+        return steps
+    removed, replaced = set(), {}
+    for j, e in enumerate(steps):
+        if e.kind != "elemwise" or e.dots or any(plan.vars[v].ndim != 2 for v in e.inputs):
+            continue
+        prods = []
+        for v in e.inputs:
+            pj = producer.get(v)
+            if pj is None or pj in removed or v in out_set or readers.get(v) != [j]:
+                continue
+            n = steps[pj].node
+            if plan.vars[v].dtype not in ("float32", "float64"):
+                continue
+            if n.op == "Gemm" and not (const1(n.inputs[1]) and const1(n.inputs[4])):
+                continue
+            if n.op == "Dot22Scalar" and not const1(n.inputs[2]):
+                continue
+            prods.append((v, pj))
+        if not prods or len(prods) > max_dots:
+            continue
+        merged = Step("elemwise", list(e.inputs), list(e.outputs), copy.deepcopy(e.scalar),
+                      out_refs=list(e.out_refs))
+        dvars, dots = [], []
+        for v, pj in prods:
+            n = steps[pj].node
+            dt = plan.vars[v].dtype
+            d_var = plan.new_var(dt, [None, None], name="matdot")
+            if n.op == "Dot22":
+                dots.append([n.inputs[0], n.inputs[1]])
+                pseudo = Step("elemwise", [d_var], [v], {"n_in": 1, "nodes": [], "out": [["i", 0]]},
+                              out_refs=[0])
+            elif n.op == "Dot22Scalar":   # dot(x, y) * a
+                dots.append([n.inputs[0], n.inputs[1]])
+                sc = {"n_in": 2, "out": [["t", 0]], "nodes": [
+                    {"op": "mul", "dtype": dt, "in": [["i", 0], ["i", 1]]}]}
+                pseudo = Step("elemwise", [d_var, n.inputs[2]], [v], sc, out_refs=[0])
+                _inline_constants(pseudo, plan)
+            else:   # Gemm(z, alpha, x, y, beta) = beta*z + alpha*dot(x, y)
+                z, al, x, y, be = n.inputs
+                dots.append([x, y])
+                sc = {"n_in": 4, "out": [["t", 2]], "nodes": [
+                    {"op": "mul", "dtype": dt, "in": [["i", 1], ["i", 0]]},
+                    {"op": "mul", "dtype": dt, "in": [["i", 3], ["i", 2]]},
+                    {"op": "add", "dtype": dt, "in": [["t", 1], ["t", 0]]}]}
+                pseudo = Step("elemwise", [d_var, al, z, be], [v], sc, out_refs=[0])
+                _inline_constants(pseudo, plan)
+            _merge_producer(merged, pseudo, v)
+            dvars.append(d_var)
+        others = [v for v in merged.inputs if v not in dvars]
+        if len(others) + len(merged.outputs) > max_ops or \
+                any(plan.vars[v].ndim != 2 for v in others):
+            continue
+        order = dvars + others
+        remap = {pos: ["i", order.index(v)] for pos, v in enumerate(merged.inputs)}
+        merged.scalar = _remap_inputs(merged.scalar, remap, len(order))
+        merged.inputs = others
+        merged.dots = dots
+        merged.kind = "gemm_epi"
+        merged.fallback = [steps[pj] for _, pj in prods] + [e]
+        replaced[j] = merged
+        removed.update(pj for _, pj in prods)
+    if not replaced:
+        return steps
+    return [replaced.get(j, s) for j, s in enumerate(steps) if j not in removed]

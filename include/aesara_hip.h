@@ -112,6 +112,20 @@ typedef struct ahip_rc_args {
   int64_t ls[AHIP_RC_MAXOPS][AHIP_RC_MAXLEAD];
 } ahip_rc_args;
 
+/* Kernel-argument block of the GENERATED small-M "GEMM chain + epilogue" kernels
+ *   extern "C" __global__ void k(ahip_ge_args a);       (codegen.generate_gemm_epilogue)
+ * out[m,n] = f(A_0 @ B_0, ..., operands[m,n]); A_d is [M, K_d] k-contiguous (row stride a_rs),
+ * B_d is [K_d, N] with element strides (b_rs, b_cs); ptr/rs/cs: epilogue operands then outputs
+ * (element strides along m / n, 0 = broadcast).                                                 */
+#define AHIP_GE_MAXDOTS 3
+#define AHIP_GE_MAXOPS 12
+typedef struct ahip_ge_args {
+  int64_t M; int64_t N; int64_t K[AHIP_GE_MAXDOTS];
+  const void* A[AHIP_GE_MAXDOTS]; int64_t a_rs[AHIP_GE_MAXDOTS];
+  const void* B[AHIP_GE_MAXDOTS]; int64_t b_rs[AHIP_GE_MAXDOTS]; int64_t b_cs[AHIP_GE_MAXDOTS];
+  void* ptr[AHIP_GE_MAXOPS]; int64_t rs[AHIP_GE_MAXOPS]; int64_t cs[AHIP_GE_MAXOPS];
+} ahip_ge_args;
+
 typedef struct ahip_device_info {
   int32_t device;
   int32_t cu_count;
@@ -243,6 +257,10 @@ int ahip_rowpass(ahip_fn_t k, const ahip_rp_args* args, int block, int rows_per_
  * tensor/special.py:372-415 (three passes) / the CAReduce-DimShuffle-Elemwise node sequences of
  * tensor/elemwise.py:1495/:222/:725.  rows_per_wave = 64 / lanes-per-row of the generated kernel. */
 int ahip_rowchain(ahip_fn_t k, const ahip_rc_args* args, int block, int rows_per_wave, void* stream);
+/* Small-M GEMM chain + Elemwise epilogue in one kernel (16 x 16*nf tile per workgroup, K split over
+ * its 4 wavefronts, epilogue on the summed accumulators).  replaces Gemm / Dot22 nodes
+ * (tensor/blas.py:872 / :1659) followed by the Elemwise that consumes them (tensor/elemwise.py:725). */
+int ahip_gemm_epilogue(ahip_fn_t k, const ahip_ge_args* args, int nf, void* stream);
 /* A_out[M,N] = A_in + alpha * x[M] y[N]^T */
 int ahip_ger(int dtype, int64_t M, int64_t N, const void* alpha, const void* x, int64_t incx,
              const void* y, int64_t incy, const void* A_in, int64_t ai_rs, int64_t ai_cs,

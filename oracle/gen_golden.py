@@ -665,6 +665,24 @@ def _():
         [N((6, 200), "float32", 1), N((300,), "float64", 2)]
 
 
+for _dt, _tol in (("float64", 1e-11), ("float32", 3e-5)):
+    def _mkmlp(dt=_dt):
+        # small-batch layers: products + bias + activation (fused GEMM-chain epilogue kernels),
+        # both weight layouts, two products feeding one Elemwise, ragged sizes
+        x, y = T(dt, (2, 2), "x"), T(dt, (2, 2), "y")
+        W, W2, U_, Wt, b = (T(dt, (2, 2), n) for n in ("W", "W2", "U", "Wt", "b2"))
+        b = T(dt, (2,), "b")
+        h1 = at.tanh(at.dot(x, W) + b)
+        h2 = at.sigmoid(at.dot(x, W2) + at.dot(y, U_)) * b
+        h3 = at.dot(x, Wt.T) * 2.0 + b
+        h4 = at.maximum(at.dot(y, U_.T[::1].T * 1.0) + at.dot(x, (Wt * 0.5).T), 0.0)
+        return [x, y, W, W2, U_, Wt, b], [h1, h2, h3, h4], \
+            [N((37, 40), dt, 1), N((37, 24), dt, 2), N((40, 52), dt, 3, 0.3),
+             N((40, 52), dt, 7, 0.3), N((24, 52), dt, 4, 0.3), N((52, 40), dt, 5, 0.3),
+             N((52,), dt, 6)]
+    case(f"mlp_layers_{_dt}", rtol=_tol, atol=_tol)(_mkmlp)
+
+
 @case("argmax_axes", exact=True)
 def _():
     x, m, v = at.dtensor3("x"), at.imatrix("m"), at.dvector("v")
