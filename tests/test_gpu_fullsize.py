@@ -233,6 +233,39 @@ def test_layernorm_rowchain_full_size():
     assert torch.allclose(y.double(), ref, rtol=2e-5, atol=2e-5)
 
 
+def test_cfg5_at_baseline_full_size_16gib():
+    """BASELINE config 5 at its full shape: N = 2^24 rows x 256 fp32 (16 GiB of X, 4.3e9 elements:
+    64-bit indexing throughout), one pass of the row-program kernel; logp / d/dw against an fp64
+    restatement accumulated over row blocks (logp rel <= 1e-6, dw <= 1e-5)."""
+    import torch
+    free, _total = torch.cuda.mem_get_info()
+    if free < 40 << 30:
+        pytest.skip("needs ~40 GiB of free HBM")
+    N, D = 1 << 24, 256
+    g = torch.Generator(device="cuda")
+    g.manual_seed(6)
+    X = torch.empty((N, D), dtype=torch.float32, device="cuda")
+    for i in range(0, N, 1 << 20):
+        X[i:i + (1 << 20)] = torch.randn((1 << 20, D), dtype=torch.float32, device="cuda", generator=g)
+    w = torch.randn((D,), dtype=torch.float32, device="cuda", generator=g) / 16
+    b = torch.tensor(0.1, dtype=torch.float32, device="cuda")
+    y = (torch.rand(N, device="cuda", generator=g) < 0.5).float()
+    logp, gw, gb = _ex("cfg5_logistic")(X, w, b, y)
+    ref_logp, ref_gb = 0.0, 0.0
+    ref_gw = torch.zeros(D, dtype=torch.float64, device="cuda")
+    for i in range(0, N, 1 << 21):
+        Xd, yd = X[i:i + (1 << 21)].double(), y[i:i + (1 << 21)].double()
+        z = Xd @ w.double() + 0.1
+        ref_logp += -(yd * torch.nn.functional.softplus(-z)
+                      + (1 - yd) * torch.nn.functional.softplus(z)).sum().item()
+        r = yd - torch.sigmoid(z)
+        ref_gb += r.sum().item()
+        ref_gw += Xd.t() @ r
+    assert abs(logp.item() - ref_logp) <= 1e-6 * abs(ref_logp)
+    assert (torch.linalg.norm(gw.double() - ref_gw) / torch.linalg.norm(ref_gw)).item() <= 1e-5
+    assert abs(gb.item() - ref_gb) <= 1e-5 * abs(ref_gb) + 0.5
+
+
 def test_large_index_ops_bit_exact():
     """Row gather / scatter-add on 2^20 indices: bit-exact against torch integer ops."""
     import torch
