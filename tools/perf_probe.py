@@ -214,6 +214,19 @@ def main():
                3 * 2 * Nb * Dd * Cc, "TFLOP/s", 157.3,
                note="flops = forward GEMM + dW GEMM + dX-free; includes log-softmax, gather, scatter")
 
+    if want("transposed"):
+        ex = PlanExecutor(plan_of("cfg1b_matrix_add"), use_graph=G)
+        x, y = randn((4096, 4096), f64, 0), randn((4096, 4096), f64, 1)
+        d, w = timeit(lambda: ex(x, y.t()), 20)
+        report("cfg1b add f64 4096^2 with y.T view (strided operand)", d, w, 3 * x.numel() * 8,
+               "GB/s", 8000.0)
+        from aesara_amd.device import DevArray
+        exi = PlanExecutor(plan_of("cfg1b_matrix_add"))
+        v = DevArray.from_torch(y).view([4096, 4096], [1, 4096])
+        d, w = timeit(lambda: exi.materialize(v), 20)
+        report("materialise transpose f64 4096^2 (strided copy)", d, w, 2 * x.numel() * 8,
+               "GB/s", 8000.0)
+
     if want("cfg5"):
         N, D = 1 << 22, 256
         ex = PlanExecutor(plan_of("cfg5_logistic"), use_graph=G)
