@@ -406,6 +406,33 @@ def red_identity(op, acc_dt):
 # ----------------------------------------------------------------------------------------
 # kernel specs
 # ----------------------------------------------------------------------------------------
+# ---- spec-key memo ---------------------------------------------------------------------------
+# A spec key is a SHA-256 over the JSON of the scalar program and the layout fields; computing it
+# for every launch of every call cost ~50 us of Python per step.  The scalar programs are
+# long-lived objects owned by the plan / the fused steps, so their identity plus the (small,
+# hashable) layout fields memoises the key; the memo keeps the objects alive so ids stay valid.
+_KEY_MEMO = {}
+
+
+def _hashable(x):
+    if isinstance(x, dict):
+        return tuple(sorted((k, _hashable(v)) for k, v in x.items()))
+    if isinstance(x, (list, tuple)):
+        return tuple(_hashable(v) for v in x)
+    return x
+
+
+def _memo_key(scalars, fields, compute):
+    sig = (tuple(id(sc) for sc in scalars), _hashable(fields))
+    hit = _KEY_MEMO.get(sig)
+    if hit is None:
+        if len(_KEY_MEMO) > 8192:       # ad-hoc scalar programs (casts) come and go
+            _KEY_MEMO.clear()
+        hit = (compute(), scalars)
+        _KEY_MEMO[sig] = hit
+    return hit[0]
+
+
 class KernelSpec:
     """Everything that determines the generated source of one fused kernel.
 
@@ -442,6 +469,11 @@ class KernelSpec:
         assert 1 <= nd <= AHIP_MAXD and len(self.inner) <= AHIP_MAXOPS
 
     def key(self):
+        fields = [self.in_dtypes, self.out_dtypes, self.out_refs, self.inner, self.nd, self.vec,
+                  self.block, self.idx64, self.reduce, self.unroll, self.nt, self.invariant, "v7"]
+        return _memo_key([self.scalar], fields, self._key)
+
+    def _key(self):
         import json
         blob = json.dumps([self.scalar, self.in_dtypes, self.out_dtypes, self.out_refs,
                            self.inner, self.nd, self.vec, self.block, self.idx64, self.reduce,
@@ -813,6 +845,11 @@ class GemvEpiSpec:
         assert len(self.in_dtypes) + len(self.out_dtypes) <= AHIP_GV_MAXOPS
 
     def key(self):
+        fields = ["gv3", self.dtype, self.dot_vec, self.in_dtypes, self.out_dtypes, self.out_refs,
+                  self.block, self.rpw, self.kvs]
+        return _memo_key([self.scalar], fields, self._key)
+
+    def _key(self):
         import json
         blob = json.dumps(["gv3", self.dtype, self.dot_vec, self.scalar, self.in_dtypes,
                            self.out_dtypes, self.out_refs, self.block, self.rpw, self.kvs],
@@ -980,6 +1017,11 @@ class RowPassSpec:
         assert len(self.in_dtypes) + len(self.out_dtypes) <= RP_MAXOPS and len(self.reds) <= RP_MAXRED
 
     def key(self):
+        fields = ["rp2", self.dtype, self.kv, self.in_dtypes, self.out_dtypes, self.out_refs,
+                  self.reds, self.col_ref, self.rpw, self.block]
+        return _memo_key([self.scalar], fields, self._key)
+
+    def _key(self):
         import json
         blob = json.dumps(["rp2", self.dtype, self.kv, self.scalar, self.in_dtypes, self.out_dtypes,
                            self.out_refs, self.reds, self.col_ref, self.rpw, self.block],
@@ -1157,6 +1199,12 @@ class RowChainSpec:
         assert L in (1, 2, 4, 8, 16, 32, 64) and block % 64 == 0 and 1 <= lnd <= RC_MAXLEAD
 
     def key(self):
+        fields = ["rc2", self.ext, self.L, self.V, self.nch, self.lnd, self.block,
+                  [[m["ins"], m.get("reduce"), m.get("stores"), m.get("rowlike")]
+                   for m in self.members]]
+        return _memo_key([m["scalar"] for m in self.members], fields, self._key)
+
+    def _key(self):
         import json
         blob = json.dumps(["rc2", self.ext, self.members, self.L, self.V, self.nch, self.lnd,
                            self.block],
@@ -1419,6 +1467,11 @@ class GemmEpiSpec:
         assert len(self.in_dtypes) + len(self.out_dtypes) <= GE_MAXOPS
 
     def key(self):
+        fields = ["ge1", self.dtype, self.nf, self.bkc, self.in_dtypes, self.out_dtypes,
+                  self.out_refs]
+        return _memo_key([self.scalar], fields, self._key)
+
+    def _key(self):
         import json
         blob = json.dumps(["ge1", self.dtype, self.nf, self.bkc, self.scalar, self.in_dtypes,
                            self.out_dtypes, self.out_refs], sort_keys=True)

@@ -21,8 +21,29 @@ _UN = {"neg": np.negative, "abs": np.abs, "sgn": np.sign, "sqr": np.square,
        "trunc": np.trunc, "sqrt": np.sqrt, "exp": np.exp, "log": np.log}
 
 
+_HOST_MEMO = {}
+
+
 def eval_scalar_host(scalar, ins):
-    """Evaluate a plan scalar expression on small host arrays (shape arithmetic only)."""
+    """Evaluate a plan scalar expression on small host arrays (shape arithmetic only).  The same
+    shape arithmetic recurs on every call of a function, so results are memoised on the
+    expression's identity and the (tiny) input values."""
+    arrs = [np.asarray(x) for x in ins]
+    sig = None
+    if all(a.size <= 8 for a in arrs):
+        sig = (id(scalar),) + tuple((a.dtype.str, a.shape, a.tobytes()) for a in arrs)
+        hit = _HOST_MEMO.get(sig)
+        if hit is not None:
+            return hit[0]
+    res = _eval_scalar_host(scalar, arrs)
+    if sig is not None:
+        if len(_HOST_MEMO) > 4096:
+            _HOST_MEMO.clear()
+        _HOST_MEMO[sig] = (res, scalar)     # keeps `scalar` alive: its id stays unique
+    return res
+
+
+def _eval_scalar_host(scalar, ins):
     temps = []
 
     def get(r):

@@ -61,3 +61,32 @@ def test_hip_graph_replay_matches_reference(c):
 def test_unfused_matches_reference(c):
     """The linker-level fusion must not change results: run with fusion disabled too."""
     assert_matches(c, _run(c, fuse=False), case_expected(c), "hip-unfused")
+
+
+def test_replay_with_fresh_input_tensors_and_host_arrays():
+    """A training loop hands over a NEW batch on every call: replay mode copies such inputs into
+    persistent staging buffers (host arrays always, device tensors from the second layout
+    repeat) and replays the recorded launch list; results equal the eager path on every call."""
+    import torch
+    from aesara_amd.executor import PlanExecutor
+    c = next(c for c in CASES if c["name"] == "nll_classifier_float32")
+    eager = PlanExecutor(case_plan(c))
+    replay = PlanExecutor(case_plan(c), use_graph=True)
+    rng = np.random.default_rng(0)
+
+    def batch(as_torch):
+        x = rng.standard_normal((48, 20)).astype("float32")
+        W = (rng.standard_normal((20, 10)) * 0.5).astype("float32")
+        b = (rng.standard_normal(10) * 0.1).astype("float32")
+        y = rng.integers(0, 10, 48)
+        vals = [x, W, b, y]
+        return [torch.from_numpy(v).cuda() for v in vals] if as_torch else vals
+
+    for as_torch in (True, False):
+        for _ in range(5):
+            ins = batch(as_torch)
+            want = [o.cpu().numpy() for o in eager(*ins)]
+            got = [o.cpu().numpy() for o in replay(*ins)]
+            for g, w in zip(got, want):
+                np.testing.assert_allclose(g, w, rtol=1e-6, atol=1e-7)
+    assert len(replay._stage) == 2 and len(replay._graphs) <= 4
