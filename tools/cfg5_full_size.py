@@ -1,9 +1,10 @@
+"""BASELINE config 5 at its full shape (N = 2^24, D = 256 fp32: 16 GiB of X) on one MI355X: timing of
+the single-pass row-program kernel and error against an fp64 restatement accumulated in row blocks."""
 import sys, time, json
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests'); sys.path.insert(0, '/root/repo/tools')
-import numpy as np, torch, ctypes as C
+import torch
 from golden_util import CASES, case_plan
 from aesara_amd.executor import PlanExecutor
-from aesara_amd._lib import check, lib
 N, D = 1 << 24, 256
 g = torch.Generator(device="cuda"); g.manual_seed(6)
 X = torch.empty((N, D), dtype=torch.float32, device="cuda")
