@@ -284,3 +284,44 @@ def test_large_index_ops_bit_exact():
     got = ex2(x, y, idx)[0]
     want = x.clone().index_add_(0, wrapped, y)
     assert torch.equal(got, want)
+
+
+def test_fused_kernels_agree_with_unfused_on_random_shapes():
+    """Shape fuzzing of the generated fused kernels (row chains, GEMM-chain epilogues, GEMV chains,
+    small-output GEMMs) against the unfused node-by-node path on ragged / degenerate shapes:
+    odd K, K smaller than a vector, single rows, sizes around the tile edges."""
+    import torch
+    rng = np.random.default_rng(123)
+
+    def close(a, b, tol):
+        return torch.allclose(a.double(), b.double(), rtol=tol, atol=tol)
+
+    sizes = [1, 2, 3, 5, 8, 15, 16, 17, 31, 33, 63, 64, 65, 100, 127, 129, 255, 257, 1000]
+    # softmax / log-softmax / layer norm: rows x K
+    for _ in range(25):
+        n, k = int(rng.choice(sizes)), int(rng.choice(sizes[1:]))
+        x = _randn((n, k), torch.float32, int(rng.integers(1 << 30)), 3.0)
+        (a,) = _ex("softmax_rows_f32")(x)
+        (b,) = _ex("softmax_rows_f32", fuse=False)(x)
+        assert close(a, b, 2e-6), (n, k)
+        xd = x.double()
+        (a,) = _ex("logsoftmax_rows_f64")(xd)
+        (b,) = _ex("logsoftmax_rows_f64", fuse=False)(xd)
+        assert close(a, b, 1e-12), (n, k)
+    for _ in range(10):
+        a_, b_, k = (int(rng.choice(sizes[:10])) for _ in range(3))
+        k = max(k, 2)
+        x = _randn((a_, b_, k), torch.float32, int(rng.integers(1 << 30)), 2.0)
+        g, bb = _randn((k,), torch.float32, 1), _randn((k,), torch.float32, 2)
+        for u, v in zip(_ex("layernorm_float32")(x, g, bb), _ex("layernorm_float32", fuse=False)(x, g, bb)):
+            assert close(u, v, 3e-5), (a_, b_, k)
+    # small-batch layers: x[m,k1] y[m,k2] W,W2[k1,n] U[k2,n] Wt[n,k1] b[n]
+    for _ in range(20):
+        m, k1, k2, n = (int(rng.choice(sizes[:16])) for _ in range(4))
+        s = int(rng.integers(1 << 30))
+        args = [_randn((m, k1), torch.float32, s), _randn((m, k2), torch.float32, s + 1),
+                _randn((k1, n), torch.float32, s + 2, 0.3), _randn((k1, n), torch.float32, s + 3, 0.3),
+                _randn((k2, n), torch.float32, s + 4, 0.3), _randn((n, k1), torch.float32, s + 5, 0.3),
+                _randn((n,), torch.float32, s + 6)]
+        for u, v in zip(_ex("mlp_layers_float32")(*args), _ex("mlp_layers_float32", fuse=False)(*args)):
+            assert close(u, v, 2e-5), (m, k1, k2, n)
