@@ -36,4 +36,46 @@ def prebuild_golden_kernels(limit=None):
             n += 1
         except Exception as e:  # a dry run cannot follow data-dependent control flow
             print(f"prebuild: {c['name']}: {type(e).__name__}: {e}")
+    n += _prebuild_full_shapes({c["name"]: c for c in data})
     return n
+
+
+def _prebuild_full_shapes(cases):
+    """The bench / smoke workloads at their real shapes select other kernel variants (flat
+    16-byte-vector streams, longer rows) than the reduced golden shapes: generate those too so
+    the first call on the GPU box only loads code objects."""
+    import numpy as np
+
+    from .device import DevArray, contiguous_strides
+    from .executor import PlanExecutor, _FakeBuf
+    from .plan import Plan
+
+    def fake(shape, dtype):
+        n = 1
+        for s in shape:
+            n *= s
+        return DevArray(_FakeBuf(max(n, 1), dtype), 0, tuple(shape), contiguous_strides(shape), dtype)
+
+    work = [
+        ("cfg2_gauss_sum", [fake((4096, 4096), "float64"), np.float64(0.1), np.float64(1.3)]),
+        ("cfg1b_matrix_add", [fake((4096, 4096), "float64"), fake((4096, 4096), "float64")]),
+        ("cfg3b_gemm_update", [fake((512, 512), "float32")] * 3),
+        ("cfg5_logistic", [fake((1 << 16, 256), "float32"), fake((256,), "float32"),
+                           np.float32(0.1), fake((1 << 16,), "float32")]),
+        ("softmax_rows_f32", [fake((4096, 1024), "float32")]),
+    ]
+    done = 0
+    for name, args in work:
+        c = cases.get(name)
+        if c is None:
+            continue
+        try:
+            PlanExecutor(Plan.from_json(c["plan"]), dry_run=True)(*args)
+            done += 1
+        except Exception as e:
+            print(f"prebuild: {name} (full shape): {type(e).__name__}: {e}")
+    return done
+
+
+if __name__ == "__main__":
+    print("prebuilt kernels for", prebuild_golden_kernels(), "golden cases")
