@@ -63,7 +63,10 @@ struct GemmArgs {
   void* C; int64_t c_bs, c_rs, c_cs;
   double alpha, beta;
   int tiles_m, tiles_n;
+  int64_t a_lim, b_lim;  // bytes from A / B (per batch item) to the end of their valid extent
 };
+
+void set_limits(GemmArgs& g, int64_t isz);
 
 // ---- staging ---------------------------------------------------------------------------
 // MODE 0: k is the contiguous axis (unit stride along k, vectorisable)
@@ -109,19 +112,24 @@ struct Stage {
 
   // 16-byte load through a buffer resource: SGPR descriptor (wave-uniform base) + 32-bit VGPR
   // byte offset (guide T8) — no 64-bit per-lane addresses to compute, keep or spill
-  static __device__ __forceinline__ vec_t bload(const char* base, unsigned off) {
+  static __device__ __forceinline__ vec_t bload(const char* base, unsigned off,
+                                                int records = 0x7FFFFFFF) {
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
     __amdgpu_buffer_rsrc_t rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, 0x7FFFFFFF, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, records, 0x00020000);
     u4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
     return __builtin_bit_cast(vec_t, v);
   }
 
   // base = byte address of element (row0, k0) of the operand (wave uniform)
-  template <bool EDGE>
+  // EM 0: interior tile, no checks.  EM 1: every vector predicated on (row, k).  EM 2 (ragged
+  // M / N, K a multiple of BK): unpredicated loads through a descriptor whose num_records ends
+  // at the operand's last valid byte — the hardware returns 0 beyond it, rows / columns past
+  // M / N read neighbouring (valid) data that only reaches outputs which are never stored.
+  template <int EM>
   static __device__ __forceinline__ void load(vec_t (&r)[NV], const char* __restrict__ base,
                                               const unsigned (&off)[NV], int stid, int64_t rs,
-                                              int64_t ks, int rows, int64_t krem) {
+                                              int64_t ks, int rows, int64_t krem, int records) {
     if constexpr (MODE == 2) {
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
@@ -134,9 +142,12 @@ struct Stage {
             val[e] = reinterpret_cast<const T*>(base)[(int64_t)row * rs + (int64_t)(k + e) * ks];
         r[j] = val;
       }
-    } else if constexpr (!EDGE) {
+    } else if constexpr (EM == 0) {
 #pragma unroll
       for (int j = 0; j < NV; ++j) r[j] = bload(base, off[j]);
+    } else if constexpr (EM == 2) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) r[j] = bload(base, off[j], records);
     } else {
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
@@ -190,8 +201,9 @@ template <> __device__ __forceinline__ int frag_row<double>(int lane, int r) {
   return (lane >> 4) + 4 * r;
 }
 
-template <typename T, int AMODE, int BMODE, bool EDGE>
+template <typename T, int AMODE, int BMODE, int EM>
 __global__ __launch_bounds__(THREADS, 4) void gemm_kernel(GemmArgs g) {
+  constexpr bool EDGE = (EM != 0);
   using Tr = Traits<T>;
   using acc_t = typename Tr::acc_t;
   using vec_t = typename Tr::vec_t;
@@ -238,6 +250,10 @@ __global__ __launch_bounds__(THREADS, 4) void gemm_kernel(GemmArgs g) {
   const int64_t s_ks = stage_a ? g.a_cs : g.b_rs;  // stride along k
   const int s_rows = stage_a ? rows_a : rows_b;
   const int64_t slab_bytes = (int64_t)BK * s_ks * (int64_t)sizeof(T);
+  // end of this operand's valid bytes (EM 2: bound of the load descriptors)
+  const char* send = stage_a
+      ? reinterpret_cast<const char*>(static_cast<const T*>(g.A) + z * g.a_bs) + g.a_lim
+      : reinterpret_cast<const char*>(static_cast<const T*>(g.B) + z * g.b_bs) + g.b_lim;
   unsigned off[NV];
   if (stage_a) Stage<T, AMODE>::offsets(off, stid, s_rs, s_ks);
   else Stage<T, BMODE>::offsets(off, stid, s_rs, s_ks);
@@ -256,8 +272,15 @@ __global__ __launch_bounds__(THREADS, 4) void gemm_kernel(GemmArgs g) {
   auto gload = [&](vec_t (&r)[NV], int t) {
     const char* base = sbase + (int64_t)t * slab_bytes;
     const int64_t krem = g.K - (int64_t)t * BK;
-    if (stage_a) Stage<T, AMODE>::template load<EDGE>(r, base, off, stid, s_rs, s_ks, s_rows, krem);
-    else Stage<T, BMODE>::template load<EDGE>(r, base, off, stid, s_rs, s_ks, s_rows, krem);
+    int records = 0x7FFFFFFF;
+    if constexpr (EM == 2) {
+      const int64_t rem = send - base;
+      records = rem <= 0 ? 0 : (rem > 0x7FFFFFFF ? 0x7FFFFFFF : (int)rem);
+    }
+    if (stage_a)
+      Stage<T, AMODE>::template load<EM>(r, base, off, stid, s_rs, s_ks, s_rows, krem, records);
+    else
+      Stage<T, BMODE>::template load<EM>(r, base, off, stid, s_rs, s_ks, s_rows, krem, records);
   };
   auto lstore = [&](const vec_t (&r)[NV], int t) {
     char* nb = smem + (t & 1) * SLAB;
@@ -746,7 +769,7 @@ int operand_mode(const void* p, int64_t rs, int64_t ks, int64_t rows, int64_t K,
   return 2;
 }
 
-template <typename T, int AM, int BMd, bool EDGE>
+template <typename T, int AM, int BMd, int EDGE>
 int launch_gemm(const GemmArgs& g, int64_t batch, hipStream_t s) {
   constexpr size_t lds = 2 * (BM + BN) * ROW_BYTES;
   static bool attr_set = false;
@@ -765,7 +788,7 @@ int launch_gemm(const GemmArgs& g, int64_t batch, hipStream_t s) {
   return AHIP_OK;
 }
 
-template <typename T, bool EDGE>
+template <typename T, int EDGE>
 int dispatch_modes(const GemmArgs& g, int am, int bm, int64_t batch, hipStream_t s) {
   switch (am * 3 + bm) {
     case 0: return launch_gemm<T, 0, 0, EDGE>(g, batch, s);
@@ -776,11 +799,30 @@ int dispatch_modes(const GemmArgs& g, int am, int bm, int64_t batch, hipStream_t
   }
   // any scalar-staged operand: always the predicated instantiation
   switch (am * 3 + bm) {
-    case 2: return launch_gemm<T, 0, 2, true>(g, batch, s);
-    case 5: return launch_gemm<T, 1, 2, true>(g, batch, s);
-    case 6: return launch_gemm<T, 2, 0, true>(g, batch, s);
-    case 7: return launch_gemm<T, 2, 1, true>(g, batch, s);
-    default: return launch_gemm<T, 2, 2, true>(g, batch, s);
+    case 2: return launch_gemm<T, 0, 2, 1>(g, batch, s);
+    case 5: return launch_gemm<T, 1, 2, 1>(g, batch, s);
+    case 6: return launch_gemm<T, 2, 0, 1>(g, batch, s);
+    case 7: return launch_gemm<T, 2, 1, 1>(g, batch, s);
+    default: return launch_gemm<T, 2, 2, 1>(g, batch, s);
+  }
+}
+
+
+// which instantiation: 0 interior, 2 ragged M / N with K a multiple of BK (bounded descriptors,
+// predicated stores only), 1 fully predicated
+template <typename T>
+int edge_mode(const GemmArgs& g) {
+  const bool kfull = g.K % Traits<T>::BK == 0;
+  if (kfull && g.M % BM == 0 && g.N % BN == 0) return 0;
+  return kfull ? 2 : 1;
+}
+
+template <typename T>
+int run_big(const GemmArgs& g, int am, int bm, int64_t batch, hipStream_t s) {
+  switch (edge_mode<T>(g)) {
+    case 0: return dispatch_modes<T, 0>(g, am, bm, batch, s);
+    case 2: return dispatch_modes<T, 2>(g, am, bm, batch, s);
+    default: return dispatch_modes<T, 1>(g, am, bm, batch, s);
   }
 }
 
@@ -817,46 +859,9 @@ int gemm_dispatch(GemmArgs& g, int64_t batch, hipStream_t s) {
     if ((int64_t)g.tiles_m * g.tiles_n * batch < limit && (g.M + 15) / 16 < 65536 && batch < 65536)
       return launch_small<T>(g, batch, s);
   }
-  // ragged M / N on a large problem: the tile-aligned block runs the unpredicated instantiation
-  // (118-123 vs ~100 TFLOP/s for the predicated one), the right / bottom strips are dispatched
-  // on their own (predicated big tiles or the small-output kernels)
-  {
-    const int64_t Mi = (g.M / BM) * BM, Ni = (g.N / BN) * BN;
-    if (g.K % Traits<T>::BK == 0 && Mi > 0 && Ni > 0 && (Mi < g.M || Ni < g.N) &&
-        (Mi / BM) * (Ni / BN) * batch >= 256) {
-      auto off = [](const void* p, int64_t e) {
-        return static_cast<const void*>(static_cast<const T*>(p) + e);
-      };
-      GemmArgs a = g;
-      a.M = Mi; a.N = Ni;
-      int rc = gemm_dispatch<T>(a, batch, s);
-      if (rc) return rc;
-      if (Ni < g.N) {                       // right strip: all rows, columns [Ni, N)
-        GemmArgs b = g;
-        b.N = g.N - Ni;
-        b.B = off(g.B, Ni * g.b_cs);
-        b.Cin = g.Cin ? off(g.Cin, Ni * g.ci_cs) : nullptr;
-        b.C = const_cast<void*>(off(g.C, Ni * g.c_cs));
-        rc = gemm_dispatch<T>(b, batch, s);
-        if (rc) return rc;
-      }
-      if (Mi < g.M) {                       // bottom strip: rows [Mi, M), columns [0, Ni)
-        GemmArgs c = g;
-        c.M = g.M - Mi; c.N = Ni;
-        c.A = off(g.A, Mi * g.a_rs);
-        c.Cin = g.Cin ? off(g.Cin, Mi * g.ci_rs) : nullptr;
-        c.C = const_cast<void*>(off(g.C, Mi * g.c_rs));
-        rc = gemm_dispatch<T>(c, batch, s);
-        if (rc) return rc;
-      }
-      return AHIP_OK;
-    }
-  }
   int am = operand_mode<T>(g.A, g.a_rs, g.a_cs, g.M, g.K, g.a_bs, batch);
   int bm = operand_mode<T>(g.B, g.b_cs, g.b_rs, g.N, g.K, g.b_bs, batch);
-  const bool interior = (g.M % BM == 0) && (g.N % BN == 0) && (g.K % Traits<T>::BK == 0);
-  return interior ? dispatch_modes<T, false>(g, am, bm, batch, s)
-                  : dispatch_modes<T, true>(g, am, bm, batch, s);
+  return run_big<T>(g, am, bm, batch, s);
 }
 
 
@@ -901,19 +906,29 @@ int gemm_splitk(const GemmArgs& g, int64_t S, void* ws, hipStream_t s) {
   p.C = ws; p.c_bs = g.M * g.N; p.c_rs = g.N; p.c_cs = 1;
   p.Cin = ws; p.ci_bs = p.c_bs; p.ci_rs = g.N; p.ci_cs = 1;
   p.alpha = 1.0; p.beta = 0.0;
+  set_limits(p, (int64_t)sizeof(T));
   p.tiles_m = (int)((g.M + BM - 1) / BM);
   p.tiles_n = (int)((g.N + BN - 1) / BN);
   int am = operand_mode<T>(p.A, p.a_rs, p.a_cs, p.M, p.K, p.a_bs, S);
   int bm = operand_mode<T>(p.B, p.b_cs, p.b_rs, p.N, p.K, p.b_bs, S);
-  const bool interior = (p.M % BM == 0) && (p.N % BN == 0) && (p.K % Traits<T>::BK == 0);
-  int rc = interior ? dispatch_modes<T, false>(p, am, bm, S, s)
-                    : dispatch_modes<T, true>(p, am, bm, S, s);
+  int rc = run_big<T>(p, am, bm, S, s);
   if (rc) return rc;
   SplitArgs r{ws, g.Cin, g.C, g.M, g.N, S, g.ci_rs, g.ci_cs, g.c_rs, g.c_cs, g.alpha, g.beta};
   int64_t n = g.M * g.N;
   unsigned blocks = (unsigned)(((n + 255) / 256) < 2048 ? ((n + 255) / 256) : 2048);
   AHIP_LAUNCH((splitk_reduce_kernel<T>), dim3(blocks), dim3(256), 0, s, r);
   return AHIP_OK;
+}
+
+// bytes from the operand's first element to one past its last valid one (non-negative strides)
+void set_limits(GemmArgs& g, int64_t isz) {
+  auto ext = [&](int64_t r, int64_t rs, int64_t c, int64_t cs) {
+    if (r <= 0 || c <= 0) return (int64_t)0;
+    const int64_t last = (r - 1) * (rs > 0 ? rs : 0) + (c - 1) * (cs > 0 ? cs : 0);
+    return (last + 1) * isz;
+  };
+  g.a_lim = ext(g.M, g.a_rs, g.K, g.a_cs);
+  g.b_lim = ext(g.K, g.b_rs, g.N, g.b_cs);
 }
 
 double host_scalar(int dtype, const void* p) {
@@ -946,6 +961,7 @@ int ahip_gemm_batched(int dtype, int64_t batch, int64_t M, int64_t N, int64_t K,
   g.Cin = (g.beta != 0.0) ? Cin : C; g.ci_bs = ci_bs; g.ci_rs = ci_rs; g.ci_cs = ci_cs;
   g.C = C; g.c_bs = c_bs; g.c_rs = c_rs; g.c_cs = c_cs;
   g.tiles_m = g.tiles_n = 0;
+  set_limits(g, dtype == AHIP_F32 ? 4 : 8);
   if (M > 0 && N > 0 && batch > 0) {
     AHIP_REQUIRE(C != nullptr, "null C");
     AHIP_REQUIRE(K == 0 || (A && B), "null A/B");
@@ -989,6 +1005,7 @@ int ahip_gemm_splitk(int dtype, int64_t M, int64_t N, int64_t K, const void* alp
   g.Cin = (g.beta != 0.0) ? Cin : C; g.ci_bs = 0; g.ci_rs = ci_rs; g.ci_cs = ci_cs;
   g.C = C; g.c_bs = 0; g.c_rs = c_rs; g.c_cs = c_cs;
   g.tiles_m = g.tiles_n = 0;
+  set_limits(g, dtype == AHIP_F32 ? 4 : 8);
   const int bk = dtype == AHIP_F32 ? Traits<float>::BK : Traits<double>::BK;
   const int64_t S = splitk_slices(M, N, K, 1, bk);
   return dtype == AHIP_F32 ? gemm_splitk<float>(g, S, ws, as_stream(stream))
