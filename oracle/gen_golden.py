@@ -683,6 +683,18 @@ for _dt, _tol in (("float64", 1e-11), ("float32", 3e-5)):
     case(f"mlp_layers_{_dt}", rtol=_tol, atol=_tol)(_mkmlp)
 
 
+@case("empty_inputs", exact=True)
+def _():
+    # zero-size operands (tests/tensor/test_elemwise.py TestCAReduce cases with 0 extents,
+    # test_subtensor.py empty index vectors)
+    from aesara.tensor.special import softmax
+    x, y, v, i = at.dmatrix("x"), at.dmatrix("y"), at.dvector("v"), at.lvector("i")
+    return [x, y, v, i], [x + y, at.exp(x) * 2.0, x.sum(), x.sum(axis=0), x.sum(axis=1),
+                          x.prod(axis=0), at.dot(x.T, y), v[i], v[i] * 2.0,
+                          at.concatenate([x, y], axis=0), x.T + 1.0], \
+        [N((0, 5), seed=1), N((0, 5), seed=2), N((7,), seed=3), I((0,), "int64", 4, 0, 7)]
+
+
 @case("argmax_axes", exact=True)
 def _():
     x, m, v = at.dtensor3("x"), at.imatrix("m"), at.dvector("v")
