@@ -50,7 +50,7 @@ static uint32_t stream_grid(int64_t items, int block) {
 
 extern "C" {
 
-size_t ahip_reduce_ws_bytes(void) { return (size_t)AHIP_MAX_PARTIALS * 8 + 4096; }
+size_t ahip_reduce_ws_bytes(void) { return (size_t)AHIP_MAX_PARTIALS * 16 + 4096; }
 
 int ahip_set_param(const char* name, int64_t value) {
   AHIP_REQUIRE(name != nullptr && value > 0, "bad parameter");
@@ -87,7 +87,7 @@ int ahip_elemwise_reduce_all(ahip_fn_t k, int nd, const int64_t* shape, int nops
   if (rc) return rc;
   a.ws = ws;
   a.out = out;
-  a.aux1 = (int64_t)AHIP_MAX_PARTIALS * 8;  // byte offset of the arrival ticket inside ws
+  a.aux1 = (int64_t)AHIP_MAX_PARTIALS * 16;  // byte offset of the shard sums / epoch inside ws
   int64_t want = 1;
   if (a.n > 0) {
     AHIP_REQUIRE(shape[nd - 1] % vec == 0, "inner extent not divisible by vec");
