@@ -470,14 +470,14 @@ class KernelSpec:
 
     def key(self):
         fields = [self.in_dtypes, self.out_dtypes, self.out_refs, self.inner, self.nd, self.vec,
-                  self.block, self.idx64, self.reduce, self.unroll, self.nt, self.invariant, "v9"]
+                  self.block, self.idx64, self.reduce, self.unroll, self.nt, self.invariant, "v10"]
         return _memo_key([self.scalar], fields, self._key)
 
     def _key(self):
         import json
         blob = json.dumps([self.scalar, self.in_dtypes, self.out_dtypes, self.out_refs,
                            self.inner, self.nd, self.vec, self.block, self.idx64, self.reduce,
-                           self.unroll, self.nt, self.invariant, "v9"],
+                           self.unroll, self.nt, self.invariant, "v10"],
                           sort_keys=True)
         return hashlib.sha256(blob.encode()).hexdigest()[:24]
 
@@ -710,73 +710,72 @@ def generate(spec: KernelSpec):
             #   in index order and publishes the shard sum the same way; workgroup 0 does the
             #   same over the shard sums, stores the result and advances the epoch.  Critical
             #   path after the last workgroup finishes: granule store -> read -> fold -> granule
-            #   store -> read -> fold (two visibility latencies; the ticket form had five
+            #   store -> read -> fold (two visibility latencies — one when the grid is small enough
+            #   for workgroup 0 to hold a thread per partial; the ticket form had five
             #   dependent round trips).  Combiners are 1/32 of the grid, so spinning ones can
             #   never starve the workgroups they wait for; every spin is bounded.  The workspace
             #   is zero-initialised once and epoch 0 never matches a live tag.
             nw = spec.block // 64
             AG = "__ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT"
             SH = 32
+            ident = red_identity(red["op"], red["acc"])
 
-            L.append("  __shared__ %s sm[%d];" % (sm_t, max(nw, SH, 128)))
+            L.append("  __shared__ %s sm[%d];" % (sm_t, nw))
             L.append("  unsigned long long* wsp = (unsigned long long*)a.ws;")
             L.append("  unsigned long long* shard_sum = (unsigned long long*)((char*)a.ws + a.aux1);")
             L.append("  unsigned* epochp = (unsigned*)((char*)a.ws + a.aux1 + 2048 + 64);")
             L.append("  const unsigned ep = ep0 + 1u;")
-            L.append("  auto publish = [&](unsigned long long* slot, unsigned long long bits) {")
-            L.append("    __hip_atomic_store(slot, ((bits >> 32) << 32) | ep, %s);" % AG)
-            L.append("    __hip_atomic_store(slot + 1, (bits << 32) | ep, %s);" % AG)
+            L.append("  auto publish = [&](unsigned long long* slot, %s v) {" % acc_t)
+            L.append("    union { unsigned long long u; %s v; } cv; cv.u = 0; cv.v = v;" % acc_t)
+            L.append("    __hip_atomic_store(slot, ((cv.u >> 32) << 32) | ep, %s);" % AG)
+            L.append("    __hip_atomic_store(slot + 1, (cv.u << 32) | ep, %s);" % AG)
             L.append("  };")
-            L.append("  auto collect = [&](unsigned long long* slot) -> unsigned long long {")
+            L.append("  auto collect = [&](unsigned long long* slot) -> %s {" % acc_t)
             L.append("    unsigned long long g0 = 0, g1 = 0;")
             L.append("    for (int spin = 0; spin < (1 << 24); ++spin) {")
             L.append("      g0 = __hip_atomic_load(slot, %s);" % AG)
             L.append("      g1 = __hip_atomic_load(slot + 1, %s);" % AG)
             L.append("      if ((unsigned)g0 == ep && (unsigned)g1 == ep) break;")
             L.append("    }")
-            L.append("    return ((g0 >> 32) << 32) | (g1 >> 32);")
+            L.append("    union { unsigned long long u; %s v; } cv; cv.u = ((g0 >> 32) << 32) | (g1 >> 32);" % acc_t)
+            L.append("    return cv.v;")
             L.append("  };")
-            # workgroup partial
-            L.extend(wave_red)
-            L.append("  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;")
-            L.append("  __syncthreads();")
-            L.append("  const unsigned nsh = (gridDim.x + %du) / %du;" % (SH - 1, SH))
-            L.append("  if (threadIdx.x == 0) {")
-            L.append("    %s part = sm[0];" % acc_t)
-            L.append("    for (int w = 1; w < %d; ++w) part = %s;" % (nw, comb("part", "(%s)sm[w]" % acc_t)))
-            L.append("    union { unsigned long long u; %s v; } cv; cv.u = 0; cv.v = part;" % acc_t)
-            L.append("    publish(wsp + 2 * (size_t)blockIdx.x, cv.u);")
-            L.append("  }")
-            L.append("  if (blockIdx.x %% %du != 0) return;" % SH)
-            # --- shard combiner: thread t reads sibling t, thread 0 folds in index order
-            L.append("  __syncthreads();")
-            L.append("  if (threadIdx.x < %du && blockIdx.x + threadIdx.x < gridDim.x) {" % SH)
-            L.append("    union { unsigned long long u; %s v; } cv;" % acc_t)
-            L.append("    cv.u = collect(wsp + 2 * (size_t)(blockIdx.x + threadIdx.x));")
-            L.append("    sm[threadIdx.x] = cv.v;")
-            L.append("  }")
-            L.append("  __syncthreads();")
-            L.append("  if (threadIdx.x == 0) {")
-            L.append("    const unsigned cnt = (gridDim.x - blockIdx.x) < %du ? (gridDim.x - blockIdx.x) : %du;" % (SH, SH))
-            L.append("    %s ssum = sm[0];" % acc_t)
-            L.append("    for (unsigned k = 1; k < cnt; ++k) ssum = %s;" % comb("ssum", "(%s)sm[k]" % acc_t))
-            L.append("    union { unsigned long long u; %s v; } cv; cv.u = 0; cv.v = ssum;" % acc_t)
-            L.append("    publish(shard_sum + 2 * (size_t)(blockIdx.x / %du), cv.u);" % SH)
-            L.append("  }")
-            L.append("  if (blockIdx.x != 0) return;")
-            # --- workgroup 0: fold the shard sums (<= 128 of them) in order
-            L.append("  __syncthreads();")
-            L.append("  if (threadIdx.x < nsh) {")
-            L.append("    union { unsigned long long u; %s v; } cv;" % acc_t)
-            L.append("    cv.u = collect(shard_sum + 2 * (size_t)threadIdx.x);")
-            L.append("    sm[threadIdx.x] = cv.v;")
-            L.append("  }")
-            L.append("  __syncthreads();")
-            L.append("  if (threadIdx.x == 0) {")
+            # fold `acc` over the workgroup in a fixed tree (wave shuffles, then the waves in
+            # order); the result is valid in thread 0
+            L.append("  auto block_fold = [&]() -> %s {" % acc_t)
+            L.extend("  " + x for x in wave_red)
+            L.append("    __syncthreads();")
+            L.append("    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;")
+            L.append("    __syncthreads();")
             L.append("    %s r = sm[0];" % acc_t)
-            L.append("    for (unsigned k = 1; k < nsh; ++k) r = %s;" % comb("r", "(%s)sm[k]" % acc_t))
-            L.append("    *(%s*)a.out = %s;" % (CTYPE[red["out"]], _store_val("r", red["acc"], red["out"])))
-            L.append("    __hip_atomic_store(epochp, ep, %s);" % AG)
+            L.append("    for (int w = 1; w < %d; ++w) r = %s;" % (nw, comb("r", "(%s)sm[w]" % acc_t)))
+            L.append("    return r;")
+            L.append("  };")
+            L.append("  {")
+            L.append("    const %s part = block_fold();" % acc_t)
+            L.append("    if (threadIdx.x == 0) publish(wsp + 2 * (size_t)blockIdx.x, part);")
+            L.append("  }")
+            # one level when a single workgroup has a thread per partial, else shards of SH
+            L.append("  const bool one_level = gridDim.x <= %du;" % spec.block)
+            L.append("  if (one_level) {")
+            L.append("    if (blockIdx.x != 0) return;")
+            L.append("    acc = threadIdx.x < gridDim.x ? collect(wsp + 2 * (size_t)threadIdx.x) : %s;" % ident)
+            L.append("  } else {")
+            L.append("    if (blockIdx.x %% %du != 0) return;" % SH)
+            L.append("    acc = (threadIdx.x < %du && blockIdx.x + threadIdx.x < gridDim.x)" % SH)
+            L.append("        ? collect(wsp + 2 * (size_t)(blockIdx.x + threadIdx.x)) : %s;" % ident)
+            L.append("    const %s ssum = block_fold();" % acc_t)
+            L.append("    if (threadIdx.x == 0) publish(shard_sum + 2 * (size_t)(blockIdx.x / %du), ssum);" % SH)
+            L.append("    if (blockIdx.x != 0) return;")
+            L.append("    const unsigned nsh = (gridDim.x + %du) / %du;" % (SH - 1, SH))
+            L.append("    acc = threadIdx.x < nsh ? collect(shard_sum + 2 * (size_t)threadIdx.x) : %s;" % ident)
+            L.append("  }")
+            L.append("  {")
+            L.append("    const %s r = block_fold();" % acc_t)
+            L.append("    if (threadIdx.x == 0) {")
+            L.append("      *(%s*)a.out = %s;" % (CTYPE[red["out"]], _store_val("r", red["acc"], red["out"])))
+            L.append("      __hip_atomic_store(epochp, ep, %s);" % AG)
+            L.append("    }")
             L.append("  }")
         elif red["kind"] == "row":
             L.extend(wave_red)
