@@ -1542,3 +1542,188 @@ def generate_gemm_epilogue(spec: GemmEpiSpec):
     S.append("  }")
     S.append("}")
     return "\n".join(S) + "\n", (name,)
+
+
+def generate_rowchain_long(spec: RowChainSpec):
+    """Row chains whose rows do not fit a wavefront's registers (K of tens of thousands: a
+    vocabulary-sized softmax): ONE WORKGROUP PER ROW.  Every reduction of the chain is a stage
+    that sweeps the row in 16-byte packs (block reduce through LDS, result broadcast to all
+    threads); Elemwise members between the reductions are RE-EVALUATED in each later stage that
+    needs them instead of being kept (exp(x - max) is computed in the sum stage and again in the
+    scale stage).  The first sweep streams the row from HBM, the later sweeps re-read it from the
+    L2 / memory-side cache (a row is a few hundred KB), so HBM traffic stays ~1 read + the stores.
+    Same spec / argument block as generate_rowchain (spec.L and spec.nch are ignored)."""
+    V = spec.V
+    T_BLOCK = spec.block
+    nw = T_BLOCK // 64
+    members = spec.members
+    name = "rcl_" + spec.key()
+    S = [PRELUDE, RC_STRUCT]
+    S.append('extern "C" __global__ __launch_bounds__(%d) void %s(RcArgs a) {' % (T_BLOCK, name))
+    S.append("  __shared__ double red_sm[%d];" % nw)
+    S.append("  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;")
+    for k, (dt, cls) in enumerate(spec.ext):
+        if cls == "s":
+            S.append("  const %s sc%d = *(const %s*)a.ptr[%d];" % (CTYPE[dt], k, CTYPE[dt], k))
+    S.append("  for (i64 row = blockIdx.x; row < a.N; row += gridDim.x) {")
+    rem = "row"
+    for d in range(spec.lnd - 1, 0, -1):
+        S.append("    const i64 q%d = %s / a.lshape[%d];" % (d, rem, d))
+        S.append("    const i64 lc%d = %s - q%d * a.lshape[%d];" % (d, rem, d, d))
+        rem = "q%d" % d
+    S.append("    const i64 lc0 = %s;" % rem)
+
+    def row_off(k):
+        return " + ".join("lc%d * a.ls[%d][%d]" % (d, k, d) for d in range(spec.lnd))
+
+    for k, (dt, cls) in enumerate(spec.ext):
+        ct = CTYPE[dt]
+        if cls == "f":
+            S.append("    const %s* __restrict__ xp%d = (const %s*)a.ptr[%d] + %s;" % (ct, k, ct, k, row_off(k)))
+        elif cls == "c":
+            S.append("    const %s* __restrict__ xp%d = (const %s*)a.ptr[%d];" % (ct, k, ct, k))
+        elif cls == "r":
+            S.append("    const %s ro%d = ((const %s*)a.ptr[%d])[%s];" % (ct, k, ct, k, row_off(k)))
+
+    rowlike = [bool(m.get("rowlike")) for m in members]
+    rdt = {}
+
+    def closure(targets):
+        """per-element members needed (in order) to evaluate `targets`"""
+        need = set()
+
+        def visit(mi):
+            if mi in need or rowlike[mi]:
+                return
+            need.add(mi)
+            for r in members[mi]["ins"]:
+                if r[0] == "f":
+                    visit(r[1])
+        for t in targets:
+            visit(t)
+        return sorted(need)
+
+    row_vals = {}     # rowlike member -> (out exprs, out dtypes), evaluated once per row
+
+    def emit_rowlike_ready(upto_reduce_done):
+        """evaluate row-like members whose inputs are all available now"""
+        for mi, m in enumerate(members):
+            if not rowlike[mi] or mi in row_vals:
+                continue
+            ok = all((r[0] == "e") or (r[0] == "r" and r[1] in rdt)
+                     or (r[0] == "f" and r[1] in row_vals) for r in m["ins"])
+            if not ok:
+                continue
+            ins, dts = [], []
+            for r in m["ins"]:
+                if r[0] == "e":
+                    dt, cls = spec.ext[r[1]]
+                    e = "ro%d" % r[1] if cls == "r" else "sc%d" % r[1]
+                    ins.append("(%s != 0)" % e if dt == "bool" else e)
+                    dts.append(dt)
+                elif r[0] == "r":
+                    ins.append("r%d" % r[1])
+                    dts.append(rdt[r[1]])
+                else:
+                    es, ds = row_vals[r[1]]
+                    ins.append(es[r[2]])
+                    dts.append(ds[r[2]])
+            lines, oe, od = emit_scalar_body(m["scalar"], ins, dts, indent="    ", suffix="_m%d_r" % mi)
+            S.extend(lines)
+            row_vals[mi] = (oe, od)
+            for oref, odt, slot in m.get("stores", []):
+                S.append("    if (threadIdx.x == 0) ((%s*)a.ptr[%d])[%s] = %s;"
+                         % (CTYPE[odt], slot, row_off(slot), _store_val(oe[oref], od[oref], odt)))
+
+    def emit_sweep(stage_id, needed, body_tail):
+        """one pass over the row: loads, per-element evaluation of `needed`, then body_tail(outs)"""
+        used_ext = sorted({r[1] for mi in needed for r in members[mi]["ins"] if r[0] == "e"
+                           and spec.ext[r[1]][1] in "fc"})
+        S.append("    for (i64 c0 = (i64)threadIdx.x * %d; c0 < a.K; c0 += %d) {" % (V, T_BLOCK * V))
+        for k in used_ext:
+            ct = CTYPE[spec.ext[k][0]]
+            S.append("      const Pack<%s, %d> x%d = *(const Pack<%s, %d>*)(xp%d + c0);" % (ct, V, k, ct, V, k))
+        for j in range(V):
+            outs = {}
+            for mi in needed:
+                m = members[mi]
+                ins, dts = [], []
+                for r in m["ins"]:
+                    if r[0] == "e":
+                        dt, cls = spec.ext[r[1]]
+                        e = {"f": "x%d.v[%d]" % (r[1], j), "c": "x%d.v[%d]" % (r[1], j),
+                             "r": "ro%d" % r[1], "s": "sc%d" % r[1]}[cls]
+                        ins.append("(%s != 0)" % e if dt == "bool" else e)
+                        dts.append(dt)
+                    elif r[0] == "r":
+                        ins.append("r%d" % r[1])
+                        dts.append(rdt[r[1]])
+                    elif rowlike[r[1]]:
+                        es, ds = row_vals[r[1]]
+                        ins.append(es[r[2]])
+                        dts.append(ds[r[2]])
+                    else:
+                        es, ds = outs[r[1]]
+                        ins.append(es[r[2]])
+                        dts.append(ds[r[2]])
+                lines, oe, od = emit_scalar_body(m["scalar"], ins, dts, indent="      ",
+                                                 suffix="_s%d_m%d_%d" % (stage_id, mi, j))
+                S.extend(lines)
+                outs[mi] = (oe, od)
+            body_tail(j, outs)
+        S.append("    }")
+
+    stage = 0
+    for mi, m in enumerate(members):
+        red = m.get("reduce")
+        if not red or rowlike[mi]:
+            continue
+        emit_rowlike_ready(True)
+        acc_t = RTYPE[red["acc"]]
+        S.append("    %s acc%d = %s;" % (acc_t, mi, red_identity(red["op"], red["acc"])))
+
+        def tail(j, outs, mi=mi, red=red):
+            oe, od = outs[mi]
+            v = _cast(oe[red["ref"]], od[red["ref"]], red["acc"])
+            S.append("      acc%d = %s;" % (mi, red_combine(red["op"], red["acc"], "acc%d" % mi, v)))
+        emit_sweep(stage, closure([mi]), tail)
+        stage += 1
+        # block reduce, result to every thread (fixed order: deterministic)
+        S.append("    for (int s_ = 32; s_ > 0; s_ >>= 1) acc%d = %s;"
+                 % (mi, red_combine(red["op"], red["acc"], "acc%d" % mi,
+                                    "shfl_xor_<%s>(acc%d, s_)" % (acc_t, mi))))
+        S.append("    __syncthreads();")
+        S.append("    if (lane == 0) ((%s*)red_sm)[wave] = acc%d;" % (acc_t, mi))
+        S.append("    __syncthreads();")
+        S.append("    %s tot%d = ((%s*)red_sm)[0];" % (acc_t, mi, acc_t))
+        S.append("    for (int w_ = 1; w_ < %d; ++w_) tot%d = %s;"
+                 % (nw, mi, red_combine(red["op"], red["acc"], "tot%d" % mi, "((%s*)red_sm)[w_]" % acc_t)))
+        S.append("    const %s r%d = %s;" % (RTYPE[red["out"]], mi, _cast("tot%d" % mi, red["acc"], red["out"])))
+        rdt[mi] = red["out"]
+        if red.get("slot") is not None:
+            S.append("    if (threadIdx.x == 0) ((%s*)a.ptr[%d])[%s] = %s;"
+                     % (CTYPE[red["out"]], red["slot"], row_off(red["slot"]),
+                        _store_val("r%d" % mi, red["out"], red["out"])))
+    emit_rowlike_ready(True)
+    # final sweep: members with full-size stores
+    storing = [mi for mi, m in enumerate(members) if m.get("stores") and not rowlike[mi]]
+    if storing:
+        packs = {}
+        for mi in storing:
+            for oref, odt, slot in members[mi]["stores"]:
+                packs[(mi, oref, slot)] = odt
+
+        def tail(j, outs):
+            for (mi, oref, slot), odt in packs.items():
+                oe, od = outs[mi]
+                if j == 0:
+                    S.append("      Pack<%s, %d> y%d;" % (CTYPE[odt], V, slot))
+                S.append("      y%d.v[%d] = %s;" % (slot, j, _store_val(oe[oref], od[oref], odt)))
+                if j == V - 1:
+                    S.append("      *(Pack<%s, %d>*)((%s*)a.ptr[%d] + %s + c0) = y%d;"
+                             % (CTYPE[odt], V, CTYPE[odt], slot, row_off(slot), slot))
+        emit_sweep(stage, closure(storing), tail)
+    S.append("    __syncthreads();")
+    S.append("  }")
+    S.append("}")
+    return "\n".join(S) + "\n", (name,)

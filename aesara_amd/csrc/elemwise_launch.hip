@@ -169,10 +169,16 @@ int ahip_rowpass(ahip_fn_t k, const ahip_rp_args* args, int block, int rows_per_
 int ahip_rowchain(ahip_fn_t k, const ahip_rc_args* args, int block, int rows_per_wave,
                   void* stream) {
   AHIP_REQUIRE(k && args, "null argument");
-  AHIP_REQUIRE(block >= 64 && block % 64 == 0 && rows_per_wave >= 1 && rows_per_wave <= 64,
+  AHIP_REQUIRE(block >= 64 && block % 64 == 0 && rows_per_wave >= 0 && rows_per_wave <= 64,
                "bad block / rows_per_wave");
   if (args->N <= 0 || args->K <= 0) return AHIP_OK;
-  int grid = ahip_rowpass_grid(args->N, block, rows_per_wave);
+  int grid;
+  if (rows_per_wave == 0) {   // long rows: one workgroup per row, grid-stride over the rows
+    int64_t cap = (int64_t)ahip_cu_count() * (2048 / block > 0 ? 2048 / block : 1);
+    grid = (int)(args->N < cap ? args->N : cap);
+  } else {
+    grid = ahip_rowpass_grid(args->N, block, rows_per_wave);
+  }
   return ahip_launch_module(k->fn, dim3((unsigned)grid, 1, 1), dim3(block, 1, 1), 0,
                             as_stream(stream), args, sizeof(*args));
 }

@@ -255,7 +255,8 @@ int ahip_rowpass(ahip_fn_t k, const ahip_rp_args* args, int block, int rows_per_
 /* Row-chain kernel: a chain of last-axis CAReduce steps and the Elemwise steps between them in one
  * pass (each operand read once; intermediates in registers).  replaces e.g. Softmax.c_code
  * tensor/special.py:372-415 (three passes) / the CAReduce-DimShuffle-Elemwise node sequences of
- * tensor/elemwise.py:1495/:222/:725.  rows_per_wave = 64 / lanes-per-row of the generated kernel. */
+ * tensor/elemwise.py:1495/:222/:725.  rows_per_wave = 64 / lanes-per-row of the generated kernel;
+ * 0 = the long-row form (one workgroup per row, rows of tens of thousands of elements).          */
 int ahip_rowchain(ahip_fn_t k, const ahip_rc_args* args, int block, int rows_per_wave, void* stream);
 /* Small-M GEMM chain + Elemwise epilogue in one kernel (16 x 16*nf tile per workgroup, K split over
  * its 4 wavefronts, epilogue on the summed accumulators).  replaces Gemm / Dot22 nodes

@@ -219,6 +219,30 @@ def test_softmax_rowchain_large_rows_match_fp64_restatement():
     assert torch.allclose(y.double(), torch.softmax(x.double(), -1), rtol=1e-6, atol=1e-12)
 
 
+def test_long_row_chains_vocabulary_sized():
+    """Rows that do not fit a wavefront's registers take the one-workgroup-per-row form of the
+    row-chain kernel (every reduction a sweep, intermediates recomputed): softmax over a 50 304
+    wide vocabulary, log-softmax fp64, layer norm over 32 768 columns; against torch fp64 and
+    against the unfused node-by-node path."""
+    import torch
+    x = _randn((2048, 50304), torch.float32, 3, 4.0)
+    (y,) = _ex("softmax_rows_f32")(x)
+    ref = torch.softmax(x.double(), dim=-1)
+    assert (y.double().sum(-1) - 1).abs().max().item() <= 5e-6
+    assert torch.allclose(y.double(), ref, rtol=3e-6, atol=1e-10)
+    (yu,) = _ex("softmax_rows_f32", fuse=False)(x)
+    assert torch.allclose(y, yu, rtol=2e-6, atol=1e-10)
+    xd = _randn((300, 20002), torch.float64, 4, 3.0)      # K % 4 != 0, K % 2 == 0
+    (ld,) = _ex("logsoftmax_rows_f64")(xd)
+    assert torch.allclose(ld, torch.log_softmax(xd, dim=-1), rtol=1e-12, atol=1e-12)
+    xl = _randn((8, 16, 32768), torch.float32, 5, 2.0) + 0.5
+    g, b = _randn((32768,), torch.float32, 6), _randn((32768,), torch.float32, 7)
+    outs = _ex("layernorm_float32")(xl, g, b)
+    outs_u = _ex("layernorm_float32", fuse=False)(xl, g, b)
+    for u, v in zip(outs, outs_u):
+        assert torch.allclose(u.double(), v.double(), rtol=3e-5, atol=3e-5)
+
+
 def test_layernorm_rowchain_full_size():
     import torch
     x = _randn((64, 512, 1024), torch.float32, 5, 2.0) + 0.5

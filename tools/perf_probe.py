@@ -167,6 +167,15 @@ def main():
         report("softmax rows f32 1048576x64 (16 rows per wave)", d, w, 2 * (1 << 20) * 64 * 4,
                "GB/s", 8000.0)
 
+    if want("vocab"):
+        Nr, Kc = 8192, 50304
+        x = randn((Nr, Kc), f32, 31) * 3
+        for label, kw in (("softmax rows f32 8192x50304 (long-row chain kernel)", {}),
+                          ("softmax rows f32 8192x50304 UNFUSED (3 passes)", {"fuse": False})):
+            ex = PlanExecutor(plan_of("softmax_rows_f32"), use_graph=G, **kw)
+            d, w = timeit(lambda: ex(x), 10, warmup=2)
+            report(label, d, w, 2 * Nr * Kc * 4, "GB/s", 8000.0)
+
     if want("layernorm"):
         x = randn((64, 1024, 1024), f32, 13)
         g, b = randn((1024,), f32, 14), randn((1024,), f32, 15)
