@@ -184,9 +184,33 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(ArgmaxArgs a) {
     const T* row = x + r * a.x_rs;
     T best = row[0];
     int64_t bi = 0;
-    for (int64_t j = lane; j < a.k; j += 64) {
-      const T v = row[j * a.x_cs];
-      if (beats(v, j, best, bi)) { best = v; bi = j; }
+    constexpr int VEC = 16 / sizeof(T);
+    if (a.x_cs == 1 && a.k % VEC == 0 && reinterpret_cast<uintptr_t>(row) % 16 == 0) {
+      // contiguous rows: 16-byte loads, two in flight per lane
+      struct alignas(16) P { T v[VEC]; };
+      const P* prow = reinterpret_cast<const P*>(row);
+      const int64_t nv = a.k / VEC;
+      int64_t j = lane;
+      for (; j + 64 < nv; j += 128) {
+        const P p0 = prow[j], p1 = prow[j + 64];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          if (beats(p0.v[e], j * VEC + e, best, bi)) { best = p0.v[e]; bi = j * VEC + e; }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          if (beats(p1.v[e], (j + 64) * VEC + e, best, bi)) { best = p1.v[e]; bi = (j + 64) * VEC + e; }
+      }
+      for (; j < nv; j += 64) {
+        const P p0 = prow[j];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          if (beats(p0.v[e], j * VEC + e, best, bi)) { best = p0.v[e]; bi = j * VEC + e; }
+      }
+    } else {
+      for (int64_t j = lane; j < a.k; j += 64) {
+        const T v = row[j * a.x_cs];
+        if (beats(v, j, best, bi)) { best = v; bi = j; }
+      }
     }
     for (int m = 32; m > 0; m >>= 1) {
       union { T t; int i[2]; } u; u.i[0] = u.i[1] = 0; u.t = best;
