@@ -1673,12 +1673,85 @@ def generate_rowchain_long(spec: RowChainSpec):
             body_tail(j, outs)
         S.append("    }")
 
+    def online_pair(mi):
+        """max over a full operand immediately followed by sum(exp(x - max)) over the same
+        operand (the head of every softmax / log-softmax): both come out of ONE sweep with the
+        running-maximum rescaling  s <- s * exp(m_old - m_new) + sum exp(x - m_new)."""
+        a_ = members[mi]
+        if not (a_.get("reduce") and a_["reduce"]["op"] == "maximum" and not a_["scalar"]["nodes"]
+                and a_["ins"] and a_["ins"][0][0] == "e" and spec.ext[a_["ins"][0][1]][1] == "f"
+                and a_["scalar"]["out"][a_["reduce"]["ref"]] == ["i", 0]
+                and spec.ext[a_["ins"][0][1]][0] in ("float32", "float64")):
+            return None
+        for bj in range(mi + 1, len(members)):
+            b_ = members[bj]
+            if rowlike[bj]:
+                continue
+            if not b_.get("reduce"):
+                return None
+            nodes = b_["scalar"]["nodes"]
+            if (b_["reduce"]["op"] == "add" and len(nodes) == 2 and nodes[0]["op"] == "sub"
+                    and nodes[1]["op"] == "exp" and nodes[1]["in"] == [["t", 0]]
+                    and b_["scalar"]["out"][b_["reduce"]["ref"]] == ["t", 1]
+                    and len(b_["ins"]) == 2 and b_["ins"][nodes[0]["in"][0][1]] == a_["ins"][0]
+                    and b_["ins"][nodes[0]["in"][1][1]] == ["r", mi]
+                    and nodes[0]["in"][0][0] == "i" and nodes[0]["in"][1][0] == "i"
+                    and nodes[0]["dtype"] == nodes[1]["dtype"] == spec.ext[a_["ins"][0][1]][0]
+                    and b_["reduce"]["acc"] in ("float32", "float64")):
+                return bj
+            return None
+        return None
+
     stage = 0
+    fused_done = set()
     for mi, m in enumerate(members):
         red = m.get("reduce")
-        if not red or rowlike[mi]:
+        if not red or rowlike[mi] or mi in fused_done:
             continue
         emit_rowlike_ready(True)
+        bj = online_pair(mi)
+        if bj is not None:
+            k = m["ins"][0][1]
+            xt = CTYPE[spec.ext[k][0]]
+            bt = RTYPE[members[bj]["reduce"]["acc"]]
+            fexp = _fname("exp", spec.ext[k][0])
+            S.append("    %s om = (%s)(-INFINITY); %s os = 0;" % (xt, xt, bt))
+            S.append("    for (i64 c0 = (i64)threadIdx.x * %d; c0 < a.K; c0 += %d) {" % (V, T_BLOCK * V))
+            S.append("      const Pack<%s, %d> xv = *(const Pack<%s, %d>*)(xp%d + c0);" % (xt, V, xt, V, k))
+            S.append("      %s cm = xv.v[0];" % xt)
+            for j in range(1, V):
+                S.append("      cm = fmax_nan<%s>(cm, xv.v[%d]);" % (xt, j))
+            S.append("      const %s nm = fmax_nan<%s>(om, cm);" % (xt, xt))
+            S.append("      if (!(nm == om)) { os = os * (%s)exp((double)om - (double)nm); om = nm; }" % bt)
+            for j in range(V):
+                S.append("      os += (%s)%s(xv.v[%d] - om);" % (bt, fexp, j))
+            S.append("    }")
+            # block combine: global max, then rescaled sums in wave / lane order
+            S.append("    %s gm = om;" % xt)
+            S.append("    for (int s_ = 32; s_ > 0; s_ >>= 1) gm = fmax_nan<%s>(gm, shfl_xor_<%s>(gm, s_));" % (xt, xt))
+            S.append("    __syncthreads();")
+            S.append("    if (lane == 0) ((%s*)red_sm)[wave] = gm;" % xt)
+            S.append("    __syncthreads();")
+            S.append("    gm = ((%s*)red_sm)[0];" % xt)
+            S.append("    for (int w_ = 1; w_ < %d; ++w_) gm = fmax_nan<%s>(gm, ((%s*)red_sm)[w_]);" % (nw, xt, xt))
+            S.append("    %s gs = (om == gm || os == 0) ? os : os * (%s)exp((double)om - (double)gm);" % (bt, bt))
+            S.append("    for (int s_ = 32; s_ > 0; s_ >>= 1) gs += shfl_xor_<%s>(gs, s_);" % bt)
+            S.append("    __syncthreads();")
+            S.append("    if (lane == 0) ((%s*)red_sm)[wave] = gs;" % bt)
+            S.append("    __syncthreads();")
+            S.append("    gs = ((%s*)red_sm)[0];" % bt)
+            S.append("    for (int w_ = 1; w_ < %d; ++w_) gs += ((%s*)red_sm)[w_];" % (nw, bt))
+            for idx, val, accd in ((mi, "gm", red["acc"]), (bj, "gs", members[bj]["reduce"]["acc"])):
+                rr = members[idx]["reduce"]
+                S.append("    const %s r%d = %s;" % (RTYPE[rr["out"]], idx, _cast(val, accd, rr["out"])))
+                rdt[idx] = rr["out"]
+                if rr.get("slot") is not None:
+                    S.append("    if (threadIdx.x == 0) ((%s*)a.ptr[%d])[%s] = %s;"
+                             % (CTYPE[rr["out"]], rr["slot"], row_off(rr["slot"]),
+                                _store_val("r%d" % idx, rr["out"], rr["out"])))
+            fused_done.add(bj)
+            stage += 1
+            continue
         acc_t = RTYPE[red["acc"]]
         S.append("    %s acc%d = %s;" % (acc_t, mi, red_identity(red["op"], red["acc"])))
 
