@@ -236,6 +236,21 @@ def main():
         report("materialise transpose f64 4096^2 (strided copy)", d, w, 2 * x.numel() * 8,
                "GB/s", 8000.0)
 
+    if want("bptt"):
+        T, H = 512, 1024
+        ex = PlanExecutor(plan_of("scan_grad_last_state_f32"), use_graph=G)
+        x = randn((T, H), f32, 41) * 0.1
+        h0 = torch.zeros(H, dtype=f32, device="cuda")
+        W = randn((H, H), f32, 42) / np.sqrt(H)
+        U = randn((H, H), f32, 43) / np.sqrt(H)
+        t0 = time.perf_counter()
+        ex(x, h0, W, U)
+        torch.cuda.synchronize()
+        first = time.perf_counter() - t0
+        d, w = timeit(lambda: ex(x, h0, W, U), 3, warmup=1)
+        report("tanh-RNN forward + BPTT (grad of last state) T=512 H=1024 f32", d, w,
+               T * 3 * H * H * 4, "GB/s", 8000.0, us_per_step=d * 1e3 / T, first_call_s=first)
+
     if want("cfg5"):
         N, D = 1 << 22, 256
         ex = PlanExecutor(plan_of("cfg5_logistic"), use_graph=G)
