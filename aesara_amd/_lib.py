@@ -45,6 +45,9 @@ AHIP_MAXDOTS = 8
 AHIP_GV_MAXOPS = 16
 
 
+AHIP_GV_MAXXIN = 4
+
+
 class GvArgs(C.Structure):
     _fields_ = [
         ("M", C.c_int64),
@@ -53,6 +56,7 @@ class GvArgs(C.Structure):
         ("x", C.c_void_p * AHIP_MAXDOTS), ("incx", C.c_int64 * AHIP_MAXDOTS),
         ("ptr", C.c_void_p * AHIP_GV_MAXOPS), ("stride", C.c_int64 * AHIP_GV_MAXOPS),
         ("ndots", C.c_int32), ("nops", C.c_int32),
+        ("xin", (C.c_void_p * AHIP_GV_MAXXIN) * AHIP_MAXDOTS), ("xout", C.c_void_p * AHIP_MAXDOTS),
     ]
 
 

@@ -814,6 +814,7 @@ struct GvArgs {
   const void* x[AHIP_MAXDOTS]; i64 incx[AHIP_MAXDOTS];
   void* ptr[AHIP_GV_MAXOPS]; i64 stride[AHIP_GV_MAXOPS];
   int ndots; int nops;
+  const void* xin[AHIP_MAXDOTS][4]; void* xout[AHIP_MAXDOTS];
 };
 """ % (AHIP_MAXDOTS, AHIP_GV_MAXOPS)
 
@@ -834,7 +835,12 @@ class GemvEpiSpec:
     """
 
     def __init__(self, dtype, dot_vec, scalar, in_dtypes, out_dtypes, out_refs, block=256,
-                 rpw=1, kvs=None):
+                 rpw=1, kvs=None, xprogs=None):
+        # xprogs: per dot None or {"scalar", "cls": ["v" | "s", ...], "out_ref", "store"}: the
+        # dot's vector is an Elemwise of <= 4 vectors / scalars, evaluated while it is loaded
+        # (and stored by the first wavefront when something else reads it).  Needs kvs.
+        self.xprogs = list(xprogs) if xprogs and any(xprogs) else None
+        assert not self.xprogs or kvs
         self.rpw = rpw  # rows per wavefront iteration (4 for short rows, 1 for long rows)
         # kvs: per dot, 16-byte vectors per lane (K = 64 * VEC * kv) when every row length is
         # such a multiple and small: the kernel is then specialised on the lengths and issues
@@ -853,14 +859,17 @@ class GemvEpiSpec:
         assert len(self.in_dtypes) + len(self.out_dtypes) <= AHIP_GV_MAXOPS
 
     def key(self):
-        fields = ["gv3", self.dtype, self.dot_vec, self.in_dtypes, self.out_dtypes, self.out_refs,
-                  self.block, self.rpw, self.kvs]
-        return _memo_key([self.scalar], fields, self._key)
+        xp = [None if x is None else [x["cls"], x["out_ref"], x["store"]] for x in (self.xprogs or [])]
+        fields = ["gv4", self.dtype, self.dot_vec, self.in_dtypes, self.out_dtypes, self.out_refs,
+                  self.block, self.rpw, self.kvs, xp]
+        return _memo_key([self.scalar] + [x["scalar"] for x in (self.xprogs or []) if x],
+                         fields, self._key)
 
     def _key(self):
         import json
-        blob = json.dumps(["gv3", self.dtype, self.dot_vec, self.scalar, self.in_dtypes,
-                           self.out_dtypes, self.out_refs, self.block, self.rpw, self.kvs],
+        blob = json.dumps(["gv4", self.dtype, self.dot_vec, self.scalar, self.in_dtypes,
+                           self.out_dtypes, self.out_refs, self.block, self.rpw, self.kvs,
+                           self.xprogs],
                           sort_keys=True)
         return hashlib.sha256(blob.encode()).hexdigest()[:24]
 
@@ -890,12 +899,40 @@ def generate_gemv_epilogue(spec: GemvEpiSpec):
                          "((m0 + %d < a.M) ? (m0 + %d) : (a.M - 1)) * a.a_rs[%d];"
                          % (T, d, r, T, d, r, r, d))
         for d in range(D):
+            xp = spec.xprogs[d] if spec.xprogs else None
             for j in range(spec.kvs[d]):
                 for r in range(R):
                     L.append("    const Pack<%s, %d> a%d_%d_%d = *(const Pack<%s, %d>*)"
                              "(row%d_%d + (%d + lane) * %d);" % (T, V, d, r, j, T, V, d, r, j * 64, V))
-                L.append("    const Pack<%s, %d> x%d_%d = *(const Pack<%s, %d>*)(xv%d + (%d + lane) * %d);"
-                         % (T, V, d, j, T, V, d, j * 64, V))
+                if xp is None:
+                    L.append("    const Pack<%s, %d> x%d_%d = *(const Pack<%s, %d>*)(xv%d + (%d + lane) * %d);"
+                             % (T, V, d, j, T, V, d, j * 64, V))
+                else:
+                    for q, c in enumerate(xp["cls"]):
+                        if c == "v":
+                            L.append("    const Pack<%s, %d> xi%d_%d_%d = *(const Pack<%s, %d>*)"
+                                     "((const %s*)a.xin[%d][%d] + (%d + lane) * %d);"
+                                     % (T, V, d, q, j, T, V, T, d, q, j * 64, V))
+                        elif j == 0:
+                            L.append("    const %s xs%d_%d = *(const %s*)a.xin[%d][%d];" % (T, d, q, T, d, q))
+        # vector prologues: x_d evaluated from its operands, stored once if something reads it
+        for d in range(D):
+            xp = spec.xprogs[d] if spec.xprogs else None
+            if xp is None:
+                continue
+            for j in range(spec.kvs[d]):
+                L.append("    Pack<%s, %d> x%d_%d;" % (T, V, d, j))
+                for e in range(V):
+                    ins_ = ["xi%d_%d_%d.v[%d]" % (d, q, j, e) if c == "v" else "xs%d_%d" % (d, q)
+                            for q, c in enumerate(xp["cls"])]
+                    lines, oe, od = emit_scalar_body(xp["scalar"], ins_, [spec.dtype] * len(ins_),
+                                                     indent="    ", suffix="_xp%d_%d_%d" % (d, j, e))
+                    L.extend(lines)
+                    L.append("    x%d_%d.v[%d] = %s;" % (d, j, e, _cast(oe[xp["out_ref"]],
+                                                                         od[xp["out_ref"]], spec.dtype)))
+                if xp["store"]:
+                    L.append("    if (m0 == 0) *(Pack<%s, %d>*)((%s*)a.xout[%d] + (%d + lane) * %d) = x%d_%d;"
+                             % (T, V, T, d, j * 64, V, d, j))
         for d in range(D):
             for r in range(R):
                 terms = ["a%d_%d_%d.v[%d] * x%d_%d.v[%d]" % (d, r, j, e, d, j, e)

@@ -176,6 +176,7 @@ def build_steps(plan: Plan, fuse: bool = True) -> List[Step]:
         steps = _fuse_rowpass(plan, steps)
         steps = _fuse_rowchain(plan, steps)
         steps = _fuse_gemm_epi(plan, steps)
+        steps = _fuse_xprologue(plan, steps)
     return steps
 
 
@@ -478,6 +479,8 @@ def _build_rowpass(plan, steps, i1, i2, xv, wv, rv, max_ops, max_red):
 # ----------------------------------------------------------------------------------------
 def _step_reads(st: Step):
     used = list(st.inputs) + [v for d in st.dots for v in d]
+    for xp in st.extra.get("xprog", {}).values():
+        used += list(xp["step"].inputs)
     for q in st.fallback + st.post:
         used += _step_reads(q)
     return used
@@ -707,3 +710,40 @@ def _fuse_gemm_epi(plan: Plan, steps: List[Step], max_dots: int = 3, max_ops: in
     if not replaced:
         return steps
     return [replaced.get(j, s) for j, s in enumerate(steps) if j not in removed]
+
+
+def _fuse_xprologue(plan: Plan, steps: List[Step]) -> List[Step]:
+    """The vector of a fused GEMV chain that is itself a small Elemwise of vectors (the
+    ``delta * (1 - h**2)`` feeding ``W . (...)`` in every step of a backward RNN Scan) is evaluated
+    by the GEMV kernel while it loads the vector (and stored by its first wavefront when anything
+    else reads it): one launch less per step.  The Elemwise step is kept inside the fused step and
+    run as before whenever the run-time layout does not qualify."""
+    out_set = set(plan.outputs)
+    readers: Dict[int, List[int]] = {}
+    made_by: Dict[int, int] = {}
+    for j, t in enumerate(steps):
+        for v in set(_step_reads(t)):
+            readers.setdefault(v, []).append(j)
+        if t.kind == "elemwise" and not t.dots and len(t.outputs) == 1:
+            made_by[t.outputs[0]] = j
+    removed = set()
+    for j, g in enumerate(steps):
+        if g.kind != "gemv_epi":
+            continue
+        for d, (_a, xv) in enumerate(g.dots):
+            pj = made_by.get(xv)
+            if pj is None or pj in removed or pj > j:
+                continue
+            P = steps[pj]
+            if not (1 <= len(P.inputs) <= 4 and len(P.scalar["nodes"]) <= 12
+                    and all(plan.vars[u].ndim <= 1 for u in P.inputs)
+                    and all(plan.vars[u].dtype == plan.vars[xv].dtype for u in P.inputs)):
+                continue
+            rd = [r for r in readers.get(xv, []) if r != j]
+            if any(pj < r < j for r in rd):
+                continue          # something between needs the vector before the GEMV runs
+            g.extra.setdefault("xprog", {})[d] = {"step": P, "store": bool(rd) or xv in out_set}
+            removed.add(pj)
+    if not removed:
+        return steps
+    return [s_ for j, s_ in enumerate(steps) if j not in removed]

@@ -74,6 +74,7 @@ typedef struct ahip_ew_args {
  * y[m] = f(dot_0[m], .., dot_{D-1}[m], operands[m]),  dot_d[m] = sum_k A_d[m*a_rs + k*a_cs] * x_d[k*incx] */
 #define AHIP_MAXDOTS 8
 #define AHIP_GV_MAXOPS 16
+#define AHIP_GV_MAXXIN 4
 typedef struct ahip_gv_args {
   int64_t M;
   const void* A[AHIP_MAXDOTS]; int64_t a_rs[AHIP_MAXDOTS]; int64_t a_cs[AHIP_MAXDOTS];
@@ -82,6 +83,10 @@ typedef struct ahip_gv_args {
   void* ptr[AHIP_GV_MAXOPS];      /* epilogue operands: inputs then outputs               */
   int64_t stride[AHIP_GV_MAXOPS]; /* element stride along m (0 = broadcast)               */
   int32_t ndots; int32_t nops;
+  /* optional vector prologue of dot d: x_d = g(xin[d][0..3]) evaluated while it is loaded (unit-
+   * stride vectors of length K_d or scalars); xout[d] != NULL: the computed x_d is also stored  */
+  const void* xin[AHIP_MAXDOTS][AHIP_GV_MAXXIN];
+  void* xout[AHIP_MAXDOTS];
 } ahip_gv_args;
 
 /* Kernel-argument block of the GENERATED single-pass "row program" kernels
