@@ -136,7 +136,7 @@ SIGNATURES = {
     "ahip_rowpass_grid": (i32, [i64, i32, i32]),
     "ahip_rowpass": (i32, [vp, C.POINTER(RpArgs), i32, i32, sz, vp]),
     "ahip_rowchain": (i32, [vp, C.POINTER(RcArgs), i32, i32, vp]),
-    "ahip_gemm_epilogue": (i32, [vp, C.POINTER(GeArgs), i32, vp]),
+    "ahip_gemm_epilogue": (i32, [vp, C.POINTER(GeArgs), i32, i32, vp]),
     "ahip_ger": (i32, [i32, i64, i64, vp, vp, i64, vp, i64, vp, i64, i64, vp, i64, i64, vp]),
     "ahip_copy_strided": (i32, [i32, i32, p_i64, vp, p_i64, vp, p_i64, i32, vp]),
     "ahip_fill": (i32, [i32, vp, vp, i64, vp]),

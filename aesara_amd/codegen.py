@@ -1425,7 +1425,7 @@ template <> struct MfmaT<double> {
 // One wavefront's share (a quarter of K) of a 16 x (16*NF) tile of A @ B; same schedule as
 // gemm_skinny_kernel in csrc/gemm.hip (A k-contiguous, B n- or k-contiguous, vector loads in
 // MFMA layout, two-group software pipeline, accumulators folded every 512 k).
-template <typename T, int NF, bool BKC>
+template <typename T, int NF, bool BKC, int NW>
 __device__ __forceinline__ void skinny_dot(const T* __restrict__ A, i64 a_rs, const T* __restrict__ B,
                                            i64 b_rs, i64 b_cs, i64 M, i64 N, i64 K, i64 m0, i64 n0,
                                            int lane, int wave, typename MfmaT<T>::acc_t (&res)[NF]) {
@@ -1436,7 +1436,7 @@ __device__ __forceinline__ void skinny_dot(const T* __restrict__ A, i64 a_rs, co
   struct alignas(sizeof(T) * NF) NV { T v[NF]; };
   struct Frag { KV a; KV bk[NF]; NV bn[VEC]; };
   const int r = lane & 15, kg = lane >> 4;
-  const i64 kq = ((K + 4 * G - 1) / (4 * G)) * G;
+  const i64 kq = ((K + NW * G - 1) / (NW * G)) * G;   // K split over the NW wavefronts
   const i64 kbeg = wave * kq;
   const i64 kend = (kbeg + kq < K) ? kbeg + kq : K;
   const bool mok = m0 + r < M;
@@ -1504,7 +1504,10 @@ class GemmEpiSpec:
     scalar: plan scalar expression; its first D inputs are the dot results
     """
 
-    def __init__(self, dtype, nf, bkc, scalar, in_dtypes, out_dtypes, out_refs):
+    def __init__(self, dtype, nf, bkc, scalar, in_dtypes, out_dtypes, out_refs, waves=4):
+        self.waves = waves   # wavefronts per workgroup = K slices (short K chains: these kernels
+        #                      are bound by memory round trips per wavefront, not by MFMA rate)
+        assert waves in (4, 8, 16)
         self.dtype, self.nf, self.bkc, self.scalar = dtype, nf, [bool(b) for b in bkc], scalar
         self.in_dtypes, self.out_dtypes, self.out_refs = list(in_dtypes), list(out_dtypes), list(out_refs)
         assert 1 <= len(self.bkc) <= GE_MAXDOTS
@@ -1512,14 +1515,14 @@ class GemmEpiSpec:
         assert len(self.in_dtypes) + len(self.out_dtypes) <= GE_MAXOPS
 
     def key(self):
-        fields = ["ge1", self.dtype, self.nf, self.bkc, self.in_dtypes, self.out_dtypes,
-                  self.out_refs]
+        fields = ["ge2", self.dtype, self.nf, self.bkc, self.in_dtypes, self.out_dtypes,
+                  self.out_refs, self.waves]
         return _memo_key([self.scalar], fields, self._key)
 
     def _key(self):
         import json
-        blob = json.dumps(["ge1", self.dtype, self.nf, self.bkc, self.scalar, self.in_dtypes,
-                           self.out_dtypes, self.out_refs], sort_keys=True)
+        blob = json.dumps(["ge2", self.dtype, self.nf, self.bkc, self.scalar, self.in_dtypes,
+                           self.out_dtypes, self.out_refs, self.waves], sort_keys=True)
         return hashlib.sha256(blob.encode()).hexdigest()[:24]
 
 
@@ -1529,23 +1532,25 @@ def generate_gemm_epilogue(spec: GemmEpiSpec):
     nin, nout = len(spec.in_dtypes), len(spec.out_dtypes)
     name = "ge_" + spec.key()
     S = [PRELUDE, GE_PRELUDE]
-    S.append('extern "C" __global__ __launch_bounds__(256) void %s(GeArgs a) {' % name)
+    NW = spec.waves
+    S.append('extern "C" __global__ __launch_bounds__(%d) void %s(GeArgs a) {' % (64 * NW, name))
     S.append("  typedef MfmaT<%s>::acc_t acc_t;" % T)
-    S.append("  __shared__ %s part[4][%d][%d];" % (T, D, 256 * NF))
+    S.append("  __shared__ %s part[%d][%d][%d];" % (T, NW, D, 256 * NF))
     S.append("  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15;")
     S.append("  const i64 m0 = (i64)blockIdx.y * 16, n0 = (i64)blockIdx.x * %d;" % (16 * NF))
     for d in range(D):
         S.append("  {")
         S.append("    acc_t res[%d];" % NF)
-        S.append("    skinny_dot<%s, %d, %s>((const %s*)a.A[%d], a.a_rs[%d], (const %s*)a.B[%d], "
+        S.append("    skinny_dot<%s, %d, %s, %d>((const %s*)a.A[%d], a.a_rs[%d], (const %s*)a.B[%d], "
                  "a.b_rs[%d], a.b_cs[%d], a.M, a.N, a.K[%d], m0, n0, lane, wave, res);"
-                 % (T, NF, "true" if spec.bkc[d] else "false", T, d, d, T, d, d, d, d))
+                 % (T, NF, "true" if spec.bkc[d] else "false", NW, T, d, d, T, d, d, d, d))
         S.append("    for (int f = 0; f < %d; ++f)" % NF)
         S.append("      for (int i = 0; i < 4; ++i)")
         S.append("        part[wave][%d][(MfmaT<%s>::frag_row(lane, i) * 16 + r) * %d + f] = res[f][i];"
                  % (d, T, NF))
         S.append("  }")
     S.append("  __syncthreads();")
+    S.append("  if (threadIdx.x >= 256) return;")
     S.append("  const int e = threadIdx.x, er = e >> 4, ec = e & 15;")
     S.append("  const i64 m = m0 + er;")
     S.append("  if (m >= a.M) return;")
@@ -1559,9 +1564,8 @@ def generate_gemm_epilogue(spec: GemmEpiSpec):
     S.append("    if (n >= a.N) continue;")
     ins, in_dts = [], []
     for d in range(D):
-        S.append("    const %s d%d = ((part[0][%d][e * %d + f] + part[1][%d][e * %d + f]) + "
-                 "part[2][%d][e * %d + f]) + part[3][%d][e * %d + f];"
-                 % (T, d, d, NF, d, NF, d, NF, d, NF))
+        S.append("    %s d%d = part[0][%d][e * %d + f];" % (T, d, d, NF))
+        S.append("    for (int w_ = 1; w_ < %d; ++w_) d%d += part[w_][%d][e * %d + f];" % (NW, d, d, NF))
         ins.append("d%d" % d)
         in_dts.append(spec.dtype)
     for k in range(nin):

@@ -183,13 +183,14 @@ int ahip_rowchain(ahip_fn_t k, const ahip_rc_args* args, int block, int rows_per
                             as_stream(stream), args, sizeof(*args));
 }
 
-int ahip_gemm_epilogue(ahip_fn_t k, const ahip_ge_args* args, int nf, void* stream) {
+int ahip_gemm_epilogue(ahip_fn_t k, const ahip_ge_args* args, int nf, int waves, void* stream) {
   AHIP_REQUIRE(k && args, "null argument");
   AHIP_REQUIRE(nf == 1 || nf == 2 || nf == 4, "nf must be 1, 2 or 4");
+  AHIP_REQUIRE(waves == 4 || waves == 8 || waves == 16, "waves must be 4, 8 or 16");
   if (args->M <= 0 || args->N <= 0) return AHIP_OK;
   const int64_t gx = (args->N + 16 * nf - 1) / (16 * nf), gy = (args->M + 15) / 16;
   AHIP_REQUIRE(gy < 65536, "M too large for the small-M kernel");
-  return ahip_launch_module(k->fn, dim3((unsigned)gx, (unsigned)gy, 1), dim3(256, 1, 1), 0,
+  return ahip_launch_module(k->fn, dim3((unsigned)gx, (unsigned)gy, 1), dim3(64 * waves, 1, 1), 0,
                             as_stream(stream), args, sizeof(*args));
 }
 

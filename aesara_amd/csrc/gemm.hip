@@ -496,21 +496,21 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs g) {
 // (BKC = true, fragment f = columns n0 + 16 f + r).  Two-group software pipeline on the loads.
 int64_t g_skinny_nf = 0;           // 0 = choose by grid size; 1/2/4 forces the tile width
 
-template <typename T, int NF, bool BKC>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
+template <typename T, int NF, bool BKC, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(GemmArgs g) {
   using acc_t = typename Traits<T>::acc_t;
   constexpr int VEC = Traits<T>::VEC;
   constexpr int G = 4 * VEC;  // k extent of one vector group (4 lane groups x VEC)
   struct alignas(sizeof(T) * VEC) KV { T v[VEC]; };
   struct alignas(sizeof(T) * NF) NV_ { T v[NF]; };
-  __shared__ T part[4][256 * NF];
+  __shared__ T part[NW][256 * NF];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, kg = lane >> 4;
   const int64_t z = blockIdx.z;
   const int64_t m0 = (int64_t)blockIdx.y * 16, n0 = (int64_t)blockIdx.x * (16 * NF);
   const T* __restrict__ A = static_cast<const T*>(g.A) + z * g.a_bs;
   const T* __restrict__ B = static_cast<const T*>(g.B) + z * g.b_bs;
-  const int64_t kq = ((g.K + 4 * G - 1) / (4 * G)) * G;
+  const int64_t kq = ((g.K + NW * G - 1) / (NW * G)) * G;   // K split over the NW wavefronts
   const int64_t kbeg = wave * kq;
   const int64_t kend = (kbeg + kq < g.K) ? kbeg + kq : g.K;
   const bool mok = m0 + r < g.M;
@@ -573,6 +573,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
     for (int i = 0; i < 4; ++i)
       part[wave][(frag_row<T>(lane, i) * 16 + r) * NF + f] = tot[f][i] + acc[f][i];
   __syncthreads();
+  if (threadIdx.x >= 256) return;
   const int e = threadIdx.x, er = e >> 4, ec = e & 15;
   if (m0 + er < g.M) {
     T* C = static_cast<T*>(g.C) + z * g.c_bs;
@@ -582,9 +583,8 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
       const int64_t col = BKC ? n0 + 16 * f + ec : n0 + NF * ec + f;
       if (col >= g.N) continue;
       T sum = part[0][e * NF + f];
-      sum += part[1][e * NF + f];
-      sum += part[2][e * NF + f];
-      sum += part[3][e * NF + f];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) sum += part[w][e * NF + f];
       T v = (T)g.alpha * sum;
       if (g.beta != 0.0) v += (T)g.beta * Cin[(m0 + er) * g.ci_rs + col * g.ci_cs];
       C[(m0 + er) * g.c_rs + col * g.c_cs] = v;
@@ -706,8 +706,17 @@ int launch_tn(const GemmArgs& g, int64_t batch, hipStream_t s) {
 template <typename T, int NF, bool BKC>
 int launch_skinny(const GemmArgs& g, int64_t batch, hipStream_t s) {
   const int64_t gx = (g.N + 16 * NF - 1) / (16 * NF), gy = (g.M + 15) / 16;
-  AHIP_LAUNCH((gemm_skinny_kernel<T, NF, BKC>), dim3((unsigned)gx, (unsigned)gy, (unsigned)batch),
-              dim3(256), 0, s, g);
+  const dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)batch);
+  // small grids are bound by the memory round trips of each wavefront's K chain, not by MFMA
+  // rate: split K over more wavefronts (batch-64 recurrent step: 12.7 -> 9.7 ms per 512 steps)
+  const int64_t wgs = gx * gy * batch;
+  if (NF <= 2 && wgs <= 512 && g.K >= 1024) {
+    AHIP_LAUNCH((gemm_skinny_kernel<T, NF, BKC, 16>), grid, dim3(1024), 0, s, g);
+  } else if (wgs <= 1024 && g.K >= 512) {
+    AHIP_LAUNCH((gemm_skinny_kernel<T, NF, BKC, 8>), grid, dim3(512), 0, s, g);
+  } else {
+    AHIP_LAUNCH((gemm_skinny_kernel<T, NF, BKC, 4>), grid, dim3(256), 0, s, g);
+  }
   return AHIP_OK;
 }
 

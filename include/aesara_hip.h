@@ -266,7 +266,8 @@ int ahip_rowchain(ahip_fn_t k, const ahip_rc_args* args, int block, int rows_per
 /* Small-M GEMM chain + Elemwise epilogue in one kernel (16 x 16*nf tile per workgroup, K split over
  * its 4 wavefronts, epilogue on the summed accumulators).  replaces Gemm / Dot22 nodes
  * (tensor/blas.py:872 / :1659) followed by the Elemwise that consumes them (tensor/elemwise.py:725). */
-int ahip_gemm_epilogue(ahip_fn_t k, const ahip_ge_args* args, int nf, void* stream);
+int ahip_gemm_epilogue(ahip_fn_t k, const ahip_ge_args* args, int nf, int waves /* 4, 8, 16: K slices */,
+                       void* stream);
 /* A_out[M,N] = A_in + alpha * x[M] y[N]^T */
 int ahip_ger(int dtype, int64_t M, int64_t N, const void* alpha, const void* x, int64_t incx,
              const void* y, int64_t incy, const void* A_in, int64_t ai_rs, int64_t ai_cs,

@@ -199,8 +199,8 @@ def main():
 
     if want("gemmsmall"):
         from aesara_amd._lib import lib as _l
-        for (M, N, K) in ((64, 1024, 1024), (1024, 1024, 1024), (2048, 1024, 1024),
-                          (1024, 1024, 4096), (2048, 2048, 512)):
+        for (M, N, K) in ((64, 1024, 1024), (8, 1024, 1024), (256, 1024, 1024), (64, 4096, 4096),
+                          (512, 512, 512), (1024, 1024, 1024), (2048, 1024, 1024)):
             Cm = torch.zeros((M, N), dtype=f32, device="cuda")
             A, B = randn((M, K), f32, 3), randn((K, N), f32, 4)
             for tiles in (1, 100000):

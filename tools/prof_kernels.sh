@@ -6,7 +6,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out -o p -- python $GRA
 python - <<PY
 import csv, collections
 rows = list(csv.DictReader(open("$out/p_kernel_trace.csv")))
-rows = [r for r in rows if r["Kernel_Name"].startswith(("ew_", "gv_", "rp_", "rc_", "void (anonymous namespace)::"))]
+rows = [r for r in rows if r["Kernel_Name"].startswith(("ew_", "gv_", "rp_", "rc_", "rcl_", "ge_", "void (anonymous namespace)::"))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 d = collections.defaultdict(list)
 gaps = []
