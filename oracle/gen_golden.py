@@ -695,6 +695,28 @@ def _():
         [N((0, 5), seed=1), N((0, 5), seed=2), N((7,), seed=3), I((0,), "int64", 4, 0, 7)]
 
 
+for _dt, _tol in (("float64", 1e-10), ("float32", 5e-5)):
+    def _mklstm(dt=_dt):
+        # LSTM (gates from one concatenated product, sliced) forward + BPTT: loss and the three
+        # parameter gradients (the backward Scan has matrix-valued mit-mot accumulators)
+        H = 8
+        x, y = T(dt, (2, 2, 2), "x"), T(dt, (2, 2), "y")
+        W, U_, b = T(dt, (2, 2), "W"), T(dt, (2, 2), "U"), T(dt, (2,), "b")
+
+        def step(x_t, h, c, W, U_, b):
+            g = at.dot(x_t, W) + at.dot(h, U_) + b
+            i, f, o, gg = (g[:, k * H:(k + 1) * H] for k in range(4))
+            c2 = at.sigmoid(f) * c + at.sigmoid(i) * at.tanh(gg)
+            return at.sigmoid(o) * at.tanh(c2), c2
+        z = at.zeros((x.shape[1], H), dtype=dt)
+        (hs, cs), _ = ae.scan(step, sequences=[x], outputs_info=[z, z], non_sequences=[W, U_, b])
+        loss = ((hs[-1] - y) ** 2).mean()
+        return [x, y, W, U_, b], [loss] + list(ae.grad(loss, [W, U_, b])), \
+            [N((5, 4, 6), dt, 1), N((4, 8), dt, 2), N((6, 32), dt, 3, 0.3), N((8, 32), dt, 4, 0.3),
+             N((32,), dt, 5, 0.1)]
+    case(f"lstm_bptt_{_dt}", rtol=_tol, atol=_tol)(_mklstm)
+
+
 @case("argmax_axes", exact=True)
 def _():
     x, m, v = at.dtensor3("x"), at.imatrix("m"), at.dvector("v")

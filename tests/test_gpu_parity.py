@@ -42,7 +42,8 @@ def test_hip_matches_reference(c):
 
 
 @pytest.mark.parametrize("c", [c for c in CASES if c["name"].startswith(
-    ("cfg", "scan_", "gru", "softmax", "logsoftmax", "layernorm", "argmax", "gemv_", "advsub1"))],
+    ("cfg", "scan_", "gru", "softmax", "logsoftmax", "layernorm", "argmax", "gemv_", "advsub1",
+     "lstm", "nll", "mlp", "cumop", "split", "advsub_nd", "advincsub_nd", "arange"))],
                          ids=lambda c: c["name"])
 def test_hip_graph_replay_matches_reference(c):
     """Same cases through hipGraph capture + replay (H1/K10 launch-list path)."""
