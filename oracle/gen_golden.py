@@ -717,6 +717,18 @@ for _dt, _tol in (("float64", 1e-10), ("float32", 5e-5)):
     case(f"lstm_bptt_{_dt}", rtol=_tol, atol=_tol)(_mklstm)
 
 
+@case("rowchain_integer", exact=True)
+def _():
+    # last-axis reduction chains on integer / bool data go through the same row-chain kernels
+    x, b = at.imatrix("x"), at.matrix("b", dtype="bool")
+    t3 = at.tensor3("t3", dtype="int64")
+    mx = x.max(axis=-1, keepdims=True)
+    return [x, b, t3], [x - mx, (x - x.min(axis=1, keepdims=True)) * 2,
+                        at.eq(x, mx).sum(axis=1), b & b.any(axis=1, keepdims=True),
+                        t3 - t3.sum(axis=2, keepdims=True), (t3 % 7).prod(axis=-1, keepdims=True) + t3], \
+        [I((37, 19), "int32", 1, -99, 99), B((11, 70), 2, 0.2), I((3, 5, 9), "int64", 3, -9, 9)]
+
+
 @case("argmax_axes", exact=True)
 def _():
     x, m, v = at.dtensor3("x"), at.imatrix("m"), at.dvector("v")
