@@ -91,3 +91,20 @@ def test_replay_with_fresh_input_tensors_and_host_arrays():
             for g, w in zip(got, want):
                 np.testing.assert_allclose(g, w, rtol=1e-6, atol=1e-7)
     assert len(replay._stage) == 2 and len(replay._graphs) <= 4
+
+
+@pytest.mark.gpu
+def test_replay_stages_zero_d_host_scalars():
+    """0-d floating host inputs (config 2's mu / sigma) keep their rank in the staging buffers."""
+    from aesara_amd.executor import PlanExecutor
+    c = next(c for c in CASES if c["name"] == "cfg2_gauss_sum")
+    eager = PlanExecutor(case_plan(c))
+    replay = PlanExecutor(case_plan(c), use_graph=True)
+    rng = np.random.default_rng(1)
+    for _ in range(4):
+        x = rng.standard_normal((37, 53))
+        mu, sg = np.float64(rng.normal()), np.asarray(1.0 + rng.random())
+        want = eager(x, mu, sg)[0].cpu().numpy()
+        got = replay(x, mu, sg)[0].cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-12)
+        np.testing.assert_allclose(got, np.exp(-(x - mu) ** 2 / (2 * sg ** 2)).sum(), rtol=1e-10)
