@@ -116,6 +116,7 @@ SIGNATURES = {
     "ahip_module_unload": (i32, [vp]),
     "ahip_launch": (i32, [vp, u32, u32, u32, u32, u32, u32, u32, vp, sz, vp]),
     "ahip_elemwise": (i32, [vp, i32, p_i64, i32, p_vp, p_i64, i32, i32, vp]),
+    "ahip_elemwise_tiled": (i32, [vp, i32, p_i64, i32, p_vp, p_i64, i32, i32, vp, vp, sz, vp]),
     "ahip_reduce_ws_bytes": (sz, []),
     "ahip_elemwise_reduce_all": (i32, [vp, i32, p_i64, i32, p_vp, p_i64, i32, i32, vp, vp, sz,
                                        vp]),

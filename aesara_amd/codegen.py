@@ -450,7 +450,7 @@ class KernelSpec:
     """
 
     def __init__(self, scalar, in_dtypes, out_dtypes, out_refs, inner, nd, vec, block=256,
-                 idx64=False, reduce=None, unroll=1, nt=False, invariant=None):
+                 idx64=False, reduce=None, unroll=1, nt=False, invariant=None, tile_dim=None):
         self.scalar = scalar
         self.in_dtypes = list(in_dtypes)
         self.out_dtypes = list(out_dtypes)
@@ -465,19 +465,24 @@ class KernelSpec:
         self.nt = nt           # non-temporal (streaming) loads for read-once operands
         # per-input flag: operand is a true scalar (all strides zero) -> loop invariant
         self.invariant = list(invariant) if invariant else [False] * len(self.in_dtypes)
+        # tiled form (generate_tiled): dim whose 64-element runs are staged through LDS for the
+        # operands of class 't' (unit stride along tile_dim instead of along the last dim)
+        self.tile_dim = tile_dim
         assert len(self.inner) == len(self.in_dtypes) + len(self.out_dtypes)
         assert 1 <= nd <= AHIP_MAXD and len(self.inner) <= AHIP_MAXOPS
 
     def key(self):
         fields = [self.in_dtypes, self.out_dtypes, self.out_refs, self.inner, self.nd, self.vec,
-                  self.block, self.idx64, self.reduce, self.unroll, self.nt, self.invariant, "v10"]
+                  self.block, self.idx64, self.reduce, self.unroll, self.nt, self.invariant,
+                  self.tile_dim, "v11" if self.tile_dim else "v10"]
         return _memo_key([self.scalar], fields, self._key)
 
     def _key(self):
         import json
         blob = json.dumps([self.scalar, self.in_dtypes, self.out_dtypes, self.out_refs,
                            self.inner, self.nd, self.vec, self.block, self.idx64, self.reduce,
-                           self.unroll, self.nt, self.invariant, "v10"],
+                           self.unroll, self.nt, self.invariant, "v10"] +
+                          ([["tile2", self.tile_dim]] if self.tile_dim is not None else []),
                           sort_keys=True)
         return hashlib.sha256(blob.encode()).hexdigest()[:24]
 
@@ -507,17 +512,16 @@ def _offset_code(spec, nops, nd_lo, nd_hi, var, idx_t, inner_vecs=None):
     return L
 
 
-def generate(spec: KernelSpec):
-    """Return (source, kernel_names) for a spec (one kernel per spec)."""
+def _kernel_prologue(spec, name, L):
+    """Kernel head shared by generate / generate_tiled: operand pointers, accumulator, and the
+    loop-invariant part (scalar operands, sub-expressions of them, reciprocals of invariant
+    divisors).  Returns (hoisted, inv_in) for emit_scalar_body."""
     nin = len(spec.in_dtypes)
     nout = len(spec.out_dtypes)
     nops = nin + nout
     V = spec.vec
-    U = spec.unroll
-    idx_t = "i64" if spec.idx64 else "int"
     red = spec.reduce
-    name = "ew_" + spec.key()
-    L = [PRELUDE]
+    L.append(PRELUDE)
     L.append('extern "C" __global__ __launch_bounds__(%d) void %s(Args a) {' % (spec.block, name))
     for k in range(nin):
         L.append("  const %s* __restrict__ p%d = (const %s*)a.ptr[%d];" %
@@ -565,6 +569,222 @@ def generate(spec: KernelSpec):
                     L.append("  const %s r%d_inv = (%s)1 / t%d_inv;" % (RTYPE[dt], k, RTYPE[dt], k))
                     L.append("  const bool ok%d_inv = recip_ok(t%d_inv, r%d_inv);" % (k, k, k))
                 hoisted[k] = ("t%d_inv" % k, rname)
+    return hoisted, inv_in
+
+
+def _reduce_all_finalize(spec, red, L):
+    """Deterministic in-kernel finalize of a full reduction (appended after the streaming loop:
+    `acc` holds the thread's partial)."""
+    acc_t = RTYPE[red["acc"]]
+    sm_t = acc_t if acc_t != "bool" else "unsigned char"
+    comb = lambda a_, b_: red_combine(red["op"], red["acc"], a_, b_)  # noqa: E731
+    wave_red = ["  for (int m = 32; m > 0; m >>= 1) acc = %s;" %
+                comb("acc", "shfl_xor_<%s>(acc, m)" % acc_t)]
+    # K2 single pass, two-level deterministic finalize on a STATIC tree, no tickets:
+    #   every workgroup publishes its 8-byte partial as two epoch-tagged granules
+    #   {hi32 | epoch}, {lo32 | epoch} (8-byte agent-scope stores: single-copy atomic,
+    #   write-through).  The first workgroup of each run of 32 consecutive workgroups
+    #   re-reads its siblings' granules until they carry this launch's epoch, folds them
+    #   in index order and publishes the shard sum the same way; workgroup 0 does the
+    #   same over the shard sums, stores the result and advances the epoch.  Critical
+    #   path after the last workgroup finishes: granule store -> read -> fold -> granule
+    #   store -> read -> fold (two visibility latencies — one when the grid is small enough
+    #   for workgroup 0 to hold a thread per partial; the ticket form had five
+    #   dependent round trips).  Combiners are 1/32 of the grid, so spinning ones can
+    #   never starve the workgroups they wait for; every spin is bounded.  The workspace
+    #   is zero-initialised once and epoch 0 never matches a live tag.
+    nw = spec.block // 64
+    AG = "__ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT"
+    SH = 32
+    ident = red_identity(red["op"], red["acc"])
+
+    L.append("  __shared__ %s sm[%d];" % (sm_t, nw))
+    L.append("  unsigned long long* wsp = (unsigned long long*)a.ws;")
+    L.append("  unsigned long long* shard_sum = (unsigned long long*)((char*)a.ws + a.aux1);")
+    L.append("  unsigned* epochp = (unsigned*)((char*)a.ws + a.aux1 + 2048 + 64);")
+    L.append("  const unsigned ep = ep0 + 1u;")
+    L.append("  auto publish = [&](unsigned long long* slot, %s v) {" % acc_t)
+    L.append("    union { unsigned long long u; %s v; } cv; cv.u = 0; cv.v = v;" % acc_t)
+    L.append("    __hip_atomic_store(slot, ((cv.u >> 32) << 32) | ep, %s);" % AG)
+    L.append("    __hip_atomic_store(slot + 1, (cv.u << 32) | ep, %s);" % AG)
+    L.append("  };")
+    L.append("  auto collect = [&](unsigned long long* slot) -> %s {" % acc_t)
+    L.append("    unsigned long long g0 = 0, g1 = 0;")
+    L.append("    for (int spin = 0; spin < (1 << 24); ++spin) {")
+    L.append("      g0 = __hip_atomic_load(slot, %s);" % AG)
+    L.append("      g1 = __hip_atomic_load(slot + 1, %s);" % AG)
+    L.append("      if ((unsigned)g0 == ep && (unsigned)g1 == ep) break;")
+    L.append("    }")
+    L.append("    union { unsigned long long u; %s v; } cv; cv.u = ((g0 >> 32) << 32) | (g1 >> 32);" % acc_t)
+    L.append("    return cv.v;")
+    L.append("  };")
+    # fold `acc` over the workgroup in a fixed tree (wave shuffles, then the waves in
+    # order); the result is valid in thread 0
+    L.append("  auto block_fold = [&]() -> %s {" % acc_t)
+    L.extend("  " + x for x in wave_red)
+    L.append("    __syncthreads();")
+    L.append("    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;")
+    L.append("    __syncthreads();")
+    L.append("    %s r = sm[0];" % acc_t)
+    L.append("    for (int w = 1; w < %d; ++w) r = %s;" % (nw, comb("r", "(%s)sm[w]" % acc_t)))
+    L.append("    return r;")
+    L.append("  };")
+    L.append("  {")
+    L.append("    const %s part = block_fold();" % acc_t)
+    L.append("    if (threadIdx.x == 0) publish(wsp + 2 * (size_t)blockIdx.x, part);")
+    L.append("  }")
+    # one level when a single workgroup has a thread per partial, else shards of SH
+    L.append("  const bool one_level = gridDim.x <= %du;" % spec.block)
+    L.append("  if (one_level) {")
+    L.append("    if (blockIdx.x != 0) return;")
+    L.append("    acc = threadIdx.x < gridDim.x ? collect(wsp + 2 * (size_t)threadIdx.x) : %s;" % ident)
+    L.append("  } else {")
+    L.append("    if (blockIdx.x %% %du != 0) return;" % SH)
+    L.append("    acc = (threadIdx.x < %du && blockIdx.x + threadIdx.x < gridDim.x)" % SH)
+    L.append("        ? collect(wsp + 2 * (size_t)(blockIdx.x + threadIdx.x)) : %s;" % ident)
+    L.append("    const %s ssum = block_fold();" % acc_t)
+    L.append("    if (threadIdx.x == 0) publish(shard_sum + 2 * (size_t)(blockIdx.x / %du), ssum);" % SH)
+    L.append("    if (blockIdx.x != 0) return;")
+    L.append("    const unsigned nsh = (gridDim.x + %du) / %du;" % (SH - 1, SH))
+    L.append("    acc = threadIdx.x < nsh ? collect(shard_sum + 2 * (size_t)threadIdx.x) : %s;" % ident)
+    L.append("  }")
+    L.append("  {")
+    L.append("    const %s r = block_fold();" % acc_t)
+    L.append("    if (threadIdx.x == 0) {")
+    L.append("      *(%s*)a.out = %s;" % (CTYPE[red["out"]], _store_val("r", red["acc"], red["out"])))
+    L.append("      __hip_atomic_store(epochp, ep, %s);" % AG)
+    L.append("    }")
+    L.append("  }")
+
+
+def generate_tiled(spec: KernelSpec):
+    """K3t — Elemwise (optionally + full reduction) with TRANSPOSED operands.
+
+    The reference walks such operands with its strided loop nest (`elemwise_cgen.py:228-305`
+    make_loop with per-operand strides); a lane-per-element GPU loop would fetch one element per
+    cache line from them.  Here the last dim and `tile_dim` are cut into T x T tiles: operands of
+    class 't' (unit stride along tile_dim) are read with the lanes running along tile_dim — full
+    lines — into a padded LDS tile, then the scalar body runs with the lanes along the last dim,
+    taking those operands from LDS (conflict-free thanks to the odd row pitch) and every other
+    operand / output directly (coalesced for class 'c', broadcast for 'b').  One workgroup of 256
+    threads per tile; remaining dims are decomposed from the tile index."""
+    nin = len(spec.in_dtypes)
+    nout = len(spec.out_dtypes)
+    nops = nin + nout
+    nd = spec.nd
+    td, T = spec.tile_dim
+    red = spec.reduce
+    assert spec.vec == 1 and spec.block == 256 and T in (32, 64) and 0 <= td < nd - 1
+    assert red is None or red["kind"] == "all"
+    LP = 256 // T          # tile lines covered per pass
+    P = T // LP            # passes
+    name = "ewt_" + spec.key()
+    L = []
+    hoisted, inv_in = _kernel_prologue(spec, name, L)
+    tk = [k for k in range(nin) if spec.inner[k] == "t" and k not in inv_in]
+    assert tk and all(spec.inner[k] != "t" for k in range(nin, nops))
+    for k in tk:
+        L.append("  __shared__ %s tile%d[%d][%d];" % (CTYPE[spec.in_dtypes[k]], k, T, T + 1))
+    outer = [d for d in range(nd - 1) if d != td]
+    L.append("  const i64 R = a.shape[%d], C = a.shape[%d];" % (td, nd - 1))
+    L.append("  const i64 tr = (R + %d) / %d, tc = (C + %d) / %d;" % (T - 1, T, T - 1, T))
+    L.append("  const i64 ntiles = tr * tc%s;" % "".join(" * a.shape[%d]" % d for d in outer))
+    L.append("  const int ta = threadIdx.x %% %d, tb = threadIdx.x / %d;" % (T, T))
+    L.append("  for (i64 tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {")
+    L.append("    i64 rem = tix;")
+    L.append("    const i64 jc = rem % tc; rem /= tc;")
+    L.append("    const i64 jr = rem % tr; rem /= tr;")
+    live = [k for k in range(nops) if k not in inv_in]
+    L.append("    i64 " + ", ".join("off%d = 0" % k for k in live) + ";")
+    for d in reversed(outer):
+        L.append("    { const i64 q = rem / a.shape[%d]; const i64 r = rem - q * a.shape[%d]; rem = q;"
+                 % (d, d))
+        for k in live:
+            L.append("      off%d += r * a.stride[%d][%d];" % (k, k, d))
+        L.append("    }")
+    L.append("    const i64 r0 = jr * %d, c0 = jc * %d;" % (T, T))
+    # every load of the tile is issued up front with clamped (always valid) coordinates — no
+    # branches between them, so P x (operands) requests per lane are in flight at once; only the
+    # compute / store / accumulate is guarded at ragged edges.
+    direct = [k for k in range(nin) if k not in inv_in and k not in tk]
+
+    def addr(k, r, c):
+        inner = {"c": " + %s" % c, "b": "", "s": " + %s * a.stride[%d][%d]" % (c, k, nd - 1)}[
+            spec.inner[k]]
+        return "off%d + %s * a.stride[%d][%d]%s" % (k, r, k, td, inner)
+
+    L.append("    const i64 rl = (r0 + ta < R) ? r0 + ta : R - 1;   // phase 1: lanes along tile_dim")
+    L.append("    const i64 cq = (c0 + ta < C) ? c0 + ta : C - 1;   // phase 2: lanes along the last dim")
+    for k in tk + direct:
+        L.append("    %s v%d[%d];" % (CTYPE[spec.in_dtypes[k]], k, P))
+    L.append("#pragma unroll")
+    L.append("    for (int j = 0; j < %d; ++j) {" % P)
+    L.append("      const i64 cl = (c0 + tb + j * %d < C) ? c0 + tb + j * %d : C - 1;" % (LP, LP))
+    for k in tk:
+        L.append("      v%d[j] = p%d[off%d + rl + cl * a.stride[%d][%d]];" % (k, k, k, k, nd - 1))
+    L.append("    }")
+    if direct:
+        L.append("#pragma unroll")
+        L.append("    for (int j = 0; j < %d; ++j) {" % P)
+        L.append("      const i64 rq = (r0 + tb + j * %d < R) ? r0 + tb + j * %d : R - 1;" % (LP, LP))
+        for k in direct:
+            L.append("      v%d[j] = p%d[%s];" % (k, k, addr(k, "rq", "cq")))
+        L.append("    }")
+    L.append("#pragma unroll")
+    L.append("    for (int j = 0; j < %d; ++j) {" % P)
+    for k in tk:
+        L.append("      tile%d[tb + j * %d][ta] = v%d[j];" % (k, LP, k))
+    L.append("    }")
+    L.append("    __syncthreads();")
+    L.append("#pragma unroll")
+    L.append("    for (int j = 0; j < %d; ++j) {" % P)
+    L.append("      const int rr = tb + j * %d;" % LP)
+    L.append("      const i64 r = r0 + rr, c = c0 + ta;")
+    L.append("      if (r < R && c < C) {")
+    ins = []
+    for k in range(nin):
+        if k in inv_in:
+            ins.append(inv_in[k])
+            continue
+        ct = CTYPE[spec.in_dtypes[k]]
+        if k in tk:
+            L.append("        const %s x%d = tile%d[ta][rr];" % (ct, k, k))
+        else:
+            L.append("        const %s x%d = v%d[j];" % (ct, k, k))
+        ins.append("(x%d != 0)" % k if spec.in_dtypes[k] == "bool" else "x%d" % k)
+    lines, outs, odts = emit_scalar_body(spec.scalar, ins, spec.in_dtypes, indent="        ",
+                                         suffix="_t", hoisted=hoisted)
+    L.extend(lines)
+    for k, ri in enumerate(spec.out_refs):
+        val = _store_val(outs[ri], odts[ri], spec.out_dtypes[k])
+        L.append("        p%d[%s] = %s;" % (nin + k, addr(nin + k, "r", "c"), val))
+    if red is not None:
+        val = _cast(outs[red["ref"]], odts[red["ref"]], red["acc"])
+        L.append("        acc = %s;" % red_combine(red["op"], red["acc"], "acc", val))
+    L.append("      }")
+    L.append("    }")
+    L.append("    __syncthreads();")
+    L.append("  }")
+    if red is not None:
+        _reduce_all_finalize(spec, red, L)
+    L.append("}")
+    return "\n".join(L) + "\n", (name,)
+
+
+def generate(spec: KernelSpec):
+    """Return (source, kernel_names) for a spec (one kernel per spec)."""
+    if spec.tile_dim is not None:
+        return generate_tiled(spec)
+    nin = len(spec.in_dtypes)
+    nout = len(spec.out_dtypes)
+    nops = nin + nout
+    V = spec.vec
+    U = spec.unroll
+    idx_t = "i64" if spec.idx64 else "int"
+    red = spec.reduce
+    name = "ew_" + spec.key()
+    L = []
+    hoisted, inv_in = _kernel_prologue(spec, name, L)
 
     def loads(elem_off_exprs, sfx=""):
         B = []
@@ -702,81 +922,7 @@ def generate(spec: KernelSpec):
         wave_red = ["  for (int m = 32; m > 0; m >>= 1) acc = %s;" %
                     comb("acc", "shfl_xor_<%s>(acc, m)" % acc_t)]
         if red["kind"] == "all":
-            # K2 single pass, two-level deterministic finalize on a STATIC tree, no tickets:
-            #   every workgroup publishes its 8-byte partial as two epoch-tagged granules
-            #   {hi32 | epoch}, {lo32 | epoch} (8-byte agent-scope stores: single-copy atomic,
-            #   write-through).  The first workgroup of each run of 32 consecutive workgroups
-            #   re-reads its siblings' granules until they carry this launch's epoch, folds them
-            #   in index order and publishes the shard sum the same way; workgroup 0 does the
-            #   same over the shard sums, stores the result and advances the epoch.  Critical
-            #   path after the last workgroup finishes: granule store -> read -> fold -> granule
-            #   store -> read -> fold (two visibility latencies — one when the grid is small enough
-            #   for workgroup 0 to hold a thread per partial; the ticket form had five
-            #   dependent round trips).  Combiners are 1/32 of the grid, so spinning ones can
-            #   never starve the workgroups they wait for; every spin is bounded.  The workspace
-            #   is zero-initialised once and epoch 0 never matches a live tag.
-            nw = spec.block // 64
-            AG = "__ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT"
-            SH = 32
-            ident = red_identity(red["op"], red["acc"])
-
-            L.append("  __shared__ %s sm[%d];" % (sm_t, nw))
-            L.append("  unsigned long long* wsp = (unsigned long long*)a.ws;")
-            L.append("  unsigned long long* shard_sum = (unsigned long long*)((char*)a.ws + a.aux1);")
-            L.append("  unsigned* epochp = (unsigned*)((char*)a.ws + a.aux1 + 2048 + 64);")
-            L.append("  const unsigned ep = ep0 + 1u;")
-            L.append("  auto publish = [&](unsigned long long* slot, %s v) {" % acc_t)
-            L.append("    union { unsigned long long u; %s v; } cv; cv.u = 0; cv.v = v;" % acc_t)
-            L.append("    __hip_atomic_store(slot, ((cv.u >> 32) << 32) | ep, %s);" % AG)
-            L.append("    __hip_atomic_store(slot + 1, (cv.u << 32) | ep, %s);" % AG)
-            L.append("  };")
-            L.append("  auto collect = [&](unsigned long long* slot) -> %s {" % acc_t)
-            L.append("    unsigned long long g0 = 0, g1 = 0;")
-            L.append("    for (int spin = 0; spin < (1 << 24); ++spin) {")
-            L.append("      g0 = __hip_atomic_load(slot, %s);" % AG)
-            L.append("      g1 = __hip_atomic_load(slot + 1, %s);" % AG)
-            L.append("      if ((unsigned)g0 == ep && (unsigned)g1 == ep) break;")
-            L.append("    }")
-            L.append("    union { unsigned long long u; %s v; } cv; cv.u = ((g0 >> 32) << 32) | (g1 >> 32);" % acc_t)
-            L.append("    return cv.v;")
-            L.append("  };")
-            # fold `acc` over the workgroup in a fixed tree (wave shuffles, then the waves in
-            # order); the result is valid in thread 0
-            L.append("  auto block_fold = [&]() -> %s {" % acc_t)
-            L.extend("  " + x for x in wave_red)
-            L.append("    __syncthreads();")
-            L.append("    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;")
-            L.append("    __syncthreads();")
-            L.append("    %s r = sm[0];" % acc_t)
-            L.append("    for (int w = 1; w < %d; ++w) r = %s;" % (nw, comb("r", "(%s)sm[w]" % acc_t)))
-            L.append("    return r;")
-            L.append("  };")
-            L.append("  {")
-            L.append("    const %s part = block_fold();" % acc_t)
-            L.append("    if (threadIdx.x == 0) publish(wsp + 2 * (size_t)blockIdx.x, part);")
-            L.append("  }")
-            # one level when a single workgroup has a thread per partial, else shards of SH
-            L.append("  const bool one_level = gridDim.x <= %du;" % spec.block)
-            L.append("  if (one_level) {")
-            L.append("    if (blockIdx.x != 0) return;")
-            L.append("    acc = threadIdx.x < gridDim.x ? collect(wsp + 2 * (size_t)threadIdx.x) : %s;" % ident)
-            L.append("  } else {")
-            L.append("    if (blockIdx.x %% %du != 0) return;" % SH)
-            L.append("    acc = (threadIdx.x < %du && blockIdx.x + threadIdx.x < gridDim.x)" % SH)
-            L.append("        ? collect(wsp + 2 * (size_t)(blockIdx.x + threadIdx.x)) : %s;" % ident)
-            L.append("    const %s ssum = block_fold();" % acc_t)
-            L.append("    if (threadIdx.x == 0) publish(shard_sum + 2 * (size_t)(blockIdx.x / %du), ssum);" % SH)
-            L.append("    if (blockIdx.x != 0) return;")
-            L.append("    const unsigned nsh = (gridDim.x + %du) / %du;" % (SH - 1, SH))
-            L.append("    acc = threadIdx.x < nsh ? collect(shard_sum + 2 * (size_t)threadIdx.x) : %s;" % ident)
-            L.append("  }")
-            L.append("  {")
-            L.append("    const %s r = block_fold();" % acc_t)
-            L.append("    if (threadIdx.x == 0) {")
-            L.append("      *(%s*)a.out = %s;" % (CTYPE[red["out"]], _store_val("r", red["acc"], red["out"])))
-            L.append("      __hip_atomic_store(epochp, ep, %s);" % AG)
-            L.append("    }")
-            L.append("  }")
+            _reduce_all_finalize(spec, red, L)
         elif red["kind"] == "row":
             L.extend(wave_red)
             L.append("  if (lane == 0) ((%s*)a.out)[o] = %s;" %

@@ -103,6 +103,37 @@ int ahip_elemwise_reduce_all(ahip_fn_t k, int nd, const int64_t* shape, int nops
   return launch(k, (uint32_t)want, 1, block, &a, stream);
 }
 
+int ahip_elemwise_tiled(ahip_fn_t k, int nd, const int64_t* shape, int nops, void* const* ptrs,
+                        const int64_t* strides, int tile_dim, int tile, void* out, void* ws,
+                        size_t ws_bytes, void* stream) {
+  AHIP_REQUIRE(k != nullptr, "null kernel");
+  AHIP_REQUIRE(nd >= 2 && tile_dim >= 0 && tile_dim < nd - 1, "bad tile_dim %d for nd=%d",
+               tile_dim, nd);
+  AHIP_REQUIRE(tile == 32 || tile == 64, "tile must be 32 or 64");
+  AHIP_REQUIRE((out == nullptr) == (ws == nullptr), "out and ws go together");
+  ahip_ew_args a;
+  int rc = pack_args(&a, nd, shape, nops, ptrs, strides);
+  if (rc) return rc;
+  int64_t tiles = 1;
+  for (int d = 0; d < nd; ++d)
+    tiles *= (d == tile_dim || d == nd - 1) ? (shape[d] + tile - 1) / tile : shape[d];
+  if (out == nullptr) {   // plain Elemwise: one workgroup per tile
+    if (a.n == 0) return AHIP_OK;
+    if (tiles > 0x7fffffffll) tiles = 0x7fffffffll;
+    return launch(k, (uint32_t)tiles, 1, 256, &a, stream);
+  }
+  // + full reduction: one partial per workgroup, tiles taken grid-stride
+  AHIP_REQUIRE(ws_bytes >= ahip_reduce_ws_bytes(), "workspace too small");
+  a.ws = ws;
+  a.out = out;
+  a.aux1 = (int64_t)AHIP_MAX_PARTIALS * 16;
+  int64_t cap = (int64_t)ahip_cu_count() * g_reduce_blocks_per_cu;
+  if (cap > AHIP_MAX_PARTIALS) cap = AHIP_MAX_PARTIALS;
+  if (tiles > cap) tiles = cap;
+  if (tiles < 1) tiles = 1;
+  return launch(k, (uint32_t)tiles, 1, 256, &a, stream);
+}
+
 int ahip_elemwise_reduce_axis(ahip_fn_t k, int mode, int nk, int nr, const int64_t* shape,
                               int nops, void* const* ptrs, const int64_t* strides, int nslices,
                               void* out_or_ws, int block, void* stream) {

@@ -182,6 +182,18 @@ int ahip_launch(ahip_fn_t f, uint32_t gx, uint32_t gy, uint32_t gz, uint32_t bx,
 int ahip_elemwise(ahip_fn_t k, int nd, const int64_t* shape, int nops, void* const* ptrs,
                   const int64_t* strides /* [nops*nd] */, int vec, int block, void* stream);
 
+/* ---- K3t: Elemwise (+ optional full CAReduce) with transposed operands --------------------
+ * replaces: the same Elemwise._c_all / CAReduce._c_all loop nests (tensor/elemwise.py:835/:1522,
+ * elemwise_cgen.py:228-305 per-operand strides) when some input has its unit stride along
+ * `tile_dim` instead of the last dim (a DimShuffle view, tensor/elemwise.py:39).  `k` is a kernel
+ * generated for (nd, tile_dim, tile): it stages tile x tile blocks of those inputs through LDS.
+ * `out`/`ws` both NULL: plain Elemwise, one workgroup per tile.  Both set: the scalar output
+ * named by the kernel is reduced over all elements into `out` (workspace as for
+ * ahip_elemwise_reduce_all).                                                                  */
+int ahip_elemwise_tiled(ahip_fn_t k, int nd, const int64_t* shape, int nops, void* const* ptrs,
+                        const int64_t* strides, int tile_dim, int tile, void* out, void* ws,
+                        size_t ws_bytes, void* stream);
+
 /* ---- K2: Elemwise fused into a full CAReduce (axis=None) --------------------------------
  * replaces: tensor/elemwise.py:1495 CAReduce.perform / :1522 _c_all (make_loop_careduce,
  * elemwise_cgen.py:502) applied to the output of the Elemwise above, without materialising

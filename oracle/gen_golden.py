@@ -118,6 +118,50 @@ def _():
         N((6, 5), view={"kind": "step", "step": 2}), N((6, 5), seed=3, view={"kind": "transpose"})]
 
 
+# transposed operands (DimShuffle views inside the graph and transposed input views): the
+# LDS-tiled Elemwise kernel, both tile sizes, ragged edges, mixed classes
+for _dt, _r, _c in (("float64", 70, 45), ("float64", 130, 97), ("float32", 64, 128),
+                    ("float32", 33, 211)):
+    def _mkT(dt=_dt, r=_r, c=_c):
+        x, y, v = T(dt, (r, c), "x"), T(dt, (c, r), "y"), T(dt, (c,), "v")
+        return [x, y, v], [x + y.T, at.exp(y.T * 0.25) * x - v, at.sqr(y.T)], \
+            [N((r, c), dt, 1), N((c, r), dt, 2), N((c,), dt, 3)]
+    case(f"ew_transposed_{_dt}_{_r}x{_c}")(_mkT)
+
+
+@case("ew_transposed_input_views")
+def _():
+    x, y, z = at.dmatrix("x"), at.dmatrix("y"), at.dmatrix("z")
+    return [x, y, z], [x + y, x * y - z], [
+        U((96, 80), seed=0), U((96, 80), seed=1, view={"kind": "transpose"}),
+        U((96, 80), seed=2, view={"kind": "step", "step": 2})]
+
+
+@case("ew_transposed_3d")
+def _():
+    x, y, z, w = at.dtensor3("x"), at.dtensor3("y"), at.dtensor3("z"), at.dmatrix("w")
+    return [x, y, z, w], [x * y.dimshuffle(0, 2, 1) + z.dimshuffle(1, 2, 0)
+                          - w.dimshuffle("x", 1, 0)], [
+        N((5, 40, 50), seed=1), N((5, 50, 40), seed=2), N((50, 5, 40), seed=3), N((50, 40), seed=4)]
+
+
+@case("ew_transposed_integer", exact=True)
+def _():
+    a, b, m = at.bmatrix("a"), at.bmatrix("b"), T("bool", (60, 37), "m")
+    i, j = at.lmatrix("i"), at.lmatrix("j")
+    return [a, b, m, i, j], [at.gt(a.T, b) & m.T, a.T + b, i.T * j - i.T // 7], [
+        I((60, 37), "int8", 1, -100, 100), I((37, 60), "int8", 2, -100, 100), B((60, 37), 3),
+        I((40, 50), "int64", 4, -1000, 1000), I((50, 40), "int64", 5, -1000, 1000)]
+
+
+for _dt, _tol in (("float64", 1e-12), ("float32", 1e-5)):
+    def _mkTR(dt=_dt):
+        x, y = T(dt, (150, 70), "x"), T(dt, (70, 150), "y")
+        return [x, y], [(x * y.T).sum(), at.max(y.T - x), at.sum(at.sqr(x.T) + y)], \
+            [N((150, 70), dt, 1), N((70, 150), dt, 2)]
+    case(f"reduce_all_transposed_{_dt}", rtol=_tol, atol=_tol)(_mkTR)
+
+
 @case("ew_same_inputs")
 def _():
     x = at.dmatrix("x")

@@ -236,6 +236,16 @@ def main():
         report("materialise transpose f64 4096^2 (strided copy)", d, w, 2 * x.numel() * 8,
                "GB/s", 8000.0)
 
+        exr = PlanExecutor(plan_of("reduce_all_transposed_float64"), use_graph=G)
+        d, w = timeit(lambda: exr(x, y), 20)
+        report("(x*y.T).sum(), max(y.T-x), sum(sqr(x.T)+y) f64 4096^2 (3 tiled reduces)", d, w,
+               3 * 2 * x.numel() * 8, "GB/s", 8000.0)
+        exf = PlanExecutor(plan_of("ew_transposed_float32_64x128"), use_graph=G)
+        xf, yf, vf = randn((8192, 4096), f32, 0), randn((4096, 8192), f32, 1), randn((4096,), f32, 2)
+        d, w = timeit(lambda: exf(xf, yf, vf), 20)
+        report("x+y.T, exp(y.T/4)*x-v, sqr(y.T) f32 8192x4096 (3 tiled kernels)", d, w,
+               (3 + 3 + 2) * xf.numel() * 4, "GB/s", 8000.0)
+
     if want("bptt"):
         T, H = 512, 1024
         ex = PlanExecutor(plan_of("scan_grad_last_state_f32"), use_graph=G)
