@@ -122,7 +122,7 @@ SIGNATURES = {
                                        vp]),
     "ahip_set_param": (i32, [C.c_char_p, i64]),
     "ahip_elemwise_reduce_axis": (i32, [vp, i32, i32, i32, p_i64, i32, p_vp, p_i64, i32, vp,
-                                        i32, vp]),
+                                        i32, i32, i32, vp]),
     "ahip_gemm": (i32, [i32, i64, i64, i64, vp, vp, i64, i64, vp, i64, i64, vp, vp, i64, i64,
                         vp, i64, i64, vp]),
     "ahip_gemm_ws_bytes": (sz, [i32, i64, i64, i64, i64]),

@@ -803,8 +803,9 @@ def generate(spec: KernelSpec):
                 B.append("      const %s x%d%s = p%d[%s];" % (ct, k, sfx, k, elem_off_exprs[k]))
         return B
 
-    def compute(elem_off_exprs, sfx=""):
+    def compute(elem_off_exprs, sfx="", accs=None):
         B = []
+        accs = accs or ["acc"] * V
         for k in range(nout):
             if V > 1:
                 B.append("      Pack<%s, %d> y%d%s;" % (CTYPE[spec.out_dtypes[k]], V, k, sfx))
@@ -834,7 +835,7 @@ def generate(spec: KernelSpec):
                     B.append("      p%d[%s] = %s;" % (nin + k, elem_off_exprs[nin + k], val))
             if red is not None:
                 val = _cast(outs[red["ref"]], odts[red["ref"]], red["acc"])
-                B.append("      acc = %s;" % red_combine(red["op"], red["acc"], "acc", val))
+                B.append("      %s = %s;" % (accs[v], red_combine(red["op"], red["acc"], accs[v], val)))
         if V > 1:
             for k in range(nout):
                 B.append("      *(Pack<%s, %d>*)(p%d + %s) = y%d%s;" %
@@ -881,56 +882,124 @@ def generate(spec: KernelSpec):
         L.extend(compute(eo))
         L.append("  }")
     else:
+        # K2 axis reductions.  Dims are [kept (nk) | reduced (nr)]; `lanes` threads cooperate:
+        #   row: the unit stride is in the reduced group.  `lanes` (<= 64, power of two) adjacent
+        #        lanes share one output, each taking vectors of V elements of the flattened
+        #        reduced index; gridDim.y slices long reductions (partials + fold pass).
+        #   col: the unit stride is in the kept group.  A workgroup is TX x TY threads: TX =
+        #        `lanes` along the kept index (V adjacent outputs per thread), TY rows of the
+        #        reduced index walked concurrently; folded with shuffles, then across the waves
+        #        through LDS, in a fixed order.
         nk, nr = red["nk"], red["nr"]
-        assert V == 1
+        G = red.get("lanes", 64 if red["kind"] == "row" else spec.block)
+        acc_t = RTYPE[red["acc"]]
+        comb = lambda a_, b_: red_combine(red["op"], red["acc"], a_, b_)  # noqa: E731
+        vec_cls = {"c": " + (i64)inner * %d" % V, "b": "", "s": ""}
         if red["kind"] == "row":
-            L.append("  const int lane = threadIdx.x & 63;")
-            L.append("  const i64 o = (i64)blockIdx.x * %d + (threadIdx.x >> 6);" % (spec.block // 64))
-            L.append("  if (o >= a.n) return;")
+            assert G <= 64 and 64 % G == 0
+            L.append("  const int gl = threadIdx.x %% %d;" % G)
+            L.append("  const i64 o = (i64)blockIdx.x * %d + threadIdx.x / %d;" % (spec.block // G, G))
+            L.append("  const bool valid = o < a.n;")
+            L.append("  i64 " + ", ".join("base%d = 0" % k for k in range(nops)) + ";")
+            L.append("  if (valid) {")
+            L.append("      i64 " + ", ".join("off%d = 0" % k for k in range(nops)) + ";")
+            L.extend(_offset_code(spec, nops, 0, nk, "o", idx_t))
+            L.append("      " + " ".join("base%d = off%d;" % (k, k) for k in range(nops)))
+            L.append("  }")
+            L.append("  const %s inner_vecs = (%s)(a.shape[%d] / %d);" % (idx_t, idx_t, nk + nr - 1, V))
+            L.append("  const i64 nredv = a.aux0 / %d;" % V)
+            L.append("  const i64 per = (nredv + a.aux1 - 1) / a.aux1;")
+            L.append("  const i64 rbeg = (i64)blockIdx.y * per;")
+            L.append("  const i64 rend = !valid ? 0 : ((rbeg + per < nredv) ? rbeg + per : nredv);")
+            # consecutive iterations are independent: unrolling keeps several loads in flight
+            L.append("#pragma unroll %d" % (U if U > 1 else 8))
+            L.append("  for (i64 r0 = rbeg + gl; r0 < rend; r0 += %d) {" % G)
+            L.append("      i64 " + ", ".join("off%d = base%d" % (k, k) for k in range(nops)) + ";")
+            L.append("      %s inner = 0;" % idx_t)
+            if V > 1:
+                L.extend(_offset_code(spec, nops, nk, nk + nr, "(%s)r0" % idx_t, idx_t,
+                                      inner_vecs="inner_vecs"))
+                eo = ["off%d%s" % (k, vec_cls[spec.inner[k]]) for k in range(nops)]
+            else:
+                L.extend(_offset_code(spec, nops, nk, nk + nr, "(%s)r0" % idx_t, idx_t))
+                eo = ["off%d" % k for k in range(nops)]
+            L.extend(loads(eo))
+            L.extend(compute(eo))
+            L.append("  }")
+            L.append("  for (int m = %d; m > 0; m >>= 1) acc = %s;" %
+                     (G // 2, comb("acc", "shfl_xor_<%s>(acc, m)" % acc_t)))
+            L.append("  if (valid && gl == 0) {")
+            L.append("    if (a.aux1 == 1) ((%s*)a.out)[o] = %s;" %
+                     (CTYPE[red["out"]], _store_val("acc", red["acc"], red["out"])))
+            L.append("    else ((%s*)a.out)[(i64)blockIdx.y * a.n + o] = acc;" % CTYPE[red["acc"]])
+            L.append("  }")
         else:
-            L.append("  const i64 o = (i64)blockIdx.x * %d + threadIdx.x;" % spec.block)
-            L.append("  if (o >= a.n) return;")
-        L.append("  i64 " + ", ".join("base%d = 0" % k for k in range(nops)) + ";")
-        L.append("  {")
-        L.append("      i64 " + ", ".join("off%d = 0" % k for k in range(nops)) + ";")
-        L.extend(_offset_code(spec, nops, 0, nk, "o", "i64"))
-        L.append("      " + " ".join("base%d = off%d;" % (k, k) for k in range(nops)))
-        L.append("  }")
-        L.append("  const i64 nred = a.aux0;")
-        # the loads of consecutive iterations are independent: unrolling keeps several in flight
-        # per lane (these loops are latency-, not issue-bound)
-        if red["kind"] == "row":
-            L.append("#pragma unroll 4")
-            L.append("  for (i64 r0 = lane; r0 < nred; r0 += 64) {")
-        else:
+            TX = G
+            assert TX <= 64 and 64 % TX == 0 and spec.block % 64 == 0
+            TY = spec.block // TX
+            nw = spec.block // 64
+            accs = ["acc"] + ["acc_%d" % v for v in range(1, V)]
+            for nm in accs[1:]:
+                L.append("  %s %s = %s;" % (acc_t, nm, red_identity(red["op"], red["acc"])))
+            L.append("  const int tx = threadIdx.x %% %d, ty = threadIdx.x / %d;" % (TX, TX))
+            L.append("  const i64 nkeptv = a.n / %d;" % V)
+            L.append("  const i64 ov = (i64)blockIdx.x * %d + tx;" % TX)
+            L.append("  const bool valid = ov < nkeptv;")
+            L.append("  i64 " + ", ".join("base%d = 0" % k for k in range(nops)) + ";")
+            L.append("  if (valid) {")
+            L.append("      i64 " + ", ".join("off%d = 0" % k for k in range(nops)) + ";")
+            if V > 1:
+                L.append("      const %s inner_vecs = (%s)(a.shape[%d] / %d);" % (idx_t, idx_t, nk - 1, V))
+                L.append("      %s inner = 0;" % idx_t)
+                L.extend(_offset_code(spec, nops, 0, nk, "(%s)ov" % idx_t, idx_t,
+                                      inner_vecs="inner_vecs"))
+                L.append("      " + " ".join("base%d = off%d%s;" % (k, k, vec_cls[spec.inner[k]])
+                                             for k in range(nops)))
+            else:
+                L.extend(_offset_code(spec, nops, 0, nk, "(%s)ov" % idx_t, idx_t))
+                L.append("      " + " ".join("base%d = off%d;" % (k, k) for k in range(nops)))
+            L.append("  }")
+            L.append("  const i64 nred = a.aux0;")
             L.append("  const i64 per = (nred + a.aux1 - 1) / a.aux1;")
             L.append("  const i64 rbeg = (i64)blockIdx.y * per;")
-            L.append("  const i64 rend = (rbeg + per < nred) ? rbeg + per : nred;")
-            L.append("#pragma unroll 4")
-            L.append("  for (i64 r0 = rbeg; r0 < rend; ++r0) {")
-        L.append("      i64 " + ", ".join("off%d = base%d" % (k, k) for k in range(nops)) + ";")
-        L.extend(_offset_code(spec, nops, nk, nk + nr, "r0", "i64"))
-        eo = ["off%d" % k for k in range(nops)]
-        L.extend(loads(eo))
-        L.extend(compute(eo))
-        L.append("  }")
+            L.append("  const i64 rend = !valid ? 0 : ((rbeg + per < nred) ? rbeg + per : nred);")
+            L.append("#pragma unroll %d" % (U if U > 1 else 8))
+            L.append("  for (i64 r0 = rbeg + ty; r0 < rend; r0 += %d) {" % TY)
+            L.append("      i64 " + ", ".join("off%d = base%d" % (k, k) for k in range(nops)) + ";")
+            L.extend(_offset_code(spec, nops, nk, nk + nr, "(%s)r0" % idx_t, idx_t))
+            eo = ["off%d" % k for k in range(nops)]
+            L.extend(loads(eo))
+            L.extend(compute(eo, accs=accs))
+            L.append("  }")
+            # fold over ty: lanes of a wave that share tx (xor masks >= TX), then the waves in order
+            sm_t = acc_t if acc_t != "bool" else "unsigned char"
+            if TX < 64:
+                for nm in accs:
+                    L.append("  for (int m = 32; m >= %d; m >>= 1) %s = %s;" %
+                             (TX, nm, comb(nm, "shfl_xor_<%s>(%s, m)" % (acc_t, nm))))
+            if nw > 1:
+                L.append("  __shared__ %s sm[%d][%d];" % (sm_t, nw, TX * V))
+                L.append("  if ((threadIdx.x & 63) < %d) {" % TX)
+                for v, nm in enumerate(accs):
+                    L.append("    sm[threadIdx.x >> 6][tx * %d + %d] = %s;" % (V, v, nm))
+                L.append("  }")
+                L.append("  __syncthreads();")
+            L.append("  if (valid && threadIdx.x < %d) {" % TX)
+            for v, nm in enumerate(accs):
+                if nw > 1:
+                    L.append("    %s r%d = sm[0][tx * %d + %d];" % (acc_t, v, V, v))
+                    L.append("    for (int w = 1; w < %d; ++w) r%d = %s;" %
+                             (nw, v, comb("r%d" % v, "(%s)sm[w][tx * %d + %d]" % (acc_t, V, v))))
+                else:
+                    L.append("    %s r%d = %s;" % (acc_t, v, nm))
+                L.append("    if (a.aux1 == 1) ((%s*)a.out)[ov * %d + %d] = %s;" %
+                         (CTYPE[red["out"]], V, v, _store_val("r%d" % v, red["acc"], red["out"])))
+                L.append("    else ((%s*)a.out)[(i64)blockIdx.y * a.n + ov * %d + %d] = r%d;" %
+                         (CTYPE[red["acc"]], V, v, v))
+            L.append("  }")
 
-    if red is not None:
-        acc_t = RTYPE[red["acc"]]
-        sm_t = acc_t if acc_t != "bool" else "unsigned char"
-        comb = lambda a_, b_: red_combine(red["op"], red["acc"], a_, b_)  # noqa: E731
-        wave_red = ["  for (int m = 32; m > 0; m >>= 1) acc = %s;" %
-                    comb("acc", "shfl_xor_<%s>(acc, m)" % acc_t)]
-        if red["kind"] == "all":
-            _reduce_all_finalize(spec, red, L)
-        elif red["kind"] == "row":
-            L.extend(wave_red)
-            L.append("  if (lane == 0) ((%s*)a.out)[o] = %s;" %
-                     (CTYPE[red["out"]], _store_val("acc", red["acc"], red["out"])))
-        else:
-            L.append("  if (a.aux1 == 1) ((%s*)a.out)[o] = %s;" %
-                     (CTYPE[red["out"]], _store_val("acc", red["acc"], red["out"])))
-            L.append("  else ((%s*)a.out)[(i64)blockIdx.y * a.n + o] = acc;" % CTYPE[red["acc"]])
+    if red is not None and red["kind"] == "all":
+        _reduce_all_finalize(spec, red, L)
     L.append("}")
     return "\n".join(L) + "\n", (name,)
 

@@ -136,10 +136,13 @@ int ahip_elemwise_tiled(ahip_fn_t k, int nd, const int64_t* shape, int nops, voi
 
 int ahip_elemwise_reduce_axis(ahip_fn_t k, int mode, int nk, int nr, const int64_t* shape,
                               int nops, void* const* ptrs, const int64_t* strides, int nslices,
-                              void* out_or_ws, int block, void* stream) {
+                              void* out_or_ws, int block, int vec, int lanes, void* stream) {
   AHIP_REQUIRE(k && out_or_ws, "null argument");
   AHIP_REQUIRE(nk >= 1 && nr >= 1 && nk + nr <= AHIP_MAXD, "bad nk/nr");
-  AHIP_REQUIRE(block >= 64 && block % 64 == 0 && nslices >= 1, "bad block/nslices");
+  AHIP_REQUIRE(block >= 64 && block % 64 == 0 && nslices >= 1 && nslices <= 65535,
+               "bad block/nslices");
+  AHIP_REQUIRE(vec >= 1 && lanes >= 1 && lanes <= 64 && (lanes & (lanes - 1)) == 0,
+               "bad vec/lanes");
   ahip_ew_args a;
   int rc = pack_args(&a, nk + nr, shape, nops, ptrs, strides);
   if (rc) return rc;
@@ -151,16 +154,17 @@ int ahip_elemwise_reduce_axis(ahip_fn_t k, int mode, int nk, int nr, const int64
   a.aux0 = nred;
   a.aux1 = nslices;
   a.out = out_or_ws;
-  uint32_t gx, gy = 1;
-  if (mode == 0) {  // row: one wavefront per output element
-    AHIP_REQUIRE(nslices == 1, "row mode does not slice");
-    int waves = block / 64;
-    gx = (uint32_t)((nkept + waves - 1) / waves);
-  } else {          // col: one thread per output element, reduce run optionally sliced
-    gx = (uint32_t)((nkept + block - 1) / block);
-    gy = (uint32_t)nslices;
+  int64_t gx;
+  if (mode == 0) {  // row: `lanes` adjacent lanes per output, vectors of `vec` along the run
+    AHIP_REQUIRE(shape[nk + nr - 1] % vec == 0, "reduced inner extent not divisible by vec");
+    int groups = block / lanes;
+    gx = (nkept + groups - 1) / groups;
+  } else {          // col: `lanes` threads x `vec` adjacent outputs per workgroup
+    AHIP_REQUIRE(shape[nk - 1] % vec == 0, "kept inner extent not divisible by vec");
+    gx = (nkept / vec + lanes - 1) / lanes;
   }
-  return launch(k, gx, gy, block, &a, stream);
+  AHIP_REQUIRE(gx <= 0x7fffffffll, "grid too large");
+  return launch(k, (uint32_t)gx, (uint32_t)nslices, block, &a, stream);
 }
 
 int ahip_gemv_epilogue(ahip_fn_t k, const ahip_gv_args* args, int block, void* stream) {

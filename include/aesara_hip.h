@@ -209,13 +209,16 @@ int ahip_elemwise_reduce_all(ahip_fn_t k, int nd, const int64_t* shape, int nops
 
 /* ---- K2: axis CAReduce (optionally with a fused Elemwise producer) ----------------------
  * The iteration space is [kept dims (nk) | reduced dims (nr)], both already collapsed by the
- * host; shape/strides cover nk+nr dims in that order.  mode 0 ("row"): one wavefront per
- * output element, lanes stride over the reduced run.  mode 1 ("col"): one thread per output
- * element, reduced dims walked sequentially; `nslices`>1 splits the reduced run over
- * gridDim.y and writes [nslices, n_kept] partials into `ws` for a second pass.              */
+ * host; shape/strides cover nk+nr dims in that order.  `k` is generated for (mode, vec,
+ * lanes).  mode 0 ("row", unit stride inside the reduced group): `lanes` (power of two <= 64)
+ * adjacent lanes per output element, each taking `vec`-element vectors of the reduced run.
+ * mode 1 ("col", unit stride inside the kept group): workgroups of `lanes` x (block/lanes)
+ * threads, `vec` adjacent outputs per thread, block/lanes reduced rows in flight, folded in a
+ * fixed order.  `nslices`>1 splits the reduced run over gridDim.y and writes
+ * [nslices, n_kept] partials (accumulator dtype) into `out_or_ws` for a second pass.       */
 int ahip_elemwise_reduce_axis(ahip_fn_t k, int mode, int nk, int nr, const int64_t* shape,
                               int nops, void* const* ptrs, const int64_t* strides, int nslices,
-                              void* out_or_ws, int block, void* stream);
+                              void* out_or_ws, int block, int vec, int lanes, void* stream);
 
 /* ---- K4/K6: GEMM on MFMA ------------------------------------------------------------------
  * replaces: tensor/blas.py:518 GemmRelated / :872 Gemm (build_gemm_call :836 -> sgemm_/dgemm_

@@ -100,6 +100,27 @@ def main():
         d, w = timeit(lambda: ex(x), 500)
         report("pure sum f64 4096^2 (streaming-read ceiling)", d, w, 4096 * 4096 * 8, "GB/s", 8000.0)
 
+    if want("axisred"):
+        from aesara_amd.plan import Node, Plan, Var
+
+        def red_plan(dt, nd, axis, op="add"):
+            out_nd = nd - len(axis)
+            return Plan("axisred", {0: Var(0, dt, [None] * nd), 1: Var(1, dt, [None] * out_nd)},
+                        [0], [1], [Node("CAReduce", [0], [1], {
+                            "scalar_op": op, "axis": list(axis),
+                            "acc_dtype": "float64" if op == "add" else dt})])
+        for dt, tdt, shape, axis, op in (
+                ("float64", f64, (4096, 4096), (0,), "add"), ("float64", f64, (4096, 4096), (1,), "add"),
+                ("float32", f32, (16384, 4096), (0,), "add"), ("float32", f32, (16384, 4096), (1,), "add"),
+                ("float32", f32, (4194304, 8), (0,), "add"), ("float32", f32, (8, 4194304), (1,), "add"),
+                ("float32", f32, (4194304, 8), (1,), "maximum"),
+                ("float32", f32, (256, 512, 256), (1,), "add"), ("float32", f32, (256, 512, 256), (0, 2), "add")):
+            ex = PlanExecutor(red_plan(dt, len(shape), axis, op), use_graph=G)
+            x = randn(shape, tdt, 3)
+            d, w = timeit(lambda: ex(x), 50)
+            report("%s axis=%s %s %s" % (op, axis, dt, "x".join(map(str, shape))), d, w,
+                   x.numel() * x.element_size(), "GB/s", 8000.0)
+
     if want("cfg3a"):
         ex = PlanExecutor(plan_of("gemv_small_float64"), use_graph=G)
         M = randn((4096, 4096), f64, 2)
