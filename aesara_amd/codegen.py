@@ -376,18 +376,19 @@ def emit_scalar_body(scalar, in_exprs, in_dts, indent="      ", suffix="", hoist
 
 def red_combine(op, acc_dt, a, b):
     T = RTYPE[acc_dt]
+    # bool: NO short-circuit operators — `b` is often a cross-lane shuffle that every lane must
+    # execute (a lane that skipped it would hand its partner an undefined value)
     if op == "add":
-        return "(%s || %s)" % (a, b) if acc_dt == "bool" else "(%s)(%s + %s)" % (T, a, b)
+        return "(bool)((int)%s | (int)%s)" % (a, b) if acc_dt == "bool" else "(%s)(%s + %s)" % (T, a, b)
     if op == "mul":
-        return "(%s && %s)" % (a, b) if acc_dt == "bool" else "(%s)(%s * %s)" % (T, a, b)
+        return "(bool)((int)%s & (int)%s)" % (a, b) if acc_dt == "bool" else "(%s)(%s * %s)" % (T, a, b)
     if op == "maximum":
         return "%s<%s>(%s, %s)" % ("fmax_nan" if _is_float(acc_dt) else "imax", T, a, b)
     if op == "minimum":
         return "%s<%s>(%s, %s)" % ("fmin_nan" if _is_float(acc_dt) else "imin", T, a, b)
+    sym = {"and": "&", "or": "|", "xor": "^"}[op]
     if acc_dt == "bool":
-        sym = {"and": "&&", "or": "||", "xor": "!="}[op]
-    else:
-        sym = {"and": "&", "or": "|", "xor": "^"}[op]
+        return "(bool)((int)%s %s (int)%s)" % (a, sym, b)
     return "(%s)(%s %s %s)" % (T, a, sym, b)
 
 

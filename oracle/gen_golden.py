@@ -308,6 +308,16 @@ def _():
     return [x], [x.sum(axis=0), x.mean(axis=0)], [N((20000, 8), "float32", seed=23)]
 
 
+@case("red_bool_any_all", exact=True)
+def _():
+    # sparse Trues / sparse Falses: a lane whose partial is already decided must still take part
+    # in the cross-lane fold (TestCAReduce any/all, tests/tensor/test_elemwise.py:565-575)
+    x, y = T("bool", (300, 70), "x"), T("bool", (300, 70), "y")
+    return [x, y], [at.any(x, axis=0), at.any(x, axis=1), at.any(x), at.all(y, axis=0),
+                    at.all(y, axis=1), at.all(y), at.any(x & y, axis=1), x.sum(axis=0)], \
+        [B((300, 70), 31, 0.004), B((300, 70), 32, 0.996)]
+
+
 @case("red_nan_propagation", exact=True)
 def _():
     x = at.dmatrix("x")
@@ -575,7 +585,7 @@ def _():
 
 
 # CheckAndRaise / SpecifyShape views (raise_op.py:28, tensor/shape.py:376)
-@case("assert_specify_shape", exact=True)
+@case("assert_specify_shape", rtol=1e-13, atol=1e-13)
 def _():
     from aesara.raise_op import Assert
     x, n = at.dmatrix("x"), at.lscalar("n")

@@ -349,3 +349,87 @@ def test_fused_kernels_agree_with_unfused_on_random_shapes():
                 _randn((n,), torch.float32, s + 6)]
         for u, v in zip(_ex("mlp_layers_float32")(*args), _ex("mlp_layers_float32", fuse=False)(*args)):
             assert close(u, v, 2e-5), (m, k1, k2, n)
+
+
+def _reduce_plan(dt, nd, axis, op, out_dt=None, acc=None):
+    from aesara_amd.plan import Node, Plan, Var
+    out_dt = out_dt or dt
+    return Plan("axisred", {0: Var(0, dt, [None] * nd), 1: Var(1, out_dt, [None] * (nd - len(axis)))},
+                [0], [1], [Node("CAReduce", [0], [1], {"scalar_op": op, "axis": list(axis),
+                                                       "acc_dtype": acc or out_dt})])
+
+
+def test_axis_reductions_all_layouts_against_torch():
+    """Axis CAReduce over shapes that exercise every layout of the generated kernels: short and
+    long rows (1-64 lanes per output), vector and scalar loads (extents not divisible by the
+    vector width, transposed views), sliced long reductions in both the row and the column
+    form, 3-d mixed axes.  Integer / bool results bit-exact, float sums vs fp64."""
+    import torch
+    from aesara_amd.device import DevArray
+    from aesara_amd.executor import PlanExecutor
+    rng = np.random.default_rng(7)
+    shapes = [((1 << 18, 8), (0,)), ((1 << 18, 8), (1,)), ((8, 1 << 18), (1,)), ((8, 1 << 18), (0,)),
+              ((5, 100003), (1,)), ((100003, 5), (0,)), ((3001, 257), (0,)), ((3001, 257), (1,)),
+              ((64, 96, 80), (0, 2)), ((64, 96, 80), (1,)), ((64, 96, 80), (0, 1)), ((7, 3, 50001), (2,)),
+              ((1, 4096), (1,)), ((4096, 1), (0,)), ((2, 2), (0,)), ((70000, 3), (1,))]
+    for shape, axis in shapes:
+        n = int(np.prod(shape))
+        # float sums (fp32 accumulates in fp64: tensor/elemwise.py:1371 _acc_dtype), max with NaN
+        for dt, tdt, acc, tol in (("float64", torch.float64, "float64", 1e-12),
+                                  ("float32", torch.float32, "float64", 2e-6)):
+            x = _randn(shape, tdt, int(rng.integers(1 << 30)))
+            (got,) = PlanExecutor(_reduce_plan(dt, len(shape), axis, "add", acc=acc))(x)
+            want = x.double().sum(dim=axis).to(tdt)
+            assert torch.allclose(got, want, rtol=tol, atol=tol * max(1.0, n ** 0.5 / 8)), (shape, axis, dt)
+            xn = x.clone()
+            xn.view(-1)[int(rng.integers(n))] = float("nan")
+            (got,) = PlanExecutor(_reduce_plan(dt, len(shape), axis, "maximum"))(xn)
+            want = xn
+            for a in sorted(axis, reverse=True):
+                want = want.max(dim=a).values    # torch.max propagates NaN like the reference
+            assert torch.equal(torch.nan_to_num(got, nan=-7.0), torch.nan_to_num(want, nan=-7.0)), \
+                (shape, axis, dt)
+        xi = torch.randint(-1000, 1000, shape, dtype=torch.int64, device="cuda")
+        (got,) = PlanExecutor(_reduce_plan("int64", len(shape), axis, "add"))(xi)
+        assert torch.equal(got, xi.sum(dim=axis)), (shape, axis)
+        xb = torch.rand(shape, device="cuda") < 1e-4
+        (got,) = PlanExecutor(_reduce_plan("bool", len(shape), axis, "or"))(xb)
+        want = xb
+        for a in sorted(axis, reverse=True):
+            want = want.any(dim=a)
+        assert torch.equal(got, want), (shape, axis)
+    # a transposed view: the unit stride moves to the other group
+    x = _randn((3000, 500), torch.float32, 5)
+    v = DevArray.from_torch(x).view([500, 3000], [1, 500])
+    for axis in ((0,), (1,)):
+        (got,) = PlanExecutor(_reduce_plan("float32", 2, axis, "add", acc="float64"))(v)
+        want = x.t().double().sum(dim=axis).float()
+        assert torch.allclose(got, want, rtol=2e-6, atol=2e-5)
+
+
+def test_tiled_transposed_elemwise_random_shapes():
+    """The LDS-tiled Elemwise kernel (transposed operands) on ragged shapes around the tile edges,
+    against torch: x + y.T, exp(y.T/4)*x - v, sqr(y.T); (x*y.T).sum() & co."""
+    import torch
+    rng = np.random.default_rng(11)
+    sizes = [16, 17, 31, 32, 33, 47, 48, 63, 64, 65, 100, 127, 129, 200, 1000]
+    for _ in range(24):
+        r, c = int(rng.choice(sizes)), int(rng.choice(sizes))
+        s = int(rng.integers(1 << 30))
+        x, y, v = _randn((r, c), torch.float32, s), _randn((c, r), torch.float32, s + 1), \
+            _randn((c,), torch.float32, s + 2)
+        a, b, d = _ex("ew_transposed_float32_64x128")(x, y, v)
+        assert torch.allclose(a, x + y.t(), rtol=1e-6, atol=1e-6), (r, c)
+        assert torch.allclose(b, torch.exp(y.t() * 0.25) * x - v, rtol=2e-6, atol=2e-6), (r, c)
+        assert torch.allclose(d, y.t() ** 2, rtol=1e-6, atol=1e-6), (r, c)
+        xd, yd = x.double(), y.double()
+        s0, m0, s1 = _ex("reduce_all_transposed_float64")(xd, yd)
+        assert torch.allclose(s0, (xd * yd.t()).sum(), rtol=1e-11, atol=1e-9), (r, c)
+        assert torch.equal(m0, (yd.t() - xd).max()), (r, c)
+        assert torch.allclose(s1, (xd.t() ** 2 + yd).sum(), rtol=1e-11, atol=1e-9), (r, c)
+    # the same kernels on a big ragged 3-d problem (transpose of the two inner dims)
+    x, y, z, w = _randn((3, 1000, 777), torch.float64, 1), _randn((3, 777, 1000), torch.float64, 2), \
+        _randn((777, 3, 1000), torch.float64, 3), _randn((777, 1000), torch.float64, 4)
+    (o,) = _ex("ew_transposed_3d")(x, y, z, w)
+    want = x * y.permute(0, 2, 1) + z.permute(1, 2, 0) - w.t()[None]
+    assert torch.allclose(o, want, rtol=1e-13, atol=1e-13)     # mul+add contracts to an fma
