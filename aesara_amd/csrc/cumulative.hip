@@ -2,13 +2,18 @@
 //
 // Replaces tensor/extra_ops.py:283 CumOp (perform :311: np.cumsum / np.cumprod; C :330-370
 // PyArray_CumSum / PyArray_CumProd).  The input is viewed as [outer, n, inner] (element strides
-// so, sn, si); the output is C-contiguous.  Two schedules:
+// so, sn, si); the output is C-contiguous.  Two line schedules:
 //   * inner >= 64: one thread per (outer, inner) line, sequential over n — adjacent threads touch
 //     adjacent addresses, so every step is one coalesced row of `inner` elements;
 //   * inner small (the last-axis case): one wavefront per line, 64 elements per step scanned with
 //     a shuffle-up Hillis-Steele pass plus a running carry.
+// Few long lines (a flat cumsum; axis 0 of a matrix) would leave the device idle, so the scanned
+// axis is cut into chunks (reduce-then-scan): pass 1 reduces every chunk, pass 2 scans the chunk
+// totals in place (the same line kernels on the [outer, nchunks, inner] totals), pass 3 scans
+// every chunk starting from the total of the chunks before it.  The input is read twice and
+// written once; the chunk count only depends on the shape, so results are reproducible.
 // Integer arithmetic wraps in the output dtype (as the reference's C loops do); floating-point
-// sums are accumulated in scan order per 64-element chunk (round-off level reordering only).
+// sums are accumulated in scan order within a chunk (round-off level reordering only).
 #include "common.h"
 
 namespace {
@@ -17,24 +22,40 @@ struct CumArgs {
   const void* x; void* out;
   int64_t outer, n, inner, so, sn, si;
   int mul;
+  // chunked form: lines are (outer, chunk, inner); `carry` holds the inclusive scan of the chunk
+  // totals [outer, nchunks, inner] (chunk c starts from carry[c - 1]); `totals` is pass 1's output
+  int64_t chunk, nchunks;
+  const void* carry; void* totals;
 };
 
 template <typename T> __device__ __forceinline__ T comb(T a, T b, int mul) { return mul ? a * b : a + b; }
 
-template <typename T>
+template <typename T, bool TOTALS>
 __global__ __launch_bounds__(256) void cum_lines_kernel(CumArgs a) {
   const T* __restrict__ x = static_cast<const T*>(a.x);
   T* __restrict__ out = static_cast<T*>(a.out);
-  const int64_t lines = a.outer * a.inner;
+  const T* __restrict__ carry = static_cast<const T*>(a.carry);
+  T* __restrict__ totals = static_cast<T*>(a.totals);
+  const int64_t lines = a.outer * a.nchunks * a.inner;
   for (int64_t l = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; l < lines;
        l += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t o = l / a.inner, i = l - o * a.inner;
+    const int64_t oc = l / a.inner, i = l - oc * a.inner;
+    const int64_t o = oc / a.nchunks, c = oc - o * a.nchunks;
+    const int64_t k0 = c * a.chunk, k1 = (k0 + a.chunk < a.n) ? k0 + a.chunk : a.n;
     const T* px = x + o * a.so + i * a.si;
     T* po = out + o * a.n * a.inner + i;
     T acc = a.mul ? (T)1 : (T)0;
-    for (int64_t k = 0; k < a.n; ++k) {
-      acc = comb<T>(acc, px[k * a.sn], a.mul);
-      po[k * a.inner] = acc;
+    if (TOTALS) {
+#pragma unroll 8
+      for (int64_t k = k0; k < k1; ++k) acc = comb<T>(acc, px[k * a.sn], a.mul);
+      totals[l] = acc;
+    } else {
+      if (carry != nullptr && c > 0) acc = carry[l - a.inner];
+#pragma unroll 8
+      for (int64_t k = k0; k < k1; ++k) {
+        acc = comb<T>(acc, px[k * a.sn], a.mul);
+        po[k * a.inner] = acc;
+      }
     }
   }
 }
@@ -57,76 +78,162 @@ __device__ __forceinline__ T shfl_up_(T v, int d) {
 }
 
 template <typename T>
+__device__ __forceinline__ T shfl_xor_(T v, int d) {
+  if constexpr (sizeof(T) == 8) {
+    union { T t; int i[2]; } u; u.t = v;
+    u.i[0] = __shfl_xor(u.i[0], d, 64); u.i[1] = __shfl_xor(u.i[1], d, 64);
+    return u.t;
+  } else if constexpr (sizeof(T) == 4) {
+    union { T t; int i; } u; u.t = v;
+    u.i = __shfl_xor(u.i, d, 64);
+    return u.t;
+  } else {
+    int w = (int)v;
+    w = __shfl_xor(w, d, 64);
+    return (T)w;
+  }
+}
+
+template <typename T, bool TOTALS>
 __global__ __launch_bounds__(256) void cum_wave_kernel(CumArgs a) {
   const T* __restrict__ x = static_cast<const T*>(a.x);
   T* __restrict__ out = static_cast<T*>(a.out);
+  const T* __restrict__ carry_in = static_cast<const T*>(a.carry);
+  T* __restrict__ totals = static_cast<T*>(a.totals);
   const int lane = threadIdx.x & 63;
-  const int64_t lines = a.outer * a.inner;
+  const int64_t lines = a.outer * a.nchunks * a.inner;
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
   const T ident = a.mul ? (T)1 : (T)0;
   for (int64_t l = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); l < lines;
        l += nwaves) {
-    const int64_t o = l / a.inner, i = l - o * a.inner;
+    const int64_t oc = l / a.inner, i = l - oc * a.inner;
+    const int64_t o = oc / a.nchunks, c = oc - o * a.nchunks;
+    const int64_t kbeg = c * a.chunk, kend = (kbeg + a.chunk < a.n) ? kbeg + a.chunk : a.n;
     const T* px = x + o * a.so + i * a.si;
     T* po = out + o * a.n * a.inner + i;
-    T carry = ident;
-    for (int64_t k0 = 0; k0 < a.n; k0 += 64) {
-      const int64_t k = k0 + lane;
-      T v = (k < a.n) ? px[k * a.sn] : ident;
-      for (int d = 1; d < 64; d <<= 1) {
-        const T up = shfl_up_<T>(v, d);
-        if (lane >= d) v = comb<T>(up, v, a.mul);
+    if (TOTALS) {
+      T acc = ident;
+#pragma unroll 4
+      for (int64_t k = kbeg + lane; k < kend; k += 64) acc = comb<T>(acc, px[k * a.sn], a.mul);
+      for (int m = 32; m > 0; m >>= 1) acc = comb<T>(acc, shfl_xor_<T>(acc, m), a.mul);
+      if (lane == 0) totals[l] = acc;
+      continue;
+    }
+    T carry = (carry_in != nullptr && c > 0) ? carry_in[l - a.inner] : ident;
+    // 4 x 64 elements per trip: the four loads are independent and issued together, the scans
+    // chain through `carry`
+    for (int64_t k0 = kbeg; k0 < kend; k0 += 256) {
+      T v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t k = k0 + 64 * u + lane;
+        v[u] = (k < kend) ? px[k * a.sn] : ident;
       }
-      v = comb<T>(carry, v, a.mul);
-      if (k < a.n) po[k * a.inner] = v;
-      union { T t; int w[2]; } u;   // carry = lane 63's value
-      u.w[0] = u.w[1] = 0;
-      u.t = v;
-      u.w[0] = __shfl(u.w[0], 63, 64);
-      if (sizeof(T) == 8) u.w[1] = __shfl(u.w[1], 63, 64);
-      carry = u.t;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t k = k0 + 64 * u + lane;
+        T w = v[u];
+        for (int d = 1; d < 64; d <<= 1) {
+          const T up = shfl_up_<T>(w, d);
+          if (lane >= d) w = comb<T>(up, w, a.mul);
+        }
+        w = comb<T>(carry, w, a.mul);
+        if (k < kend) po[k * a.inner] = w;
+        union { T t; int q[2]; } c63;   // carry = lane 63's value
+        c63.q[0] = c63.q[1] = 0;
+        c63.t = w;
+        c63.q[0] = __shfl(c63.q[0], 63, 64);
+        if (sizeof(T) == 8) c63.q[1] = __shfl(c63.q[1], 63, 64);
+        carry = c63.t;
+      }
     }
   }
 }
 
-template <typename T>
-int run_cum(CumArgs& a, hipStream_t s) {
-  const int64_t lines = a.outer * a.inner;
+// chunk count for a problem (depends on the shape only); 1 = single pass
+int64_t cum_chunks(int64_t outer, int64_t n, int64_t inner) {
+  const int64_t lines = outer * inner;
+  if (lines <= 0 || n <= 0) return 1;
+  int64_t want, max_chunks;
+  if (inner >= 64) {          // thread per line: fill ~1024 threads per CU, chunks of >= 64
+    want = ((int64_t)ahip_cu_count() * 1024 + lines - 1) / lines;
+    max_chunks = n / 64;
+  } else {                    // wave per line: ~32 waves per CU, chunks of >= 1024
+    want = ((int64_t)ahip_cu_count() * 32 + lines - 1) / lines;
+    max_chunks = n / 1024;
+  }
+  if (want > max_chunks) want = max_chunks;
+  return want < 2 ? 1 : want;
+}
+
+template <typename T, bool TOTALS>
+int launch_cum(const CumArgs& a, hipStream_t s) {
+  const int64_t lines = a.outer * a.nchunks * a.inner;
   int64_t cap = (int64_t)ahip_cu_count() * 8;
   if (a.inner >= 64) {
     int64_t want = (lines + 255) / 256;
     if (want > cap) want = cap;
-    AHIP_LAUNCH((cum_lines_kernel<T>), dim3((unsigned)want), dim3(256), 0, s, a);
+    AHIP_LAUNCH((cum_lines_kernel<T, TOTALS>), dim3((unsigned)want), dim3(256), 0, s, a);
   } else {
     int64_t want = (lines + 3) / 4;
     if (want > cap) want = cap;
-    AHIP_LAUNCH((cum_wave_kernel<T>), dim3((unsigned)want), dim3(256), 0, s, a);
+    AHIP_LAUNCH((cum_wave_kernel<T, TOTALS>), dim3((unsigned)want), dim3(256), 0, s, a);
   }
   return AHIP_OK;
+}
+
+template <typename T>
+int run_cum(CumArgs& a, void* ws, size_t ws_bytes, hipStream_t s) {
+  const int64_t nch = cum_chunks(a.outer, a.n, a.inner);
+  a.chunk = a.n; a.nchunks = 1; a.carry = nullptr; a.totals = nullptr;
+  if (nch == 1) return launch_cum<T, false>(a, s);
+  a.chunk = (a.n + nch - 1) / nch;
+  a.nchunks = (a.n + a.chunk - 1) / a.chunk;
+  const size_t need = (size_t)(a.outer * a.nchunks * a.inner) * sizeof(T);
+  AHIP_REQUIRE(ws != nullptr && ws_bytes >= need, "cumulative: workspace of %zu bytes needed", need);
+  a.totals = ws;
+  int rc = launch_cum<T, true>(a, s);                    // pass 1: chunk totals
+  if (rc) return rc;
+  // pass 2: inclusive scan of the totals along the chunk axis, in place
+  CumArgs t{ws, ws, a.outer, a.nchunks, a.inner, a.nchunks * a.inner, a.inner, 1, a.mul,
+            a.nchunks, 1, nullptr, nullptr};
+  rc = launch_cum<T, false>(t, s);
+  if (rc) return rc;
+  a.carry = ws; a.totals = nullptr;                       // pass 3: scan with carry-in
+  return launch_cum<T, false>(a, s);
 }
 
 }  // namespace
 
 extern "C" {
 
+size_t ahip_cumulative_ws_bytes(int dtype, int64_t outer, int64_t n, int64_t inner) {
+  if (outer <= 0 || n <= 0 || inner <= 0) return 0;
+  const int64_t nch = cum_chunks(outer, n, inner);
+  if (nch == 1) return 0;
+  const int64_t chunk = (n + nch - 1) / nch;
+  return (size_t)(outer * ((n + chunk - 1) / chunk) * inner) * (size_t)ahip_itemsize(dtype);
+}
+
 int ahip_cumulative(int dtype, int mul, const void* x, int64_t outer, int64_t n, int64_t inner,
-                    int64_t x_so, int64_t x_sn, int64_t x_si, void* out, void* stream) {
+                    int64_t x_so, int64_t x_sn, int64_t x_si, void* out, void* ws,
+                    size_t ws_bytes, void* stream) {
   AHIP_REQUIRE(outer >= 0 && n >= 0 && inner >= 0, "negative extent");
   if (outer == 0 || n == 0 || inner == 0) return AHIP_OK;
   AHIP_REQUIRE(x && out, "null argument");
-  CumArgs a{x, out, outer, n, inner, x_so, x_sn, x_si, mul ? 1 : 0};
+  CumArgs a{x, out, outer, n, inner, x_so, x_sn, x_si, mul ? 1 : 0, n, 1, nullptr, nullptr};
   hipStream_t s = as_stream(stream);
   switch (dtype) {
-    case AHIP_BOOL: case AHIP_U8: return run_cum<uint8_t>(a, s);
-    case AHIP_I8: return run_cum<int8_t>(a, s);
-    case AHIP_I16: return run_cum<int16_t>(a, s);
-    case AHIP_U16: return run_cum<uint16_t>(a, s);
-    case AHIP_I32: return run_cum<int32_t>(a, s);
-    case AHIP_U32: return run_cum<uint32_t>(a, s);
-    case AHIP_I64: return run_cum<int64_t>(a, s);
-    case AHIP_U64: return run_cum<uint64_t>(a, s);
-    case AHIP_F32: return run_cum<float>(a, s);
-    case AHIP_F64: return run_cum<double>(a, s);
+    case AHIP_BOOL: case AHIP_U8: return run_cum<uint8_t>(a, ws, ws_bytes, s);
+    case AHIP_I8: return run_cum<int8_t>(a, ws, ws_bytes, s);
+    case AHIP_I16: return run_cum<int16_t>(a, ws, ws_bytes, s);
+    case AHIP_U16: return run_cum<uint16_t>(a, ws, ws_bytes, s);
+    case AHIP_I32: return run_cum<int32_t>(a, ws, ws_bytes, s);
+    case AHIP_U32: return run_cum<uint32_t>(a, ws, ws_bytes, s);
+    case AHIP_I64: return run_cum<int64_t>(a, ws, ws_bytes, s);
+    case AHIP_U64: return run_cum<uint64_t>(a, ws, ws_bytes, s);
+    case AHIP_F32: return run_cum<float>(a, ws, ws_bytes, s);
+    case AHIP_F64: return run_cum<double>(a, ws, ws_bytes, s);
     default: ahip_set_error("bad dtype %d", dtype); return AHIP_EINVAL;
   }
 }

@@ -168,11 +168,15 @@ template <> __device__ __forceinline__ bool is_nan_<double>(double v) { return v
 template <typename T>
 __device__ __forceinline__ bool beats(T a, int64_t ia, T b, int64_t ib) {
   const bool na = is_nan_(a), nb = is_nan_(b);
-  if (na || nb) return na && (!nb || ia < ib);
-  return a > b || (a == b && ia < ib);
+  const bool nan_case = na & (!nb | (ia < ib));            // branch-free: both forms always evaluated
+  const bool num_case = (a > b) | ((a == b) & (ia < ib));
+  return (na | nb) ? nan_case : num_case;
 }
 
-struct ArgmaxArgs { const void* x; int64_t* out; int64_t nrows, k, x_rs, x_cs; };
+struct ArgmaxArgs {
+  const void* x; int64_t* out; int64_t nrows, k, x_rs, x_cs;
+  void* pval; int64_t* pidx; int64_t nslices;   // column form: per-slice partial (value, index)
+};
 
 template <typename T>
 __global__ __launch_bounds__(256) void argmax_rows_kernel(ArgmaxArgs a) {
@@ -224,11 +228,116 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(ArgmaxArgs a) {
   }
 }
 
+// Column form (axis 0 of a matrix: the outputs are adjacent in memory, x_rs == 1): 64 lanes x V
+// adjacent outputs per workgroup row, 4 rows of the reduced index in flight, gridDim.y slices of
+// the reduced run; `beats` is a total order on (value, index), so any fold order gives np.argmax.
+template <typename T, int V>
+__global__ __launch_bounds__(256) void argmax_cols_kernel(ArgmaxArgs a) {
+  struct alignas(sizeof(T) * V >= 16 ? 16 : sizeof(T) * V) P { T v[V]; };
+  const T* __restrict__ x = static_cast<const T*>(a.x);
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int64_t o0 = ((int64_t)blockIdx.x * 64 + tx) * V;
+  const bool valid = o0 < a.nrows;
+  const int64_t per = (a.k + a.nslices - 1) / a.nslices;
+  const int64_t kb = (int64_t)blockIdx.y * per, ke = (kb + per < a.k) ? kb + per : a.k;
+  T best[V];
+  int64_t bi[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) { best[e] = (T)0; bi[e] = -1; }
+  if (valid && kb + ty < ke) {
+    int64_t j = kb + ty;
+    {
+      const P p = *reinterpret_cast<const P*>(x + j * a.x_cs + o0);
+#pragma unroll
+      for (int e = 0; e < V; ++e) { best[e] = p.v[e]; bi[e] = j; }
+    }
+#pragma unroll 8
+    for (j += 4; j < ke; j += 4) {
+      const P p = *reinterpret_cast<const P*>(x + j * a.x_cs + o0);
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const bool take = beats(p.v[e], j, best[e], bi[e]);
+        best[e] = take ? p.v[e] : best[e];
+        bi[e] = take ? j : bi[e];
+      }
+    }
+  }
+  __shared__ T sv[4][64 * V];
+  __shared__ int64_t si[4][64 * V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) { sv[ty][tx * V + e] = best[e]; si[ty][tx * V + e] = bi[e]; }
+  __syncthreads();
+  if (ty != 0 || !valid) return;
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    for (int w = 1; w < 4; ++w) {
+      const T v = sv[w][tx * V + e];
+      const int64_t i = si[w][tx * V + e];
+      const bool take = (i >= 0) & ((bi[e] < 0) | beats(v, i, best[e], bi[e]));
+      best[e] = take ? v : best[e];
+      bi[e] = take ? i : bi[e];
+    }
+    if (a.nslices == 1) {
+      a.out[o0 + e] = bi[e];
+    } else {
+      static_cast<T*>(a.pval)[(int64_t)blockIdx.y * a.nrows + o0 + e] = best[e];
+      a.pidx[(int64_t)blockIdx.y * a.nrows + o0 + e] = bi[e];
+    }
+  }
+}
+
 template <typename T>
-int run_argmax(ArgmaxArgs& a, hipStream_t s) {
-  int64_t want = (a.nrows + 3) / 4, cap = (int64_t)ahip_cu_count() * 8;
-  if (want > cap) want = cap;
-  AHIP_LAUNCH((argmax_rows_kernel<T>), dim3((unsigned)want), dim3(256), 0, s, a);
+__global__ __launch_bounds__(256) void argmax_fold_kernel(ArgmaxArgs a) {
+  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= a.nrows) return;
+  T best = (T)0;
+  int64_t bi = -1;
+#pragma unroll 16
+  for (int64_t s = 0; s < a.nslices; ++s) {   // independent loads: keep 16 slices in flight
+    const T v = static_cast<const T*>(a.pval)[s * a.nrows + o];
+    const int64_t i = a.pidx[s * a.nrows + o];
+    const bool take = (i >= 0) & ((bi < 0) | beats(v, i, best, bi));
+    best = take ? v : best;
+    bi = take ? i : bi;
+  }
+  a.out[o] = bi;
+}
+
+int64_t argmax_slices(int itemsize, int64_t nrows, int64_t k, int64_t x_rs, int64_t x_cs) {
+  if (x_rs != 1 || x_cs == 1 || nrows < 16 || k < 64) return 0;    // 0 = row form
+  const int64_t per_block = 64 * (16 / itemsize);                   // outputs per workgroup (vector form)
+  const int64_t bx = (nrows + per_block - 1) / per_block;
+  int64_t want = (8 * (int64_t)ahip_cu_count() + bx - 1) / bx;
+  if (want > 64) want = 64;
+  if (want > k / 32) want = k / 32;
+  return want < 1 ? 1 : want;
+}
+
+template <typename T>
+int run_argmax(ArgmaxArgs& a, void* ws, size_t ws_bytes, hipStream_t s) {
+  int64_t ns = argmax_slices((int)sizeof(T), a.nrows, a.k, a.x_rs, a.x_cs);
+  if (ns == 0) {
+    int64_t want = (a.nrows + 3) / 4, cap = (int64_t)ahip_cu_count() * 8;
+    if (want > cap) want = cap;
+    AHIP_LAUNCH((argmax_rows_kernel<T>), dim3((unsigned)want), dim3(256), 0, s, a);
+    return AHIP_OK;
+  }
+  if (ns > 1 && (ws == nullptr || ws_bytes < (size_t)(ns * a.nrows) * 16)) ns = 1;
+  a.nslices = ns;
+  a.pval = ws;
+  a.pidx = reinterpret_cast<int64_t*>(static_cast<char*>(ws) + (size_t)(ns * a.nrows) * 8);
+  constexpr int VEC = 16 / sizeof(T);
+  const bool vec = VEC > 1 && a.nrows % VEC == 0 && (a.x_cs * (int64_t)sizeof(T)) % 16 == 0 &&
+                   reinterpret_cast<uintptr_t>(a.x) % 16 == 0;
+  if (vec) {
+    const int64_t bx = (a.nrows / VEC + 63) / 64;
+    AHIP_LAUNCH((argmax_cols_kernel<T, VEC>), dim3((unsigned)bx, (unsigned)ns), dim3(256), 0, s, a);
+  } else {
+    const int64_t bx = (a.nrows + 63) / 64;
+    AHIP_LAUNCH((argmax_cols_kernel<T, 1>), dim3((unsigned)bx, (unsigned)ns), dim3(256), 0, s, a);
+  }
+  if (ns > 1)
+    AHIP_LAUNCH((argmax_fold_kernel<T>), dim3((unsigned)((a.nrows + 255) / 256)), dim3(256), 0, s, a);
   return AHIP_OK;
 }
 
@@ -301,25 +410,31 @@ int ahip_scatter_rows(int dtype, void* dst, int64_t nrows, int64_t dst_rs, int64
   return dispatch(accumulate ? 1 : 2, dtype, idx_dtype, a, as_stream(stream));
 }
 
+size_t ahip_argmax_ws_bytes(int dtype, int64_t nrows, int64_t k, int64_t x_rs, int64_t x_cs) {
+  if (nrows <= 0 || k <= 0 || ahip_itemsize(dtype) <= 0) return 0;
+  const int64_t ns = argmax_slices(ahip_itemsize(dtype), nrows, k, x_rs, x_cs);
+  return ns > 1 ? (size_t)(ns * nrows) * 16 : 0;
+}
+
 int ahip_argmax_rows(int dtype, const void* x, int64_t nrows, int64_t k, int64_t x_rs, int64_t x_cs,
-                     int64_t* out, void* stream) {
+                     int64_t* out, void* ws, size_t ws_bytes, void* stream) {
   AHIP_REQUIRE(nrows >= 0 && k >= 0, "negative extent");
   if (nrows == 0) return AHIP_OK;
   AHIP_REQUIRE(k > 0, "attempt to get argmax of an empty sequence");
   AHIP_REQUIRE(x && out, "null argument");
-  ArgmaxArgs a{x, out, nrows, k, x_rs, x_cs};
+  ArgmaxArgs a{x, out, nrows, k, x_rs, x_cs, nullptr, nullptr, 1};
   hipStream_t s = as_stream(stream);
   switch (dtype) {
-    case AHIP_BOOL: case AHIP_U8: return run_argmax<uint8_t>(a, s);
-    case AHIP_I8: return run_argmax<int8_t>(a, s);
-    case AHIP_I16: return run_argmax<int16_t>(a, s);
-    case AHIP_I32: return run_argmax<int32_t>(a, s);
-    case AHIP_I64: return run_argmax<int64_t>(a, s);
-    case AHIP_U16: return run_argmax<uint16_t>(a, s);
-    case AHIP_U32: return run_argmax<uint32_t>(a, s);
-    case AHIP_U64: return run_argmax<uint64_t>(a, s);
-    case AHIP_F32: return run_argmax<float>(a, s);
-    case AHIP_F64: return run_argmax<double>(a, s);
+    case AHIP_BOOL: case AHIP_U8: return run_argmax<uint8_t>(a, ws, ws_bytes, s);
+    case AHIP_I8: return run_argmax<int8_t>(a, ws, ws_bytes, s);
+    case AHIP_I16: return run_argmax<int16_t>(a, ws, ws_bytes, s);
+    case AHIP_I32: return run_argmax<int32_t>(a, ws, ws_bytes, s);
+    case AHIP_I64: return run_argmax<int64_t>(a, ws, ws_bytes, s);
+    case AHIP_U16: return run_argmax<uint16_t>(a, ws, ws_bytes, s);
+    case AHIP_U32: return run_argmax<uint32_t>(a, ws, ws_bytes, s);
+    case AHIP_U64: return run_argmax<uint64_t>(a, ws, ws_bytes, s);
+    case AHIP_F32: return run_argmax<float>(a, ws, ws_bytes, s);
+    case AHIP_F64: return run_argmax<double>(a, ws, ws_bytes, s);
     default: ahip_set_error("bad dtype %d", dtype); return AHIP_EINVAL;
   }
 }

@@ -328,14 +328,22 @@ int ahip_linearize_indices(int nidx, const void* const* idx, const int* idx_dtyp
 /* ---- K12: cumulative sum / product along one axis --------------------------------------------
  * replaces: tensor/extra_ops.py:283 CumOp (perform :311 np.cumsum / np.cumprod).  x is viewed as
  * [outer, n, inner] with element strides (x_so, x_sn, x_si); out is C-contiguous [outer, n, inner].
- * mul = 0: sum, 1: product.  Integers wrap in `dtype`.                                            */
+ * mul = 0: sum, 1: product.  Integers wrap in `dtype`.  Few long lines are cut into chunks
+ * (reduce, scan the chunk totals, scan with carry-in): that form needs a caller-provided
+ * workspace of ahip_cumulative_ws_bytes() bytes (0 = single pass, `ws` may be NULL).            */
+size_t ahip_cumulative_ws_bytes(int dtype, int64_t outer, int64_t n, int64_t inner);
 int ahip_cumulative(int dtype, int mul, const void* x, int64_t outer, int64_t n, int64_t inner,
-                    int64_t x_so, int64_t x_sn, int64_t x_si, void* out, void* stream);
+                    int64_t x_so, int64_t x_sn, int64_t x_si, void* out, void* ws,
+                    size_t ws_bytes, void* stream);
 /* Row argmax, replaces tensor/math.py:330 Argmax (perform :388: np.argmax over the reduced axes
  * moved last and flattened).  x is viewed as [nrows, k] with element strides x_rs / x_cs; out[r]
- * = index of the first maximum of row r; a NaN counts as the maximum (first NaN wins).         */
+ * = index of the first maximum of row r; a NaN counts as the maximum (first NaN wins).  When
+ * the outputs are adjacent in memory (x_rs == 1: argmax over axis 0) a column form slices the
+ * reduced run over several workgroups; it takes an optional workspace of
+ * ahip_argmax_ws_bytes() bytes for the per-slice partials (without it: one slice).              */
+size_t ahip_argmax_ws_bytes(int dtype, int64_t nrows, int64_t k, int64_t x_rs, int64_t x_cs);
 int ahip_argmax_rows(int dtype, const void* x, int64_t nrows, int64_t k, int64_t x_rs, int64_t x_cs,
-                     int64_t* out, void* stream);
+                     int64_t* out, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- H1/K10: launch-list capture & replay (the CVM analogue) --------------------------------
  * replaces: link/vm.py:388 Loop.__call__ / link/c/c_code/lazylinker_c.c:752 CLazyLinker_call and

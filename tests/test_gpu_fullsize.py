@@ -433,3 +433,68 @@ def test_tiled_transposed_elemwise_random_shapes():
     (o,) = _ex("ew_transposed_3d")(x, y, z, w)
     want = x * y.permute(0, 2, 1) + z.permute(1, 2, 0) - w.t()[None]
     assert torch.allclose(o, want, rtol=1e-13, atol=1e-13)     # mul+add contracts to an fma
+
+
+def _one_node_plan(op, in_vars, out_var, params):
+    from aesara_amd.plan import Node, Plan, Var
+    vs = {i: Var(i, dt, [None] * nd) for i, (dt, nd) in enumerate(in_vars + [out_var])}
+    n = len(in_vars)
+    return Plan("one", vs, list(range(n)), [n], [Node(op, list(range(n)), [n], params)])
+
+
+def test_cumulative_chunked_scans_against_torch():
+    """CumOp on few long lines (flat vectors, axis 0 of matrices): the chunked reduce-then-scan
+    form.  Integers bit-exact (wrapping), floats against an fp64 scan."""
+    import torch
+    from aesara_amd.executor import PlanExecutor
+    cases = [((1 << 22) + 3,), (3000, 700), (700, 3000), (9, 40000, 5), (4, 100000), (70000, 4), (1,), (5, 1)]
+    for shape in cases:
+        nd = len(shape)
+        for axis in range(nd):
+            xi = torch.randint(-3, 4, shape, dtype=torch.int64, device="cuda")
+            (got,) = PlanExecutor(_one_node_plan("CumOp", [("int64", nd)], ("int64", nd),
+                                                 {"axis": axis, "mode": "add"}))(xi)
+            assert torch.equal(got, xi.cumsum(dim=axis)), (shape, axis)
+            x = _randn(shape, torch.float32, 17 + axis)
+            (got,) = PlanExecutor(_one_node_plan("CumOp", [("float32", nd)], ("float32", nd),
+                                                 {"axis": axis, "mode": "add"}))(x)
+            want = x.double().cumsum(dim=axis)
+            scale = float(want.abs().max()) + 1.0
+            assert float((got.double() - want).abs().max()) <= 4e-6 * scale, (shape, axis)
+        # products of +-1 / 2 / 1: exact in int64 for short runs, wrapping for long ones
+        xm = torch.where(torch.rand(shape, device="cuda") < 0.001, -1, 1).to(torch.int64)
+        (got,) = PlanExecutor(_one_node_plan("CumOp", [("int64", nd)], ("int64", nd),
+                                             {"axis": 0, "mode": "mul"}))(xm)
+        assert torch.equal(got, xm.cumprod(dim=0)), shape
+
+
+def test_argmax_row_and_column_forms_against_torch():
+    """Argmax over the last axis (wave per row) and over axis 0 (column form, sliced): first
+    maximum on ties, NaN counts as the maximum (np.argmax), vector and scalar load paths."""
+    import torch
+    from aesara_amd.executor import PlanExecutor
+
+    def np_argmax(x, axis):
+        # np.argmax semantics with torch: NaN is the maximum, first occurrence wins
+        key = torch.where(torch.isnan(x), torch.full_like(x, float("inf")), x) if x.is_floating_point() else x
+        mx = key.max(dim=axis, keepdim=True).values
+        hit = key == mx
+        if x.is_floating_point():
+            anynan = torch.isnan(x).any(dim=axis, keepdim=True)
+            hit = torch.where(anynan, torch.isnan(x), hit)
+        idx = torch.arange(x.shape[axis], device=x.device).reshape([-1 if d == axis else 1 for d in range(x.ndim)])
+        big = x.shape[axis]
+        return torch.where(hit, idx, big).min(dim=axis).values
+
+    for shape in ((5000, 300), (300, 5000), (4099, 257), (64, 64), (100000, 16), (16, 100000)):
+        for axis in (0, 1):
+            xi = torch.randint(-5, 6, shape, dtype=torch.int32, device="cuda")      # many ties
+            (got,) = PlanExecutor(_one_node_plan("Argmax", [("int32", 2)], ("int64", 1), {"axis": [axis]}))(xi)
+            assert torch.equal(got, np_argmax(xi, axis)), (shape, axis)
+            x = torch.round(_randn(shape, torch.float64, 3) * 2)
+            x.view(-1)[::7919] = float("nan")
+            (got,) = PlanExecutor(_one_node_plan("Argmax", [("float64", 2)], ("int64", 1), {"axis": [axis]}))(x)
+            assert torch.equal(got, np_argmax(x, axis)), (shape, axis)
+            xf = _randn(shape, torch.float32, 4)
+            (got,) = PlanExecutor(_one_node_plan("Argmax", [("float32", 2)], ("int64", 1), {"axis": [axis]}))(xf)
+            assert torch.equal(got, xf.argmax(dim=axis)), (shape, axis)

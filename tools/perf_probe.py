@@ -121,6 +121,47 @@ def main():
             report("%s axis=%s %s %s" % (op, axis, dt, "x".join(map(str, shape))), d, w,
                    x.numel() * x.element_size(), "GB/s", 8000.0)
 
+    if want("misc"):
+        # secondary ops of the path at scale: which of them are far from the HBM roofline?
+        from aesara_amd.plan import Node, Plan, Var
+        from aesara_amd.device import DevArray
+
+        def one(op, in_vars, out_var, params):
+            vs = {i: Var(i, dt, list(sh)) for i, (dt, sh) in enumerate(in_vars + [out_var])}
+            n = len(in_vars)
+            return Plan("misc", vs, list(range(n)), [n], [Node(op, list(range(n)), [n], params)])
+
+        def ew(opname, dts, shapes, odt):
+            sc = {"n_in": len(dts), "nodes": [{"op": opname, "in": [["i", k] for k in range(len(dts))],
+                                                "dtype": odt}], "out": [["t", 0]]}
+            return one("Elemwise", list(zip(dts, shapes)), (odt, shapes[0]), {"scalar": sc})
+
+        x = randn((8192, 4096), f32, 1)
+        b, c = randn((1, 4096), f32, 2), randn((8192, 1), f32, 3)
+        nb = x.numel() * 4
+        for name, pl, ins_, byt in (
+                ("ew x+b[None,:] f32 8192x4096", ew("add", ["float32"] * 2, [[None, None], [1, None]], "float32"), (x, b), 2 * nb),
+                ("ew x*c[:,None] f32 8192x4096", ew("mul", ["float32"] * 2, [[None, None], [None, 1]], "float32"), (x, c), 2 * nb),
+                ("cumsum axis=0 f32 8192x4096", one("CumOp", [("float32", [None, None])], ("float32", [None, None]), {"axis": 0, "mode": "add"}), (x,), 2 * nb),
+                ("cumsum axis=1 f32 8192x4096", one("CumOp", [("float32", [None, None])], ("float32", [None, None]), {"axis": 1, "mode": "add"}), (x,), 2 * nb),
+                ("cumsum flat f32 2^25", one("CumOp", [("float32", [None])], ("float32", [None]), {"axis": 0, "mode": "add"}), (x.view(-1),), 2 * nb),
+                ("argmax axis=1 f32 8192x4096", one("Argmax", [("float32", [None, None])], ("int64", [None]), {"axis": [1]}), (x,), nb),
+                ("argmax axis=0 f32 8192x4096", one("Argmax", [("float32", [None, None])], ("int64", [None]), {"axis": [0]}), (x,), nb),
+        ):
+            ex = PlanExecutor(pl, use_graph=G)
+            d, w = timeit(lambda: ex(*ins_), 10)
+            report(name, d, w, byt, "GB/s", 8000.0)
+        exs = PlanExecutor(ew("mul", ["float32"] * 2, [[None, None], [1, 1]], "float32"), use_graph=G)
+        two = torch.full((1, 1), 2.0, dtype=f32, device="cuda")
+        xs = DevArray.from_torch(x).view([4096, 2048], [8192, 2])
+        d, w = timeit(lambda: exs(xs, two), 10)
+        report("ew x[::2, ::2]*2 f32 (4096x2048 of 8192x4096)", d, w, 2 * 4096 * 2048 * 4, "GB/s", 8000.0)
+        idx = torch.randint(0, 8192, (65536,), device="cuda")
+        ext = PlanExecutor(one("AdvancedSubtensor1", [("float32", [None, None]), ("int64", [None])],
+                               ("float32", [None, None]), {}), use_graph=G)
+        d, w = timeit(lambda: ext(x, idx), 10)
+        report("take 65536 rows of 4096 f32", d, w, 2 * 65536 * 4096 * 4, "GB/s", 8000.0)
+
     if want("cfg3a"):
         ex = PlanExecutor(plan_of("gemv_small_float64"), use_graph=G)
         M = randn((4096, 4096), f64, 2)
