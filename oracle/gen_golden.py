@@ -427,6 +427,69 @@ def _():
         [I((9, 11), seed=1), K(3, "int64")]
 
 
+# modelled on tests/tensor/test_subtensor.py (TestSubtensor.test_slice_*, test_ellipsis, test_newaxis,
+# test_noncontiguous, test_shape_i_*): 3-d views, out-of-range slice bounds (clipped like NumPy),
+# negative steps, symbolic bounds / steps, new axes and ellipsis — all bit-exact index work
+@case("subtensor_3d_slices", exact=True)
+def _():
+    x = at.itensor3("x")
+    a, b, st = at.lscalar("a"), at.lscalar("b"), at.lscalar("st")
+    outs = [x[1:, :, ::2], x[-3:-1], x[:, -1], x[..., 2], x[2, ...], x[1, 2, 3:], x[::-1, ::-2, ::-3],
+            x[100:], x[:100], x[-100:2], x[5:2], x[2:5:-1], x[::5], x[:, None, 1:3], x[None, 0, :, None],
+            x[a:b], x[a:b:st], x[::st], x[b:a:-st], x[-a:], x[:, a, b:], x[a], x[-a, -b, -a]]
+    return [x, a, b, st], [o + 0 for o in outs], [I((6, 7, 8), seed=1), K(1, "int64"), K(5, "int64"),
+                                                   K(2, "int64")]
+
+
+@case("subtensor_symbolic_edge_bounds", exact=True)
+def _():
+    v = at.lvector("v")
+    a, b, st = at.lscalar("a"), at.lscalar("b"), at.lscalar("st")
+    outs = [v[a:b:st], v[b:a:st], v[a::st], v[:b:st], v[a:b], v[-b:-a], v[::st], v[st], v[-st]]
+    return [v, a, b, st], [o * 1 for o in outs], [I((17,), "int64", seed=2, low=-99, high=99),
+                                                   K(-20, "int64"), K(30, "int64"), K(-3, "int64")]
+
+
+@case("subtensor_of_views_and_dimshuffles", exact=True)
+def _():
+    x = at.lmatrix("x")
+    y = x.T[1:, ::2]                       # view of a view of a transposed view
+    z = x.dimshuffle(1, "x", 0)[2:, :, ::-1]
+    return [x], [y + 0, y[::-1, 1:] * 2, z + 0, z[0, 0, 1:4] - 1, x[::2][1:][::-1] + 0], \
+        [I((9, 12), "int64", seed=3, low=-1000, high=1000)]
+
+
+@case("incsubtensor_views_steps_broadcast", exact=True)
+def _():
+    x, y, r = at.ltensor3("x"), at.lmatrix("y"), at.lvector("r")
+    s = at.lscalar("s")
+    return [x, y, r, s], [
+        at.set_subtensor(x[1], y), at.inc_subtensor(x[:, 2], y[:4, :5]), at.inc_subtensor(x[::-1, ::2, 1], 3),
+        at.set_subtensor(x[..., -1], r[:6]), at.inc_subtensor(x[1:3, 1:3, 1:3], s),
+        at.set_subtensor(x[::2, ::-3, ::2], y[None, :2, :3]), at.inc_subtensor(x[2:, -2:, :][0], y[:2, :5] * 0 + r[:5]),
+        at.inc_subtensor(at.set_subtensor(x[0], 1)[0, 1], r[:5])], \
+        [I((4, 6, 5), "int64", seed=1), I((6, 5), "int64", seed=2), I((8,), "int64", seed=3), K(11, "int64")]
+
+
+@case("advsub1_variants", exact=True, ref_py=True)
+def _():
+    x, m = at.ltensor3("x"), at.lmatrix("m")
+    idx, idx8, j = at.lvector("idx"), at.bvector("idx8"), at.bvector("j")
+    return [x, m, idx, idx8, j], [x[idx], m[idx8], m.T[idx8], x[idx][:, 1], m[idx][::-1], x[:, j], m[:, idx8], x[..., j],
+                               at.inc_subtensor(m[idx8], 5), at.set_subtensor(m[idx[:3]], m[:3] * 2)], \
+        [I((7, 3, 4), "int64", seed=1), I((7, 5), "int64", seed=2), I((11,), "int64", 3, -7, 7),
+         I((4,), "int8", 4, -5, 5), I((3,), "int8", 5, -3, 3)]
+
+
+@case("join_split_axes", exact=True)
+def _():
+    x, y, z = at.ltensor3("x"), at.ltensor3("y"), at.ltensor3("z")
+    parts = at.split(at.join(2, x, y, z), [2, 5, 4], 3, axis=2)
+    return [x, y, z], [at.join(0, x, x), at.join(-1, x, y, z), at.join(1, x.dimshuffle(0, 2, 1), z.dimshuffle(0, 2, 1)),
+                       at.stack([x, x * 2], axis=1), parts[0] + 0, parts[1] * 1, parts[2] - 1], \
+        [I((3, 4, 2), "int64", seed=1), I((3, 4, 5), "int64", seed=2), I((3, 4, 4), "int64", seed=3)]
+
+
 @case("incsubtensor", exact=True)
 def _():
     x, y, r = at.imatrix("x"), at.imatrix("y"), at.ivector("r")

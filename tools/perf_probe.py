@@ -162,6 +162,63 @@ def main():
         d, w = timeit(lambda: ext(x, idx), 10)
         report("take 65536 rows of 4096 f32", d, w, 2 * 65536 * 4096 * 4, "GB/s", 8000.0)
 
+    if want("misc2"):
+        from aesara_amd.plan import Node, Plan, Var
+
+        def plan_n(op, in_vars, out_var, params):
+            vs = {i: Var(i, dt, list(sh)) for i, (dt, sh) in enumerate(in_vars + [out_var])}
+            n = len(in_vars)
+            return Plan("misc2", vs, list(range(n)), [n], [Node(op, list(range(n)), [n], params)])
+
+        def ew1(opname, idt, odt):
+            sc = {"n_in": 1, "nodes": [{"op": opname, "in": [["i", 0]], "dtype": odt}], "out": [["t", 0]]}
+            return plan_n("Elemwise", [(idt, [None, None])], (odt, [None, None]), {"scalar": sc})
+        x = randn((8192, 4096), f32, 1)
+        nb = x.numel() * 4
+        x8 = (x * 40).to(torch.int8)
+        sc_gt = {"n_in": 2, "nodes": [{"op": "gt", "in": [["i", 0], ["i", 1]], "dtype": "bool"}], "out": [["t", 0]]}
+        for name, pl, ins_, byt in (
+                ("cast f32->f64 8192x4096", ew1("cast", "float32", "float64"), (x,), 3 * nb),
+                ("neg int8 8192x4096", ew1("neg", "int8", "int8"), (x8,), 2 * x8.numel()),
+                ("gt(int8,int8)->bool 8192x4096", plan_n("Elemwise", [("int8", [None, None])] * 2, ("bool", [None, None]), {"scalar": sc_gt}), (x8, x8), 3 * x8.numel()),
+                ("exp f32 1024 (latency)", ew1("exp", "float32", "float32"), (x[:1, :1024],), 2 * 4096),
+                ("join axis=0 2x(8192x4096 f32)", plan_n("Join", [("int64", []), ("float32", [None, None]), ("float32", [None, None])], ("float32", [None, None]), {}), (np.int64(0), x, x), 4 * nb),
+                ("join axis=1 2x(8192x4096 f32)", plan_n("Join", [("int64", []), ("float32", [None, None]), ("float32", [None, None])], ("float32", [None, None]), {}), (np.int64(1), x, x), 4 * nb),
+                ("alloc scalar -> 8192x4096 f32", plan_n("Alloc", [("float32", []), ("int64", []), ("int64", [])], ("float32", [None, None]), {}), (x[0, 0], np.int64(8192), np.int64(4096)), nb),
+        ):
+            ex = PlanExecutor(pl, use_graph=G)
+            d, w = timeit(lambda: ex(*ins_), 10)
+            report(name, d, w, byt, "GB/s", 8000.0)
+        idx = torch.randint(0, 8192, (65536,), device="cuda")
+        y = randn((65536, 1024), f32, 2)
+        z = randn((8192, 1024), f32, 3)
+        exs = PlanExecutor(plan_n("AdvancedIncSubtensor1", [("float32", [None, None]), ("float32", [None, None]), ("int64", [None])],
+                                  ("float32", [None, None]), {"set_instead_of_inc": False, "inplace": False}), use_graph=G)
+        d, w = timeit(lambda: exs(z, y, idx), 10)
+        report("scatter-add 65536 rows of 1024 f32 into 8192 rows", d, w, 2 * y.numel() * 4, "GB/s", 8000.0)
+
+    if want("gemmshapes"):
+        # Dot22 / BatchedDot / Ger over shapes away from the square headline case
+        from aesara_amd.plan import Node, Plan, Var
+
+        def dot_plan(op, dt, nd):
+            vs = {i: Var(i, dt, [None] * nd) for i in range(3)}
+            return Plan("dot", vs, [0, 1], [2], [Node(op, [0, 1], [2], {})])
+        for dt, tdt, pk in (("float32", f32, 157.3), ("float64", f64, 78.6)):
+            exd = PlanExecutor(dot_plan("Dot22", dt, 2), use_graph=G)
+            for M, N, K in ((8192, 8192, 512), (512, 512, 65536), (16384, 64, 1024), (64, 16384, 1024),
+                            (2048, 2048, 2048), (4096, 4096, 64), (4000, 4000, 4000), (1024, 1024, 1024),
+                            (65536, 256, 256), (256, 256, 256)):
+                A, B = randn((M, K), tdt, 1), randn((K, N), tdt, 2)
+                d, w = timeit(lambda: exd(A, B), 10)
+                report("dot22 %s %dx%dx%d" % (dt, M, N, K), d, w, 2 * M * N * K, "TFLOP/s", pk)
+            exb = PlanExecutor(dot_plan("BatchedDot", dt, 3), use_graph=G)
+            for Bn, M, N, K in ((64, 512, 512, 512), (1024, 64, 64, 64), (16, 2048, 128, 2048)):
+                A, B = randn((Bn, M, K), tdt, 1), randn((Bn, K, N), tdt, 2)
+                d, w = timeit(lambda: exb(A, B), 10)
+                report("batched_dot %s %dx(%dx%dx%d)" % (dt, Bn, M, N, K), d, w, 2 * Bn * M * N * K,
+                       "TFLOP/s", pk)
+
     if want("cfg3a"):
         ex = PlanExecutor(plan_of("gemv_small_float64"), use_graph=G)
         M = randn((4096, 4096), f64, 2)
