@@ -419,6 +419,26 @@ def _():
 # ---------------------------------------------------------------------------------------
 # Subtensor / IncSubtensor / AdvancedSubtensor1 / Alloc / Join (bit-exact)
 # ---------------------------------------------------------------------------------------
+# TestBlasStrides (tests/tensor/test_blas.py:2085-2500): Dot22 / Gemm / Gemv / Ger on operands that
+# are stepped, reversed and transposed views of larger buffers
+for _dt, _tol in (("float64", 1e-12), ("float32", 2e-5)):
+    def _mkBS(dt=_dt):
+        a, b, c = T(dt, (8, 12), "a"), T(dt, (12, 10), "b"), T(dt, (8, 10), "c")
+        v, w = T(dt, (12,), "v"), T(dt, (8,), "w")
+        k4 = np.asarray(0.4, dt)
+        k8 = np.asarray(0.8, dt)
+        outs = [at.dot(a[::2, ::3], b[::3, ::2]), at.dot(a[::-1, ::-3], b[::-3, ::-1]),
+                at.dot(a.T[::3, ::2].T, b[::3]), at.dot(b.T[::2, ::3], a.T[::3, ::-2]),
+                k4 * c[::2, ::2] + k8 * at.dot(a[::2, ::3], b[::3, ::2]),
+                k4 * c[::-2, ::-2] + k8 * at.dot(a[::-2, ::3], b[::3, ::-2]),
+                at.dot(a[::2, ::-1], v[::-1]), w[::2] * k4 + k8 * at.dot(a[::2], v),
+                at.dot(a.T[::-2, ::2], w[::2]), at.dot(v[::3], b[::3, ::-1]),
+                c[::2, ::5] + k4 * at.outer(w[::-2], v[::6]), at.dot(v[::-2], v[::2])]
+        return [a, b, c, v, w], outs, [N((8, 12), dt, 1), N((12, 10), dt, 2), N((8, 10), dt, 3),
+                                       N((12,), dt, 4), N((8,), dt, 5)]
+    case(f"blas_strides_{_dt}", rtol=_tol, atol=_tol)(_mkBS)
+
+
 @case("subtensor_basic", exact=True)
 def _():
     x = at.imatrix("x")
