@@ -560,6 +560,16 @@ def _register_handlers():
         ctx.emit("AdvancedIncSubtensor", node, {
             "set_instead_of_inc": bool(op.set_instead_of_inc), "inplace": bool(op.inplace)})
 
+    from aesara.ifelse import IfElse
+
+    @hip_lower.register(IfElse)
+    def _(op, node, ctx):
+        # reference: ifelse.py:61 IfElse(cond, *then, *else) — a lazy Op: the VM computes only the
+        # branch the condition selects (make_thunk ifelse.py:240, lazy scheduling link/vm.py:430
+        # Stack.__call__ / lazylinker_c.c:544 lazy_rec_eval).  The executor keeps that: steps
+        # that only feed one branch run after the condition is known.
+        ctx.emit("IfElse", node, {"n_outs": int(op.n_outs)})
+
     from aesara.tensor.basic import Split
     from aesara.tensor.extra_ops import CumOp
 

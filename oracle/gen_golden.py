@@ -419,6 +419,36 @@ def _():
 # ---------------------------------------------------------------------------------------
 # Subtensor / IncSubtensor / AdvancedSubtensor1 / Alloc / Join (bit-exact)
 # ---------------------------------------------------------------------------------------
+# IfElse (tests/test_ifelse.py: test_lazy_if :79, test_multiple_out :176, test_grad_lazy_if :115,
+# test_nested / test_pushout*): scalar condition, several outputs, gradients, nesting, branches with
+# work the lazy VM skips
+for _cv in (0, 1):
+    @case(f"ifelse_lazy_c{_cv}", rtol=1e-12, atol=1e-12)
+    def _(cv=_cv):
+        from aesara.ifelse import ifelse
+        x, y, c = at.dvector("x"), at.dvector("y"), at.iscalar("c")
+        z = ifelse(c, at.exp(x) * 2, at.dot(at.outer(y, y), y) - 1)         # expensive else-branch
+        z1, z2 = ifelse(c, (x + 1, y * 2), (x * x, y - 3))                     # test_multiple_out
+        g = ae.grad(ifelse(c, (x ** 2).sum(), (y ** 3).sum()), [x, y])       # test_grad_lazy_if
+        inner = ifelse(at.gt(x.sum(), 0), x.max(), y.min())                  # condition computed on device
+        nested = ifelse(c, ifelse(at.lt(y[0], 0), x * 3, x * 5), ifelse(c, x, x - y))
+        return [x, y, c], [z, z1, z2, g[0], g[1], inner + 0, nested], \
+            [N((7,), seed=1), N((7,), seed=2), K(cv, "int32")]
+
+
+@case("ifelse_in_scan_and_shapes", rtol=1e-12, atol=1e-12)
+def _():
+    from aesara.ifelse import ifelse
+    x, c = at.dmatrix("x"), at.iscalar("c")
+    # branches of different run-time shapes (IfElse only requires equal types)
+    sh = ifelse(c, x[:2], x[1:])
+    # an IfElse inside a Scan step: accumulate rows with a data-dependent rule
+    acc, _ = ae.scan(lambda row, a: ifelse(at.gt(row.sum(), 0), a + row, a - 2 * row),
+                     sequences=[x], outputs_info=[at.zeros_like(x[0])])
+    return [x, c], [sh * 2, acc[-1], ifelse(at.eq(c, 0), x.sum(axis=0), x.sum(axis=0) * 0)], \
+        [N((5, 4), seed=3), K(0, "int32")]
+
+
 # TestBlasStrides (tests/tensor/test_blas.py:2085-2500): Dot22 / Gemm / Gemv / Ger on operands that
 # are stepped, reversed and transposed views of larger buffers
 for _dt, _tol in (("float64", 1e-12), ("float32", 2e-5)):

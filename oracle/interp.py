@@ -393,6 +393,10 @@ def run_plan(plan, inputs):
             r = [a[0]]
         elif op in ("ScalarFromTensor", "TensorFromScalar", "ViewOp"):
             r = [a[0]]
+        elif op == "IfElse":
+            # reference: ifelse.py:61 IfElse (the oracle evaluates both branches, then selects)
+            no = p["n_outs"]
+            r = list(a[1:1 + no]) if bool(np.asarray(a[0])) else list(a[1 + no:1 + 2 * no])
         elif op == "Assert":
             # reference: raise_op.py:94 CheckAndRaise.perform
             if not np.all([np.asarray(c) for c in a[1:]]):

@@ -168,3 +168,19 @@ def test_subtensor_out_of_bounds_index_error():
     x = np.zeros((9, 11), "int32")
     with pytest.raises(IndexError):
         ex(x, np.int64(9))
+
+
+def test_ifelse_runs_only_the_selected_branch():
+    """IfElse is lazy (reference: ifelse.py:240 make_thunk + the VM's lazy scheduling): steps
+    that only feed the branch not taken are never launched; nested IfElse keep their own."""
+    c0, c1 = _case("ifelse_lazy_c0"), _case("ifelse_lazy_c1")
+    ex = PlanExecutor(case_plan(c0), dry_run=True)
+    assert ex._owned, "no step was found to be branch-exclusive"
+    ex(*case_inputs(c0))
+    t0 = list(ex.trace)
+    ex.trace.clear()
+    ex(*case_inputs(c1))
+    t1 = list(ex.trace)
+    # the else-branch of the first output is outer(y, y) @ y - 1: Ger + Gemv chain
+    assert any(n in t0 for n in ("ahip_ger", "ahip_gemv", "ahip_gemv_epilogue"))
+    assert not any(n in t1 for n in ("ahip_ger", "ahip_gemv", "ahip_gemv_epilogue"))
