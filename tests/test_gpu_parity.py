@@ -43,7 +43,8 @@ def test_hip_matches_reference(c):
 
 @pytest.mark.parametrize("c", [c for c in CASES if c["name"].startswith(
     ("cfg", "scan_", "gru", "softmax", "logsoftmax", "layernorm", "argmax", "gemv_", "advsub1",
-     "lstm", "nll", "mlp", "cumop", "split", "advsub_nd", "advincsub_nd", "arange"))],
+     "lstm", "nll", "mlp", "cumop", "split", "advsub_nd", "advincsub_nd", "arange", "ifelse",
+     "red_large", "reduce_all_t", "ew_transposed", "subtensor_3d", "blas_strides"))],
                          ids=lambda c: c["name"])
 def test_hip_graph_replay_matches_reference(c):
     """Same cases through hipGraph capture + replay (H1/K10 launch-list path)."""
@@ -57,7 +58,7 @@ def test_hip_graph_replay_matches_reference(c):
 
 
 @pytest.mark.parametrize("c", [c for c in CASES if c["name"].startswith(
-    ("cfg", "red_", "ew_t", "softmax", "logsoftmax", "layernorm"))],
+    ("cfg", "red_", "ew_t", "softmax", "logsoftmax", "layernorm", "ifelse"))],
                          ids=lambda c: c["name"])
 def test_unfused_matches_reference(c):
     """The linker-level fusion must not change results: run with fusion disabled too."""
