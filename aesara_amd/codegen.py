@@ -1684,6 +1684,19 @@ __device__ __forceinline__ void skinny_dot(const T* __restrict__ A, i64 a_rs, co
       for (int f = 0; f < NF; ++f)
         MfmaT<T>::mma(acc[f], fr.a.v[j], BKC ? fr.bk[f].v[j] : fr.bn[j].v[f]);
   };
+  constexpr int DEPTH = 64 / G;
+  if (kend - kbeg <= DEPTH * G) {
+    // short K slice (a recurrent step: K / NW = 64): every load is issued before the first MFMA,
+    // one memory round trip instead of one per pipeline stage (these kernels are latency-bound)
+    Frag fr[DEPTH];
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) load(kbeg + u * G, fr[u]);   // beyond kend: zeros, no access
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) compute(fr[u]);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) res[f] = acc[f];
+    return;
+  }
   Frag f0, f1;
   i64 k0 = kbeg, next_fold = kbeg + 512;
   if (k0 < kend) load(k0, f0);
@@ -1731,13 +1744,13 @@ class GemmEpiSpec:
         assert len(self.in_dtypes) + len(self.out_dtypes) <= GE_MAXOPS
 
     def key(self):
-        fields = ["ge2", self.dtype, self.nf, self.bkc, self.in_dtypes, self.out_dtypes,
+        fields = ["ge3", self.dtype, self.nf, self.bkc, self.in_dtypes, self.out_dtypes,
                   self.out_refs, self.waves]
         return _memo_key([self.scalar], fields, self._key)
 
     def _key(self):
         import json
-        blob = json.dumps(["ge2", self.dtype, self.nf, self.bkc, self.scalar, self.in_dtypes,
+        blob = json.dumps(["ge3", self.dtype, self.nf, self.bkc, self.scalar, self.in_dtypes,
                            self.out_dtypes, self.out_refs, self.waves], sort_keys=True)
         return hashlib.sha256(blob.encode()).hexdigest()[:24]
 

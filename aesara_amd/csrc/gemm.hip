@@ -553,6 +553,16 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(GemmArgs g) {
   for (int f = 0; f < NF; ++f) tot[f] = acc_t{0, 0, 0, 0};
   Frag f0, f1;
   int64_t k0 = kbeg, next_fold = kbeg + FOLD;
+  constexpr int DEPTH = 64 / G;
+  if (kend - kbeg <= DEPTH * G) {
+    // short K slice: issue every load before the first MFMA (one memory round trip per wave)
+    Frag fr[DEPTH];
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) load(kbeg + u * G, fr[u]);   // beyond kend: zeros, no access
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) compute(fr[u]);
+    k0 = kend;
+  }
   if (k0 < kend) load(k0, f0);
   for (; k0 < kend; k0 += 2 * G) {
     if (k0 + G < kend) load(k0 + G, f1);
