@@ -129,6 +129,7 @@ class _Ctx:
     def __init__(self, plan, inner_rewriter=None):
         self.plan = plan
         self.vmap = {}
+        self.slices = {}     # SliceType variable -> [start, stop, step] variables (MakeSlice)
         self.inner_rewriter = inner_rewriter
 
     def vid(self, v):
@@ -545,20 +546,80 @@ def _register_handlers():
         if not 1 <= len(idx_vars) <= 8:
             raise UnsupportedOp("advanced indexing with more than 8 index arrays")
 
+    from aesara.graph.basic import Constant as _Constant
+    from aesara.tensor.type_other import MakeSlice, NoneTypeT, SliceType
+
+    @hip_lower.register(MakeSlice)
+    def _(op, node, ctx):
+        # reference: tensor/type_other.py:27 MakeSlice(start, stop, step): the bounds of a slice
+        # inside an advanced index.  No plan node: the consumer reads the recorded components.
+        ctx.slices[node.outputs[0]] = [None if isinstance(v.type, NoneTypeT) else v
+                                       for v in node.inputs]
+
+    def _adv_index(op, idx_vars, ctx):
+        """Entries of an advanced index mixing integer arrays with slices / newaxis ->
+        (entries, extra input variables).  {"array": k} | {"slice": [c, c, c]} with c = None |
+        int | {"in": k} (k = position among the extra inputs) | {"newaxis": true}."""
+        from aesara.tensor.type import TensorType
+        entries, ins = [], []
+        for v in idx_vars:
+            if isinstance(v.type, TensorType) and v.type.dtype.startswith(("int", "uint")):
+                entries.append({"array": len(ins)})
+                ins.append(v)
+            elif isinstance(v.type, SliceType):
+                if v in ctx.slices:
+                    comps = ctx.slices[v]
+                elif isinstance(v, _Constant):
+                    comps = [v.data.start, v.data.stop, v.data.step]
+                else:
+                    raise UnsupportedOp(f"{type(op).__name__}: slice of unknown origin")
+                enc = []
+                for c in comps:
+                    if c is None:
+                        enc.append(None)
+                    elif not hasattr(c, "owner"):          # python / NumPy integer of a constant slice
+                        enc.append(int(np.asarray(c).reshape(())))
+                    else:
+                        enc.append({"in": len(ins)})
+                        ins.append(c)
+                entries.append({"slice": enc})
+            elif isinstance(v.type, NoneTypeT):
+                entries.append({"newaxis": True})
+            else:
+                raise UnsupportedOp(f"{type(op).__name__} with a {v.type} index: boolean masks "
+                                    "(data-dependent shapes) are outside the path")
+        if not 1 <= sum(1 for e in entries if "array" in e) <= 8:
+            raise UnsupportedOp("advanced indexing with more than 8 index arrays")
+        return entries, ins
+
+    def _only_arrays(idx_vars):
+        from aesara.tensor.type import TensorType
+        return all(isinstance(v.type, TensorType) for v in idx_vars)
+
     @hip_lower.register(AdvancedSubtensor)
     def _(op, node, ctx):
-        # reference: tensor/subtensor.py:2543 AdvancedSubtensor (perform :2607), integer arrays
-        _int_array_indices(op, node.inputs[1:])
-        ctx.emit("AdvancedSubtensor", node)
+        # reference: tensor/subtensor.py:2543 AdvancedSubtensor (perform :2607): integer arrays,
+        # optionally mixed with slices / newaxis (NumPy placement rules)
+        if _only_arrays(node.inputs[1:]):
+            _int_array_indices(op, node.inputs[1:])
+            ctx.emit("AdvancedSubtensor", node)
+            return
+        entries, ins = _adv_index(op, node.inputs[1:], ctx)
+        ctx.emit("AdvancedSubtensor", node, {"index": entries}, inputs=[node.inputs[0]] + ins)
 
     @hip_lower.register(AdvancedIncSubtensor)
     def _(op, node, ctx):
         # reference: tensor/subtensor.py:2647 AdvancedIncSubtensor (perform :2688: np.add.at / set)
-        _int_array_indices(op, node.inputs[2:])
         if getattr(op, "ignore_duplicates", False):
             raise UnsupportedOp("AdvancedIncSubtensor(ignore_duplicates=True)")
-        ctx.emit("AdvancedIncSubtensor", node, {
-            "set_instead_of_inc": bool(op.set_instead_of_inc), "inplace": bool(op.inplace)})
+        params = {"set_instead_of_inc": bool(op.set_instead_of_inc), "inplace": bool(op.inplace)}
+        if _only_arrays(node.inputs[2:]):
+            _int_array_indices(op, node.inputs[2:])
+            ctx.emit("AdvancedIncSubtensor", node, params)
+            return
+        entries, ins = _adv_index(op, node.inputs[2:], ctx)
+        ctx.emit("AdvancedIncSubtensor", node, dict(params, index=entries),
+                 inputs=list(node.inputs[:2]) + ins)
 
     from aesara.ifelse import IfElse
 

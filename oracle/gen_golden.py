@@ -531,6 +531,32 @@ def _():
          I((4,), "int8", 4, -5, 5), I((3,), "int8", 5, -3, 3)]
 
 
+# integer arrays mixed with slices / newaxis (NumPy placement rules: adjacent arrays keep their
+# position, separated ones move the broadcast block to the front) — tests/tensor/test_subtensor.py
+# TestAdvancedSubtensor.test_adv_subtensor_w_slice / test_advinc_subtensor / test_adv_sub_3d
+@case("advsub_mixed_slices", exact=True, ref_py=True)
+def _():
+    x = at.ltensor4("x")
+    i, j, m = at.lvector("i"), at.lvector("j"), at.lmatrix("m")
+    a = at.lscalar("a")
+    outs = [x[i, 1:3], x[1:, i], x[:, i, j], x[i, :, j], x[:, :, i, j], x[::2, m, 1:], x[i, None, j],
+            x[a:, i, ::-1], x[:, m[:, :2], :, i[:2]], x[..., i], x[i, ..., j]]
+    return [x, i, j, m, a], outs, [I((5, 4, 6, 3), "int64", seed=1, low=-99, high=99),
+                                   I((3,), "int64", 2, -3, 3), I((3,), "int64", 3, -3, 3),
+                                   I((2, 3), "int64", 4, -3, 3), K(1, "int64")]
+
+
+@case("advincsub_mixed_slices", exact=True, ref_py=True)
+def _():
+    x, y = at.ltensor3("x"), at.lmatrix("y")
+    i, j = at.lvector("i"), at.lvector("j")
+    return [x, y, i, j], [at.inc_subtensor(x[i, 1:3], 5), at.set_subtensor(x[:, i], y[:3, :4][None] * 0 + 7),
+                          at.inc_subtensor(x[:, i, j], y[:4, :3]), at.set_subtensor(x[i, :, j], y[:3, :5]),
+                          at.inc_subtensor(x[1:, i, ::2], y[:3, :2]), at.inc_subtensor(x[i, ::-1, j[0]], y[:3, :5])], \
+        [I((4, 5, 4), "int64", seed=1), I((6, 6), "int64", seed=2), I((3,), "int64", 3, -4, 4),
+         I((3,), "int64", 4, -4, 4)]
+
+
 @case("join_split_axes", exact=True)
 def _():
     x, y, z = at.ltensor3("x"), at.ltensor3("y"), at.ltensor3("z")

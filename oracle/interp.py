@@ -330,6 +330,23 @@ def specify_shape_check(xshape, p, given):
         raise AssertionError(f"SpecifyShape: Got shape {tuple(xshape)}, expected {tuple(want)}.")
 
 
+def adv_index(params, extra):
+    """The NumPy index tuple of an AdvancedSubtensor / AdvancedIncSubtensor node: integer arrays
+    only (no "index" param), or arrays mixed with slices / newaxis (tensor/subtensor.py:2543)."""
+    if "index" not in params:
+        return tuple(np.asarray(i) for i in extra)
+    idx = []
+    for e in params["index"]:
+        if "array" in e:
+            idx.append(np.asarray(extra[e["array"]]))
+        elif "slice" in e:
+            idx.append(slice(*[c if (c is None or isinstance(c, int)) else int(np.asarray(extra[c["in"]]))
+                               for c in e["slice"]]))
+        else:
+            idx.append(None)
+    return tuple(idx)
+
+
 def run_plan(plan, inputs):
     """Interpret ``plan`` on NumPy arrays; returns the list of outputs."""
     env = {}
@@ -429,11 +446,11 @@ def run_plan(plan, inputs):
             r = [np.arange(st, sp, se, dtype=p["dtype"])]
         elif op == "AdvancedSubtensor":
             # reference: tensor/subtensor.py:2607 AdvancedSubtensor.perform
-            r = [np.asarray(a[0])[tuple(np.asarray(i) for i in a[1:])]]
+            r = [np.asarray(a[0])[adv_index(p, a[1:])]]
         elif op == "AdvancedIncSubtensor":
             # reference: tensor/subtensor.py:2688 AdvancedIncSubtensor.perform
             out = np.array(a[0], copy=True)
-            idx = tuple(np.asarray(i) for i in a[2:])
+            idx = adv_index(p, a[2:])
             if p["set_instead_of_inc"]:
                 out[idx] = a[1]
             else:
