@@ -143,6 +143,28 @@ __device__ __forceinline__ float softplus_(float x) {                           
 __device__ __forceinline__ double softplus_(double x) {
   return x < -37.0 ? exp(x) : (x < 18.0 ? log1p(exp(x)) : (x < 33.3 ? x + exp(-x) : x));
 }
+// Psi :361 — the reference's C body: Bernardo (1976), Algorithm AS 103 (0 for x <= 0, like it)
+__device__ __forceinline__ double psi_as103(double x) {
+  double y = x, psi = 0.0;
+  if (y <= 0.0) return psi;
+  if (y <= 1.0e-5) return -0.5772156649 - 1.0 / y;
+  while (y < 8.5) { psi = psi - 1.0 / y; y = y + 1; }
+  double R = 1.0 / y;
+  psi = psi + log(y) - .5 * R;
+  R = R * R;
+  psi = psi - R * (8.333333333e-2 - R * (8.333333333e-3 - R * 3.968253968e-3));
+  return psi;
+}
+// TriGamma :454 — the reference's C body: Algorithm AS 121 (0 for x <= 0, like it)
+__device__ __forceinline__ double trigamma_as121(double x) {
+  if (x <= 0) return 0.0;
+  if (x <= 0.0001) return 1.0 / x / x;
+  double value = 0.0, z = x;
+  while (z < 5.0) { value += 1.0 / z / z; z += 1.0; }
+  const double y = 1.0 / z / z;
+  value += 0.5 * y + (1.0 + y * (0.1666666667 + y * (-0.03333333333 + y * (0.02380952381 + y * -0.03333333333)))) / z;
+  return value;
+}
 __device__ __forceinline__ float log1mexp_(float x) { return x < -0.6931471805599453f ? log1pf(-expf(x)) : logf(-expm1f(x)); }
 __device__ __forceinline__ double log1mexp_(double x) { return x < -0.6931471805599453 ? log1p(-exp(x)) : log(-expm1(x)); }
 __device__ __forceinline__ float round_away(float x) { return x < 0 ? ceilf(x - 0.5f) : floorf(x + 0.5f); }
@@ -169,6 +191,10 @@ _FLOAT_FN = {
     "cosh": "cosh", "tanh": "tanh", "arcsinh": "asinh", "arccosh": "acosh", "arctanh": "atanh",
     "ceil": "ceil", "floor": "floor", "trunc": "trunc", "round_half_to_even": "rint",
     "erf": "erf", "erfc": "erfc",
+    # scalar/math.py: Gamma :283 (tgamma), GammaLn :317 (lgamma), Erfcx :108, Erfinv :173,
+    # Erfcinv :219, J0 :978 / J1 :947 (libm j0 / j1), I0 :1064 / I1 :1038 (scipy.special.i0 / i1)
+    "gamma": "tgamma", "gammaln": "lgamma", "erfcx": "erfcx", "erfinv": "erfinv",
+    "erfcinv": "erfcinv", "j0": "j0", "j1": "j1", "i0": "cyl_bessel_i0", "i1": "cyl_bessel_i1",
 }
 
 _IDENT = {  # reduction identities
@@ -299,6 +325,10 @@ def scalar_node_expr(op, ins, in_dts, dt):
         return "softplus_(%s)" % c[0]
     if op == "log1mexp":
         return "log1mexp_(%s)" % c[0]
+    if op == "psi" and _is_float(dt):
+        return "(%s)psi_as103((double)%s)" % (T, c[0])
+    if op == "tri_gamma" and _is_float(dt):
+        return "(%s)trigamma_as121((double)%s)" % (T, c[0])
     if op == "deg2rad":
         return "(%s * (%s)0.017453292519943295)" % (c[0], T)
     if op == "rad2deg":

@@ -35,6 +35,10 @@ SCALAR_OP_NAMES = {
     "IsNan": "isnan", "IsInf": "isinf", "Sigmoid": "sigmoid", "Softplus": "softplus",
     "Erf": "erf", "Erfc": "erfc", "Log1mexp": "log1mexp", "Deg2Rad": "deg2rad",
     "Rad2Deg": "rad2deg",
+    # scalar/math.py special functions (unary, floating point)
+    "Erfcx": "erfcx", "Erfinv": "erfinv", "Erfcinv": "erfcinv", "Gamma": "gamma",
+    "GammaLn": "gammaln", "Psi": "psi", "TriGamma": "tri_gamma", "J0": "j0", "J1": "j1",
+    "I0": "i0", "I1": "i1",
 }
 
 
@@ -620,6 +624,30 @@ def _register_handlers():
         entries, ins = _adv_index(op, node.inputs[2:], ctx)
         ctx.emit("AdvancedIncSubtensor", node, dict(params, index=entries),
                  inputs=list(node.inputs[:2]) + ins)
+
+    from aesara.tensor.basic import AllocDiag, ExtractDiag, Eye, Tri
+
+    @hip_lower.register(Eye)
+    def _(op, node, ctx):
+        # reference: tensor/basic.py:1257 Eye(n, m, k) (perform :1278 np.eye)
+        ctx.emit("Eye", node, {"dtype": str(op.dtype)})
+
+    @hip_lower.register(Tri)
+    def _(op, node, ctx):
+        # reference: tensor/basic.py:982 Tri(N, M, k) (perform :1000 np.tri)
+        ctx.emit("Tri", node, {"dtype": str(op.dtype)})
+
+    @hip_lower.register(ExtractDiag)
+    def _(op, node, ctx):
+        # reference: tensor/basic.py:3327 ExtractDiag (perform :3402 x.diagonal(offset, axis1, axis2))
+        ctx.emit("ExtractDiag", node, {"offset": int(op.offset), "axis1": int(op.axis1),
+                                       "axis2": int(op.axis2), "view": bool(op.view)})
+
+    @hip_lower.register(AllocDiag)
+    def _(op, node, ctx):
+        # reference: tensor/basic.py:3487 AllocDiag (perform :3523)
+        ctx.emit("AllocDiag", node, {"offset": int(op.offset), "axis1": int(op.axis1),
+                                     "axis2": int(op.axis2)})
 
     from aesara.ifelse import IfElse
 

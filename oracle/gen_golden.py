@@ -118,6 +118,19 @@ def _():
         N((6, 5), view={"kind": "step", "step": 2}), N((6, 5), seed=3, view={"kind": "transpose"})]
 
 
+# scalar/math.py special functions (tests/scalar/test_math.py, tests/tensor/test_math_scipy.py):
+# Gamma / GammaLn / Psi / TriGamma (the reference's own AS 103 / AS 121 C bodies), Erfcx / Erfinv /
+# Erfcinv, Bessel J0 J1 I0 I1
+for _dt, _rt, _at in (("float64", 2e-12, 2e-12), ("float32", 2e-5, 2e-6)):
+    def _mkSP(dt=_dt):
+        p, u, w = T(dt, (40,), "p"), T(dt, (40,), "u"), T(dt, (40,), "w")
+        return [p, u, w], [at.gamma(p), at.gammaln(p), at.psi(p), at.tri_gamma(p), at.gammaln(p + 30) - at.gammaln(p),
+                           at.erfcx(w), at.erfinv(u), at.erfcinv(u + 1), at.j0(w), at.j1(w), at.i0(u * 5),
+                           at.i1(u * 5), at.psi(w), at.exp(at.gammaln(p) - at.gammaln(p + 0.5)) * at.erfcx(p)], \
+            [U((40,), dt, 1, 0.05, 9.0), U((40,), dt, 2, -0.98, 0.98), U((40,), dt, 3, -4.0, 12.0)]
+    case(f"ew_special_functions_{_dt}", rtol=_rt, atol=_at)(_mkSP)
+
+
 # transposed operands (DimShuffle views inside the graph and transposed input views): the
 # LDS-tiled Elemwise kernel, both tile sizes, ragged edges, mixed classes
 for _dt, _r, _c in (("float64", 70, 45), ("float64", 130, 97), ("float32", 64, 128),
@@ -555,6 +568,24 @@ def _():
                           at.inc_subtensor(x[1:, i, ::2], y[:3, :2]), at.inc_subtensor(x[i, ::-1, j[0]], y[:3, :5])], \
         [I((4, 5, 4), "int64", seed=1), I((6, 6), "int64", seed=2), I((3,), "int64", 3, -4, 4),
          I((3,), "int64", 4, -4, 4)]
+
+
+# Eye / Tri / ExtractDiag / AllocDiag (tests/tensor/test_basic.py TestEye :841, TestTriangle :905,
+# TestDiag / test_diag* :3593-3720)
+@case("eye_tri_diag", exact=True)
+def _():
+    n, m = at.lscalar("n"), at.lscalar("m")
+    x, t3, v = at.lmatrix("x"), at.ltensor3("t3"), at.lvector("v")
+    return [n, m, x, t3, v], [
+        at.eye(n, m, 0, dtype="int64") * 3, at.eye(n, m, 2, dtype="int32"), at.eye(m, n, -3, dtype="int8"),
+        at.eye(n, n, 9, dtype="int64"), at.tri(n, m, 0, dtype="int64"), at.tri(n, m, 2, dtype="int32"),
+        at.tri(m, n, -2, dtype="int8"), at.tril(x), at.triu(x, 1), at.tril(x.T, -1),
+        at.diag(x), at.diagonal(x, offset=2), at.diagonal(x, offset=-3), at.diagonal(x.T[::2], offset=1),
+        at.diagonal(t3, offset=1, axis1=0, axis2=2), at.diagonal(t3, offset=-1, axis1=2, axis2=1),
+        at.diag(v), at.diag(v, 2), at.diag(v, -1), at.diag(at.diag(x[:5, :5]) * 2),
+        at.basic.AllocDiag(offset=1, axis1=0, axis2=2)(x[:3, :4])], \
+        [K(5, "int64"), K(7, "int64"), I((6, 8), "int64", seed=1), I((4, 5, 6), "int64", seed=2),
+         I((4,), "int64", seed=3)]
 
 
 @case("join_split_axes", exact=True)

@@ -58,6 +58,58 @@ def _erfc(x):
     return special.erfc(x)
 
 
+def _psi_as103(x):
+    # scalar/math.py:361 Psi.c_support_code (AS 103); what the reference's C linker computes
+    x = np.asarray(x)
+    out = np.zeros(x.shape, "float64")
+    for idx in np.ndindex(x.shape):
+        y = float(x[idx])
+        psi = 0.0
+        if y <= 0.0:
+            out[idx] = 0.0
+            continue
+        if y <= 1.0e-5:
+            out[idx] = -0.5772156649 - 1.0 / y
+            continue
+        while y < 8.5:
+            psi = psi - 1.0 / y
+            y = y + 1
+        R = 1.0 / y
+        psi = psi + np.log(y) - .5 * R
+        R = R * R
+        psi = psi - R * (8.333333333e-2 - R * (8.333333333e-3 - R * 3.968253968e-3))
+        out[idx] = psi
+    return out.astype(x.dtype if x.dtype.kind == "f" else "float64")
+
+
+def _trigamma_as121(x):
+    # scalar/math.py:454 TriGamma.c_support_code (AS 121)
+    x = np.asarray(x)
+    out = np.zeros(x.shape, "float64")
+    for idx in np.ndindex(x.shape):
+        v = float(x[idx])
+        if v <= 0:
+            continue
+        if v <= 0.0001:
+            out[idx] = 1.0 / v / v
+            continue
+        value, z = 0.0, v
+        while z < 5.0:
+            value += 1.0 / z / z
+            z += 1.0
+        y = 1.0 / z / z
+        value += 0.5 * y + (1.0 + y * (0.1666666667 + y * (-0.03333333333 + y * (0.02380952381 + y * -0.03333333333)))) / z
+        out[idx] = value
+    return out.astype(x.dtype if x.dtype.kind == "f" else "float64")
+
+
+def _special(name):
+    def f(x):
+        from scipy import special
+        return getattr(special, name)(x)
+    return f
+
+
 def _round_away(x):
     # scalar/basic.py:2799 RoundHalfAwayFromZero
     return np.where(x < 0, np.ceil(x - 0.5), np.floor(x + 0.5))
@@ -75,6 +127,10 @@ _UNARY = {
     "isnan": np.isnan, "isinf": np.isinf, "sigmoid": _sigmoid, "softplus": _softplus,
     "erf": _erf, "erfc": _erfc, "log1mexp": _log1mexp, "deg2rad": np.deg2rad,
     "rad2deg": np.rad2deg,
+    "erfcx": _special("erfcx"), "erfinv": _special("erfinv"), "erfcinv": _special("erfcinv"),
+    "gamma": _special("gamma"), "gammaln": _special("gammaln"), "psi": _psi_as103,
+    "tri_gamma": _trigamma_as121, "j0": _special("j0"), "j1": _special("j1"),
+    "i0": _special("i0"), "i1": _special("i1"),
 }
 
 _BINARY = {
@@ -90,7 +146,8 @@ _NARY = {"add": np.add, "mul": np.multiply, "maximum": np.maximum, "minimum": np
 _FLOAT_FUNCS = {"sqrt", "exp", "exp2", "expm1", "log", "log2", "log10", "log1p", "sin", "cos",
                 "tan", "arcsin", "arccos", "arctan", "sinh", "cosh", "tanh", "arcsinh",
                 "arccosh", "arctanh", "sigmoid", "softplus", "erf", "erfc", "log1mexp",
-                "deg2rad", "rad2deg", "reciprocal", "true_div", "arctan2"}
+                "deg2rad", "rad2deg", "reciprocal", "true_div", "arctan2", "erfcx", "erfinv",
+                "erfcinv", "gamma", "gammaln", "psi", "tri_gamma", "j0", "j1", "i0", "i1"}
 
 
 def eval_scalar_expr(s, ins):
@@ -440,6 +497,30 @@ def run_plan(plan, inputs):
             # reference: tensor/extra_ops.py:311 CumOp.perform (result in the output dtype)
             fn = np.cumsum if p["mode"] == "add" else np.cumprod
             r = [fn(a[0], axis=p["axis"], dtype=ov[0].dtype)]
+        elif op == "Eye":
+            # reference: tensor/basic.py:1278 Eye.perform
+            r = [np.eye(int(np.asarray(a[0])), int(np.asarray(a[1])), int(np.asarray(a[2])), dtype=p["dtype"])]
+        elif op == "Tri":
+            # reference: tensor/basic.py:1000 Tri.perform
+            r = [np.tri(int(np.asarray(a[0])), int(np.asarray(a[1])), int(np.asarray(a[2])), dtype=p["dtype"])]
+        elif op == "ExtractDiag":
+            # reference: tensor/basic.py:3402 ExtractDiag.perform
+            r = [np.array(np.asarray(a[0]).diagonal(p["offset"], p["axis1"], p["axis2"]), copy=True)]
+        elif op == "AllocDiag":
+            # reference: tensor/basic.py:3523 AllocDiag.perform
+            xx = np.asarray(a[0])
+            ax1, ax2 = min(p["axis1"], p["axis2"]), max(p["axis1"], p["axis2"])
+            off = p["offset"]
+            res = np.zeros(xx.shape[:-1] + (xx.shape[-1] + abs(off),) * 2, dtype=xx.dtype)
+            ids = np.arange(xx.shape[-1])
+            res[(Ellipsis, ids + max(0, -off), ids + max(0, off))] = xx
+            if xx.ndim > 1:
+                axes = list(range(xx.ndim - 1))
+                last = axes[-1]
+                axes = axes[:ax1] + [last + 1] + axes[ax1:]
+                axes = axes[:ax2] + [last + 2] + axes[ax2:]
+                res = res.transpose(axes)
+            r = [res]
         elif op == "ARange":
             # reference: tensor/basic.py:2937 ARange.perform
             st, sp, se = (np.asarray(v).item() for v in a)
