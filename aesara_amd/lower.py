@@ -649,6 +649,17 @@ def _register_handlers():
         ctx.emit("AllocDiag", node, {"offset": int(op.offset), "axis1": int(op.axis1),
                                      "axis2": int(op.axis2)})
 
+    from aesara.tensor.math import MatMul
+
+    @hip_lower.register(MatMul)
+    def _(op, node, ctx):
+        # reference: tensor/math.py:2871 MatMul (perform :2941 np.matmul): stacks of matrices in
+        # the last two dims, batch dims broadcast, 1-d operands promoted
+        dts = {v.type.dtype for v in node.inputs} | {node.outputs[0].type.dtype}
+        if len(dts) != 1 or dts.pop() not in ("float32", "float64"):
+            raise UnsupportedOp("MatMul is lowered for float32 / float64 operands of one dtype")
+        ctx.emit("MatMul", node)
+
     from aesara.ifelse import IfElse
 
     @hip_lower.register(IfElse)

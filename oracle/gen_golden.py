@@ -570,6 +570,24 @@ def _():
          I((3,), "int64", 4, -4, 4)]
 
 
+# MatMul (tests/tensor/test_math.py TestMatMul :3440): stacks, broadcast batch dims, promoted vectors
+for _dt, _tol in (("float64", 1e-12), ("float32", 2e-5)):
+    def _mkMM(dt=_dt):
+        # (the reference's MatMul.make_node only accepts fully static N-d shapes: math.py:2924)
+        def TS(shp, name):
+            return TensorType(dt, shape=tuple(shp))(name)
+        a3, b3, m, v = TS((4, 5, 6), "a3"), TS((4, 6, 3), "b3"), TS((6, 3), "m"), TS((6,), "v")
+        a4, b4 = TS((2, 1, 5, 6), "a4"), TS((1, 3, 6, 2), "b4")
+        mm = lambda p, q: at.matmul(p, q, dtype=dt)  # noqa: E731  (default: config.floatX)
+        return [a3, b3, m, v, a4, b4], [mm(a3, b3), mm(a3, m), mm(a3, v), mm(v, b3),
+                                        mm(v, v), mm(a4, b4), mm(m.T, m),
+                                        mm(b3.dimshuffle(0, 2, 1), a3.dimshuffle(0, 2, 1)),
+                                        mm(a4, m), mm(b4.dimshuffle(0, 1, 3, 2), a4.dimshuffle(0, 1, 3, 2))], \
+            [N((4, 5, 6), dt, 1), N((4, 6, 3), dt, 2), N((6, 3), dt, 3), N((6,), dt, 4),
+             N((2, 1, 5, 6), dt, 5), N((1, 3, 6, 2), dt, 6)]
+    case(f"matmul_{_dt}", rtol=_tol, atol=_tol, ref_py=True)(_mkMM)
+
+
 # Eye / Tri / ExtractDiag / AllocDiag (tests/tensor/test_basic.py TestEye :841, TestTriangle :905,
 # TestDiag / test_diag* :3593-3720)
 @case("eye_tri_diag", exact=True)

@@ -497,6 +497,9 @@ def run_plan(plan, inputs):
             # reference: tensor/extra_ops.py:311 CumOp.perform (result in the output dtype)
             fn = np.cumsum if p["mode"] == "add" else np.cumprod
             r = [fn(a[0], axis=p["axis"], dtype=ov[0].dtype)]
+        elif op == "MatMul":
+            # reference: tensor/math.py:2941 MatMul.perform
+            r = [np.matmul(a[0], a[1])]
         elif op == "Eye":
             # reference: tensor/basic.py:1278 Eye.perform
             r = [np.eye(int(np.asarray(a[0])), int(np.asarray(a[1])), int(np.asarray(a[2])), dtype=p["dtype"])]
