@@ -36,6 +36,19 @@ def contiguous_strides(shape):
     return tuple(reversed(st))
 
 
+_DTYPE_NAMES = {}
+
+
+def dtype_name(dt) -> str:
+    """``np.dtype.name`` through a dict (NumPy 2 builds the string on every access: ~1 us, and the
+    call path asks for it several times per input)."""
+    try:
+        return _DTYPE_NAMES[dt]
+    except KeyError:
+        name = _DTYPE_NAMES[dt] = dt.name
+        return name
+
+
 class DevArray:
     """A strided view of device memory: (buffer, element offset, shape, element strides)."""
 
@@ -58,7 +71,7 @@ class DevArray:
     @staticmethod
     def from_numpy(a: np.ndarray, device) -> "DevArray":
         a = np.asarray(a)
-        name = a.dtype.name
+        name = dtype_name(a.dtype)
         if name not in TORCH_DTYPES:
             raise TypeError(f"dtype {name} is not supported on the HIP path")
         src = np.ascontiguousarray(a)
