@@ -42,6 +42,16 @@ class HipLinker(JITLinker):
         self.executor_factory = executor_factory
         self.plan = None
 
+    def __getstate__(self):
+        # a pickled / deep-copied Function is re-linked when it is loaded (the reference pickles the
+        # FunctionMaker, compile/function/types.py:1125 _pickle_Function): device executors,
+        # module handles and the lowered plan are rebuilt then, never serialised
+        state = dict(self.__dict__)
+        for k in ("executor", "plan", "_update_outputs"):
+            state.pop(k, None)
+        state["plan"] = None
+        return state
+
     # -- JITLinker API ---------------------------------------------------------------
     def fgraph_convert(self, fgraph, order=None, input_storage=None, output_storage=None,
                        storage_map=None, **kwargs):

@@ -198,3 +198,31 @@ def test_committed_plans_are_what_the_linker_lowers(ae, name):
     plan.name = name
     committed = next(c for c in CASES if c["name"] == name)["plan"]
     assert json.dumps(plan.to_json(), sort_keys=True) == json.dumps(committed, sort_keys=True)
+
+
+def _picklable_oracle_factory(plan):
+    import interp
+    return lambda *a: interp.run_plan(plan, a)
+
+
+def test_function_api_surface_clone_copy_swap_pickle_profile(ae):
+    """What `Function` / `Mode` do to a linker besides calling it: `Mode.clone` with
+    link kwargs (`Linker.clone`, link/basic.py:190), `Function.copy(swap=...)` (types.py:558),
+    pickling (re-links on load, types.py:1125), `profile=True`."""
+    import pickle
+    import aesara.tensor as at
+    from aesara.compile.mode import Mode
+    from aesara_amd.linker import HIP_QUERY, HipLinker
+    m = Mode(HipLinker(executor_factory=_picklable_oracle_factory, return_numpy=True), HIP_QUERY)
+    m2 = m.clone(link_kwargs=dict(allow_gc=False))
+    assert isinstance(m2.linker, HipLinker) and m2.linker.allow_gc is False and m2.linker.return_numpy
+    x = at.dvector("x")
+    f = ae.function([x], (x * 2).sum(), mode=m2)
+    assert f(np.arange(4.0)) == 12.0 and f.copy()(np.arange(5.0)) == 20.0
+    s = ae.shared(np.ones(3))
+    g = ae.function([], s * 2, mode=m)
+    np.testing.assert_array_equal(g.copy(swap={s: ae.shared(np.full(3, 5.0))})(), [10.0] * 3)
+    f2 = pickle.loads(pickle.dumps(f))
+    assert f2(np.arange(3.0)) == 6.0
+    fp = ae.function([x], (x ** 2).sum(), mode=m, profile=True)
+    assert fp(np.arange(4.0)) == 14.0 and fp.profile.fct_call_time > 0
