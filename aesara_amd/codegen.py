@@ -105,6 +105,8 @@ template <typename T> __device__ __forceinline__ T upow(T b, T e) {
 template <typename T> __device__ __forceinline__ T fmax_nan(T x, T y) { return (y > x) ? y : ((x >= y) ? x : (T)NAN); }
 template <typename T> __device__ __forceinline__ T fmin_nan(T x, T y) { return (y < x) ? y : ((x <= y) ? x : (T)NAN); }
 template <typename T> __device__ __forceinline__ T imax(T x, T y) { return x > y ? x : y; }
+// MulWithoutZeros.c_code (tensor/math.py:2731): zeros are skipped, 0 is the identity
+template <typename T> __device__ __forceinline__ T mwz_(T x, T y) { return x == 0 ? y : (y == 0 ? x : (T)(y * x)); }
 template <typename T> __device__ __forceinline__ T imin(T x, T y) { return x < y ? x : y; }
 // x / c for a loop-invariant c with r = 1/c precomputed: Markstein refinement gives the correctly
 // rounded quotient when c and r are normal numbers (ok: hoisted, wave-uniform) and nothing
@@ -199,6 +201,7 @@ _FLOAT_FN = {
 
 _IDENT = {  # reduction identities
     "add": lambda dt: "0", "mul": lambda dt: "1", "or": lambda dt: "0", "xor": lambda dt: "0",
+    "mul_without_zeros": lambda dt: "0",      # MulWithoutZeros.identity (tensor/math.py:2720)
     "and": lambda dt: "true" if dt == "bool" else "(%s)~(%s)0" % (RTYPE[dt], RTYPE[dt]),
 }
 
@@ -412,6 +415,8 @@ def red_combine(op, acc_dt, a, b):
         return "(bool)((int)%s | (int)%s)" % (a, b) if acc_dt == "bool" else "(%s)(%s + %s)" % (T, a, b)
     if op == "mul":
         return "(bool)((int)%s & (int)%s)" % (a, b) if acc_dt == "bool" else "(%s)(%s * %s)" % (T, a, b)
+    if op == "mul_without_zeros":
+        return "mwz_<%s>(%s, %s)" % (T, a, b)
     if op == "maximum":
         return "%s<%s>(%s, %s)" % ("fmax_nan" if _is_float(acc_dt) else "imax", T, a, b)
     if op == "minimum":

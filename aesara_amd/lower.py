@@ -39,6 +39,8 @@ SCALAR_OP_NAMES = {
     "Erfcx": "erfcx", "Erfinv": "erfinv", "Erfcinv": "erfcinv", "Gamma": "gamma",
     "GammaLn": "gammaln", "Psi": "psi", "TriGamma": "tri_gamma", "J0": "j0", "J1": "j1",
     "I0": "i0", "I1": "i1",
+    # tensor/math.py:2713 MulWithoutZeros (the CAReduce inside ProdWithoutZeros: grad of prod)
+    "MulWithoutZeros": "mul_without_zeros",
 }
 
 
@@ -241,7 +243,7 @@ def _register_handlers():
     def _(op, node, ctx):
         # reference: tensor/elemwise.py:1221 CAReduce; acc rule _acc_dtype :1371; perform :1495
         sname = SCALAR_OP_NAMES.get(type(op.scalar_op).__name__)
-        if sname not in ("add", "mul", "maximum", "minimum", "and", "or", "xor"):
+        if sname not in ("add", "mul", "maximum", "minimum", "and", "or", "xor", "mul_without_zeros"):
             raise UnsupportedOp(f"CAReduce over scalar op {op.scalar_op}")
         idtype = node.inputs[0].type.dtype
         odtype = node.outputs[0].type.dtype

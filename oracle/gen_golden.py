@@ -331,6 +331,15 @@ def _():
         [B((300, 70), 31, 0.004), B((300, 70), 32, 0.996)]
 
 
+@case("prod_grad_with_zeros", rtol=1e-12, atol=1e-12)
+def _():
+    # Prod.L_op (tensor/math.py:2577): rows with one zero get the product of the others through
+    # ProdWithoutZeros = CAReduce(MulWithoutZeros :2713); rows with two zeros get 0
+    x = at.dmatrix("x")
+    return [x], [ae.grad(x.prod(axis=1).sum(), x), ae.grad(x.prod(), x), ae.grad(x.prod(axis=0).sum(), x)], \
+        [I((6, 5), "float64", 5, -2, 4)]
+
+
 @case("red_nan_propagation", exact=True)
 def _():
     x = at.dmatrix("x")

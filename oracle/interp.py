@@ -215,9 +215,16 @@ _REDUCE = {"add": np.add, "mul": np.multiply, "maximum": np.maximum, "minimum": 
 def careduce(x, scalar_op, axis, acc_dtype, out_dtype):
     """reference: tensor/elemwise.py:1495 CAReduce.perform — ``ufunc.reduce`` applied axis by
     axis with ``dtype=acc_dtype`` and a final cast to the output dtype (:1506-1513)."""
-    ufunc = _REDUCE[scalar_op]
     if axis is None:
         axis = list(range(x.ndim))
+    if scalar_op == "mul_without_zeros":
+        # tensor/math.py:2713 MulWithoutZeros (identity 0, zeros skipped): the product of the
+        # non-zero entries, 0 when there is none
+        xa = np.asarray(x).astype(acc_dtype)
+        ax = tuple(axis)
+        v = np.where(xa == 0, 1, xa).prod(axis=ax) * (xa != 0).any(axis=ax)
+        return np.asarray(v, dtype=acc_dtype).astype(out_dtype)
+    ufunc = _REDUCE[scalar_op]
     v = x
     acc = np.dtype(acc_dtype)
     for a in sorted(axis, reverse=True):
