@@ -383,6 +383,24 @@ __global__ __launch_bounds__(256) void linearize_kernel(LinArgs a) {
   }
 }
 
+// ---- Nonzero: coordinates of the set entries of a flat inclusive count (compaction) ----
+constexpr int NZ_MAXD = 8;
+struct NzArgs { const int64_t* cnt; int64_t n; int nd; int64_t shape[NZ_MAXD]; int64_t* out[NZ_MAXD]; };
+
+__global__ __launch_bounds__(256) void nonzero_write_kernel(NzArgs a) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t c = a.cnt[i], prev = i ? a.cnt[i - 1] : 0;
+    if (c == prev) continue;            // entry i is zero
+    int64_t rem = i;
+    for (int d = a.nd - 1; d >= 0; --d) {
+      const int64_t q = rem / a.shape[d];
+      a.out[d][c - 1] = rem - q * a.shape[d];
+      rem = q;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -437,6 +455,19 @@ int ahip_argmax_rows(int dtype, const void* x, int64_t nrows, int64_t k, int64_t
     case AHIP_F64: return run_argmax<double>(a, ws, ws_bytes, s);
     default: ahip_set_error("bad dtype %d", dtype); return AHIP_EINVAL;
   }
+}
+
+int ahip_nonzero_write(const int64_t* counts, int64_t n, int nd, const int64_t* shape,
+                       int64_t* const* outs, void* stream) {
+  AHIP_REQUIRE(nd >= 1 && nd <= NZ_MAXD, "1..8 dims");
+  AHIP_REQUIRE(n >= 0, "negative extent");
+  if (n == 0) return AHIP_OK;
+  AHIP_REQUIRE(counts && shape && outs, "null argument");
+  NzArgs a{};
+  a.cnt = counts; a.n = n; a.nd = nd;
+  for (int d = 0; d < nd; ++d) { a.shape[d] = shape[d]; a.out[d] = outs[d]; }
+  AHIP_LAUNCH(nonzero_write_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), a);
+  return AHIP_OK;
 }
 
 int ahip_linearize_indices(int nidx, const void* const* idx, const int* idx_dtypes,

@@ -591,16 +591,21 @@ def _register_handlers():
                 entries.append({"slice": enc})
             elif isinstance(v.type, NoneTypeT):
                 entries.append({"newaxis": True})
+            elif isinstance(v.type, TensorType) and v.type.dtype == "bool" and v.type.ndim >= 1:
+                # a boolean mask stands for the index arrays of its non-zero entries (NumPy;
+                # subtensor.py:2543): expanded at run time through the Nonzero kernels
+                entries.append({"mask": len(ins), "ndim": int(v.type.ndim)})
+                ins.append(v)
             else:
-                raise UnsupportedOp(f"{type(op).__name__} with a {v.type} index: boolean masks "
-                                    "(data-dependent shapes) are outside the path")
-        if not 1 <= sum(1 for e in entries if "array" in e) <= 8:
+                raise UnsupportedOp(f"{type(op).__name__} with a {v.type} index")
+        n_arr = sum(e.get("ndim", 1) for e in entries if "array" in e or "mask" in e)
+        if not 1 <= n_arr <= 8:
             raise UnsupportedOp("advanced indexing with more than 8 index arrays")
         return entries, ins
 
     def _only_arrays(idx_vars):
         from aesara.tensor.type import TensorType
-        return all(isinstance(v.type, TensorType) for v in idx_vars)
+        return all(isinstance(v.type, TensorType) and v.type.dtype != "bool" for v in idx_vars)
 
     @hip_lower.register(AdvancedSubtensor)
     def _(op, node, ctx):
@@ -650,6 +655,16 @@ def _register_handlers():
         # reference: tensor/basic.py:3487 AllocDiag (perform :3523)
         ctx.emit("AllocDiag", node, {"offset": int(op.offset), "axis1": int(op.axis1),
                                      "axis2": int(op.axis2)})
+
+    from aesara.tensor.basic import Nonzero
+
+    @hip_lower.register(Nonzero)
+    def _(op, node, ctx):
+        # reference: tensor/basic.py:845 Nonzero (perform :870 np.nonzero): ndim int64 vectors
+        # whose length is known only at run time (one device->host read of the count)
+        if not 1 <= node.inputs[0].type.ndim <= 8:
+            raise UnsupportedOp("Nonzero of a 0-d or > 8-d array")
+        ctx.emit("Nonzero", node)
 
     from aesara.tensor.math import MatMul
 

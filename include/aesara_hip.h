@@ -318,6 +318,13 @@ int ahip_scatter_rows(int dtype, void* dst, int64_t nrows, int64_t dst_rs, int64
                       const void* idx, int idx_dtype, int64_t nidx, int64_t idx_stride,
                       const void* src, int64_t src_rs, int accumulate, int64_t* bad_index,
                       void* stream);
+/* Nonzero, replaces tensor/basic.py:845 Nonzero (perform :870 np.nonzero) and boolean-mask
+ * indexing built on it.  `counts` is the inclusive running count of set entries over the
+ * C-order flattened array (n entries; the caller makes it with ahip_cumulative and reads
+ * counts[n-1] to size the outputs); entry i is set iff counts[i] != counts[i-1].  Writes the
+ * coordinates of the set entries, in C order, to outs[0..nd-1] (int64, counts[n-1] each).       */
+int ahip_nonzero_write(const int64_t* counts, int64_t n, int nd, const int64_t* shape,
+                       int64_t* const* outs, void* stream);
 /* N-d integer-array indexing, tensor/subtensor.py:2543 AdvancedSubtensor / :2647 AdvancedIncSubtensor
  * (perform :2607 / :2688) with integer index arrays only: out[j] = sum_d wrap(idx_d[j*stride_d]) * mults[d]
  * is the flat row index consumed by ahip_take_rows / ahip_scatter_rows; each index wraps once

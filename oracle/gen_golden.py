@@ -615,6 +615,21 @@ def _():
          I((4,), "int64", seed=3)]
 
 
+# Nonzero and boolean-mask indexing (tests/tensor/test_basic.py TestNonzero :4116,
+# tests/tensor/test_subtensor.py test_boolean / test_adv_boolean :2450-2560): run-time sized results
+@case("nonzero_and_masks", exact=True, ref_py=True)
+def _():
+    x, t3, v = at.lmatrix("x"), at.ltensor3("t3"), at.lvector("v")
+    m1 = at.gt(v, 0)
+    outs = list(at.nonzero(x)) + list(at.nonzero(t3 > 5)) + [at.flatnonzero(v), at.nonzero(x, return_matrix=True)]
+    outs += [x[x > 0], x[at.lt(x, -50)] * 2, t3[t3 > 90], x[m1[:6]], x[m1[:6], 1:3], t3[:, at.gt(x[:5, :6], 0)],
+             v[m1].sum(), at.set_subtensor(x[x > 0], 0), at.inc_subtensor(x[at.lt(x, 0)], 100),
+             at.set_subtensor(t3[t3 > 0], v[0]), at.inc_subtensor(x[m1[:6]], x[0] * 0 + 7),
+             x[(x > 200).nonzero()], x[at.eq(x, x)].sum()]
+    return [x, t3, v], outs, [I((6, 8), "int64", seed=1, low=-99, high=99), I((4, 5, 6), "int64", seed=2, low=-99, high=99),
+                              I((9,), "int64", seed=3, low=-5, high=5)]
+
+
 @case("join_split_axes", exact=True)
 def _():
     x, y, z = at.ltensor3("x"), at.ltensor3("y"), at.ltensor3("z")

@@ -403,6 +403,8 @@ def adv_index(params, extra):
     for e in params["index"]:
         if "array" in e:
             idx.append(np.asarray(extra[e["array"]]))
+        elif "mask" in e:
+            idx.append(np.asarray(extra[e["mask"]], dtype=bool))
         elif "slice" in e:
             idx.append(slice(*[c if (c is None or isinstance(c, int)) else int(np.asarray(extra[c["in"]]))
                                for c in e["slice"]]))
@@ -504,6 +506,9 @@ def run_plan(plan, inputs):
             # reference: tensor/extra_ops.py:311 CumOp.perform (result in the output dtype)
             fn = np.cumsum if p["mode"] == "add" else np.cumprod
             r = [fn(a[0], axis=p["axis"], dtype=ov[0].dtype)]
+        elif op == "Nonzero":
+            # reference: tensor/basic.py:870 Nonzero.perform
+            r = [np.asarray(i, dtype="int64") for i in np.nonzero(np.asarray(a[0]))]
         elif op == "MatMul":
             # reference: tensor/math.py:2941 MatMul.perform
             r = [np.matmul(a[0], a[1])]
