@@ -491,6 +491,15 @@ for _dt, _tol in (("float64", 1e-12), ("float32", 2e-5)):
     case(f"blas_strides_{_dt}", rtol=_tol, atol=_tol)(_mkBS)
 
 
+@case("gemv_symbolic_alpha_beta", rtol=1e-12, atol=1e-12)
+def _():
+    # alpha / beta of Gemv as run-time 0-d values, row-major and transposed matrices
+    A, v, w, s, t = at.dmatrix("A"), at.dvector("v"), at.dvector("w"), at.dscalar("s"), at.dscalar("t")
+    return [A, v, w, s, t], [s * at.dot(A, v) + w, t * w + s * at.dot(A, v), s * at.dot(A.T, w) + t * v,
+                             at.dot(A.T[::2], w) * s], \
+        [N((9, 14), seed=1), N((14,), seed=2), N((9,), seed=3), K(0.7, "float64"), K(-1.3, "float64")]
+
+
 @case("subtensor_basic", exact=True)
 def _():
     x = at.imatrix("x")

@@ -138,3 +138,193 @@ def test_random_elemwise_and_reduce_plans_match_the_oracle(seed):
                                                err_msg=str(ctx))
                 else:
                     assert np.array_equal(g, w), ctx
+
+
+def _rand_basic_index(rng, shape):
+    """Random basic index (ints and slices, negative / out-of-range bounds and steps included) and
+    its plan encoding (constants inline, some entries dynamic)."""
+    idx, enc, dyn = [], [], []
+
+    def maybe_dyn(v):
+        if v is not None and rng.random() < 0.4:
+            dyn.append(np.int64(v))
+            return "in"
+        return v
+    for n in shape[:int(rng.integers(1, len(shape) + 1))]:
+        if rng.random() < 0.3 and n > 0:
+            i = int(rng.integers(-n, n))
+            idx.append(i)
+            enc.append({"index": maybe_dyn(i)})
+        else:
+            def bound():
+                return None if rng.random() < 0.3 else int(rng.integers(-n - 3, n + 4))
+            st, sp = bound(), bound()
+            se = None if rng.random() < 0.4 else int(rng.choice([-3, -2, -1, 1, 2, 3]))
+            idx.append(slice(st, sp, se))
+            enc.append({"slice": [maybe_dyn(st), maybe_dyn(sp), maybe_dyn(se)]})
+    return tuple(idx), enc, dyn
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_random_indexing_plans_are_bit_exact(seed):
+    """Subtensor views, IncSubtensor (set / inc, broadcast values), AdvancedSubtensor1 /
+    AdvancedIncSubtensor1 and mixed advanced indices with random bounds, steps, negative and
+    repeated indices: bit-exact against NumPy indexing (through the oracle)."""
+    import interp
+    from aesara_amd.executor import PlanExecutor
+    from aesara_amd.plan import Node, Plan, Var
+    rng = np.random.default_rng(2000 + seed)
+    ident = {"n_in": 1, "nodes": [{"op": "neg", "in": [["i", 0]], "dtype": "int64"}], "out": [["t", 0]]}
+    for trial in range(40):
+        nd = int(rng.integers(1, 4))
+        shape = [int(rng.integers(1, 9)) for _ in range(nd)]
+        x = rng.integers(-1000, 1000, shape).astype("int64")
+        index, enc, dyn = _rand_basic_index(rng, shape)
+        sub = x[index]
+        vs = {0: Var(0, "int64", [None] * nd)}
+        for k in range(len(dyn)):
+            vs[1 + k] = Var(1 + k, "int64", [])
+        b = 1 + len(dyn)
+        dyn_ids = list(range(1, b))
+        vs[b] = Var(b, "int64", [None] * sub.ndim)              # the view
+        vs[b + 1] = Var(b + 1, "int64", [None] * sub.ndim)      # -view (forces a kernel on it)
+        yshape = [s if rng.random() < 0.6 else 1 for s in sub.shape][int(rng.integers(0, sub.ndim + 1)):]
+        y = rng.integers(-50, 50, yshape).astype("int64")
+        vs[b + 2] = Var(b + 2, "int64", [1 if s == 1 else None for s in yshape])
+        vs[b + 3] = Var(b + 3, "int64", [None] * nd)
+        vs[b + 4] = Var(b + 4, "int64", [None] * nd)
+        nodes = [Node("Subtensor", [0] + dyn_ids, [b], {"idx_list": enc}),
+                 Node("Elemwise", [b], [b + 1], {"scalar": ident}),
+                 Node("IncSubtensor", [0, b + 2] + dyn_ids, [b + 3],
+                      {"idx_list": enc, "set_instead_of_inc": True, "inplace": False}),
+                 Node("IncSubtensor", [0, b + 2] + dyn_ids, [b + 4],
+                      {"idx_list": enc, "set_instead_of_inc": False, "inplace": False})]
+        ins_ids = [0] + dyn_ids + [b + 2]
+        plan = Plan("fuzz_idx", vs, ins_ids, [b + 1, b + 3, b + 4], nodes)
+        args = [x] + dyn + [y]
+        want = interp.run_plan(plan, args)
+        got = PlanExecutor(plan)(*[_to_dev(a) if np.ndim(a) else a for a in args])
+        for g, w in zip(got, want):
+            g = g.cpu().numpy() if hasattr(g, "cpu") else np.asarray(g)
+            assert g.shape == np.shape(w) and np.array_equal(g, w), (seed, trial, shape, index, yshape)
+        # integer-vector rows: gather, scatter-set (unique rows), scatter-add (repeats)
+        rows = int(rng.integers(2, 12))
+        m = rng.integers(-1000, 1000, (rows, int(rng.integers(1, 6)))).astype("int64")
+        k = int(rng.integers(1, 15))
+        idx = rng.integers(-rows, rows, k).astype(str(rng.choice(["int64", "int32", "int8"])))
+        uniq = rng.permutation(rows)[:min(k, rows)].astype("int64")
+        yv = rng.integers(-9, 9, (k, m.shape[1])).astype("int64")
+        vs = {0: Var(0, "int64", [None, None]), 1: Var(1, idx.dtype.name, [None]), 2: Var(2, "int64", [None, None]),
+              3: Var(3, "int64", [None]), 4: Var(4, "int64", [None, None]), 5: Var(5, "int64", [None, None]),
+              6: Var(6, "int64", [None, None])}
+        nodes = [Node("AdvancedSubtensor1", [0, 1], [4], {}),
+                 Node("AdvancedIncSubtensor1", [0, 2, 1], [5], {"set_instead_of_inc": False, "inplace": False}),
+                 Node("AdvancedIncSubtensor1", [0, 4, 3], [6], {"set_instead_of_inc": True, "inplace": False})]
+        # output 6: x[uniq] = x[idx][:len(uniq)] — build y for the set from the gather
+        plan = Plan("fuzz_adv1", vs, [0, 1, 2, 3], [4, 5], nodes[:2])
+        args = [m, idx, yv, uniq]
+        want = interp.run_plan(plan, args)
+        got = PlanExecutor(plan)(*[_to_dev(a) for a in args])
+        for g, w in zip(got, want):
+            assert np.array_equal(g.cpu().numpy(), w), (seed, trial, "adv1", rows, idx)
+        ys = rng.integers(-9, 9, (len(uniq), m.shape[1])).astype("int64")
+        vs2 = {0: Var(0, "int64", [None, None]), 1: Var(1, "int64", [None, None]), 2: Var(2, "int64", [None]),
+               3: Var(3, "int64", [None, None])}
+        plan = Plan("fuzz_set1", vs2, [0, 1, 2], [3], [Node("AdvancedIncSubtensor1", [0, 1, 2], [3],
+                                                            {"set_instead_of_inc": True, "inplace": False})])
+        (want,) = interp.run_plan(plan, [m, ys, uniq])
+        (got,) = PlanExecutor(plan)(_to_dev(m), _to_dev(ys), _to_dev(uniq))
+        assert np.array_equal(got.cpu().numpy(), want), (seed, trial, "set1")
+        # mixed advanced index on a 3-d array: arrays / slices / newaxis in random positions
+        t3 = rng.integers(-1000, 1000, [int(rng.integers(2, 6)) for _ in range(3)]).astype("int64")
+        n_arr = int(rng.integers(1, 3))
+        pos = sorted(rng.permutation(3)[:n_arr].tolist())
+        L = int(rng.integers(1, 5))
+        entries, extra, np_idx = [], [], []
+        for d in range(3):
+            if d in pos:
+                ia = rng.integers(-t3.shape[d], t3.shape[d], L).astype("int64")
+                entries.append({"array": len(extra)})
+                extra.append(ia)
+                np_idx.append(ia)
+            elif d < max(pos) or rng.random() < 0.7:
+                se = int(rng.choice([-2, -1, 1, 2]))
+                entries.append({"slice": [None, None, se]})
+                np_idx.append(slice(None, None, se))
+            else:
+                break
+            if rng.random() < 0.15:
+                entries.append({"newaxis": True})
+                np_idx.append(None)
+        res = t3[tuple(np_idx)]
+        vs3 = {0: Var(0, "int64", [None] * 3)}
+        for q in range(len(extra)):
+            vs3[1 + q] = Var(1 + q, "int64", [None])
+        o = 1 + len(extra)
+        vs3[o] = Var(o, "int64", [None] * res.ndim)
+        plan = Plan("fuzz_advmix", vs3, list(range(o)), [o],
+                    [Node("AdvancedSubtensor", list(range(o)), [o], {"index": entries})])
+        (want,) = interp.run_plan(plan, [t3] + extra)
+        assert np.array_equal(want, res)
+        (got,) = PlanExecutor(plan)(*[_to_dev(a) for a in [t3] + extra])
+        assert np.array_equal(got.cpu().numpy(), res), (seed, trial, "advmix", t3.shape, entries)
+
+
+@pytest.mark.parametrize("seed", range(2))
+def test_random_blas_shapes_and_layouts(seed):
+    """Gemm / Gemv / Ger / BatchedDot with random extents (0, 1, ragged, around the tile edges),
+    operand layouts (row-major, transposed, stepped views) and alpha / beta, against an fp64
+    NumPy restatement: Frobenius-relative 2e-6 in fp32 (the bar of BASELINE config 3b), 1e-13 fp64."""
+    from aesara_amd.executor import PlanExecutor
+    from aesara_amd.plan import Node, Plan, Var
+    rng = np.random.default_rng(3000 + seed)
+    sizes = [0, 1, 2, 3, 7, 16, 17, 31, 33, 64, 65, 100, 128, 129, 200, 257]
+
+    def close(got, want, dt):
+        got = got.cpu().numpy().astype("float64")
+        tol = 2e-6 if dt == "float32" else 1e-13
+        denom = max(np.linalg.norm(want), 1e-30)
+        return got.shape == want.shape and (want.size == 0 or np.linalg.norm(got - want) / denom <= tol
+                                            or np.abs(got - want).max() <= tol)
+
+    def mat(shape, dt):
+        return _rand_view(rng, rng.standard_normal(shape).astype(dt))
+    for trial in range(40):
+        dt = str(rng.choice(FLOATS))
+        M, N, K = (int(rng.choice(sizes)) for _ in range(3))
+        al, be = float(rng.choice([1.0, 0.8, -1.5])), float(rng.choice([0.0, 1.0, 0.4]))
+        z, x, y = mat((M, N), dt), mat((M, K), dt), mat((K, N), dt)
+        v2 = [Var(0, dt, [None, None]), Var(1, dt, []), Var(2, dt, [None, None]), Var(3, dt, [None, None]),
+              Var(4, dt, []), Var(5, dt, [None, None])]
+        plan = Plan("fz_gemm", {v.id: v for v in v2}, [0, 1, 2, 3, 4], [5],
+                    [Node("Gemm", [0, 1, 2, 3, 4], [5], {"inplace": False})])
+        (got,) = PlanExecutor(plan)(_to_dev(z), np.asarray(al, dt), _to_dev(x), _to_dev(y), np.asarray(be, dt))
+        want = be * z.astype("float64") + al * (x.astype("float64") @ y.astype("float64"))
+        assert close(got, want, dt), ("gemm", seed, trial, dt, M, N, K, al, be)
+        # Gemv: y <- beta y + alpha A x
+        yv, xv = rng.standard_normal(M).astype(dt), rng.standard_normal(K).astype(dt)
+        if rng.random() < 0.5 and K:
+            xv = np.ascontiguousarray(np.repeat(xv, 2))[::2]
+        vv = [Var(0, dt, [None]), Var(1, dt, []), Var(2, dt, [None, None]), Var(3, dt, [None]), Var(4, dt, []),
+              Var(5, dt, [None])]
+        plan = Plan("fz_gemv", {v.id: v for v in vv}, [0, 1, 2, 3, 4], [5],
+                    [Node("Gemv", [0, 1, 2, 3, 4], [5], {"inplace": False})])
+        (got,) = PlanExecutor(plan)(_to_dev(yv), np.asarray(al, dt), _to_dev(x), _to_dev(xv), np.asarray(be, dt))
+        want = be * yv.astype("float64") + al * (x.astype("float64") @ xv.astype("float64"))
+        assert close(got, want, dt), ("gemv", seed, trial, dt, M, K, al, be)
+        # Ger: A + alpha outer(u, w)
+        u, w = rng.standard_normal(M).astype(dt), rng.standard_normal(N).astype(dt)
+        vg = [Var(0, dt, [None, None]), Var(1, dt, []), Var(2, dt, [None]), Var(3, dt, [None]), Var(4, dt, [None, None])]
+        plan = Plan("fz_ger", {v.id: v for v in vg}, [0, 1, 2, 3], [4],
+                    [Node("Ger", [0, 1, 2, 3], [4], {"destructive": False})])
+        (got,) = PlanExecutor(plan)(_to_dev(z), np.asarray(al, dt), _to_dev(u), _to_dev(w))
+        want = z.astype("float64") + al * np.outer(u.astype("float64"), w.astype("float64"))
+        assert close(got, want, dt), ("ger", seed, trial, dt, M, N)
+        # BatchedDot
+        B = int(rng.choice([1, 2, 5]))
+        m2, n2, k2 = (int(rng.choice(sizes[1:10])) for _ in range(3))
+        a3, b3 = mat((B, m2, k2), dt), mat((B, k2, n2), dt)
+        vb = [Var(0, dt, [None] * 3), Var(1, dt, [None] * 3), Var(2, dt, [None] * 3)]
+        plan = Plan("fz_bdot", {v.id: v for v in vb}, [0, 1], [2], [Node("BatchedDot", [0, 1], [2], {})])
+        (got,) = PlanExecutor(plan)(_to_dev(a3), _to_dev(b3))
+        assert close(got, a3.astype("float64") @ b3.astype("float64"), dt), ("bdot", seed, trial, dt, B, m2, n2, k2)
