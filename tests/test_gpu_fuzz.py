@@ -328,3 +328,55 @@ def test_random_blas_shapes_and_layouts(seed):
         plan = Plan("fz_bdot", {v.id: v for v in vb}, [0, 1], [2], [Node("BatchedDot", [0, 1], [2], {})])
         (got,) = PlanExecutor(plan)(_to_dev(a3), _to_dev(b3))
         assert close(got, a3.astype("float64") @ b3.astype("float64"), dt), ("bdot", seed, trial, dt, B, m2, n2, k2)
+
+
+def test_row_chains_and_gemm_epilogues_on_operand_views():
+    """The fused row-chain / GEMM-epilogue / GEMV-chain kernels with transposed, stepped and
+    reversed operand storage (they must fall back or address the views correctly): fused ==
+    unfused == oracle on random shapes."""
+    import interp
+    from golden_util import CASES, case_plan
+    from aesara_amd.executor import PlanExecutor
+    rng = np.random.default_rng(77)
+
+    def plan_of(name):
+        return case_plan(next(c for c in CASES if c["name"] == name))
+    sizes = [1, 2, 5, 16, 17, 33, 64, 100, 129]
+    for name, tol in (("softmax_rows_f32", 3e-6), ("logsoftmax_rows_f64", 1e-12)):
+        dt = "float32" if name.endswith("f32") else "float64"
+        for _ in range(12):
+            n, k = int(rng.choice(sizes)), int(rng.choice(sizes[1:]))
+            x = _rand_view(rng, (rng.standard_normal((n, k)) * 3).astype(dt))
+            (want,) = interp.run_plan(plan_of(name), [np.asarray(x)])
+            for fuse in (True, False):
+                (got,) = PlanExecutor(plan_of(name), fuse=fuse)(_to_dev(x))
+                np.testing.assert_allclose(got.cpu().numpy(), want, rtol=tol, atol=tol, err_msg=str((name, n, k, fuse)))
+    for _ in range(10):
+        a_, b_, k = int(rng.choice(sizes[:6])), int(rng.choice(sizes[:6])), int(rng.choice(sizes[1:]))
+        x = _rand_view(rng, (rng.standard_normal((a_, b_, k)) * 2).astype("float32"))
+        g, bb = _rand_view(rng, rng.standard_normal(k).astype("float32")), rng.standard_normal(k).astype("float32")
+        want = interp.run_plan(plan_of("layernorm_float32"), [np.asarray(x), np.asarray(g), bb])
+        got = PlanExecutor(plan_of("layernorm_float32"))(_to_dev(x), _to_dev(g), _to_dev(bb))
+        for u, w in zip(got, want):
+            np.testing.assert_allclose(u.cpu().numpy(), w, rtol=5e-5, atol=5e-5, err_msg=str((a_, b_, k)))
+    # small-batch layers: x[m,k1] y[m,k2] W,W2[k1,n] U[k2,n] Wt[n,k1] b[n]
+    for _ in range(12):
+        m, k1, k2, n = (int(rng.choice(sizes[:8])) for _ in range(4))
+        mk = lambda *sh: _rand_view(rng, (rng.standard_normal(sh) * 0.3).astype("float32"))  # noqa: E731
+        args = [mk(m, k1), mk(m, k2), mk(k1, n), mk(k1, n), mk(k2, n), mk(n, k1), mk(n)]
+        want = interp.run_plan(plan_of("mlp_layers_float32"), [np.asarray(a) for a in args])
+        got = PlanExecutor(plan_of("mlp_layers_float32"))(*[_to_dev(a) for a in args])
+        for u, w in zip(got, want):
+            np.testing.assert_allclose(u.cpu().numpy(), w, rtol=3e-5, atol=3e-5, err_msg=str((m, k1, k2, n)))
+    # GLM pattern (config 5) and GEMV chains on views
+    for _ in range(8):
+        n, d = int(rng.choice([64, 100, 257, 1024])), int(rng.choice([16, 64, 100, 256]))
+        X = _rand_view(rng, rng.standard_normal((n, d)).astype("float32"))
+        w = _rand_view(rng, (rng.standard_normal(d) / 8).astype("float32"))
+        y = (rng.random(n) < 0.5).astype("float32")
+        args = [X, w, np.asarray(0.1, "float32"), y]
+        want = interp.run_plan(plan_of("cfg5_logistic"), [np.asarray(a) for a in args])
+        got = PlanExecutor(plan_of("cfg5_logistic"))(*[_to_dev(a) if np.ndim(a) else a for a in args])
+        for u, w_ in zip(got, want):
+            u = u.cpu().numpy() if hasattr(u, "cpu") else np.asarray(u)
+            np.testing.assert_allclose(u, w_, rtol=5e-5, atol=2e-3, err_msg=str((n, d)))
