@@ -724,6 +724,51 @@ def _():
     return [x, init, w], [res], [N((15,), seed=1, scale=0.1), N((2,), seed=2), K(0.7, "float64")]
 
 
+# programmatically varied Scans (tests/scan/test_basic.py: test_using_taps_sequence :1012,
+# test_past_future_taps_shared :1166, test_backwards :713, test_multiple_outs_taps :1330, n_steps,
+# gradients through all of them): sequence taps, output taps, nit-sot outputs, non-sequences,
+# go_backwards, explicit n_steps, matrix states — and d(sum of everything)/d(inputs)
+def _scan_variant(k):
+    def mk():
+        rng = np.random.default_rng(900 + k)
+        H = 4
+        x, z, W, h0 = at.dmatrix("x"), at.dmatrix("z"), at.dmatrix("W"), at.dmatrix("h0")
+        seq_taps = [[0], [0, -1], [-1, 1], [0, 2]][k % 4]
+        out_taps = [[-1], [-1, -2], [-1, -3]][k % 3]
+        two_seq = k % 2 == 1
+        backwards = k % 5 == 2
+        with_nit = k % 3 != 1
+        fixed_steps = k % 4 == 3
+
+        def step(*a):
+            a = list(a)
+            xs = [a.pop(0) for _ in seq_taps]
+            zs = [a.pop(0)] if two_seq else []
+            hs = [a.pop(0) for _ in out_taps]
+            Wm = a.pop(0)
+            pre = sum(xs[1:], xs[0]) * 0.5 + (zs[0] * 0.25 if zs else 0)
+            h = at.tanh(at.dot(hs[0], Wm) + pre) + sum((0.1 * (q + 1) * t for q, t in enumerate(hs[1:])), 0)
+            return [h, (h * h).sum() + pre.max()] if with_nit else h
+        seqs = [dict(input=x, taps=seq_taps)] + ([z] if two_seq else [])
+        outs_info = [dict(initial=h0[:len(set(out_taps)) if out_taps == [-1] else -min(out_taps)],
+                          taps=out_taps)] + ([None] if with_nit else [])
+        if out_taps == [-1]:
+            outs_info[0] = h0[0]
+        kw = dict(n_steps=5) if fixed_steps else {}
+        res, _ = ae.scan(step, sequences=seqs, outputs_info=outs_info, non_sequences=[W],
+                         go_backwards=backwards, **kw)
+        res = res if isinstance(res, list) else [res]
+        cost = sum((r ** 2).sum() for r in res)
+        grads = ae.grad(cost, [x, W, h0])
+        return [x, z, W, h0], res + grads, [N((9, H), seed=1, scale=0.5), N((9, H), seed=2, scale=0.5),
+                                            N((H, H), seed=3, scale=0.4), N((3, H), seed=4, scale=0.3)]
+    return mk
+
+
+for _k in range(12):
+    case(f"scan_variant_{_k}", rtol=1e-10, atol=1e-11)(_scan_variant(_k))
+
+
 @case("scan_nitsot_map", rtol=1e-12, atol=1e-12)
 def _():
     x, W = at.dmatrix("x"), at.dmatrix("W")
