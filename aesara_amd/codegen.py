@@ -971,9 +971,11 @@ def generate(spec: KernelSpec):
             L.append("  }")
         else:
             TX = G
-            assert TX <= 64 and 64 % TX == 0 and spec.block % 64 == 0
+            assert (TX <= 64 and 64 % TX == 0 or TX % 64 == 0) and spec.block % TX == 0
             TY = spec.block // TX
-            nw = spec.block // 64
+            # rows of the LDS fold: the waves (TX <= 64: a wave holds 64 / TX reduced rows, folded
+            # by shuffles first) or the TY thread rows (TX > 64: every wave is part of one row)
+            nw = spec.block // 64 if TX <= 64 else TY
             accs = ["acc"] + ["acc_%d" % v for v in range(1, V)]
             for nm in accs[1:]:
                 L.append("  %s %s = %s;" % (acc_t, nm, red_identity(red["op"], red["acc"])))
@@ -1015,9 +1017,14 @@ def generate(spec: KernelSpec):
                              (TX, nm, comb(nm, "shfl_xor_<%s>(%s, m)" % (acc_t, nm))))
             if nw > 1:
                 L.append("  __shared__ %s sm[%d][%d];" % (sm_t, nw, TX * V))
-                L.append("  if ((threadIdx.x & 63) < %d) {" % TX)
+                if TX <= 64:
+                    L.append("  if ((threadIdx.x & 63) < %d) {" % TX)
+                    row = "threadIdx.x >> 6"
+                else:
+                    L.append("  {")
+                    row = "ty"
                 for v, nm in enumerate(accs):
-                    L.append("    sm[threadIdx.x >> 6][tx * %d + %d] = %s;" % (V, v, nm))
+                    L.append("    sm[%s][tx * %d + %d] = %s;" % (row, V, v, nm))
                 L.append("  }")
                 L.append("  __syncthreads();")
             L.append("  if (valid && threadIdx.x < %d) {" % TX)

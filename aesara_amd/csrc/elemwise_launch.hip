@@ -58,6 +58,7 @@ int ahip_set_param(const char* name, int64_t value) {
   else if (!strcmp(name, "reduce_blocks_per_cu")) g_reduce_blocks_per_cu = value;
   else if (!strcmp(name, "gemm_small_max_tiles")) ahip_gemm_set_small_max_tiles(value);
   else if (!strcmp(name, "gemm_skinny_nf")) ahip_gemm_set_skinny_nf(value);
+  else if (!strcmp(name, "gemv_col_blocks_per_cu")) ahip_gemv_set_col_blocks_per_cu(value);
   else { ahip_set_error("unknown parameter %s", name); return AHIP_EINVAL; }
   return AHIP_OK;
 }
@@ -141,8 +142,8 @@ int ahip_elemwise_reduce_axis(ahip_fn_t k, int mode, int nk, int nr, const int64
   AHIP_REQUIRE(nk >= 1 && nr >= 1 && nk + nr <= AHIP_MAXD, "bad nk/nr");
   AHIP_REQUIRE(block >= 64 && block % 64 == 0 && nslices >= 1 && nslices <= 65535,
                "bad block/nslices");
-  AHIP_REQUIRE(vec >= 1 && lanes >= 1 && lanes <= 64 && (lanes & (lanes - 1)) == 0,
-               "bad vec/lanes");
+  AHIP_REQUIRE(vec >= 1 && lanes >= 1 && lanes <= (mode == 0 ? 64 : block) &&
+               (lanes & (lanes - 1)) == 0, "bad vec/lanes");
   ahip_ew_args a;
   int rc = pack_args(&a, nk + nr, shape, nops, ptrs, strides);
   if (rc) return rc;

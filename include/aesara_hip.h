@@ -212,7 +212,7 @@ int ahip_elemwise_reduce_all(ahip_fn_t k, int nd, const int64_t* shape, int nops
  * host; shape/strides cover nk+nr dims in that order.  `k` is generated for (mode, vec,
  * lanes).  mode 0 ("row", unit stride inside the reduced group): `lanes` (power of two <= 64)
  * adjacent lanes per output element, each taking `vec`-element vectors of the reduced run.
- * mode 1 ("col", unit stride inside the kept group): workgroups of `lanes` x (block/lanes)
+ * mode 1 ("col", unit stride inside the kept group; `lanes` up to block): workgroups of `lanes` x (block/lanes)
  * threads, `vec` adjacent outputs per thread, block/lanes reduced rows in flight, folded in a
  * fixed order.  `nslices`>1 splits the reduced run over gridDim.y and writes
  * [nslices, n_kept] partials (accumulator dtype) into `out_or_ws` for a second pass.       */
