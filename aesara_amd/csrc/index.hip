@@ -228,15 +228,16 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(ArgmaxArgs a) {
   }
 }
 
-// Column form (axis 0 of a matrix: the outputs are adjacent in memory, x_rs == 1): 64 lanes x V
-// adjacent outputs per workgroup row, 4 rows of the reduced index in flight, gridDim.y slices of
+// Column form (axis 0 of a matrix: the outputs are adjacent in memory, x_rs == 1): 128 lanes x V
+// adjacent outputs per workgroup row, 2 rows of the reduced index in flight, gridDim.y slices of
 // the reduced run; `beats` is a total order on (value, index), so any fold order gives np.argmax.
 template <typename T, int V>
 __global__ __launch_bounds__(256) void argmax_cols_kernel(ArgmaxArgs a) {
   struct alignas(sizeof(T) * V >= 16 ? 16 : sizeof(T) * V) P { T v[V]; };
   const T* __restrict__ x = static_cast<const T*>(a.x);
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int64_t o0 = ((int64_t)blockIdx.x * 64 + tx) * V;
+  constexpr int TX = 128, TY = 2;   // 2 KiB (fp32 x4) of every row per workgroup
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const int64_t o0 = ((int64_t)blockIdx.x * TX + tx) * V;
   const bool valid = o0 < a.nrows;
   const int64_t per = (a.k + a.nslices - 1) / a.nslices;
   const int64_t kb = (int64_t)blockIdx.y * per, ke = (kb + per < a.k) ? kb + per : a.k;
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(256) void argmax_cols_kernel(ArgmaxArgs a) {
       for (int e = 0; e < V; ++e) { best[e] = p.v[e]; bi[e] = j; }
     }
 #pragma unroll 8
-    for (j += 4; j < ke; j += 4) {
+    for (j += TY; j < ke; j += TY) {
       const P p = *reinterpret_cast<const P*>(x + j * a.x_cs + o0);
 #pragma unroll
       for (int e = 0; e < V; ++e) {
@@ -262,15 +263,15 @@ __global__ __launch_bounds__(256) void argmax_cols_kernel(ArgmaxArgs a) {
       }
     }
   }
-  __shared__ T sv[4][64 * V];
-  __shared__ int64_t si[4][64 * V];
+  __shared__ T sv[TY][TX * V];
+  __shared__ int64_t si[TY][TX * V];
 #pragma unroll
   for (int e = 0; e < V; ++e) { sv[ty][tx * V + e] = best[e]; si[ty][tx * V + e] = bi[e]; }
   __syncthreads();
   if (ty != 0 || !valid) return;
 #pragma unroll
   for (int e = 0; e < V; ++e) {
-    for (int w = 1; w < 4; ++w) {
+    for (int w = 1; w < TY; ++w) {
       const T v = sv[w][tx * V + e];
       const int64_t i = si[w][tx * V + e];
       const bool take = (i >= 0) & ((bi[e] < 0) | beats(v, i, best[e], bi[e]));
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(256) void argmax_fold_kernel(ArgmaxArgs a) {
 
 int64_t argmax_slices(int itemsize, int64_t nrows, int64_t k, int64_t x_rs, int64_t x_cs) {
   if (x_rs != 1 || x_cs == 1 || nrows < 16 || k < 64) return 0;    // 0 = row form
-  const int64_t per_block = 64 * (16 / itemsize);                   // outputs per workgroup (vector form)
+  const int64_t per_block = 128 * (16 / itemsize);                   // outputs per workgroup (vector form)
   const int64_t bx = (nrows + per_block - 1) / per_block;
   int64_t want = (8 * (int64_t)ahip_cu_count() + bx - 1) / bx;
   if (want > 64) want = 64;
@@ -330,10 +331,10 @@ int run_argmax(ArgmaxArgs& a, void* ws, size_t ws_bytes, hipStream_t s) {
   const bool vec = VEC > 1 && a.nrows % VEC == 0 && (a.x_cs * (int64_t)sizeof(T)) % 16 == 0 &&
                    reinterpret_cast<uintptr_t>(a.x) % 16 == 0;
   if (vec) {
-    const int64_t bx = (a.nrows / VEC + 63) / 64;
+    const int64_t bx = (a.nrows / VEC + 127) / 128;
     AHIP_LAUNCH((argmax_cols_kernel<T, VEC>), dim3((unsigned)bx, (unsigned)ns), dim3(256), 0, s, a);
   } else {
-    const int64_t bx = (a.nrows + 63) / 64;
+    const int64_t bx = (a.nrows + 127) / 128;
     AHIP_LAUNCH((argmax_cols_kernel<T, 1>), dim3((unsigned)bx, (unsigned)ns), dim3(256), 0, s, a);
   }
   if (ns > 1)
