@@ -286,8 +286,9 @@ double host_scalar(int dtype, const void* p) {
 
 }  // namespace
 
-void ahip_gemv_set_col_blocks_per_cu(int64_t v) {
-  if (v >= 1000) g_col_tm_max = v - 1000; else g_col_blocks_per_cu = v;   // 1000 + tm: tuning hook
+void ahip_gemv_set_col_blocks_per_cu(int64_t v) { g_col_blocks_per_cu = v; }
+void ahip_gemv_set_col_strip_lanes(int64_t v) {
+  if (v >= 1 && v <= 256 && (v & (v - 1)) == 0) g_col_tm_max = v;
 }
 
 extern "C" {

@@ -154,7 +154,9 @@ int ahip_get_device_info(ahip_device_info* out);
 int ahip_stream_synchronize(void* stream);
 /* launch-shape tunables: "stream_blocks_per_cu" (default 8), "reduce_blocks_per_cu" (default 8),
  * "gemm_small_max_tiles" (default 64: below that many 128x128 tiles ahip_gemm uses the
- * 16x16-tile split-K kernel that gives every CU work on small outputs)                        */
+ * 16x16-tile split-K kernel that gives every CU work on small outputs), "gemm_skinny_nf",
+ * "gemv_col_blocks_per_cu" (default 4) and "gemv_col_strip_lanes" (default 128: lanes x 16 B
+ * of every row per workgroup in the transposed-matrix GEMV)                                    */
 int ahip_set_param(const char* name, int64_t value);
 
 /* ---- runtime compilation of generated kernels ------------------------------------------
