@@ -656,6 +656,23 @@ def _register_handlers():
         ctx.emit("AllocDiag", node, {"offset": int(op.offset), "axis1": int(op.axis1),
                                      "axis2": int(op.axis2)})
 
+    from aesara.tensor.sort import ArgSortOp, SortOp
+
+    def _sort_common(op, node, ctx, name):
+        # reference: tensor/sort.py:29 SortOp / :150 ArgSortOp (x, axis); structured-array
+        # `order` is meaningless for plain tensors
+        if getattr(op, "order", None) is not None:
+            raise UnsupportedOp(f"{name} with a field order")
+        ctx.emit(name, node, {"kind": str(op.kind)})
+
+    @hip_lower.register(SortOp)
+    def _(op, node, ctx):
+        _sort_common(op, node, ctx, "Sort")
+
+    @hip_lower.register(ArgSortOp)
+    def _(op, node, ctx):
+        _sort_common(op, node, ctx, "ArgSort")
+
     from aesara.tensor.basic import Nonzero
 
     @hip_lower.register(Nonzero)

@@ -320,6 +320,15 @@ int ahip_scatter_rows(int dtype, void* dst, int64_t nrows, int64_t dst_rs, int64
                       const void* idx, int idx_dtype, int64_t nidx, int64_t idx_stride,
                       const void* src, int64_t src_rs, int accumulate, int64_t* bad_index,
                       void* stream);
+/* ---- K13: sort / argsort of rows ----------------------------------------------------------------
+ * replaces: tensor/sort.py:29 SortOp (perform :48 np.sort) / :150 ArgSortOp (perform :184
+ * np.argsort) along the last axis.  x is viewed as [rows, n] with element strides x_rs / x_cs;
+ * keys_out (same dtype, may be NULL) and idx_out (int64, may be NULL) are C-contiguous [rows, n].
+ * Ascending, NaN last, ties in input order (NumPy's stable order; its default introsort leaves
+ * ties unspecified).  One workgroup per row, bitonic network in LDS: n <= ahip_sort_max_row().  */
+int ahip_sort_max_row(int dtype);
+int ahip_sort_rows(int dtype, const void* x, int64_t rows, int64_t n, int64_t x_rs, int64_t x_cs,
+                   void* keys_out, int64_t* idx_out, void* stream);
 /* Nonzero, replaces tensor/basic.py:845 Nonzero (perform :870 np.nonzero) and boolean-mask
  * indexing built on it.  `counts` is the inclusive running count of set entries over the
  * C-order flattened array (n entries; the caller makes it with ahip_cumulative and reads

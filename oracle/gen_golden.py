@@ -624,6 +624,21 @@ def _():
          I((4,), "int64", seed=3)]
 
 
+# Sort / ArgSort (tests/tensor/test_sort.py TestSort :50, test_argsort :186, test_argsort_grad):
+# distinct keys (NumPy's default introsort leaves the order of ties unspecified), NaN last,
+# every axis, negative axis, axis=None, gradients through the permutation
+@case("sort_argsort", rtol=1e-12, atol=1e-12)
+def _():
+    x, t3, iv = at.dmatrix("x"), at.dtensor3("t3"), at.lvector("iv")
+    xn = at.switch(at.gt(x, 1.5), np.nan, x)
+    return [x, t3, iv], [at.sort(x), at.sort(x, axis=0), at.argsort(x, axis=1), at.argsort(x, axis=0),
+                         at.sort(t3, axis=1), at.argsort(t3, axis=-1), at.sort(x, axis=None), at.argsort(x, axis=None),
+                         at.sort(iv), at.argsort(iv), at.sort(xn, axis=1), at.sort(x.T[::2], axis=0),
+                         ae.grad((at.sort(x, axis=1) * at.arange(11)).sum(), x),
+                         x[at.arange(7)[:, None], at.argsort(x, axis=1)][:, :3]], \
+        [N((7, 11), seed=1), N((3, 6, 5), seed=2), {"kind": "perm", "seed": 3, "shape": [9], "dtype": "int64", "n": 50}]
+
+
 # Nonzero and boolean-mask indexing (tests/tensor/test_basic.py TestNonzero :4116,
 # tests/tensor/test_subtensor.py test_boolean / test_adv_boolean :2450-2560): run-time sized results
 @case("nonzero_and_masks", exact=True, ref_py=True)

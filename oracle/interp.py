@@ -506,6 +506,13 @@ def run_plan(plan, inputs):
             # reference: tensor/extra_ops.py:311 CumOp.perform (result in the output dtype)
             fn = np.cumsum if p["mode"] == "add" else np.cumprod
             r = [fn(a[0], axis=p["axis"], dtype=ov[0].dtype)]
+        elif op in ("Sort", "ArgSort"):
+            # reference: tensor/sort.py:48 SortOp.perform / :184 ArgSortOp.perform.  Ties in input
+            # order (kind="stable"): the only defined order; equal to the default introsort's result
+            # whenever the keys are distinct
+            ax = None if a[1] is None or np.asarray(a[1]).dtype == object else int(np.asarray(a[1]))
+            fn = np.sort if op == "Sort" else np.argsort
+            r = [np.asarray(fn(np.asarray(a[0]), axis=ax, kind="stable"), dtype=ov[0].dtype)]
         elif op == "Nonzero":
             # reference: tensor/basic.py:870 Nonzero.perform
             r = [np.asarray(i, dtype="int64") for i in np.nonzero(np.asarray(a[0]))]
