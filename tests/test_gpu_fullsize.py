@@ -498,3 +498,36 @@ def test_argmax_row_and_column_forms_against_torch():
             xf = _randn(shape, torch.float32, 4)
             (got,) = PlanExecutor(_one_node_plan("Argmax", [("float32", 2)], ("int64", 1), {"axis": [axis]}))(xf)
             assert torch.equal(got, xf.argmax(dim=axis)), (shape, axis)
+
+
+def test_sort_and_argsort_rows_against_torch_stable_sort():
+    """Sort / ArgSort at the LDS capacity, odd lengths, many ties (stable order), NaNs (last),
+    several dtypes and axes; rows that do not fit are refused loudly."""
+    import torch
+    from aesara_amd.executor import PlanExecutor
+
+    def plans(dt, nd):
+        from aesara_amd.plan import Node, Plan, Var
+        out = []
+        for op, odt in (("Sort", dt), ("ArgSort", "int64")):
+            vs = {0: Var(0, dt, [None] * nd), 1: Var(1, "int64", []), 2: Var(2, odt, [None] * nd)}
+            out.append(Plan(op, vs, [0, 1], [2], [Node(op, [0, 1], [2], {"kind": "quicksort"})]))
+        return out
+    for shape, axis in (((300, 4096), 1), ((4096, 70), 0), ((5, 1000, 7), 1), ((2000, 3), 1), ((1, 1), 0),
+                        ((33, 1025), -1)):
+        for tdt, dt in ((torch.float64, "float64"), (torch.float32, "float32"), (torch.int32, "int32"),
+                        (torch.int8, "int8")):
+            if tdt.is_floating_point:
+                x = torch.round(_randn(shape, tdt, 9) * 3)          # many ties
+                x.view(-1)[::997] = float("nan")
+            else:
+                x = torch.randint(-20, 20, shape, dtype=tdt, device="cuda")
+            ps, pa = plans(dt, len(shape))
+            (vals,) = PlanExecutor(ps)(x, np.int64(axis))
+            (idx,) = PlanExecutor(pa)(x, np.int64(axis))
+            wv, wi = torch.sort(x, dim=axis, stable=True)
+            assert torch.equal(torch.nan_to_num(vals, nan=1e30), torch.nan_to_num(wv, nan=1e30)), (shape, axis, dt)
+            assert torch.equal(idx, wi), (shape, axis, dt)
+    ps, _ = plans("float64", 2)
+    with pytest.raises(NotImplementedError):
+        PlanExecutor(ps)(_randn((2, 5000), torch.float64, 1), np.int64(1))
