@@ -328,6 +328,8 @@ def scalar_node_expr(op, ins, in_dts, dt):
         return "softplus_(%s)" % c[0]
     if op == "log1mexp":
         return "log1mexp_(%s)" % c[0]
+    if op == "softsign" and _is_float(dt):
+        return "(%s / ((%s)1 + %s(%s)))" % (c[0], T, _fname("fabs", dt), c[0])
     if op == "psi" and _is_float(dt):
         return "(%s)psi_as103((double)%s)" % (T, c[0])
     if op == "tri_gamma" and _is_float(dt):

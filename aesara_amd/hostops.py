@@ -18,7 +18,8 @@ _BIN = {"sub": np.subtract, "int_div": np.floor_divide, "mod": np.mod, "pow": np
         "true_div": np.true_divide}
 _UN = {"neg": np.negative, "abs": np.abs, "sgn": np.sign, "sqr": np.square,
        "identity": lambda x: x, "invert": np.invert, "ceil": np.ceil, "floor": np.floor,
-       "trunc": np.trunc, "sqrt": np.sqrt, "exp": np.exp, "log": np.log}
+       "trunc": np.trunc, "sqrt": np.sqrt, "exp": np.exp, "log": np.log,
+       "reciprocal": np.reciprocal, "round_half_to_even": np.around}
 
 
 _HOST_MEMO = {}

@@ -25,8 +25,23 @@ from aesara.link.basic import JITLinker
 
 from .lower import lower_fgraph
 
+# the query below names rewrites of tensor/nnet/basic.py: they must be registered before a query
+# mentions them (a RewriteDatabase refuses to register a name that a query has already created)
+import aesara.tensor.nnet.basic  # noqa: E402,F401  isort:skip
+
 HIP_QUERY = RewriteDatabaseQuery(
-    include=["fast_run"], exclude=["cxx_only", "inplace", "c_blas", "BlasOpt_inplace"]
+    include=["fast_run"],
+    exclude=["cxx_only", "inplace", "c_blas", "BlasOpt_inplace",
+             # tensor/nnet/basic.py rewrites that replace Softmax / log / indexing sub-graphs by the
+             # CPU-specific fused Ops SoftmaxWithBias (:321), CrossentropySoftmaxArgmax1HotWithBias
+             # (:1016/:1043/:1214), CrossentropySoftmax1HotWithBiasDx (:1108/:1262): the primitives
+             # they start from are what the row-chain kernels fuse here
+             "local_softmax_with_bias", "crossentropy_to_crossentropy_with_softmax_with_bias",
+             "crossentropy_to_crossentropy_with_softmax", "xent",
+             "local_softmax_grad_to_crossentropy_with_softmax_grad",
+             "local_crossentropy_to_crossentropy_with_softmax_grad", "local_argmax_pushdown",
+             "local_advanced_indexing_crossentropy_onehot",
+             "local_advanced_indexing_crossentropy_onehot_grad"],
 )
 
 

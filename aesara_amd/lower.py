@@ -41,6 +41,7 @@ SCALAR_OP_NAMES = {
     "I0": "i0", "I1": "i1",
     # tensor/math.py:2713 MulWithoutZeros (the CAReduce inside ProdWithoutZeros: grad of prod)
     "MulWithoutZeros": "mul_without_zeros",
+    "ScalarSoftsign": "softsign",      # tensor/nnet/basic.py:2040: x / (1 + |x|)
 }
 
 
@@ -655,6 +656,46 @@ def _register_handlers():
         # reference: tensor/basic.py:3487 AllocDiag (perform :3523)
         ctx.emit("AllocDiag", node, {"offset": int(op.offset), "axis1": int(op.axis1),
                                      "axis2": int(op.axis2)})
+
+    from aesara.tensor.nnet.basic import (CrossentropyCategorical1Hot,
+                                          CrossentropyCategorical1HotGrad)
+
+    def _row_pick(ctx, coding, idx):
+        """coding[arange(N), idx] on plan variables -> (gathered vid, arange vid, N vid, K vid)"""
+        n = ctx.raw("Shape_i", [coding], "int64", [], {"i": 0})
+        k = ctx.raw("Shape_i", [coding], "int64", [], {"i": 1})
+        zero, one = ctx.plan.add_const(0, "int64"), ctx.plan.add_const(1, "int64")
+        ar = ctx.raw("ARange", [zero, n, one], "int64", [None], {"dtype": "int64"})
+        dt = ctx.plan.vars[coding].dtype
+        picked = ctx.raw("AdvancedSubtensor", [coding, ar, idx], dt, [None])
+        return picked, ar, n, k
+
+    @hip_lower.register(CrossentropyCategorical1Hot)
+    def _(op, node, ctx):
+        # reference: tensor/nnet/basic.py:940 CrossentropyCategorical1Hot (perform :990):
+        # y[i] = -log(coding_dist[i, true_one_of_n[i]]) — a row gather + one Elemwise
+        coding, idx = (ctx.vid(v) for v in node.inputs)
+        dt = node.outputs[0].type.dtype
+        picked, _, _, _ = _row_pick(ctx, coding, idx)
+        sc = {"n_in": 1, "nodes": [{"op": "log", "in": [["i", 0]], "dtype": dt},
+                                   {"op": "neg", "in": [["t", 0]], "dtype": dt}], "out": [["t", 1]]}
+        ctx.vmap[node.outputs[0]] = ctx.raw("Elemwise", [picked], dt, [None], {"scalar": sc})
+
+    @hip_lower.register(CrossentropyCategorical1HotGrad)
+    def _(op, node, ctx):
+        # reference: tensor/nnet/basic.py:905 CrossentropyCategorical1HotGrad (perform :928):
+        # zeros_like(coding) with g[i, idx[i]] = -g_y[i] / coding[i, idx[i]]
+        g_y, coding, idx = (ctx.vid(v) for v in node.inputs)
+        dt = node.outputs[0].type.dtype
+        picked, ar, n, k = _row_pick(ctx, coding, idx)
+        sc = {"n_in": 2, "nodes": [{"op": "neg", "in": [["i", 0]], "dtype": dt},
+                                   {"op": "true_div", "in": [["t", 0], ["i", 1]], "dtype": dt}],
+              "out": [["t", 1]]}
+        val = ctx.raw("Elemwise", [g_y, picked], dt, [None], {"scalar": sc})
+        zeros = ctx.raw("Alloc", [ctx.plan.add_const(0, dt), n, k], dt, [None, None])
+        ctx.vmap[node.outputs[0]] = ctx.raw(
+            "AdvancedIncSubtensor", [zeros, val, ar, idx], dt, [None, None],
+            {"set_instead_of_inc": True, "inplace": False})
 
     from aesara.tensor.sort import ArgSortOp, SortOp
 

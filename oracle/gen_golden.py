@@ -624,6 +624,26 @@ def _():
          I((4,), "int64", seed=3)]
 
 
+# tensor/nnet front-end functions (tests/tensor/nnet/test_basic.py: test_softmax_with_bias,
+# TestCrossEntropyCategorical1Hot :417, test_crossentropy_softmax_1hot_with_bias_dx): the
+# logistic-regression tutorial graph — categorical_crossentropy(softmax(x W + b), y) with its
+# gradients and an SGD update — and the activation helpers
+for _dt, _tol in (("float64", 1e-12), ("float32", 2e-5)):
+    def _mkLR(dt=_dt):
+        import aesara.tensor.nnet as nn
+        x, W, b, y = T(dt, (24, 10), "x"), T(dt, (10, 6), "W"), T(dt, (6,), "b"), at.lvector("y")
+        p = nn.softmax(at.dot(x, W) + b)
+        loss = nn.categorical_crossentropy(p, y).mean() + np.asarray(1e-3, dt) * (W ** 2).sum()
+        gW, gb = ae.grad(loss, [W, b])
+        lr = np.asarray(0.1, dt)
+        return [x, W, b, y], [loss, W - lr * gW, b - lr * gb, at.argmax(p, axis=1),
+                              nn.categorical_crossentropy(p, y), nn.relu(x), nn.relu(x, 0.1), nn.elu(x),
+                              nn.softsign(x), nn.hard_sigmoid(x),
+                              nn.binary_crossentropy(at.sigmoid(at.dot(x, W)), at.gt(at.dot(x, W), 0.3)).mean()], \
+            [N((24, 10), dt, 1), N((10, 6), dt, 2, 0.3), N((6,), dt, 3, 0.1), I((24,), "int64", 4, 0, 6)]
+    case(f"nnet_logreg_tutorial_{_dt}", rtol=_tol, atol=_tol)(_mkLR)
+
+
 # Sort / ArgSort (tests/tensor/test_sort.py TestSort :50, test_argsort :186, test_argsort_grad):
 # distinct keys (NumPy's default introsort leaves the order of ties unspecified), NaN last,
 # every axis, negative axis, axis=None, gradients through the permutation

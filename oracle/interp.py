@@ -131,6 +131,7 @@ _UNARY = {
     "gamma": _special("gamma"), "gammaln": _special("gammaln"), "psi": _psi_as103,
     "tri_gamma": _trigamma_as121, "j0": _special("j0"), "j1": _special("j1"),
     "i0": _special("i0"), "i1": _special("i1"),
+    "softsign": lambda x: x / (1.0 + np.abs(x)),     # tensor/nnet/basic.py:2048
 }
 
 _BINARY = {
@@ -147,7 +148,7 @@ _FLOAT_FUNCS = {"sqrt", "exp", "exp2", "expm1", "log", "log2", "log10", "log1p",
                 "tan", "arcsin", "arccos", "arctan", "sinh", "cosh", "tanh", "arcsinh",
                 "arccosh", "arctanh", "sigmoid", "softplus", "erf", "erfc", "log1mexp",
                 "deg2rad", "rad2deg", "reciprocal", "true_div", "arctan2", "erfcx", "erfinv",
-                "erfcinv", "gamma", "gammaln", "psi", "tri_gamma", "j0", "j1", "i0", "i1"}
+                "erfcinv", "gamma", "gammaln", "psi", "tri_gamma", "j0", "j1", "i0", "i1", "softsign"}
 
 
 def eval_scalar_expr(s, ins):
