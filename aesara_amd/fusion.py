@@ -56,7 +56,7 @@ def _inline_constants(step: Step, plan: Plan):
     keep, remap = [], {}
     for pos, vid in enumerate(step.inputs):
         v = plan.vars[vid]
-        if v.const is not None and len(v.const["data"]) == 1:
+        if v.const is not None and len(v.const.get("data", ())) == 1:
             val = v.const["data"][0]
             remap[pos] = ["c", val, v.dtype]
         else:
@@ -218,7 +218,7 @@ def _split_gemv(plan: Plan, node: Node, steps, producer) -> Step:
     steps.append(dot)
     producer[d_var] = dot
     beta = plan.vars[bv]
-    beta_zero = beta.const is not None and len(beta.const["data"]) == 1 and \
+    beta_zero = beta.const is not None and len(beta.const.get("data", ())) == 1 and \
         float(beta.const["data"][0]) == 0.0
     if beta_zero:
         # BLAS semantics: beta == 0 never reads y (it is usually an uninitialised AllocEmpty)
@@ -309,7 +309,7 @@ def hoist_sequence_dots(plan: Plan, seq_inputs: List[int], invariant: set):
     "mat": invariant id, "alpha": float, "out": var id (appended to the plan inputs)}."""
     def const_value(vid):
         v = plan.vars[vid]
-        if v.const is not None and len(v.const["data"]) == 1:
+        if v.const is not None and len(v.const.get("data", ())) == 1:
             return float(v.const["data"][0])
         return None
 
@@ -639,7 +639,7 @@ def _fuse_gemm_epi(plan: Plan, steps: List[Step], max_dots: int = 3, max_ops: in
 
     def const1(vid):
         v = plan.vars[vid]
-        return v.const is not None and len(v.const["data"]) == 1
+        return v.const is not None and len(v.const.get("data", ())) == 1
 
     producer = {}
     for j, t in enumerate(steps):

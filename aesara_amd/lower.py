@@ -146,8 +146,6 @@ class _Ctx:
             return self.vmap[v]
         if isinstance(v, Constant):
             data = np.asarray(v.data)
-            if data.size > 4096:
-                raise UnsupportedOp("large graph constants are not embedded in plans")
             vid = self.plan.add_const(data, dtype=v.type.dtype, name=None)
             # keep static broadcast pattern of the constant's type
             self.plan.vars[vid].shape = _static_shape(v.type)

@@ -61,7 +61,10 @@ class Var:
         if self.name:
             d["name"] = self.name
         if self.const is not None:
-            d["const"] = self.const
+            c = self.const
+            if "array" in c:    # large constants are held as arrays; a list only when serialised
+                c = {"shape": c["shape"], "data": np.asarray(c["array"]).ravel().tolist()}
+            d["const"] = c
         return d
 
     @staticmethod
@@ -70,6 +73,8 @@ class Var:
 
     def const_value(self) -> np.ndarray:
         assert self.const is not None
+        if "array" in self.const:
+            return np.asarray(self.const["array"], dtype=self.dtype).reshape(self.const["shape"])
         arr = np.array(self.const["data"], dtype=self.dtype)
         return arr.reshape(self.const["shape"])
 
@@ -127,7 +132,11 @@ class Plan:
 
     def add_const(self, value, dtype=None, name=None) -> int:
         arr = np.asarray(value, dtype=dtype)
-        const = {"shape": list(arr.shape), "data": arr.ravel().tolist()}
+        if arr.size > 4096:
+            # data embedded in the graph (a design matrix, a lookup table): kept by reference
+            const = {"shape": list(arr.shape), "array": np.ascontiguousarray(arr)}
+        else:
+            const = {"shape": list(arr.shape), "data": arr.ravel().tolist()}
         shape = [1 if s == 1 else int(s) for s in arr.shape]
         return self.new_var(arr.dtype.name, shape, name, const)
 

@@ -226,3 +226,25 @@ def test_function_api_surface_clone_copy_swap_pickle_profile(ae):
     assert f2(np.arange(3.0)) == 6.0
     fp = ae.function([x], (x ** 2).sum(), mode=m, profile=True)
     assert fp(np.arange(4.0)) == 14.0 and fp.profile.fct_call_time > 0
+
+
+def test_large_graph_constants_are_kept_by_reference(ae):
+    """Data embedded in the graph (`at.as_tensor(X)` of a design matrix): the plan holds the array
+    itself, serialises it only on demand, and the executor uploads it once."""
+    import aesara.tensor as at
+    from aesara.compile.mode import Mode
+    from aesara_amd.executor import PlanExecutor
+    from aesara_amd.linker import HIP_QUERY
+    from aesara_amd.plan import Plan
+    import interp
+    X = np.random.default_rng(0).standard_normal((200, 50))
+    w = at.dvector("w")
+    out = at.dot(at.as_tensor(X), w).sum() + (at.as_tensor(X) ** 2).sum(axis=0)[:3].sum()
+    f = ae.function([w], out, mode=Mode(_oracle_linker(), HIP_QUERY))
+    wv = np.arange(50.0)
+    np.testing.assert_allclose(f(wv), (X @ wv).sum() + (X ** 2).sum(axis=0)[:3].sum(), rtol=1e-12)
+    plan = f.maker.linker.plan
+    big = [v for v in plan.vars.values() if v.const is not None and "array" in v.const]
+    assert len(big) == 1 and big[0].const["array"].shape == (200, 50)
+    np.testing.assert_allclose(interp.run_plan(Plan.loads(plan.dumps()), [wv])[0], f(wv), rtol=1e-12)
+    PlanExecutor(plan, dry_run=True)(wv)
