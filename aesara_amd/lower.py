@@ -45,6 +45,10 @@ SCALAR_OP_NAMES = {
 }
 
 
+_PLAN_DTYPES = {"float32", "float64", "int8", "int16", "int32", "int64", "uint8", "uint16", "uint32",
+                "uint64", "bool"}
+
+
 class UnsupportedOp(NotImplementedError):
     """Raised for Ops outside the hot path: the linker reports them loudly."""
 
@@ -157,6 +161,9 @@ class _Ctx:
         t = v.type
         if not hasattr(t, "dtype"):
             raise UnsupportedOp(f"non-tensor variable type {t}")
+        if str(t.dtype) not in _PLAN_DTYPES:
+            raise UnsupportedOp(f"dtype {t.dtype} of {v} has no HIP kernels (SURVEY §8a H2: "
+                                "float32/64, int8-64, uint8-64, bool)")
         shape = _static_shape(t)
         vid = self.plan.new_var(t.dtype, shape, getattr(v, "name", None))
         self.vmap[v] = vid
