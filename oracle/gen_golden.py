@@ -624,6 +624,32 @@ def _():
          I((4,), "int64", seed=3)]
 
 
+# an end-to-end probabilistic-model graph: hierarchical normal + Poisson log-density over a packed
+# parameter vector with data embedded as graph constants, and its gradient (what a sampler or
+# optimiser evaluates per step): Subtensor / AdvancedSubtensor1 + scatter-add in the gradient,
+# Gemv, fused Elemwise / Sum chains, gammaln, switch bounds
+@case("hierarchical_logp_and_grad", rtol=1e-11, atol=1e-11, ref_py=True)
+def _():
+    rng = np.random.default_rng(0)
+    Nn, G, D = 500, 8, 3
+    Xd, gidx, yd = rng.standard_normal((Nn, D)), rng.integers(0, G, Nn), rng.standard_normal(Nn)
+    cnt = rng.poisson(3.0, Nn)
+    theta = at.dvector("theta")
+    mu_g, log_sd_g, beta = theta[:G], theta[G], theta[G + 1:G + 1 + D]
+    log_sigma, log_lam = theta[G + 1 + D], theta[G + 2 + D]
+    sd_g, sigma = at.exp(log_sd_g), at.exp(log_sigma)
+
+    def normal_logp(v, m, sd):
+        return -0.5 * ((v - m) / sd) ** 2 - at.log(sd) - 0.5 * np.log(2 * np.pi)
+    lp = normal_logp(mu_g, 0.0, sd_g).sum() + normal_logp(beta, 0.0, 10.0).sum() + normal_logp(log_sd_g, 0.0, 1.0)
+    mu = mu_g[gidx] + at.dot(at.as_tensor(Xd), beta)
+    lp += normal_logp(at.as_tensor(yd), mu, sigma).sum()
+    lam = at.exp(log_lam + 0.1 * mu)
+    lp += (at.as_tensor(cnt) * at.log(lam) - lam - at.gammaln(at.as_tensor(cnt) + 1.0)).sum()
+    lp += at.switch(sigma > 50, -np.inf, 0.0) + log_sd_g + log_sigma
+    return [theta], [lp, ae.grad(lp, theta)], [N((G + 3 + D,), seed=5, scale=0.3)]
+
+
 # tensor/nnet front-end functions (tests/tensor/nnet/test_basic.py: test_softmax_with_bias,
 # TestCrossEntropyCategorical1Hot :417, test_crossentropy_softmax_1hot_with_bias_dx): the
 # logistic-regression tutorial graph — categorical_crossentropy(softmax(x W + b), y) with its

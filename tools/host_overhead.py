@@ -3,7 +3,7 @@ sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
 import numpy as np, torch
 from golden_util import CASES, case_plan, case_inputs
 from aesara_amd.executor import PlanExecutor
-for name in ("nll_classifier_float32", "mlp_layers_float32", "cfg2_gauss_sum", "softmax_rows_f32", "lstm_bptt_float32"):
+for name in ("nll_classifier_float32", "mlp_layers_float32", "cfg2_gauss_sum", "softmax_rows_f32", "hierarchical_logp_and_grad", "lstm_bptt_float32"):
     c = next(c for c in CASES if c["name"]==name)
     ins = [torch.from_numpy(np.ascontiguousarray(x)).cuda() if np.asarray(x).ndim else np.asarray(x) for x in case_inputs(c)]
     for mode in (False, True):
