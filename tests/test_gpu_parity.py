@@ -93,6 +93,14 @@ def test_replay_with_fresh_input_tensors_and_host_arrays():
             for g, w in zip(got, want):
                 np.testing.assert_allclose(g, w, rtol=1e-6, atol=1e-7)
     assert len(replay._stage) == 2 and len(replay._graphs) <= 4
+    # CPU torch tensors are host buffers too: mutated in place between calls, same storage
+    cpu = [torch.from_numpy(v) for v in batch(False)]
+    for _ in range(3):
+        cpu[0].mul_(1.5)
+        want = [o.cpu().numpy() for o in eager(*[t.numpy() for t in cpu])]
+        got = [o.cpu().numpy() for o in replay(*cpu)]
+        for g, w in zip(got, want):
+            np.testing.assert_allclose(g, w, rtol=1e-6, atol=1e-7)
 
 
 @pytest.mark.gpu
