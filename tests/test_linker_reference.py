@@ -248,3 +248,46 @@ def test_large_graph_constants_are_kept_by_reference(ae):
     assert len(big) == 1 and big[0].const["array"].shape == (200, 50)
     np.testing.assert_allclose(interp.run_plan(Plan.loads(plan.dumps()), [wv])[0], f(wv), rtol=1e-12)
     PlanExecutor(plan, dry_run=True)(wv)
+
+
+def test_rnn_language_model_adam_step_matches_reference(ae):
+    """Embedding gather -> Scan (tanh RNN over a batch) -> softmax cross-entropy (tensor.nnet) ->
+    `aesara.grad` -> Adam updates of six parameters with their moment buffers (19 shared-variable
+    updates), three consecutive steps: losses and parameters follow the reference's linker."""
+    import aesara.tensor as at
+    import aesara.tensor.nnet as nn
+    from aesara.compile.mode import Mode
+    from aesara_amd.linker import HIP_QUERY, HipLinker
+    V, E, H, T, B = 30, 8, 12, 7, 5
+
+    def build(mode):
+        r0 = np.random.default_rng(1)
+        params = [ae.shared(r0.standard_normal(s) * 0.2)
+                  for s in ((V, E), (E, H), (H, H), (H,), (H, V), (V,))]
+        Wemb, Wx, Wh, bh, Wo, bo = params
+        tok, tgt = at.lmatrix("tok"), at.lmatrix("tgt")
+        emb = Wemb[tok.flatten()].reshape((T, B, E))
+        hs, _ = ae.scan(lambda x_t, h: at.tanh(at.dot(x_t, Wx) + at.dot(h, Wh) + bh),
+                        sequences=[emb], outputs_info=[at.zeros((B, H))])
+        logits = at.dot(hs.reshape((T * B, H)), Wo) + bo
+        loss = nn.categorical_crossentropy(nn.softmax(logits), tgt.flatten()).mean()
+        t = ae.shared(np.float64(0.0))
+        ups = [(t, t + 1)]
+        for p, g in zip(params, ae.grad(loss, params)):
+            m, v = (ae.shared(np.zeros(p.get_value().shape)) for _ in range(2))
+            m2, v2 = 0.9 * m + 0.1 * g, 0.999 * v + 0.001 * g * g
+            mh, vh = m2 / (1 - 0.9 ** (t + 1)), v2 / (1 - 0.999 ** (t + 1))
+            ups += [(m, m2), (v, v2), (p, p - 0.01 * mh / (at.sqrt(vh) + 1e-8))]
+        return ae.function([tok, tgt], loss, updates=ups, mode=mode), params
+
+    f_hip, p_hip = build(Mode(HipLinker(executor_factory=_picklable_oracle_factory, return_numpy=True),
+                              HIP_QUERY))
+    f_ref, p_ref = build(Mode("py", "fast_run"))
+    rng = np.random.default_rng(0)
+    for _ in range(3):
+        tok, tgt = rng.integers(0, V, (T, B)), rng.integers(0, V, (T, B))
+        np.testing.assert_allclose(f_hip(tok, tgt), f_ref(tok, tgt), rtol=1e-10)
+    for a, b in zip(p_hip, p_ref):
+        np.testing.assert_allclose(a.get_value(), b.get_value(), rtol=1e-8, atol=1e-10)
+    from aesara_amd.executor import PlanExecutor
+    PlanExecutor(f_hip.maker.linker.plan, dry_run=True)     # every step has a kernel / launch plan
