@@ -650,6 +650,27 @@ def _():
     return [theta], [lp, ae.grad(lp, theta)], [N((G + 3 + D,), seed=5, scale=0.3)]
 
 
+# RNN language-model step: embedding gather -> Scan (tanh RNN over a batch of states) -> nnet
+# softmax cross-entropy -> gradients w.r.t. all six parameters (scatter-add into the embedding,
+# BPTT through the Scan)
+@case("rnn_lm_loss_and_grads", rtol=1e-10, atol=1e-11, ref_py=True)
+def _():
+    import aesara.tensor.nnet as nn
+    V, E, H, Tt, Bb = 30, 8, 12, 7, 5
+    shapes = ((V, E), (E, H), (H, H), (H,), (H, V), (V,))
+    params = [T("float64", sh, f"p{k}") for k, sh in enumerate(shapes)]
+    Wemb, Wx, Wh, bh, Wo, bo = params
+    tok, tgt = at.lmatrix("tok"), at.lmatrix("tgt")
+    emb = Wemb[tok.flatten()].reshape((Tt, Bb, E))
+    hs, _ = ae.scan(lambda x_t, h: at.tanh(at.dot(x_t, Wx) + at.dot(h, Wh) + bh),
+                    sequences=[emb], outputs_info=[at.zeros((Bb, H))])
+    logits = at.dot(hs.reshape((Tt * Bb, H)), Wo) + bo
+    loss = nn.categorical_crossentropy(nn.softmax(logits), tgt.flatten()).mean()
+    return [tok, tgt] + params, [loss] + ae.grad(loss, params), \
+        [I((Tt, Bb), "int64", 1, 0, V), I((Tt, Bb), "int64", 2, 0, V)] + \
+        [N(sh, seed=10 + k, scale=0.2) for k, sh in enumerate(shapes)]
+
+
 # tensor/nnet front-end functions (tests/tensor/nnet/test_basic.py: test_softmax_with_bias,
 # TestCrossEntropyCategorical1Hot :417, test_crossentropy_softmax_1hot_with_bias_dx): the
 # logistic-regression tutorial graph — categorical_crossentropy(softmax(x W + b), y) with its
