@@ -729,6 +729,14 @@ def _register_handlers():
             raise UnsupportedOp("Nonzero of a 0-d or > 8-d array")
         ctx.emit("Nonzero", node)
 
+    from aesara.tensor.extra_ops import FillDiagonal
+
+    @hip_lower.register(FillDiagonal)
+    def _(op, node, ctx):
+        # reference: tensor/extra_ops.py:870 FillDiagonal(a, val) (perform :906): a copy of `a` with
+        # `val` on the main diagonal (rectangular 2-d allowed; n-d needs equal extents)
+        ctx.emit("FillDiagonal", node)
+
     from aesara.tensor.math import MatMul
 
     @hip_lower.register(MatMul)

@@ -619,7 +619,9 @@ def _():
         at.diag(x), at.diagonal(x, offset=2), at.diagonal(x, offset=-3), at.diagonal(x.T[::2], offset=1),
         at.diagonal(t3, offset=1, axis1=0, axis2=2), at.diagonal(t3, offset=-1, axis1=2, axis2=1),
         at.diag(v), at.diag(v, 2), at.diag(v, -1), at.diag(at.diag(x[:5, :5]) * 2),
-        at.basic.AllocDiag(offset=1, axis1=0, axis2=2)(x[:3, :4])], \
+        at.basic.AllocDiag(offset=1, axis1=0, axis2=2)(x[:3, :4]),
+        at.extra_ops.fill_diagonal(x, 7), at.extra_ops.fill_diagonal(x.T, v[0]),
+        at.extra_ops.fill_diagonal(t3[:, :4, :4], -1)], \
         [K(5, "int64"), K(7, "int64"), I((6, 8), "int64", seed=1), I((4, 5, 6), "int64", seed=2),
          I((4,), "int64", seed=3)]
 

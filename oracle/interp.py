@@ -517,6 +517,14 @@ def run_plan(plan, inputs):
         elif op == "Nonzero":
             # reference: tensor/basic.py:870 Nonzero.perform
             r = [np.asarray(i, dtype="int64") for i in np.nonzero(np.asarray(a[0]))]
+        elif op == "FillDiagonal":
+            # reference: tensor/extra_ops.py:906 FillDiagonal.perform
+            aa = np.array(a[0], copy=True)
+            if aa.ndim == 2:
+                aa.flat[:aa.shape[1] * aa.shape[1]:aa.shape[1] + 1] = a[1]
+            else:
+                np.fill_diagonal(aa, a[1])
+            r = [aa]
         elif op == "MatMul":
             # reference: tensor/math.py:2941 MatMul.perform
             r = [np.matmul(a[0], a[1])]
