@@ -853,6 +853,26 @@ for _k in range(12):
     case(f"scan_variant_{_k}", rtol=1e-10, atol=1e-11)(_scan_variant(_k))
 
 
+@case("scan_nested_with_grad", rtol=1e-11, atol=1e-12)
+def _():
+    # a Scan whose step runs another Scan (tests/scan/test_basic.py test_inner_scan :2306 /
+    # nested gradients), truncate_gradient, strict non-sequences, integer counters
+    x, W, v = at.dmatrix("x"), at.dmatrix("W"), at.dvector("v")
+
+    def outer(row, acc):
+        inner, _ = ae.scan(lambda e, st: st * 0.5 + e, sequences=[row], outputs_info=[at.zeros_like(row[0])])
+        return acc + inner[-1] * row
+    r, _ = ae.scan(outer, sequences=[x], outputs_info=[at.zeros_like(x[0])])
+    h, _ = ae.scan(lambda a, hh, Wm: at.tanh(at.dot(hh, Wm) + a), sequences=[x], outputs_info=[at.zeros_like(x[0])],
+                   non_sequences=[W], truncate_gradient=3)
+    hs, _ = ae.scan(lambda a, hh, Wm, vv: at.tanh(at.dot(hh, Wm) + a * vv), sequences=[x], outputs_info=[v],
+                    non_sequences=[W, v], strict=True)
+    (cnt, val), _ = ae.scan(lambda i, c, q: (c + 1, q * 2 + i), sequences=[at.arange(5)],
+                            outputs_info=[at.as_tensor(np.int64(0)), at.as_tensor(np.int64(1))])
+    return [x, W, v], [r[-1], ae.grad(r[-1].sum(), x)] + ae.grad(h[-1].sum(), [x, W]) + \
+        [hs, ae.grad(hs.sum(), v), cnt, val], [N((6, 4), seed=1), N((4, 4), seed=2, scale=0.3), N((4,), seed=3)]
+
+
 @case("scan_nitsot_map", rtol=1e-12, atol=1e-12)
 def _():
     x, W = at.dmatrix("x"), at.dmatrix("W")
