@@ -109,6 +109,70 @@ def sweep2():
     return E2, VALS2
 
 
+def sweep3():
+    """tensor.nnet front end"""
+    import aesara.tensor.nnet as nn
+    rng = np.random.default_rng(0)
+    x = at.dmatrix("x"); W = at.dmatrix("W"); b = at.dvector("b"); y = at.lvector("y"); t = at.dmatrix("t")
+    vals = {x: rng.standard_normal((6, 5)), W: rng.standard_normal((5, 4)), b: rng.standard_normal(4), y: rng.integers(0, 4, 6), t: rng.random((6, 4))}
+    E = {
+     "logreg_tutorial": lambda: [nn.categorical_crossentropy(nn.softmax(at.dot(x, W) + b), y).mean()] + ae.grad(nn.categorical_crossentropy(nn.softmax(at.dot(x, W) + b), y).mean(), [W, b]),
+     "xent_onehot_dense": lambda: ae.grad(nn.categorical_crossentropy(nn.softmax(at.dot(x, W)), t / t.sum(axis=1, keepdims=True)).sum(), W),
+     "neg_log_likelihood": lambda: ae.grad(-at.mean(at.log(nn.softmax(at.dot(x, W) + b))[at.arange(y.shape[0]), y]), [W, b]),
+     "binary_xent": lambda: ae.grad(nn.binary_crossentropy(at.sigmoid(at.dot(x, W)), t).mean(), W),
+     "relu_elu_softplus": lambda: [nn.relu(x), nn.relu(x, 0.1), nn.elu(x), nn.softsign(x), nn.hard_sigmoid(x)],
+     "logsoftmax_nnet": lambda: ae.grad(nn.logsoftmax(at.dot(x, W))[at.arange(6), y].sum(), W),
+     "confusion_argmax": lambda: [at.argmax(nn.softmax(at.dot(x, W)), axis=1), at.neq(at.argmax(at.dot(x, W), axis=1), y).mean()],
+     "sigmoid_bce_logits": lambda: ae.grad(nn.sigmoid_binary_crossentropy(at.dot(x, W), t).sum(), W) if hasattr(nn, "sigmoid_binary_crossentropy") else x,
+     "l2_weight_decay_sgd": lambda: [W - 0.1 * ae.grad(nn.categorical_crossentropy(nn.softmax(at.dot(x, W) + b), y).mean() + 1e-3 * (W ** 2).sum(), W)],
+     "batchnorm_like": lambda: ae.grad((((x - x.mean(0)) / at.sqrt(x.var(0) + 1e-5)) * b[:4].sum()).sum() + (x ** 2).sum(), x),
+     "dropout_mask_mul": lambda: x * (t[:, :1] > 0.5) / 0.5,
+     "onehot_xent": lambda: nn.categorical_crossentropy(nn.softmax(at.dot(x, W)), at.extra_ops.to_one_hot(y, 4)).mean(),
+    }
+    return E, vals
+
+
+def sweep4():
+    """gradient helpers, extra_ops, odds and ends"""
+    from aesara.gradient import grad_clip, disconnected_grad, zero_grad
+    rng = np.random.default_rng(0)
+    x = at.dmatrix("x"); v = at.dvector("v"); i = at.lvector("i")
+    vals = {x: rng.standard_normal((5, 4)), v: rng.standard_normal(4), i: np.array([3, 0, 2, 2])}
+    E = {
+     "grad_clip": lambda: ae.grad((grad_clip(x, -0.1, 0.1) ** 2).sum(), x),
+     "disconnected_zero_grad": lambda: ae.grad((disconnected_grad(x) * x + zero_grad(x.sum()) * x).sum(), x),
+     "print_op": lambda: ae.printing.Print("dbg")(x) * 2 if False else x * 2,
+     "fill_diagonal": lambda: at.extra_ops.fill_diagonal(x[:4], 7.0),
+     "squeeze_bcast": lambda: at.squeeze(x.dimshuffle(0, "x", 1)) + 1,
+     "ravel_unravel": lambda: list(at.extra_ops.unravel_index(i, (2, 2))) + [at.extra_ops.ravel_multi_index((i % 2, i // 2), (2, 2))],
+     "broadcast_arrays": lambda: at.extra_ops.broadcast_arrays(v, x)[0] * 1,
+     "choose": lambda: at.choose(i % 2, [v, v * 2]),
+     "minimum_where_nan": lambda: at.where(at.isnan(x / (x - x)), 0.0, x),
+     "outer_sub": lambda: v[:, None] - v[None, :],
+     "stack_list_scalars": lambda: at.stack([x[0, 0], x[1, 1], v[2]]) * 2,
+     "as_tensor_const_big": lambda: x + np.arange(20.0).reshape(5, 4),
+     "const_big_5000": lambda: v[0] + at.as_tensor(np.arange(5000.0)).sum(),
+     "mean_dtype": lambda: [x.mean(dtype="float32"), x.sum(dtype="float32", axis=0), at.cast(x, "int32").mean()],
+     "pow_grad": lambda: ae.grad((abs(x) ** v).sum(), [x, v]),
+     "second_fill_like": lambda: at.fill(x, v[0]) + at.zeros_like(x, dtype="int32"),
+     "isfinite_any": lambda: at.any(at.isinf(x)) | at.all(at.isnan(x)),
+     "shape_of_shape": lambda: at.as_tensor(x.shape).sum() + x.shape[0] * x.ndim,
+     "set_sub_scalar_idx": lambda: at.set_subtensor(x[i[0], i[1]], 5.0),
+     "inc_sub_neg_step": lambda: at.inc_subtensor(x[::-1, ::-2], 1.0),
+     "tensordot_axes2": lambda: at.tensordot(x, x, axes=2),
+     "dot_vec_vec": lambda: at.dot(v, v) + at.dot(x, v).sum(),
+     "rsub_rdiv_scalars": lambda: (1 - x) / (2 / (x + 3)),
+     "neg_pow_int": lambda: (-x) ** 2 + (x ** 2) ** 0.5,
+     "int_true_div": lambda: i / 2 + i // 2 + at.true_div(i, i + 1),
+     "clip_int": lambda: at.clip(i, 1, 2),
+     "max_keepdims_sub": lambda: at.exp(x - x.max(axis=1, keepdims=True)).sum(axis=1),
+     "flatten_ndim": lambda: at.flatten(x.dimshuffle(0, 1, "x"), ndim=2) * 1,
+     "join_vectors_scalar": lambda: at.concatenate([v, at.stack([x.sum()]), v[:2]]),
+     "alloc_broadcast_grad": lambda: ae.grad((at.alloc(v, 3, 4) * x[:3]).sum(), v),
+    }
+    return E, vals
+
+
 def run(exprs, vals):
     ok, bad = [], []
     ins = list(vals)
@@ -137,7 +201,8 @@ def run(exprs, vals):
 if __name__ == "__main__":
     total_ok = 0
     lines = []
-    for label, (exprs, vals) in (("tensor API", sweep1()), ("dtypes / gradients / scans", sweep2())):
+    for label, (exprs, vals) in (("tensor API", sweep1()), ("dtypes / gradients / scans", sweep2()),
+                                 ("tensor.nnet front end", sweep3()), ("gradient helpers / extra_ops", sweep4())):
         ok, bad = run(exprs, vals)
         total_ok += len(ok)
         lines.append("== %s: %d of %d match the reference (C linker; Python linker where a C thunk does not build here)" % (label, len(ok), len(exprs)))
