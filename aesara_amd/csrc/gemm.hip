@@ -16,7 +16,10 @@
 //     26 % (SQ_WAIT_ANY ~1900 of ~5500 cycles per wave-slab).  Four waves per SIMD plus a
 //     two-slab-deep register prefetch cover that latency.
 //   * both operands are staged through LDS in a [row][k] image with 144-byte rows (128 B + 16 B
-//     pad): fragments are fetched with one conflict-free ds_read_b64 per lane.  Waves 0-3 stage
+//     pad): fragments are fetched with one ds_read_b64 per lane (the rows of a fragment land on
+//     distinct banks; measured on the shipped kernel, rocprofv3 r02: SQ_LDS_BANK_CONFLICT /
+//     SQ_LDS_IDX_ACTIVE = 0.43 over reads + staging stores, the LDS array itself busy 34 % of the
+//     kernel's cycles — profiles/r02_gemm_pmc_summary.json).  Waves 0-3 stage
 //     A, waves 4-7 stage B (4 x 16-byte vectors per thread per slab) through per-thread 32-bit
 //     offsets from a wave-uniform base (SGPR base + VGPR offset addressing: no per-slab address
 //     arithmetic).  Operands whose contiguous axis is k go straight into the image; operands

@@ -1,20 +1,49 @@
-"""Multi-GPU sharding of the hot path: one process per GPU, RCCL over xGMI.
+"""Multi-GPU execution of a lowered plan: one process per GPU, RCCL over xGMI.
 
 The reference has no data-parallel execution at all (its only communication code is the
-optional mpi4py point-to-point ops of tensor/io.py:108-262), so there is nothing to translate:
+optional mpi4py point-to-point ops of tensor/io.py:108-262), so there is nothing to translate.
+Two graph-level transformations, both decided on the *plan* (never on run-time values):
 
-* independent evaluations / independent graph outputs shard embarrassingly (replicas);
-* a batch (row) axis that has been split across ranks needs exactly one exchange: a ``CAReduce``
-  over the split axis becomes local-reduce + ``all_reduce(SUM)`` of the partial — a few bytes
-  (config 2: one f64; config 5: 258 values), i.e. latency-bound on xGMI, so it is issued
-  asynchronously and consecutive evals pipeline;
-* a ``Gemv`` on ``X.T`` (reduction over the split axis) is local GEMV + all-reduce of the D-vector.
+1. **Batch-axis split** (:func:`shard_plan`, :class:`ShardedPlan`).  Some plan inputs are declared
+   split along an axis (``X`` and ``y`` of BASELINE config 5 along the rows).  A sharding state is
+   propagated through every node:
 
-``torch.distributed`` (backend "nccl" == RCCL on ROCm, "gloo" in the CPU tests) is the transport.
+   * ``rep``      — the same value on every rank;
+   * ``split(a)`` — the rank holds its block of the value along axis ``a``;
+   * ``partial(op)`` — the true value is ``op`` over the ranks' values (``add`` / ``maximum`` /
+     ``minimum``): what a ``CAReduce`` over the split axis, or a contraction over it
+     (``Gemv(X.T, r)``, ``Dot22(A.T, B)``), leaves on each rank;
+   * ``extent``   — ``Shape_i`` of a split value along its split axis (local length; the global
+     length is the sum).
+
+   A ``partial`` (or an ``extent`` read by anything but an allocation) has to be combined before
+   it is read: the plan is cut into *rounds*; round k runs locally, then ONE packed
+   ``all_reduce`` per (reduction op, exchange dtype) sums / maxes all of round k's partials, and
+   round k+1 continues on the combined values.  Floating-point sums are exchanged in the
+   **accumulator dtype** (``CAReduce.acc_dtype``; float64 for the float32 contraction partials)
+   and cast to the node's output dtype after the collective (SURVEY §8e "the Sum's f64->f32
+   cast happens after the reduce").  Anything that cannot be proven row-local raises
+   :class:`ShardingError` — never a silently wrong per-rank partial.
+
+2. **Independent-output placement** (:func:`place_outputs`, :class:`PlacedPlan`).  Outputs whose
+   ancestor sets share no computed value are assigned to different ranks (largest-first onto the
+   least-loaded rank); each rank runs only its own sub-plan, no communication at all.
+
+``torch.distributed`` (backend "nccl" == RCCL on ROCm, "gloo" in the CPU tests) is the transport;
+a :class:`LocalGroup` runs k logical shards in one process (single-GPU boxes, tests).
 """
 from __future__ import annotations
 
-from typing import List, Sequence, Tuple
+import copy
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .plan import Node, Plan
+
+
+class ShardingError(ValueError):
+    """The plan cannot be evaluated on row blocks with the declared split."""
 
 
 def shard_rows(n_rows: int, world: int, rank: int) -> Tuple[int, int]:
@@ -27,37 +56,635 @@ def shard_rows(n_rows: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def plan_split_outputs(plan, split_input: int) -> List[str]:
-    """For a plan whose input ``split_input`` is row-sharded, classify each output:
-    ``"allreduce"`` (a full CAReduce{add} / Gemv over the split axis: sum the per-rank results)
-    or ``"local"`` (row-wise result: stays sharded).  Conservative: anything else raises."""
-    producers = {}
-    for n in plan.nodes:
-        for o in n.outputs:
-            producers[o] = n
-    kinds = []
-    for o in plan.outputs:
-        n = producers.get(o)
-        if n is not None and n.op == "CAReduce" and n.params["scalar_op"] == "add" and \
-                (n.params["axis"] is None or 0 in n.params["axis"]):
-            kinds.append("allreduce")
-        elif n is not None and n.op == "Gemv":
-            a = producers.get(n.inputs[2])
-            if a is not None and a.op == "DimShuffle" and a.params["new_order"] == [1, 0]:
-                kinds.append("allreduce")  # X.T @ r: contraction over the split axis
-            else:
-                kinds.append("local")
+# ---------------------------------------------------------------------------------------------
+# sharding-state propagation
+# ---------------------------------------------------------------------------------------------
+REP = ("rep",)
+_RED_OPS = {"add": "add", "maximum": "maximum", "minimum": "minimum"}
+_VIEW_REP_ONLY = {"Subtensor", "IncSubtensor", "AdvancedSubtensor1", "AdvancedIncSubtensor1",
+                  "AdvancedSubtensor", "AdvancedIncSubtensor", "Reshape", "Join", "Split", "Scan",
+                  "CumOp", "Argmax", "MaxAndArgmax", "Sort", "ArgSort", "IfElse", "BatchedDot",
+                  "MatMul", "Ger"}
+
+
+def _const_scalar(plan: Plan, vid: int):
+    v = plan.vars[vid]
+    if v.const is not None and len(v.const.get("data", ())) == 1:
+        return float(v.const["data"][0])
+    return None
+
+
+def _ident_scalar(n_in=1):
+    return {"n_in": n_in, "nodes": [], "out": [["i", 0]]}
+
+
+def _cast_scalar(dtype):
+    return {"n_in": 1, "nodes": [{"op": "cast", "in": [["i", 0]], "dtype": dtype}], "out": [["t", 0]]}
+
+
+class ShardedPlanSpec:
+    """Result of :func:`shard_plan`: ``rounds`` = list of ``(plan, exchanges)``; the plan of round
+    k takes the original inputs followed by every earlier round's carried values; ``exchanges``
+    = ``[(output position in the round plan, op, exchange dtype)]`` — those outputs are combined
+    across the ranks before the next round reads them.  ``out_state[i]`` is the sharding state of
+    original output i (``rep`` after the final combine, or ``split(a)``: stays sharded)."""
+
+    def __init__(self, rounds, carried, out_src, out_state, state):
+        self.rounds, self.carried, self.out_src = rounds, carried, out_src
+        self.out_state, self.state = out_state, state
+
+    @property
+    def n_exchange_rounds(self):
+        return sum(1 for _, ex in self.rounds if ex)
+
+
+def shard_plan(plan: Plan, split_inputs: Dict[int, int]) -> ShardedPlanSpec:
+    """Propagate sharding states (module docstring) and cut ``plan`` into rounds.
+
+    ``split_inputs``: ``{input position: axis}`` — which plan inputs arrive as per-rank blocks."""
+    plan = copy.deepcopy(plan)
+    state: Dict[int, tuple] = {}
+    rnd: Dict[int, int] = {}            # round in which a var's *usable* (combined) value exists
+    for vid, v in plan.vars.items():
+        if v.const is not None:
+            state[vid], rnd[vid] = REP, 0
+    for pos, vid in enumerate(plan.inputs):
+        if pos in split_inputs:
+            ax = split_inputs[pos]
+            if not (0 <= ax < plan.vars[vid].ndim):
+                raise ShardingError(f"input {pos}: split axis {ax} out of range")
+            state[vid] = ("split", ax)
         else:
-            kinds.append("local")
-    return kinds
+            state[vid] = REP
+        rnd[vid] = 0
+
+    # var -> (raw var holding the per-rank partial, op, exchange dtype); the var itself names the
+    # combined value (available one round later)
+    pending: Dict[int, tuple] = {}
+    node_round: List[int] = []
+    extra_nodes: Dict[int, List[Node]] = {}     # node index -> nodes appended after it (casts)
+    post_nodes: Dict[int, List[Node]] = {}      # var -> nodes that finish it after the combine
+
+    def use(vid, as_alloc_dim=False):
+        """State under which a consumer sees ``vid`` and the round from which it may read it."""
+        st = state[vid]
+        if st[0] == "partial":
+            return REP, rnd[vid] + 1
+        if st[0] == "extent":
+            if as_alloc_dim:
+                return st, rnd[vid]
+            return REP, rnd[vid] + 1      # read through its global twin (see global_extent)
+        return st, rnd[vid]
+
+    producer_idx: Dict[int, int] = {}
+    extent_twin: Dict[int, int] = {}
+
+    def global_extent(vid):
+        """Non-allocation readers of a local extent get the SUM over the ranks: a twin variable
+        that is exchanged like any other partial (the local value stays for allocations)."""
+        g = extent_twin.get(vid)
+        if g is None:
+            raw = plan.new_var("int64", [], name=f"v{vid}_local_extent")
+            g = plan.new_var("int64", [], name=f"v{vid}_global_extent")
+            extra_nodes.setdefault(producer_idx[vid], []).append(
+                Node("Elemwise", [vid], [raw], {"scalar": _cast_scalar("int64")}))
+            post_nodes[g] = [Node("Elemwise", [raw], [g], {"scalar": _cast_scalar("int64")})]
+            pending[g] = (raw, "add", "int64")
+            state[g], rnd[g] = ("partial", "add"), rnd[vid]
+            state[raw], rnd[raw] = ("partial", "add"), rnd[vid]
+            extent_twin[vid] = g
+        return g
+
+    def make_partial(node_idx, out, op, acc_dtype):
+        """``out`` of node ``node_idx`` is a per-rank partial: exchange it in ``acc_dtype``."""
+        v = plan.vars[out]
+        xdt = acc_dtype if v.dtype.startswith("float") else v.dtype
+        if op == "add" and v.dtype == "float32":
+            xdt = "float64" if acc_dtype in (None, "float32", "float64") else acc_dtype
+        if op != "add":
+            xdt = v.dtype
+        raw = out
+        if xdt != v.dtype:
+            raw = plan.new_var(xdt, list(v.shape), name=(v.name or f"v{out}") + "_partial")
+            n = plan.nodes[node_idx]
+            if n.op == "CAReduce":
+                # the reduction itself delivers the accumulator dtype: no intermediate rounding
+                n.outputs[n.outputs.index(out)] = raw
+            else:
+                extra_nodes.setdefault(node_idx, []).append(
+                    Node("Elemwise", [out], [raw], {"scalar": _cast_scalar(xdt)}))
+            post_nodes[out] = [Node("Elemwise", [raw], [out], {"scalar": _cast_scalar(v.dtype)})]
+        pending[out] = (raw, op, xdt)
+        state[out] = ("partial", op)
+        state[raw], rnd[raw] = ("partial", op), rnd[out]
+
+    for ni, n in enumerate(plan.nodes):
+        op = n.op
+        for o in n.outputs:
+            producer_idx[o] = ni
+        if op in ("AllocEmpty", "Alloc"):
+            first_dim = 0 if op == "AllocEmpty" else 1
+            sts = [use(i, as_alloc_dim=(k >= first_dim)) for k, i in enumerate(n.inputs)]
+        else:
+            n.inputs = [global_extent(i) if state[i][0] == "extent" else i for i in n.inputs]
+            sts = [use(i) for i in n.inputs]
+        r = max([q for _, q in sts], default=0)
+        ins = [s for s, _ in sts]
+        node_round.append(r)
+        for o in n.outputs:
+            rnd[o] = r
+
+        def all_rep():
+            return all(s == REP for s in ins)
+
+        if all_rep() and op != "Shape_i":
+            for o in n.outputs:
+                state[o] = REP
+            continue
+
+        if op == "Elemwise":
+            axes = {s[1] for s in ins if s[0] == "split"}
+            if len(axes) != 1:
+                raise ShardingError(f"Elemwise mixes split axes {sorted(axes)}")
+            ax = axes.pop()
+            for vid, s in zip(n.inputs, ins):
+                v = plan.vars[vid]
+                if s == REP and v.ndim and (ax >= v.ndim or v.shape[ax] != 1):
+                    raise ShardingError(
+                        f"Elemwise: replicated operand v{vid} spans the split axis {ax} "
+                        "(declare it in split_inputs)")
+            for o in n.outputs:
+                state[o] = ("split", ax)
+        elif op == "DimShuffle":
+            (s,) = ins
+            order = n.params["new_order"]
+            if s[1] not in order:
+                raise ShardingError("DimShuffle drops the split axis")
+            state[n.outputs[0]] = ("split", order.index(s[1]))
+        elif op in ("ViewOp", "DeepCopyOp", "SpecifyShape", "Assert", "Unbroadcast"):
+            if any(s != REP for s in ins[1:]):
+                raise ShardingError(f"{op}: only the first operand may be split")
+            state[n.outputs[0]] = ins[0]
+        elif op == "Shape_i":
+            (s,) = ins
+            if s[0] == "split" and s[1] == n.params["i"]:
+                state[n.outputs[0]] = ("extent",)
+            else:
+                state[n.outputs[0]] = REP
+        elif op in ("AllocEmpty", "Alloc"):
+            dims = ins[first_dim:]
+            ext = [k for k, s in enumerate(dims) if s[0] == "extent"]
+            if any(s != REP for s in ins[:first_dim]) or len(ext) != 1 or \
+                    any(s[0] not in ("rep", "extent") for s in dims):
+                raise ShardingError(f"{op}: needs a replicated value and exactly one split extent")
+            state[n.outputs[0]] = ("split", ext[0])
+        elif op == "CAReduce":
+            (s,) = ins
+            axis = n.params["axis"]
+            nd = plan.vars[n.inputs[0]].ndim
+            axes = list(range(nd)) if axis is None else [a % nd for a in axis]
+            if s[1] in axes:
+                rop = _RED_OPS.get(n.params["scalar_op"])
+                if rop is None:
+                    raise ShardingError(
+                        f"CAReduce{{{n.params['scalar_op']}}} over the split axis is not combinable")
+                make_partial(ni, n.outputs[0], rop, n.params.get("acc_dtype"))
+            else:
+                state[n.outputs[0]] = ("split", s[1] - sum(1 for a in axes if a < s[1]))
+        elif op == "Gemv":
+            sy, sal, sA, sx, sbe = ins
+            beta = _const_scalar(plan, n.inputs[4])
+            if sal != REP or sbe != REP:
+                raise ShardingError("Gemv: alpha / beta must be replicated")
+            if sA == ("split", 0) and sx == REP and (sy == ("split", 0) or (beta == 0.0 and sy[0] in ("rep", "split"))):
+                state[n.outputs[0]] = ("split", 0)                 # row-wise
+            elif sA == ("split", 1) and sx == ("split", 0) and beta == 0.0:
+                make_partial(ni, n.outputs[0], "add", "float64")   # contraction over the split axis
+            else:
+                raise ShardingError(f"Gemv with operand states y={sy} A={sA} x={sx} beta={beta}")
+        elif op in ("Dot22", "Dot", "Dot22Scalar", "Gemm"):
+            if op == "Gemm":
+                sC, sal, sA, sB, sbe = ins
+                beta = _const_scalar(plan, n.inputs[4])
+                if sal != REP or sbe != REP:
+                    raise ShardingError("Gemm: alpha / beta must be replicated")
+            else:
+                sA, sB = ins[0], ins[1]
+                sC, beta = None, 0.0
+                if any(s != REP for s in ins[2:]):
+                    raise ShardingError(f"{op}: scalar must be replicated")
+            ndA, ndB = plan.vars[n.inputs[2 if op == "Gemm" else 0]].ndim, \
+                plan.vars[n.inputs[3 if op == "Gemm" else 1]].ndim
+            kA, kB = ndA - 1, 0
+            c_ok = sC is None or beta == 0.0
+            if sA[0] == "split" and sA[1] != kA and sB == REP and (c_ok or sC == ("split", 0)):
+                state[n.outputs[0]] = ("split", 0)
+            elif sA == REP and sB[0] == "split" and sB[1] != kB and ndB == 2 and \
+                    (c_ok or sC == ("split", ndA - 1)):
+                state[n.outputs[0]] = ("split", ndA - 1)
+            elif sA == ("split", kA) and sB == ("split", kB) and c_ok:
+                make_partial(ni, n.outputs[0], "add", "float64")
+            else:
+                raise ShardingError(f"{op} with operand states A={sA} B={sB} C={sC} beta={beta}")
+        elif op in ("ScalarFromTensor", "TensorFromScalar"):
+            state[n.outputs[0]] = ins[0]
+        else:
+            raise ShardingError(f"{op}: not provably row-local for a split operand "
+                                f"(operand states {ins})")
+
+    # ---- outputs: a partial output needs one more (final) round for its combine + cast --------
+    out_state, last = [], 0
+    for o in plan.outputs:
+        st = state[o]
+        if st[0] == "extent":
+            raise ShardingError("an output is the local extent of a split axis")
+        if st[0] == "partial":
+            out_state.append(REP)
+            last = max(last, rnd[o] + 1)
+        else:
+            out_state.append(st)
+            last = max(last, rnd[o])
+    n_rounds = max(last, max(node_round, default=0)) + 1
+
+    # ---- build one plan per round ----------------------------------------------------------
+    producer_round = {}
+    for ni, n in enumerate(plan.nodes):
+        for o in n.outputs:
+            producer_round[o] = node_round[ni]
+        for en in extra_nodes.get(ni, []):
+            for o in en.outputs:
+                producer_round[o] = node_round[ni]
+    # combined value of a pending var becomes available in round rnd+1 (as input, raw var slot)
+    rounds, carried = [], []          # carried: vars made available to later rounds, in order
+    avail: Dict[int, int] = {}        # var -> round it became an input of later rounds
+    for k in range(n_rounds):
+        nodes_k: List[Node] = []
+        # finish values combined after round k-1
+        for v, (raw, _op, _xdt) in pending.items():
+            if rnd[v] + 1 == k:
+                nodes_k.extend(post_nodes.get(v, []))
+        for ni, n in enumerate(plan.nodes):
+            if node_round[ni] == k:
+                nodes_k.append(n)
+                nodes_k.extend(extra_nodes.get(ni, []))
+        produced = {o for n in nodes_k for o in n.outputs}
+        needed_later = set()
+        for k2 in range(k + 1, n_rounds):
+            for ni, n in enumerate(plan.nodes):
+                if node_round[ni] == k2:
+                    needed_later.update(n.inputs)
+        exchanges, outs_k = [], []
+        for v, (raw, rop, xdt) in pending.items():
+            if rnd[v] == k:
+                exchanges.append((len(outs_k), rop, xdt))
+                outs_k.append(raw)
+        n_ex = len(outs_k)
+        for v in sorted(produced):
+            is_raw = any(raw == v for raw, _, _ in pending.values())
+            if v in needed_later and not is_raw and state.get(v, REP)[0] != "partial":
+                outs_k.append(v)
+        for o in plan.outputs:
+            fin = rnd[o] + (1 if state[o][0] == "partial" else 0)
+            if fin == k and o not in outs_k[n_ex:]:
+                outs_k.append(o)
+        p_k = Plan(f"{plan.name}_round{k}", plan.vars, list(plan.inputs) + list(carried),
+                   list(outs_k), nodes_k)
+        rounds.append((p_k, exchanges))
+        for v in outs_k:
+            if v not in avail and v not in plan.inputs:
+                avail[v] = k
+                carried.append(v)
+    out_src = []
+    for o in plan.outputs:
+        fin = rnd[o] + (1 if state[o][0] == "partial" else 0)
+        out_src.append((fin, rounds[fin][0].outputs.index(o)))
+    return ShardedPlanSpec(rounds, carried, out_src, out_state, state)
+
+
+def plan_split_outputs(plan: Plan, split_input: int, axis: int = 0) -> List[str]:
+    """Classify each output of ``plan`` when input ``split_input`` (and every other input the
+    analysis needs split along the same rows — vectors of matching length are NOT guessed) is
+    row-sharded: ``"allreduce"`` (per-rank partials are summed) or ``"local"`` (stays sharded).
+    Raises :class:`ShardingError` for anything not provably one of the two."""
+    spec = None
+    err = None
+    # the row vectors that go with a row-split matrix (y of config 5) must be split too: try the
+    # declared input alone first, then together with the 1-d inputs
+    one_d = {p: 0 for p, vid in enumerate(plan.inputs)
+             if p != split_input and plan.vars[vid].ndim == 1 and plan.vars[vid].shape != [1]}
+    cands = [{split_input: axis}] + [{split_input: axis, p: 0} for p in one_d]
+    if len(one_d) > 1:
+        cands.append({split_input: axis, **one_d})
+    for sp in cands:
+        try:
+            spec = shard_plan(plan, sp)
+            break
+        except ShardingError as e:
+            err = e
+    if spec is None:
+        raise err
+    return ["local" if st[0] == "split" else
+            ("allreduce" if spec.state[o][0] == "partial" else "replicated")
+            for o, st in zip(plan.outputs, spec.out_state)]
+
+
+# ---------------------------------------------------------------------------------------------
+# process groups
+# ---------------------------------------------------------------------------------------------
+class LocalGroup:
+    """k logical ranks inside ONE process (a single-GPU box, unit tests): ``all_reduce`` is
+    handed the list of every rank's buffer and combines them in place, in rank order."""
+
+    def __init__(self, world: int):
+        self.world = world
+
+    def all_reduce_many(self, bufs: Sequence, op: str):
+        import torch
+        acc = bufs[0].clone()
+        for b in bufs[1:]:
+            if op == "add":
+                acc += b
+            elif op == "maximum":
+                torch.maximum(acc, b, out=acc)
+            else:
+                torch.minimum(acc, b, out=acc)
+        for b in bufs:
+            b.copy_(acc)
+
+
+def _dist_reduce(buf, op, group, async_op=False):
+    import torch.distributed as dist
+    rop = {"add": dist.ReduceOp.SUM, "maximum": dist.ReduceOp.MAX, "minimum": dist.ReduceOp.MIN}[op]
+    return dist.all_reduce(buf, op=rop, group=group, async_op=async_op)
+
+
+_TORCH = None
+
+
+def _torch_dtype(name):
+    import torch
+    return {"float64": torch.float64, "float32": torch.float32, "int64": torch.int64,
+            "int32": torch.int32, "int16": torch.int16, "int8": torch.int8, "uint8": torch.uint8,
+            "bool": torch.bool}[name]
+
+
+class ShardedPlan:
+    """Evaluate a plan on this rank's blocks of the split inputs (module docstring, 1.).
+
+    ``executor_factory(plan, use_graph)`` builds the per-round evaluator (default: the HIP
+    :class:`~aesara_amd.executor.PlanExecutor`); tests on CPU pass an oracle-backed factory.
+    Per evaluation: round 0 replay, then per exchange round ONE ``all_reduce`` per (op, dtype)
+    class over a persistent packed buffer that the producing kernels write into directly, then
+    the next round's replay reading views of that buffer."""
+
+    def __init__(self, plan: Plan, split_inputs: Dict[int, int], group=None, use_graph=False,
+                 executor_factory: Optional[Callable] = None, device=None):
+        self.spec = shard_plan(plan, split_inputs)
+        self.group = group
+        self.plan = plan
+        if executor_factory is None:
+            from .executor import PlanExecutor
+
+            def executor_factory(p, use_graph=use_graph):
+                return PlanExecutor(p, use_graph=use_graph, device=device)
+        self.execs = [executor_factory(p) for p, _ in self.spec.rounds]
+        self._packs: Dict[tuple, list] = {}
+
+    # -- world size of the group this instance communicates over --------------------------------
+    def _world(self):
+        if isinstance(self.group, LocalGroup):
+            return self.group.world
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(self.group)
+        return 1
+
+    def _pack_buffers(self, k, shapes, like):
+        """Persistent packed exchange buffers of round k: one per (op, dtype) class, plus the
+        per-output views into them (so pointers stay stable across replays)."""
+        import torch
+        if True:
+            _, exchanges = self.spec.rounds[k]
+            classes: Dict[tuple, list] = {}
+            for (pos, rop, xdt), shp in zip(exchanges, shapes):
+                classes.setdefault((rop, xdt), []).append((pos, shp))
+            bufs, views = {}, {}
+            for cls, items in classes.items():
+                total = sum(int(np.prod(s)) if len(s) else 1 for _, s in items)
+                dev = like.device if hasattr(like, "device") else None
+                buf = torch.zeros(total, dtype=_torch_dtype(cls[1]), device=dev)
+                off = 0
+                for pos, shp in items:
+                    n = int(np.prod(shp)) if len(shp) else 1
+                    views[pos] = buf[off:off + n].view(tuple(shp))
+                    off += n
+                bufs[cls] = buf
+        return bufs, views
+
+    def __call__(self, *local_inputs, async_op=False):
+        """Evaluate on this rank's blocks.  ``async_op``: the LAST round's collectives are
+        issued asynchronously and their handles returned next to the outputs (which are only
+        valid after ``wait()``), so that consecutive evaluations pipeline."""
+        import torch
+        if isinstance(self.group, LocalGroup):
+            raise RuntimeError("logical shards of one process run through run_local_shards()")
+        spec = self.spec
+        n_orig = len(self.plan.inputs)
+        carried_vals: Dict[int, object] = {}
+        results: List[list] = []
+        handles = []
+        world = self._world()
+        sig = tuple(tuple(getattr(x, "shape", ())) for x in local_inputs)
+        for k, ((p_k, exchanges), ex) in enumerate(zip(spec.rounds, self.execs)):
+            ins = list(local_inputs) + [carried_vals[v] for v in p_k.inputs[n_orig:]]
+            if not p_k.nodes:        # nothing left to compute: combined values pass through
+                outs = [ins[p_k.inputs.index(v)] for v in p_k.outputs]
+            elif not exchanges:
+                outs = list(ex(*ins))
+            else:
+                ent = self._packs.get((k, sig))
+                if ent is None or not getattr(ex, "accepts_out", False):
+                    outs = list(ex(*ins))
+                else:
+                    outs = list(ex(*ins, out=ent[2]))
+                if ent is None:
+                    # first evaluation: learn the partial shapes, build the packed buffers
+                    shapes = [tuple(getattr(outs[pos], "shape", ())) for pos, _, _ in exchanges]
+                    like = next((o for o in outs if isinstance(o, torch.Tensor)), None)
+                    if like is None:
+                        like = next((x for x in local_inputs if isinstance(x, torch.Tensor)),
+                                    torch.zeros(1))
+                    bufs, views = self._pack_buffers(k, shapes, like)
+                    targets = [views.get(pos) for pos in range(len(p_k.outputs))]
+                    ent = self._packs[(k, sig)] = (bufs, views, targets)
+                bufs, views, _ = ent
+                for pos, _rop, xdt in exchanges:
+                    o = outs[pos]
+                    if not isinstance(o, torch.Tensor):
+                        o = torch.as_tensor(np.asarray(o), dtype=_torch_dtype(xdt))
+                    if o.data_ptr() != views[pos].data_ptr():
+                        views[pos].copy_(o.reshape(views[pos].shape))
+                    outs[pos] = views[pos]
+                if world > 1:
+                    last = k + 1 == len(spec.rounds) or not any(
+                        q.nodes for q, _ in spec.rounds[k + 1:])
+                    for (rop, _xdt), buf in bufs.items():
+                        h = _dist_reduce(buf, rop, self.group, async_op=async_op and last)
+                        if async_op and last:
+                            handles.append(h)
+            results.append(outs)
+            for v, o in zip(p_k.outputs, outs):
+                carried_vals[v] = o
+        final = [results[r][pos] for r, pos in spec.out_src]
+        return (final, handles) if async_op else final
+
+
+def run_local_shards(plan: Plan, split_inputs: Dict[int, int], shard_inputs: Sequence[Sequence],
+                     executor_factory=None, use_graph=False):
+    """Evaluate ``plan`` over k logical shards in THIS process (one device): every shard runs
+    each round, the partials are combined with :class:`LocalGroup` between rounds — the same
+    code path as the multi-process run minus the transport.  Returns the per-shard outputs."""
+    import torch
+    k = len(shard_inputs)
+    grp = LocalGroup(k)
+    sps = [ShardedPlan(plan, split_inputs, group=grp, use_graph=use_graph,
+                       executor_factory=executor_factory) for _ in range(k)]
+    spec = sps[0].spec
+    carried = [dict() for _ in range(k)]
+    results = [[] for _ in range(k)]
+    n_orig = len(plan.inputs)
+    for r, (p_r, exchanges) in enumerate(spec.rounds):
+        outs_all = []
+        for s in range(k):
+            ins = list(shard_inputs[s]) + [carried[s][v] for v in p_r.inputs[n_orig:]]
+            outs_all.append(list(sps[s].execs[r](*ins)))
+        for pos, rop, xdt in exchanges:
+            bufs = []
+            for s in range(k):
+                o = outs_all[s][pos]
+                if not isinstance(o, torch.Tensor):
+                    o = torch.as_tensor(np.asarray(o), dtype=_torch_dtype(xdt))
+                bufs.append(o.clone())
+            grp.all_reduce_many(bufs, rop)
+            for s in range(k):
+                outs_all[s][pos] = bufs[s]
+        for s in range(k):
+            results[s].append(outs_all[s])
+            for v, o in zip(p_r.outputs, outs_all[s]):
+                carried[s][v] = o
+    return [[results[s][r][pos] for r, pos in spec.out_src] for s in range(k)], spec
+
+
+# ---------------------------------------------------------------------------------------------
+# independent-output placement
+# ---------------------------------------------------------------------------------------------
+def _ancestors(plan: Plan, out: int, producer: Dict[int, int]) -> set:
+    seen, stack = set(), [out]
+    while stack:
+        v = stack.pop()
+        ni = producer.get(v)
+        if ni is None or ni in seen:
+            continue
+        seen.add(ni)
+        stack.extend(plan.nodes[ni].inputs)
+    return seen
+
+
+def _node_cost(plan: Plan, n: Node) -> int:
+    """Static work estimate used only to balance ranks: heavy for contractions and Scan, the
+    operand count for streaming ops (shapes are dynamic, so this is a rank, not a time)."""
+    if n.op in ("Gemm", "Dot22", "Dot22Scalar", "BatchedDot", "MatMul"):
+        return 64
+    if n.op == "Scan":
+        return 256
+    if n.op in ("Gemv", "Dot", "Ger"):
+        return 8
+    if n.op in ("Elemwise", "CAReduce"):
+        return 1 + sum(plan.vars[i].ndim > 0 for i in n.inputs)
+    return 1
+
+
+def place_outputs(plan: Plan, world: int) -> List[List[int]]:
+    """Assign plan outputs to ranks so that no computed value is needed on two ranks.
+
+    Outputs whose ancestor node sets intersect are kept together (one component); components
+    are placed largest-first on the least-loaded rank.  Returns, per rank, the positions of
+    the outputs it computes (plan inputs / constants are replicated, never communicated)."""
+    producer = {o: ni for ni, n in enumerate(plan.nodes) for o in n.outputs}
+    anc = [_ancestors(plan, o, producer) for o in plan.outputs]
+    comp = list(range(len(plan.outputs)))
+
+    def find(a):
+        while comp[a] != a:
+            comp[a] = comp[comp[a]]
+            a = comp[a]
+        return a
+    for i in range(len(anc)):
+        for j in range(i):
+            if anc[i] & anc[j]:
+                comp[find(i)] = find(j)
+    groups: Dict[int, List[int]] = {}
+    for i in range(len(anc)):
+        groups.setdefault(find(i), []).append(i)
+    costs = []
+    for root, members in groups.items():
+        nodes = set().union(*(anc[m] for m in members))
+        costs.append((sum(_node_cost(plan, plan.nodes[ni]) for ni in nodes), members))
+    costs.sort(key=lambda t: (-t[0], t[1]))
+    load = [0] * world
+    placed: List[List[int]] = [[] for _ in range(world)]
+    for c, members in costs:
+        r = min(range(world), key=lambda q: (load[q], q))
+        load[r] += max(c, 1)
+        placed[r].extend(members)
+    return [sorted(p) for p in placed]
+
+
+def subplan_for_outputs(plan: Plan, positions: Sequence[int]) -> Plan:
+    """The part of ``plan`` that computes the outputs at ``positions`` (same inputs)."""
+    producer = {o: ni for ni, n in enumerate(plan.nodes) for o in n.outputs}
+    keep = set()
+    for p in positions:
+        keep |= _ancestors(plan, plan.outputs[p], producer)
+    return Plan(plan.name + "_outs" + "_".join(map(str, positions)), plan.vars, list(plan.inputs),
+                [plan.outputs[p] for p in positions], [n for ni, n in enumerate(plan.nodes)
+                                                       if ni in keep])
+
+
+class PlacedPlan:
+    """Independent graph outputs on different GPUs (module docstring, 2.): this rank evaluates
+    only the outputs :func:`place_outputs` gave it; ``__call__`` returns a list with ``None`` in
+    the positions other ranks own — no communication."""
+
+    def __init__(self, plan: Plan, world: int, rank: int, use_graph=False, executor_factory=None,
+                 device=None):
+        self.placement = place_outputs(plan, world)
+        self.mine = self.placement[rank]
+        self.n_out = len(plan.outputs)
+        self.exec = None
+        if self.mine:
+            sub = subplan_for_outputs(plan, self.mine)
+            if executor_factory is None:
+                from .executor import PlanExecutor
+                self.exec = PlanExecutor(sub, use_graph=use_graph, device=device)
+            else:
+                self.exec = executor_factory(sub)
+
+    def owner(self, position: int) -> int:
+        return next(r for r, ps in enumerate(self.placement) if position in ps)
+
+    def __call__(self, *inputs):
+        res = [None] * self.n_out
+        if self.exec is not None:
+            for p, o in zip(self.mine, self.exec(*inputs)):
+                res[p] = o
+        return res
 
 
 class ShardedFunction:
-    """Evaluate a plan on this rank's row block and combine outputs across ranks.
-
-    ``executor`` maps the local inputs to local outputs (the HIP executor on a GPU; any callable
-    in tests).  Outputs tagged "allreduce" are summed over the process group; the handles of the
-    asynchronous collectives are returned so that callers can pipeline evaluations."""
+    """Thin combiner kept for callers that evaluate the local block themselves: outputs tagged
+    "allreduce" are summed over the process group (asynchronously on request, so consecutive
+    evaluations pipeline behind the latency-bound collective)."""
 
     def __init__(self, executor, kinds: Sequence[str], group=None):
         self.executor = executor

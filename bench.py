@@ -1,16 +1,27 @@
 #!/usr/bin/env python
 """Benchmark of the HIP linker hot path (driver contract: see the repo prompt / DESIGN.md §5).
 
-Workload at N=1 = BASELINE.json configs[1]: the fused Elemwise chain
+Headline (``value``) = BASELINE.json configs[1]: the fused Elemwise chain
 ``exp(-(x-mu)**2 / (2*sigma**2)).sum()`` on a float64 4096x4096 matrix — the plan is the one the
 HIP linker lowers from the reference's FAST_RUN graph (tests/golden: cfg2_gauss_sum; shapes are
 dynamic, so the same plan runs at 4096x4096).  One "step" = one evaluation of the compiled
 function: one launch-list replay (a single host call into libaesara_hip.so) that issues the ONE
 fused Elemwise+Sum kernel (in-kernel deterministic finalize), with ``x`` resident in HBM.
 
-N>1 (weak scaling): every rank evaluates its own 4096x4096 row block of a (N*4096)x4096 matrix;
-the CAReduce partial is summed over ranks with one RCCL all-reduce per eval (issued
-asynchronously so consecutive evals pipeline) — the only collective, SURVEY §8e.
+The same JSON line carries ``"secondary"``: every other BASELINE config at its full shape, each
+with its own ``roofline`` timed by HIP events in this run and a correctness assert against an
+fp64 restatement on the same data:
+
+* cfg3b  Gemm fp32 4096^3 (the ``check_blas.py:54-57`` update ``C <- 0.4*C + 0.8*dot(A,B)``), MFMA-bound
+* cfg3a  Gemv fp64 4096^2 (``M.dot(v)*alpha + beta*y``), HBM-bound
+* cfg1b  matrix add fp64 4096^2, HBM-bound
+* cfg4   Scan GRU T=512 H=1024 fp32, B=1 (vector state) and B=64 (matrix state)
+* cfg5   logistic-regression logp + grad, N=2^24 x 256 fp32 (16 GiB of X) — row-sharded over the
+         ranks for N>1 (strong scaling: 2^24/N rows per rank, ONE all-reduce of the 258 fp64 partials)
+
+N>1: the headline stays config 2 under weak scaling (every rank evaluates its own 4096x4096 row
+block; the CAReduce partial is summed with one bucketed asynchronous RCCL all-reduce), so the
+driver's N=1,2,4,8 series is one workload; config 5's strong-scaling figure rides in ``secondary``.
 
 Prints ONE JSON line (rank 0).  ``roofline`` is measured live with HIP events on the launch
 stream; ``cpu_baseline`` times the oracle's C port of the reference C linker's loops on the
@@ -28,8 +39,50 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (guide: 8.0 TB/s; ~6.3 TB/s achievable)
+MFMA_F32_PEAK = 157.3          # TFLOP/s, v_mfma_f32_16x16x4_f32 dense (guide)
 ROWS, COLS = 4096, 4096
 ALGO_BYTES = ROWS * COLS * 8   # x read once (134 217 728 B per eval)
+
+
+class DevTimer:
+    """HIP events on the launch stream (torch.cuda.Event only sees torch's current stream —
+    here they coincide, but the events are created through the C-ABI like the launches)."""
+
+    def __init__(self, C, lib, check, torch):
+        self.C, self.lib, self.check, self.torch = C, lib, check, torch
+        self.e0, self.e1 = C.c_void_p(), C.c_void_p()
+        check(lib.ahip_event_create(C.byref(self.e0)))
+        check(lib.ahip_event_create(C.byref(self.e1)))
+
+    def stream(self):
+        return self.C.c_void_p(self.torch.cuda.current_stream().cuda_stream)
+
+    def time(self, fn, iters, warmup=3):
+        """(device ms per call, wall ms per call) over `iters` back-to-back calls."""
+        for _ in range(warmup):
+            fn()
+        self.torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        self.check(self.lib.ahip_event_record(self.e0, self.stream()))
+        for _ in range(iters):
+            fn()
+        self.check(self.lib.ahip_event_record(self.e1, self.stream()))
+        self.torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / iters
+        ms = self.C.c_float()
+        self.check(self.lib.ahip_event_elapsed_ms(self.e0, self.e1, self.C.byref(ms)))
+        return ms.value / iters, wall * 1e3
+
+
+def roof(bound, work, dev_ms, peak, **extra):
+    if bound == "hbm":
+        ach, unit = work / (dev_ms * 1e-3) / 1e9, "GB/s"
+    else:
+        ach, unit = work / (dev_ms * 1e-3) / 1e12, "TFLOP/s"
+    r = {"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+         "kernel_ms": dev_ms, "algorithmic": work}
+    r.update(extra)
+    return r
 
 
 def main():
@@ -38,7 +91,12 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--eager", action="store_true", help="no hipGraph (per-node launches)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="headline only (used by the rocprofv3 passes of tools/profile_bench.sh)")
+    ap.add_argument("--only-secondary", default="",
+                    help="comma list of secondary workloads to run (default: all)")
+    ap.add_argument("--cfg5-log2n", type=int, default=24, help="config 5 rows = 2**k (total)")
+    ap.add_argument("--eager", action="store_true", help="no launch-list replay (per-node launches)")
     args = ap.parse_args()
 
     import ctypes as C
@@ -70,25 +128,35 @@ def main():
     from aesara_amd._lib import check, lib
     from aesara_amd.executor import PlanExecutor
 
-    plan = case_plan(next(c for c in CASES if c["name"] == "cfg2_gauss_sum"))
-    ex = PlanExecutor(plan, use_graph=not args.eager)
+    G = not args.eager
+
+    def plan_of(name):
+        return case_plan(next(c for c in CASES if c["name"] == name))
+
+    def randn(shape, dtype, seed):
+        g = torch.Generator(device="cuda")
+        g.manual_seed(seed)
+        return torch.randn(*shape, dtype=dtype, device="cuda", generator=g)
+
+    timer = DevTimer(C, lib, check, torch)
+    f64, f32 = torch.float64, torch.float32
+
+    ex = PlanExecutor(plan_of("cfg2_gauss_sum"), use_graph=G)
 
     # synthetic input of the named shape, generated on device (rank-specific row block)
-    g = torch.Generator(device="cuda")
-    g.manual_seed(1 + rank)
-    x = torch.randn(ROWS, COLS, dtype=torch.float64, device="cuda", generator=g)
-    mu = torch.tensor(0.1, dtype=torch.float64, device="cuda")
-    sigma = torch.tensor(1.3, dtype=torch.float64, device="cuda")
+    x = randn((ROWS, COLS), f64, 1 + rank)
+    mu = torch.tensor(0.1, dtype=f64, device="cuda")
+    sigma = torch.tensor(1.3, dtype=f64, device="cuda")
 
     from aesara_amd.dist import ShardedFunction, plan_split_outputs
 
-    kinds = plan_split_outputs(plan, 0)           # ["allreduce"]: Sum over the split row axis
+    kinds = plan_split_outputs(plan_of("cfg2_gauss_sum"), 0)   # ["allreduce"]: Sum over the split rows
     # ring of result slots: the fused kernel of eval i writes its partial straight into
     # ring[i % R] (executor out=), and every BUCKET evals ONE asynchronous RCCL all-reduce sums
     # a bucket of partials over the ranks (bucketed: the 8-byte payload is latency-bound on xGMI),
     # so consecutive evals pipeline behind the collective
     R, BUCKET = 32, 8
-    ring = torch.zeros(R, dtype=torch.float64, device="cuda")
+    ring = torch.zeros(R, dtype=f64, device="cuda")
     slots = [ring[i] for i in range(R)]
     state = {"i": 0}
     reducer = ShardedFunction(lambda bucket: [bucket], kinds)
@@ -124,7 +192,7 @@ def main():
         h.wait()
     barrier()
 
-    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    stream = timer.stream()
     ev0, ev1 = C.c_void_p(), C.c_void_p()
     check(lib.ahip_event_create(C.byref(ev0)))
     check(lib.ahip_event_create(C.byref(ev1)))
@@ -147,14 +215,38 @@ def main():
     ms = C.c_float()
     check(lib.ahip_event_elapsed_ms(ev0, ev1, C.byref(ms)))
 
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
+    elapsed = torch.tensor([t1 - t0], dtype=f64, device="cuda")
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = elapsed.item()
 
+    # the driver's --steps may be small (20 evals = 0.55 ms): a longer untimed-by-contract run
+    # of the same step gives the sustained figure next to it
+    sustained = None
+    if world == 1:
+        d_ms, w_ms = timer.time(lambda: ex(x, mu, sigma), max(args.steps, 2000), warmup=0)
+        sustained = {"evals": max(args.steps, 2000), "kernel_ms": d_ms, "evals_per_s": 1e3 / max(d_ms, w_ms),
+                     "frac": ALGO_BYTES / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+    secondary = []
+    if not args.no_secondary:
+        only = [s for s in args.only_secondary.split(",") if s]
+        ctx = dict(torch=torch, np=np, dist=dist, timer=timer, plan_of=plan_of, randn=randn,
+                   PlanExecutor=PlanExecutor, G=G, rank=rank, world=world, args=args)
+        for name, fn in SECONDARY:
+            if only and name not in only:
+                continue
+            if world > 1 and name != "cfg5":
+                continue              # replicas only: measured at N=1
+            r = fn(ctx)
+            if rank == 0:
+                secondary.extend(r if isinstance(r, list) else [r])
+            torch.cuda.empty_cache()
+
     if rank == 0:
         dev_ms_per_eval = ms.value / args.steps          # device time per eval on the stream
         achieved = ALGO_BYTES / (dev_ms_per_eval * 1e-3) / 1e9
+        traffic, traffic_src = measured_traffic()
         res = {
             "metric": "compiled-fn evals/sec + achieved HBM GB/s (elemwise) / MFMA % (gemm), 1->8 GPU",
             "value": args.steps * world / elapsed,
@@ -173,12 +265,15 @@ def main():
                        "rows_per_gpu": ROWS, "cols": COLS,
                        "parallelism": "row-sharded x%d, bucketed async RCCL all-reduce of the CAReduce "
                                       "partials (8 evals per collective)" % world
-                                      if world > 1 else "single GPU"},
+                                      if world > 1 else "single GPU",
+                       "sustained": sustained},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(),
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": dev_ms_per_eval, "algorithmic_bytes": ALGO_BYTES},
         }
+        if secondary:
+            res["secondary"] = secondary
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(np)
         print(json.dumps(res))
@@ -186,21 +281,207 @@ def main():
         dist.destroy_process_group()
 
 
+# ---------------------------------------------------------------------------------------------
+# secondary workloads: the other BASELINE configs at full shape
+# ---------------------------------------------------------------------------------------------
+
+def sec_cfg3b(c):
+    """Gemm fp32 4096^3 through the plan the linker lowers for check_blas.py:54-57's update."""
+    torch = c["torch"]
+    f32 = torch.float32
+    ex = c["PlanExecutor"](c["plan_of"]("cfg3b_gemm_update"), use_graph=c["G"])
+    Cm = c["randn"]((4096, 4096), f32, 1)
+    A, B = c["randn"]((4096, 4096), f32, 3), c["randn"]((4096, 4096), f32, 4)
+    (out,) = ex(Cm, A, B)
+    ref = 0.4 * Cm.double() + 0.8 * (A.double() @ B.double())
+    rel = (torch.linalg.norm(out.double() - ref) / torch.linalg.norm(ref)).item()
+    assert rel <= 1e-6, f"cfg3b Frobenius rel err {rel}"
+    del ref
+    rows = []
+    for name, a, b in (("NN", A, B), ("NT", A, B.t()), ("TN", A.t(), B), ("TT", A.t(), B.t())):
+        d, w = c["timer"].time(lambda: ex(Cm, a, b), 30)
+        rows.append({"config": "cfg3b Gemm fp32 4096^3 0.4*C+0.8*A@B (%s)" % name, "dtype": "f32",
+                     "evals_per_s": 1e3 / max(d, w),
+                     "roofline": roof("mfma", 2 * 4096 ** 3, d, MFMA_F32_PEAK,
+                                      kernel="gemm.hip 128x128 v_mfma_f32_16x16x4_f32"),
+                     "check": {"frobenius_rel_err_vs_fp64": rel, "bar": 1e-6} if name == "NN" else None})
+    return rows
+
+
+def sec_cfg3a(c):
+    torch = c["torch"]
+    f64 = torch.float64
+    plan = c["plan_of"]("gemv_beta_float64")        # beta*y + alpha*M.v (alpha, beta: plan constants)
+    ex = c["PlanExecutor"](plan, use_graph=c["G"])
+    alpha, beta = (float(plan.vars[k].const["data"][0]) for k in (3, 4))
+    M = c["randn"]((4096, 4096), f64, 2)
+    v, y = c["randn"]((4096,), f64, 3), c["randn"]((4096,), f64, 4)
+    (out,) = ex(y, M, v)
+    ref = alpha * (M @ v) + beta * y
+    err = ((out - ref).abs().max() / ref.abs().max()).item()
+    assert err <= 1e-10, f"cfg3a rel err {err}"
+    d, w = c["timer"].time(lambda: ex(y, M, v), 200)
+    return {"config": "cfg3a Gemv fp64 4096^2 alpha*M.v + beta*y", "dtype": "f64",
+            "evals_per_s": 1e3 / max(d, w),
+            "roofline": roof("hbm", 4096 * 4096 * 8 + 2 * 4096 * 8, d, HBM_PEAK_GBS),
+            "check": {"max_rel_err_vs_fp64": err, "bar": 1e-10}}
+
+
+def sec_cfg1b(c):
+    torch = c["torch"]
+    f64 = torch.float64
+    ex = c["PlanExecutor"](c["plan_of"]("cfg1b_matrix_add"), use_graph=c["G"])
+    x, y = c["randn"]((4096, 4096), f64, 0), c["randn"]((4096, 4096), f64, 1)
+    (out,) = ex(x, y)
+    assert torch.equal(out, x + y)
+    d, w = c["timer"].time(lambda: ex(x, y), 200)
+    return {"config": "cfg1b matrix add fp64 4096^2", "dtype": "f64", "evals_per_s": 1e3 / max(d, w),
+            "roofline": roof("hbm", 3 * 4096 * 4096 * 8, d, HBM_PEAK_GBS), "check": {"exact": True}}
+
+
+def _gru_ref(torch, x, h0, Ws):
+    """fp64 restatement of the GRU step of tests/golden cfg4 (oracle/gen_golden.py), all T steps."""
+    Wz, Uz, Wr, Ur, Wh, Uh = [W.double() for W in Ws]
+    h = h0.double()
+    xd = x.double()
+    xz, xr, xh = xd @ Wz, xd @ Wr, xd @ Wh
+    for t in range(x.shape[0]):
+        z = torch.sigmoid(xz[t] + h @ Uz)
+        r = torch.sigmoid(xr[t] + h @ Ur)
+        hh = torch.tanh(xh[t] + (r * h) @ Uh)
+        h = (1 - z) * h + z * hh
+    return h
+
+
+def sec_cfg4(c):
+    torch, np = c["torch"], c["np"]
+    f32 = torch.float32
+    T, H = 512, 1024
+    rows = []
+    Ws = [c["randn"]((H, H), f32, 5 + k) / np.sqrt(H) for k in range(6)]
+    for B, case in ((1, "cfg4_gru_b1_f32"), (64, "cfg4_gru_b8_f32")):
+        ex = c["PlanExecutor"](c["plan_of"](case), use_graph=c["G"])
+        shp = (T, H) if B == 1 else (T, B, H)
+        x = c["randn"](shp, f32, 4) * 0.1
+        h0 = torch.zeros((H,) if B == 1 else (B, H), dtype=f32, device="cuda")
+        t0 = time.perf_counter()
+        outs = ex(x, h0, *Ws)
+        torch.cuda.synchronize()
+        first = time.perf_counter() - t0
+        hT = outs[-1].double()
+        ref = _gru_ref(torch, x, h0, Ws)
+        err = ((hT - ref).abs().max() / ref.abs().max()).item()
+        assert err <= 1e-5, f"cfg4 B={B} h_T rel err {err}"
+        d, w = c["timer"].time(lambda: ex(x, h0, *Ws), 5, warmup=1)
+        kind = getattr(ex, "scan_modes", None)
+        if B == 1:
+            # two bounds (SURVEY §8d): weights re-streamed every step vs kept on chip
+            rl = roof("hbm", T * 6 * H * H * 4, d, HBM_PEAK_GBS, us_per_step=d * 1e3 / T,
+                      note="algorithmic = 6 HxH fp32 matrices re-streamed every step (the reference's "
+                           "per-step work); resident bound = 24 MiB once + x + outputs",
+                      resident_bound_bytes=6 * H * H * 4 + 2 * T * H * 4)
+        else:
+            rl = roof("mfma", T * 6 * 2 * B * H * H, d, MFMA_F32_PEAK, us_per_step=d * 1e3 / T)
+        rows.append({"config": "cfg4 Scan GRU T=512 H=1024 fp32 B=%d" % B, "dtype": "f32",
+                     "evals_per_s": 1e3 / max(d, w), "first_call_s": first, "scan_path": kind,
+                     "roofline": rl, "check": {"hT_max_rel_err_vs_fp64_all_steps": err, "bar": 1e-5}})
+        del ex
+    return rows
+
+
+def sec_cfg5(c):
+    """Config 5 at full shape, row-sharded over the ranks (strong scaling): every rank runs the
+    single-pass row program on its 2^k/N rows, ONE all-reduce sums the 258 accumulator-dtype
+    partials (aesara_amd/dist.py), the casts to the output dtype happen after it."""
+    torch, dist = c["torch"], c["dist"]
+    f32 = torch.float32
+    world, rank = c["world"], c["rank"]
+    N, D = 1 << c["args"].cfg5_log2n, 256
+    n_loc = N // world
+    g = torch.Generator(device="cuda")
+    g.manual_seed(6 + 1000 * rank)
+    X = torch.empty((n_loc, D), dtype=f32, device="cuda")
+    blk = 1 << 20
+    for i in range(0, n_loc, blk):
+        X[i:i + blk] = torch.randn((min(blk, n_loc - i), D), dtype=f32, device="cuda", generator=g)
+    gw_ = torch.Generator(device="cuda")
+    gw_.manual_seed(7)
+    wv = torch.randn((D,), dtype=f32, device="cuda", generator=gw_) / 16
+    b = torch.tensor(0.1, dtype=f32, device="cuda")
+    yv = (torch.rand(n_loc, device="cuda", generator=g) < 0.5).to(f32)
+
+    from aesara_amd.dist import ShardedPlan
+    sp = ShardedPlan(c["plan_of"]("cfg5_logistic"), split_inputs={0: 0, 3: 0}, use_graph=c["G"],
+                     group=None if world == 1 else dist.group.WORLD)
+    outs = sp(X, wv, b, yv)
+    torch.cuda.synchronize()
+    logp, gw, gb = [o.clone() for o in outs]
+    # fp64 restatement in row blocks (local rows), summed over the ranks
+    acc = torch.zeros(D + 2, dtype=torch.float64, device="cuda")
+    for i in range(0, n_loc, 1 << 21):
+        Xd = X[i:i + (1 << 21)].double()
+        yd = yv[i:i + (1 << 21)].double()
+        z = Xd @ wv.double() + 0.1
+        acc[0] += -(yd * torch.nn.functional.softplus(-z) + (1 - yd) * torch.nn.functional.softplus(z)).sum()
+        r = yd - torch.sigmoid(z)
+        acc[1] += r.sum()
+        acc[2:] += Xd.t() @ r
+        del Xd, yd, z, r
+    if world > 1:
+        dist.all_reduce(acc)
+    e_logp = abs(logp.item() - acc[0].item()) / abs(acc[0].item())
+    e_gb = abs(gb.item() - acc[1].item()) / max(abs(acc[1].item()), 1.0)
+    e_gw = (torch.linalg.norm(gw.double() - acc[2:]) / torch.linalg.norm(acc[2:])).item()
+    assert e_logp <= 1e-6 and e_gw <= 1e-5, (e_logp, e_gb, e_gw)
+
+    iters = 20
+    for _ in range(3):
+        sp(X, wv, b, yv)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    d, w = c["timer"].time(lambda: sp(X, wv, b, yv), iters, warmup=0)
+    t = torch.tensor([max(d, w)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ms_job = t.item()
+    local_bytes = n_loc * D * 4 + n_loc * 4
+    return {"config": "cfg5 logistic logp+grad fp32 N=2^%d D=256, %d rank(s) x %d rows, strong scaling"
+                      % (c["args"].cfg5_log2n, world, n_loc),
+            "dtype": "f32", "n_gpus": world, "scaling": "strong",
+            "evals_per_s": 1e3 / ms_job, "ms_per_eval": ms_job,
+            "collective": None if world == 1 else "1 all-reduce(sum) of 258 fp64 per eval",
+            "aggregate_GBs": world * local_bytes / (ms_job * 1e-3) / 1e9,
+            "roofline": roof("hbm", local_bytes, d, HBM_PEAK_GBS,
+                             note="per-rank: local X once + y; kernel_ms includes the collective for N>1"),
+            "check": {"logp_rel_err": e_logp, "gb_rel_err": e_gb, "gw_rel_err": e_gw,
+                      "bars": [1e-6, 1e-6, 1e-5]}}
+
+
+SECONDARY = [("cfg3b", sec_cfg3b), ("cfg3a", sec_cfg3a), ("cfg1b", sec_cfg1b), ("cfg4", sec_cfg4),
+             ("cfg5", sec_cfg5)]
+
+
 def measured_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_bench_traffic.json: FETCH_SIZE doubled per the gfx950 correction of
-    MI355X_MICROARCH.md §HBM, + WRITE_SIZE); null when no profile has been committed."""
-    path = os.path.join(ROOT, "profiles", "r01_bench_traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f)["hbm_bytes_per_launch"]
-    except Exception:
-        return None
+    """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes of this command
+    (separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs, tools/profile_bench.sh; FETCH_SIZE
+    doubled per the gfx950 correction of MI355X_MICROARCH.md §HBM).  Counters cannot be read
+    inside an unprofiled run, so the figure comes from the newest committed pass; null if none."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                return json.load(f)["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+        except Exception:
+            continue
+    return None, None
 
 
 def cpu_baseline(np):
     """Oracle C port of the reference C linker's loops for the same graph, same shape, on the
-    host: bounded sample (a few evals, ~0.2 s each), single thread like the reference default."""
+    host: bounded sample (a few evals, ~0.1 s each), single thread like the reference default
+    (openmp=False, configdefaults.py:1037), plus the `openmp=True` form (the Elemwise loop
+    under `#pragma omp parallel for`, elemwise.py:1108-1123; the Sum stays sequential)."""
     import cport
     xh = np.random.default_rng(1).standard_normal((ROWS, COLS))
     cport.cfg2_eval(xh, 0.1, 1.3)  # warm-up (page faults)
@@ -209,10 +490,25 @@ def cpu_baseline(np):
         cport.cfg2_eval(xh, 0.1, 1.3)
         n += 1
     dt = (time.perf_counter() - t0) / n
-    return {"value": 1.0 / dt, "unit": "evals/s", "cores": 1, "kind": "port",
-            "sample": "%d evals of the same 4096x4096 fp64 graph (oracle/c_port.c: unfused "
-                      "Composite loop + Sum loop as the reference C linker runs them)" % n,
-            "ms_per_eval": dt * 1e3, "host_cores_visible": os.cpu_count()}
+    res = {"value": 1.0 / dt, "unit": "evals/s", "cores": 1, "kind": "port",
+           "sample": "%d evals of the same 4096x4096 fp64 graph (oracle/c_port.c: unfused "
+                     "Composite loop + Sum loop as the reference C linker runs them)" % n,
+           "ms_per_eval": dt * 1e3, "host_cores_visible": os.cpu_count()}
+    try:
+        threads = min(os.cpu_count() or 1, 64)
+        cport.cfg2_eval_omp(xh, 0.1, 1.3, threads)
+        n, t0 = 0, time.perf_counter()
+        while n < 40 and time.perf_counter() - t0 < 8.0:
+            cport.cfg2_eval_omp(xh, 0.1, 1.3, threads)
+            n += 1
+        dt = (time.perf_counter() - t0) / n
+        res["openmp"] = {"value": 1.0 / dt, "unit": "evals/s", "cores": threads, "kind": "port",
+                         "ms_per_eval": dt * 1e3,
+                         "sample": "%d evals, AESARA_FLAGS=openmp=True form: Elemwise loop parallel, "
+                                   "Sum sequential" % n}
+    except Exception as e:  # pragma: no cover - libgomp missing on the host
+        res["openmp"] = {"error": str(e)}
+    return res
 
 
 if __name__ == "__main__":

@@ -40,6 +40,28 @@ double cport_cfg2_eval(const double* x, long n, double mu, double sigma) {
   return acc;
 }
 
+/* The same graph as the reference runs it under AESARA_FLAGS=openmp=True: only the Elemwise
+ * loop carries `#pragma omp parallel for` (tensor/elemwise.py:1108-1123, above
+ * config.openmp_elemwise_minsize); the CAReduce loop has no OpenMP form and stays sequential. */
+double cport_cfg2_eval_omp(const double* x, long n, double mu, double sigma, int threads) {
+  const double sig2 = sigma * sigma;
+  const double c = -0.5;
+  double* tmp = (double*)malloc((size_t)n * sizeof(double));
+  if (!tmp) return NAN;
+#pragma omp parallel for num_threads(threads) schedule(static)
+  for (long i = 0; i < n; ++i) {
+    const double t0 = x[i] - mu;
+    const double t1 = t0 * t0;
+    const double t2 = c * t1;
+    const double t3 = t2 / sig2;
+    tmp[i] = exp(t3);
+  }
+  double acc = 0.0;
+  for (long i = 0; i < n; ++i) acc += tmp[i];
+  free(tmp);
+  return acc;
+}
+
 /* BASELINE config 1b: Elemwise{add,no_inplace} on two C-contiguous matrices (fresh output) */
 void cport_cfg1b_add(const double* x, const double* y, double* out, long n) {
   for (long i = 0; i < n; ++i) out[i] = x[i] + y[i];

@@ -1,7 +1,8 @@
-"""Multi-process (world_size 2, gloo, CPU) test of the sharded path of SURVEY §8e: row-shard the
-batch, evaluate the local block, all-reduce the CAReduce partials — must equal the unsharded
-result.  The per-rank evaluation uses the oracle here (no GPU in this tier); on the GPU box the
-same ShardedFunction wraps the HIP executor (bench.py --gpus N)."""
+"""Multi-GPU path on CPU: the sharding analysis (`aesara_amd.dist.shard_plan`), the
+round structure + packed accumulator-dtype exchange (`ShardedPlan`) over a world_size-2 `gloo`
+group, k logical shards in one process (`run_local_shards`), and independent-output placement.
+The per-rank evaluation uses the oracle here (no GPU in this tier); tests/test_gpu_dist.py runs
+the same classes over the HIP executor."""
 import os
 import sys
 
@@ -12,6 +13,12 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+from dist_plans import (colsoftmax_plan, gemv_beta_plan, mean_plan, oracle_factory,  # noqa: E402
+                        prod_plan, two_tower_plan)
 
 
 def _worker(rank, world, port, case_name, q):
@@ -22,47 +29,169 @@ def _worker(rank, world, port, case_name, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        import interp
         from golden_util import CASES, case_inputs, case_plan
-        from aesara_amd.dist import ShardedFunction, plan_split_outputs, shard_rows
+        from aesara_amd.dist import ShardedPlan, shard_rows
 
-        c = next(c for c in CASES if c["name"] == case_name)
-        plan, ins = case_plan(c), case_inputs(c)
+        if case_name == "colsoftmax":
+            plan = colsoftmax_plan()
+            ins = [np.random.default_rng(3).standard_normal((37, 5))]
+            split = {0: 0}
+        elif case_name == "mean":
+            plan = mean_plan()
+            ins = [np.random.default_rng(4).standard_normal((41, 6)).astype(np.float32)]
+            split = {0: 0}
+        else:
+            c = next(c for c in CASES if c["name"] == case_name)
+            plan, ins = case_plan(c), case_inputs(c)
+            split = {0: 0, 3: 0} if case_name == "cfg5_logistic" else {0: 0}
         n = ins[0].shape[0]
         lo, hi = shard_rows(n, world, rank)
-        if case_name == "cfg5_logistic":
-            local = [ins[0][lo:hi], ins[1], ins[2], ins[3][lo:hi]]
-        else:
-            local = [ins[0][lo:hi]] + ins[1:]
-        kinds = plan_split_outputs(plan, 0)
-        fn = ShardedFunction(
-            lambda *a: [torch.from_numpy(np.array(o, dtype=np.float64)) for o in interp.run_plan(plan, a)],
-            kinds)
-        outs = fn(*local)
-        if rank == 0:
-            q.put((kinds, [o.numpy() for o in outs]))
+        local = [x[lo:hi] if k in split else x for k, x in enumerate(ins)]
+        sp = ShardedPlan(plan, split, executor_factory=oracle_factory)
+        outs = sp(*local)
+        outs2 = sp(*local)             # second call: packed buffers are reused
+        res = [np.asarray(o) for o in outs]
+        for a, b in zip(res, outs2):
+            np.testing.assert_array_equal(a, np.asarray(b))
+        q.put((rank, sp.spec.n_exchange_rounds, [st[0] for st in sp.spec.out_state], res))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case_name", ["cfg2_gauss_sum", "cfg5_logistic"])
-def test_row_sharded_allreduce_matches_unsharded(case_name):
-    from golden_util import CASES, case_expected
+def _run2(case_name):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 2000)
     procs = [ctx.Process(target=_worker, args=(r, 2, port, case_name, q)) for r in range(2)]
     for p in procs:
         p.start()
-    kinds, outs = q.get(timeout=120)
+    got = sorted([q.get(timeout=180) for _ in range(2)], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
+    return got
+
+
+@pytest.mark.parametrize("case_name", ["cfg2_gauss_sum", "cfg5_logistic"])
+def test_row_sharded_allreduce_matches_unsharded(case_name):
+    """BASELINE configs 2 and 5 row-sharded over 2 gloo ranks: ONE exchange round of
+    accumulator-dtype (fp64) partials; logp / db within 1e-6 of the reference's output, dw within
+    the reference's own fp32 error."""
+    from golden_util import CASES, case_expected
+    got = _run2(case_name)
     c = next(c for c in CASES if c["name"] == case_name)
     exp = case_expected(c)
-    assert all(k == "allreduce" for k in kinds)
-    for o, e in zip(outs, exp):
-        np.testing.assert_allclose(o, e.astype(np.float64), rtol=1e-4, atol=1e-3)
+    for rank, n_rounds, states, outs in got:
+        assert n_rounds == 1 and all(s == "rep" for s in states)
+        for k, (o, e) in enumerate(zip(outs, exp)):
+            assert o.dtype == e.dtype and o.shape == e.shape
+            tol = 1e-6 if e.ndim == 0 else 1e-5
+            np.testing.assert_allclose(o.astype(np.float64), e.astype(np.float64), rtol=tol,
+                                       atol=tol * max(1.0, float(np.abs(e).max())))
+    for a, b in zip(got[0][3], got[1][3]):      # every rank holds the same combined value
+        np.testing.assert_array_equal(a, b)
+
+
+def test_two_exchange_rounds_and_split_output_gloo():
+    """Column softmax over the split axis: max (round 0) -> sum of exp (round 1) -> row-local
+    quotient: two exchange rounds, the output stays sharded."""
+    got = _run2("colsoftmax")
+    x = np.random.default_rng(3).standard_normal((37, 5))
+    e = np.exp(x - x.max(axis=0, keepdims=True))
+    want = e / e.sum(axis=0, keepdims=True)
+    from aesara_amd.dist import shard_rows
+    for rank, n_rounds, states, outs in got:
+        assert n_rounds == 2 and states == ["split"]
+        lo, hi = shard_rows(37, 2, rank)
+        np.testing.assert_allclose(outs[0], want[lo:hi], rtol=1e-12)
+
+
+def test_global_extent_mean_gloo():
+    """mean over the split axis = Sum / Shape_i: the local extent is exchanged (summed) for the
+    division while allocations would keep the local one."""
+    got = _run2("mean")
+    x = np.random.default_rng(4).standard_normal((41, 6)).astype(np.float32)
+    for rank, n_rounds, states, outs in got:
+        assert states == ["rep"]
+        np.testing.assert_allclose(outs[0], x.astype(np.float64).mean(axis=0).astype(np.float32),
+                                   rtol=1e-6)
+
+
+def test_unprovable_plans_raise():
+    from golden_util import CASES, case_plan
+    from aesara_amd.dist import ShardingError, plan_split_outputs, shard_plan
+    with pytest.raises(ShardingError):      # product over the split axis is not combinable here
+        shard_plan(prod_plan(), {0: 0})
+    with pytest.raises(ShardingError):      # beta*y would be summed world-size times
+        shard_plan(gemv_beta_plan(), {1: 1, 2: 0})
+    cfg5 = case_plan(next(c for c in CASES if c["name"] == "cfg5_logistic"))
+    with pytest.raises(ShardingError):      # y spans the split axis but was not declared split
+        shard_plan(cfg5, {0: 0})
+    assert plan_split_outputs(cfg5, 0) == ["allreduce"] * 3
+    scan = case_plan(next(c for c in CASES if c["name"] == "cfg4_gru_b1_f32"))
+    with pytest.raises(ShardingError):      # Scan over a split sequence: replicas only
+        shard_plan(scan, {0: 0})
+    # replicated everywhere: a single local round, nothing exchanged
+    spec = shard_plan(scan, {})
+    assert spec.n_exchange_rounds == 0 and len(spec.rounds) == 1
+
+
+def test_exchange_dtype_is_the_accumulator_dtype():
+    from golden_util import CASES, case_plan
+    from aesara_amd.dist import shard_plan
+    spec = shard_plan(case_plan(next(c for c in CASES if c["name"] == "cfg5_logistic")), {0: 0, 3: 0})
+    (p0, ex0), (p1, ex1) = spec.rounds
+    assert [(op, dt) for _, op, dt in ex0] == [("add", "float64")] * 3 and ex1 == []
+    # the float32 results are produced only after the combine
+    assert {p1.vars[o].dtype for o in p1.outputs} == {"float32"}
+    assert all(n.op == "Elemwise" for n in p1.nodes)
+
+
+def test_logical_shards_in_one_process_match_unsharded():
+    import interp
+    from golden_util import CASES, case_inputs, case_plan
+    from aesara_amd.dist import run_local_shards, shard_rows
+    c = next(c for c in CASES if c["name"] == "cfg5_logistic")
+    plan, ins = case_plan(c), case_inputs(c)
+    want = interp.run_plan(plan, ins)
+    for k in (1, 2, 3):
+        shards = []
+        for r in range(k):
+            lo, hi = shard_rows(ins[0].shape[0], k, r)
+            shards.append([ins[0][lo:hi], ins[1], ins[2], ins[3][lo:hi]])
+        outs, spec = run_local_shards(plan, {0: 0, 3: 0}, shards, executor_factory=oracle_factory)
+        for s in range(k):
+            for o, w in zip(outs[s], want):
+                tol = 2e-6 if w.ndim == 0 else 1e-5      # dw: the reference's own fp32 error
+                np.testing.assert_allclose(np.asarray(o), w, rtol=tol,
+                                           atol=tol * max(1.0, float(np.abs(w).max())))
+
+
+def test_independent_outputs_are_placed_on_different_ranks():
+    import interp
+    from aesara_amd.dist import PlacedPlan, place_outputs
+    plan = two_tower_plan()
+    placement = place_outputs(plan, 2)
+    # outputs 0 and 2 share the first tower (kept together), output 1 is the heavier GEMM tower
+    assert sorted(map(tuple, placement)) == [(0, 2), (1,)]
+    assert place_outputs(plan, 1) == [[0, 1, 2]]
+    rng = np.random.default_rng(0)
+    ins = [rng.standard_normal((6, 4)), rng.standard_normal((4, 4)), rng.standard_normal((4, 3))]
+    want = interp.run_plan(plan, ins)
+    seen = set()
+    for rank in range(2):
+        pp = PlacedPlan(plan, 2, rank, executor_factory=oracle_factory)
+        outs = pp(*ins)
+        for k, o in enumerate(outs):
+            if o is not None:
+                assert pp.owner(k) == rank and k not in seen
+                seen.add(k)
+                np.testing.assert_allclose(np.asarray(o), want[k], rtol=1e-12)
+    assert seen == {0, 1, 2}
+    # each rank's sub-plan holds only its own tower's nodes
+    n_nodes = [len(PlacedPlan(plan, 2, r, executor_factory=oracle_factory).exec.plan.nodes)
+               for r in range(2)]
+    assert sum(n_nodes) == len(plan.nodes)
 
 
 def test_shard_rows_partition():

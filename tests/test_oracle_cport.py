@@ -18,3 +18,8 @@ def test_cport_cfg1b():
     out = np.empty(1000)
     lib.cport_cfg1b_add(x.ctypes.data, y.ctypes.data, out.ctypes.data, 1000)
     assert np.array_equal(out, x + y)
+
+
+def test_cport_openmp_form_equals_serial():
+    x = np.random.default_rng(5).standard_normal((257, 129))
+    assert cport.cfg2_eval_omp(x, 0.1, 1.3, 4) == cport.cfg2_eval(x, 0.1, 1.3)
