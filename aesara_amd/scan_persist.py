@@ -1,0 +1,456 @@
+"""K10p — the Scan step loop as ONE persistent kernel (SURVEY §8a H11 "v2", BASELINE north_star).
+
+Replaces, for the recurrent-vector class of inner graphs, what ``Scan.perform`` drives from the
+host (scan/op.py:1673) through ``scan_perform.pyx:309-541``: per step, slice the sequences and
+taps, run the inner function, write the outputs into the (circular) output buffers.  The
+launch-list path (executor._scan_loop) issues the fused step kernels T times and re-streams every
+weight matrix from L2 / HBM on every step; here one launch runs all T steps:
+
+* the workgroups partition the output rows; each keeps ITS rows of every loop-invariant matrix in
+  LDS for the whole loop (BASELINE config 4: 3 x 1024 x 1024 fp32 = 12 MiB over 256 CUs = 48 KiB
+  per CU), so HBM sees the weights once per evaluation, not once per step;
+* a vector that a later dot product needs in full (the new state h_t, an intermediate such as
+  r*h) is exchanged through L2 as 8-byte ``{tag, value}`` granules written with ONE agent-scope
+  store each (single-copy atomic, write-through: MI355X guide "handoff-1to1" / "allgather" rows);
+  a consumer polls the granules it needs with relaxed agent-scope loads until they carry the tag
+  of the producing step, stages the values in LDS and goes on — no grid barrier, no fences, no
+  separate flags.  Tags are ``base + step + 1`` with ``base`` read from a device counter that
+  workgroup 0 advances by T at the end, so replays (hipGraph) never see a stale tag; four slots
+  per vector (step & 3) keep a fast producer from overwriting what a slow consumer still reads;
+* everything a row owner needs again (its previous state rows, the rows of sequence operands of
+  the next step) stays in registers: lane i of a wavefront owns one output row.
+
+Eligibility (anything else runs the launch-list path, and ``PlanExecutor.scan_modes`` says which
+was taken): no mit-mot / shared outputs / do-while, every recurrent output has the single tap -1,
+the fused inner steps are Gemv chains + Elemwise on float32 vectors of one length M, matrices are
+loop invariant and row-contiguous with K % 4 == 0, at least one exchanged vector, T >= 2, and the
+matrix rows of a workgroup fit in LDS.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import hashlib
+import json
+import os
+
+from . import codegen as cg
+
+SP_MAXMAT = 8
+SP_MAXSEQ = 12
+SP_MAXNSQ = 12
+SP_MAXOUT = 8
+SPIN_LIMIT = 1 << 21
+LDS_BUDGET = 150 * 1024
+CTLS = []          # control words of live workspaces (error flags; debugging aid)
+
+
+class SpArgs(C.Structure):
+    _fields_ = [
+        ("T", C.c_int64),
+        ("mat", C.c_void_p * SP_MAXMAT), ("mat_rs", C.c_int64 * SP_MAXMAT),
+        ("seq", C.c_void_p * SP_MAXSEQ), ("seq_ts", C.c_int64 * SP_MAXSEQ),
+        ("seq_es", C.c_int64 * SP_MAXSEQ),
+        ("nsq", C.c_void_p * SP_MAXNSQ), ("nsq_es", C.c_int64 * SP_MAXNSQ),
+        ("out", C.c_void_p * SP_MAXOUT), ("out_rs", C.c_int64 * SP_MAXOUT),
+        ("out_store", C.c_int64 * SP_MAXOUT), ("out_pos0", C.c_int64 * SP_MAXOUT),
+        ("xch", C.c_void_p), ("ctl", C.c_void_p),
+    ]
+
+
+SP_STRUCT = r"""
+#define SP_MAXMAT %d
+#define SP_MAXSEQ %d
+#define SP_MAXNSQ %d
+#define SP_MAXOUT %d
+struct SpArgs {
+  i64 T;
+  const void* mat[SP_MAXMAT]; i64 mat_rs[SP_MAXMAT];
+  const void* seq[SP_MAXSEQ]; i64 seq_ts[SP_MAXSEQ]; i64 seq_es[SP_MAXSEQ];
+  const void* nsq[SP_MAXNSQ]; i64 nsq_es[SP_MAXNSQ];
+  void* out[SP_MAXOUT]; i64 out_rs[SP_MAXOUT]; i64 out_store[SP_MAXOUT]; i64 out_pos0[SP_MAXOUT];
+  unsigned long long* xch; unsigned* ctl;
+};
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64;
+""" % (SP_MAXMAT, SP_MAXSEQ, SP_MAXNSQ, SP_MAXOUT)
+
+
+# ---------------------------------------------------------------------------------------------
+# static analysis of the fused inner steps (once per inner executor)
+# ---------------------------------------------------------------------------------------------
+class Program:
+    """What the loop does, in terms of vector ids (= inner plan variable ids):
+
+    ``seq``    : var -> sequence slot (rows of a [T, ...] array, incl. hoisted sequence dots)
+    ``state``  : var -> recurrent output index k (value of the previous step)
+    ``nsq``    : var -> invariant slot (vector / scalar operand) ; ``mats``: var -> matrix slot
+    ``phases`` : [{"dots": [(matrix var, vector var)], "ins": [...], "outs": [...], "scalar",
+                   "out_refs"}]
+    ``outs``   : per inner-plan output: (produced var, "rec" | "nit", index)
+    """
+
+    def __init__(self):
+        self.seq, self.state, self.nsq, self.mats = {}, {}, {}, {}
+        self.phases, self.outs = [], []
+        self.new_of_state = {}      # state var -> var holding its new value
+        self.exchanged = []         # produced vars that some dot needs in full
+
+
+def analyze(inner, p, n_seqdots):
+    """Returns (Program, None) or (None, reason)."""
+    plan = inner.plan
+    n_seqs = p["n_seqs"]
+    if p.get("mit_mot_in_slices") or p.get("n_shared_outs", 0) or p.get("as_while", False):
+        return None, "mit-mot / shared outputs / do-while"
+    taps = [list(t) for t in p["mit_sot_in_slices"]] + [list(t) for t in p["sit_sot_in_slices"]]
+    if any(t != [-1] for t in taps):
+        return None, "taps other than [-1]"
+    n_rec, n_nit = len(taps), p["n_nit_sot"]
+    if n_rec == 0:
+        return None, "no recurrent state"
+    pr = Program()
+    ins = list(plan.inputs)
+    n_fixed = len(ins) - n_seqdots
+    for s, v in enumerate(ins[:n_seqs]):
+        pr.seq[v] = s
+    for k, v in enumerate(ins[n_seqs:n_seqs + n_rec]):
+        pr.state[v] = k
+    inv = ins[n_seqs + n_rec:n_fixed]
+    for j, v in enumerate(ins[n_fixed:]):
+        pr.seq[v] = n_seqs + j
+    if len(pr.seq) > SP_MAXSEQ:
+        return None, "too many sequence operands"
+    inv_set = set(inv)
+    produced = {}
+    for st in inner.steps:
+        if st.kind not in ("gemv_epi", "elemwise") or st.reduce is not None or st.post or \
+                st.fallback or st.extra.get("xprog"):
+            return None, f"step kind {st.kind} ({st.node.op if st.node else ''})"
+        dots = []
+        for a, x in st.dots:
+            if a not in inv_set or plan.vars[a].ndim != 2:
+                return None, "dot with a loop-varying matrix"
+            if a not in pr.mats:
+                pr.mats[a] = len(pr.mats)
+            if not (x in pr.seq or x in pr.state or x in produced or x in inv_set):
+                return None, "dot vector of unknown origin"
+            if x in inv_set and x not in pr.nsq:
+                pr.nsq[x] = len(pr.nsq)
+            dots.append((a, x))
+        for v in st.inputs:
+            if v in inv_set:
+                if plan.vars[v].ndim > 1:
+                    return None, "matrix used element-wise"
+                if v not in pr.nsq:
+                    pr.nsq[v] = len(pr.nsq)
+            elif not (v in pr.seq or v in pr.state or v in produced):
+                return None, "operand of unknown origin"
+            if plan.vars[v].dtype != "float32":
+                return None, "non-float32 operand"
+        for o in st.outputs:
+            if plan.vars[o].ndim != 1 or plan.vars[o].dtype != "float32":
+                return None, "step output is not a float32 vector"
+            produced[o] = len(pr.phases)
+        pr.phases.append({"dots": dots, "ins": list(st.inputs), "outs": list(st.outputs),
+                          "scalar": st.scalar, "out_refs": list(st.out_refs)})
+    if len(pr.mats) > SP_MAXMAT or len(pr.nsq) > SP_MAXNSQ or not pr.mats:
+        return None, "no / too many matrices"
+    if len(plan.outputs) != n_rec + n_nit or len(plan.outputs) > SP_MAXOUT:
+        return None, "output count"
+    for j, o in enumerate(plan.outputs):
+        if o not in produced:
+            return None, "a step output is not computed by a fused step"
+        pr.outs.append((o, "rec" if j < n_rec else "nit", j))
+    for v, k in pr.state.items():
+        pr.new_of_state[v] = plan.outputs[k]
+    # which produced vectors have to be exchanged (some dot reads them in full)
+    need = []
+    for ph in pr.phases:
+        for _a, x in ph["dots"]:
+            src = pr.new_of_state.get(x, x)
+            if (x in pr.state or x in produced) and src not in need:
+                need.append(src)
+    if not need:
+        return None, "no recurrent dot product"
+    pr.exchanged = need
+    return pr, None
+
+
+# ---------------------------------------------------------------------------------------------
+# kernel generator
+# ---------------------------------------------------------------------------------------------
+class Spec:
+    """Shape-specialised persistent kernel: M rows, K per matrix, R rows per workgroup."""
+
+    def __init__(self, prog: Program, plan, M, Ks, lens, R, nw):
+        self.prog, self.plan, self.M, self.Ks, self.lens, self.R, self.nw = \
+            prog, plan, M, dict(Ks), dict(lens), R, nw
+        assert R % nw == 0
+        # polling shape (measured defaults; environment overrides for sweeps)
+        self.var = {"pollw": min(nw, int(os.environ.get("AESARA_HIP_SP_POLLW", 2))),
+                    "sleep": int(os.environ.get("AESARA_HIP_SP_SLEEP", "1")),
+                    "repoll": int(os.environ.get("AESARA_HIP_SP_REPOLL", "0"))}
+
+    def key(self):
+        pr = self.prog
+        blob = json.dumps(["sp4", sorted(self.var.items()), self.M, sorted(self.Ks.items()), sorted(self.lens.items()),
+                           self.R, self.nw, sorted(pr.seq.items()), sorted(pr.state.items()),
+                           sorted(pr.nsq.items()), sorted(pr.mats.items()),
+                           [[ph["dots"], ph["ins"], ph["outs"], ph["scalar"], ph["out_refs"]]
+                            for ph in pr.phases], pr.outs, pr.exchanged], sort_keys=True)
+        return hashlib.sha256(blob.encode()).hexdigest()[:24]
+
+
+def xch_layout(prog, lens):
+    """granule offsets of the exchange buffer: per exchanged vector 4 slots of padded length."""
+    off, total = {}, 0
+    for v in prog.exchanged:
+        lp = (lens[v] + 15) // 16 * 16
+        off[v] = (total, lp)
+        total += 4 * lp
+    return off, total
+
+
+def generate(spec: Spec):
+    pr, M, R, NW = spec.prog, spec.M, spec.R, spec.nw
+    BLOCK = 64 * NW
+    RPW = R // NW                         # rows per wavefront = lanes that run the epilogue
+    name = "sp_" + spec.key()
+    L = [cg.PRELUDE, SP_STRUCT]
+    AG = "__ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT"
+
+    # ---- LDS: matrix rows of this workgroup + staged dot vectors (two step parities) ----------
+    woff, wtot = {}, 0
+    for a, slot in sorted(pr.mats.items(), key=lambda t: t[1]):
+        woff[a] = wtot
+        wtot += R * spec.Ks[a]
+    # staged vectors: key (var, "prev" | "cur" | "glob"); invariant dot vectors are staged once
+    stage, stot = {}, 0
+    inv_stage, itot = {}, 0
+    for ph in pr.phases:
+        for a, x in ph["dots"]:
+            K = spec.Ks[a]
+            if x in pr.nsq:
+                if x not in inv_stage:
+                    inv_stage[x] = itot
+                    itot += K
+            else:
+                kind = "prev" if x in pr.state else ("cur" if x not in pr.seq else "glob")
+                if (x, kind) not in stage:
+                    stage[(x, kind)] = stot
+                    stot += K
+    xoff, _xtot = xch_layout(pr, spec.lens)
+    L.append('extern "C" __global__ __launch_bounds__(%d) void %s(SpArgs a) {' % (BLOCK, name))
+    L.append("  __shared__ __attribute__((aligned(16))) float Wl[%d];" % max(wtot, 4))
+    L.append("  __shared__ __attribute__((aligned(16))) float Vl[2][%d];" % max(stot, 4))
+    if itot:
+        L.append("  __shared__ __attribute__((aligned(16))) float Il[%d];" % itot)
+    L.append("  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;")
+    L.append("  const i64 row0 = (i64)blockIdx.x * %d;" % R)
+    L.append("  const i64 myrow = row0 + wave * %d + lane;     // row owned by this lane (lane < %d)" % (RPW, RPW))
+    L.append("  const bool owner = lane < %d && myrow < %d;" % (RPW, M))
+    L.append("  const unsigned base = __hip_atomic_load(a.ctl, %s);" % AG)
+    L.append("  unsigned* errp = a.ctl + 1;")
+    # ---- matrix rows -> LDS ------------------------------------------------------------------
+    for av, slot in sorted(pr.mats.items(), key=lambda t: t[1]):
+        K = spec.Ks[av]
+        K4 = K // 4
+        L.append("  for (int idx = threadIdx.x; idx < %d; idx += %d) {" % (R * K4, BLOCK))
+        L.append("    const int j = idx / %d, k4 = idx %% %d;" % (K4, K4))
+        L.append("    const i64 r = row0 + j;")
+        L.append("    f4 v = {0.f, 0.f, 0.f, 0.f};")
+        L.append("    if (r < %d) v = *(const f4*)((const float*)a.mat[%d] + r * a.mat_rs[%d] + 4 * k4);"
+                 % (M, slot, slot))
+        L.append("    *(f4*)(Wl + %d + j * %d + 4 * k4) = v;" % (woff[av], K))
+        L.append("  }")
+    for x, off in inv_stage.items():
+        K = spec.lens[x]
+        L.append("  for (int k = threadIdx.x; k < %d; k += %d) Il[%d + k] = "
+                 "((const float*)a.nsq[%d])[k * a.nsq_es[%d]];" % (K, BLOCK, off, pr.nsq[x], pr.nsq[x]))
+    # ---- registers of the row owner --------------------------------------------------------------
+    out_of = {}
+    for o, kind, j in pr.outs:
+        out_of.setdefault(o, []).append((kind, j))
+    for v, k in pr.state.items():
+        # value of the previous step: row (pos0 - 1) of the output buffer holds the initial state
+        L.append("  float own_%d = 0.f;" % v)
+        L.append("  if (owner) own_%d = ((const float*)a.out[%d])[((a.out_pos0[%d] + a.out_store[%d] - 1) %% "
+                 "a.out_store[%d]) * a.out_rs[%d] + myrow];" % (v, k, k, k, k, k))
+    pw_nsq = sorted({v for ph in pr.phases for v in ph["ins"] if v in pr.nsq})
+    for v in pw_nsq:
+        es_one = spec.lens[v] == 1
+        L.append("  float own_%d = 0.f;" % v)
+        L.append("  if (owner) own_%d = ((const float*)a.nsq[%d])[%s];"
+                 % (v, pr.nsq[v], "0" if es_one else "myrow * a.nsq_es[%d]" % pr.nsq[v]))
+    pw_seq = sorted({v for ph in pr.phases for v in ph["ins"] if v in pr.seq})
+    for v in pw_seq:
+        s = pr.seq[v]
+        idx = "0" if spec.lens[v] == 1 else "myrow * a.seq_es[%d]" % s
+        L.append("  float nxt_%d = 0.f, own_%d = 0.f;" % (v, v))
+        L.append("  if (owner && a.T > 0) nxt_%d = ((const float*)a.seq[%d])[%s];" % (v, s, idx))
+    for ph in pr.phases:
+        for o in ph["outs"]:
+            L.append("  float own_%d = 0.f;" % o)
+    L.append("  __syncthreads();")
+    L.append("  for (i64 t = 0; t < a.T; ++t) {")
+    L.append("    const int par = (int)(t & 1);")
+    for v in pw_seq:
+        s = pr.seq[v]
+        idx = "0" if spec.lens[v] == 1 else "myrow * a.seq_es[%d]" % s
+        L.append("    own_%d = nxt_%d;" % (v, v))
+        L.append("    if (owner && t + 1 < a.T) nxt_%d = ((const float*)a.seq[%d])[(t + 1) * a.seq_ts[%d] + %s];"
+                 % (v, s, s, idx))
+    staged_this_step = set()
+    for pi, ph in enumerate(pr.phases):
+        L.append("    // ---- phase %d" % pi)
+        # -- gather the dot vectors that are not staged yet
+        need_sync = False
+        for a_, x in ph["dots"]:
+            if x in pr.nsq:
+                continue
+            kind = "prev" if x in pr.state else ("cur" if x not in pr.seq else "glob")
+            if (x, kind) in staged_this_step:
+                continue
+            staged_this_step.add((x, kind))
+            need_sync = True
+            K = spec.Ks[a_]
+            so = stage[(x, kind)]
+            NG = (K + BLOCK - 1) // BLOCK
+            if kind == "glob":
+                s = pr.seq[x]
+                L.append("    for (int k = threadIdx.x; k < %d; k += %d) Vl[par][%d + k] = "
+                         "((const float*)a.seq[%d])[t * a.seq_ts[%d] + k * a.seq_es[%d]];"
+                         % (K, BLOCK, so, s, s, s))
+                continue
+            src = pr.new_of_state.get(x, x)
+            xo, lp = xoff[src]
+            if kind == "prev":
+                k_out = pr.state[x]
+                L.append("    if (t == 0) {")
+                L.append("      const float* ini = (const float*)a.out[%d] + ((a.out_pos0[%d] + a.out_store[%d] - 1) %% "
+                         "a.out_store[%d]) * a.out_rs[%d];" % (k_out, k_out, k_out, k_out, k_out))
+                L.append("      for (int k = threadIdx.x; k < %d; k += %d) Vl[par][%d + k] = ini[k];" % (K, BLOCK, so))
+                L.append("    } else {")
+                step_expr, ind = "(t - 1)", "      "
+            else:
+                L.append("    {")
+                step_expr, ind = "t", "      "
+            PT = 64 * spec.var["pollw"]
+            NGp = (K + PT - 1) // PT
+            pg = "" if PT == BLOCK else "if (threadIdx.x < %d) " % PT
+            L.append(ind + "const u64* src = a.xch + %d + (%s & 3) * %d;" % (xo, step_expr, lp))
+            L.append(ind + "const unsigned want = base + (unsigned)%s + 1u;" % step_expr)
+            L.append(ind + pg + "{")
+            L.append(ind + "u64 g[%d];" % NGp)
+            if spec.var["repoll"]:
+                L.append(ind + "bool have[%d];" % NGp)
+                for q in range(NGp):
+                    L.append(ind + "have[%d] = %s;" % (q, "false" if (q + 1) * PT <= K else
+                                                      "!(threadIdx.x + %d < %d)" % (q * PT, K)))
+            L.append(ind + "for (int spin = 0;; ++spin) {")
+            L.append(ind + "  bool ok = true;")
+            for q in range(NGp):
+                if spec.var["repoll"]:
+                    L.append(ind + "  if (!have[%d]) { g[%d] = __hip_atomic_load(src + threadIdx.x + %d, %s); }"
+                             % (q, q, q * PT, AG))
+                else:
+                    guard = "" if (q + 1) * PT <= K else "if (threadIdx.x + %d < %d) " % (q * PT, K)
+                    L.append(ind + "  %s{ g[%d] = __hip_atomic_load(src + threadIdx.x + %d, %s); "
+                             "ok = ok && ((unsigned)(g[%d] >> 32) == want); }" % (guard, q, q * PT, AG, q))
+            if spec.var["repoll"]:
+                for q in range(NGp):
+                    L.append(ind + "  if (!have[%d]) { have[%d] = ((unsigned)(g[%d] >> 32) == want); ok = ok && have[%d]; }"
+                             % (q, q, q, q))
+            L.append(ind + "  if (ok) break;")
+            # bounded spin; once any workgroup has given up every later wait ends within 256 polls
+            L.append(ind + "  if (spin > %d || ((spin & 255) == 255 && __hip_atomic_load(errp, %s) != 0u)) "
+                     "{ __hip_atomic_store(errp, 1u, %s); break; }" % (SPIN_LIMIT, AG, AG))
+            if spec.var["sleep"]:
+                L.append(ind + "  __builtin_amdgcn_s_sleep(%d);" % spec.var["sleep"])
+            L.append(ind + "}")
+            for q in range(NGp):
+                guard = "" if (q + 1) * PT <= K else "if (threadIdx.x + %d < %d) " % (q * PT, K)
+                L.append(ind + "%sVl[par][%d + threadIdx.x + %d] = __uint_as_float((unsigned)g[%d]);"
+                         % (guard, so, q * PT, q))
+            L.append(ind + "}")
+            L.append("    }")
+        if need_sync:
+            L.append("    __syncthreads();")
+        # -- row dots: wavefront `wave` owns rows wave*RPW .. +RPW
+        D = len(ph["dots"])
+        for d, (a_, x) in enumerate(ph["dots"]):
+            K = spec.Ks[a_]
+            K4 = K // 4
+            if x in pr.nsq:
+                vsrc = "Il + %d" % inv_stage[x]
+            else:
+                kind = "prev" if x in pr.state else ("cur" if x not in pr.seq else "glob")
+                vsrc = "Vl[par] + %d" % stage[(x, kind)]
+            for i in range(RPW):
+                L.append("    float acc%d_%d_%d = 0.f;" % (pi, d, i))
+            L.append("    {")
+            L.append("      const float* vx = %s;" % vsrc)
+            L.append("      const float* wr = Wl + %d + (wave * %d) * %d;" % (woff[a_], RPW, K))
+            L.append("#pragma unroll")
+            L.append("      for (int k4 = lane; k4 < %d; k4 += 64) {" % K4)
+            L.append("        const f4 xv = *(const f4*)(vx + 4 * k4);")
+            for i in range(RPW):
+                L.append("        { const f4 wv = *(const f4*)(wr + %d + 4 * k4); "
+                         "acc%d_%d_%d += wv.x * xv.x + wv.y * xv.y + wv.z * xv.z + wv.w * xv.w; }"
+                         % (i * K, pi, d, i))
+            L.append("      }")
+            L.append("    }")
+        if D:
+            L.append("    for (int s = 32; s > 0; s >>= 1) {")
+            for d in range(D):
+                for i in range(RPW):
+                    L.append("      acc%d_%d_%d += shfl_xor_<float>(acc%d_%d_%d, s);" % (pi, d, i, pi, d, i))
+            L.append("    }")
+        for d in range(D):
+            sel = "acc%d_%d_%d" % (pi, d, RPW - 1)
+            for i in range(RPW - 2, -1, -1):
+                sel = "(lane == %d ? acc%d_%d_%d : %s)" % (i, pi, d, i, sel)
+            L.append("    const float dot_%d_%d = %s;" % (pi, d, sel))
+        # -- epilogue on the row owners
+        L.append("    if (owner) {")
+        ins = ["dot_%d_%d" % (pi, d) for d in range(D)] + ["own_%d" % v for v in ph["ins"]]
+        lines, outs, odts = cg.emit_scalar_body(ph["scalar"], ins, ["float32"] * len(ins),
+                                                indent="      ", suffix="_p%d" % pi)
+        L.extend(lines)
+        for k, (o, ri) in enumerate(zip(ph["outs"], ph["out_refs"])):
+            L.append("      own_%d = %s;" % (o, cg._cast(outs[ri], odts[ri], "float32")))
+            if o in xoff:
+                xo, lp = xoff[o]
+                L.append("      __hip_atomic_store(a.xch + %d + (t & 3) * %d + myrow, "
+                         "((u64)(base + (unsigned)t + 1u) << 32) | (u64)__float_as_uint(own_%d), %s);"
+                         % (xo, lp, o, AG))
+            for kind, j in out_of.get(o, []):
+                L.append("      ((float*)a.out[%d])[((a.out_pos0[%d] + t) %% a.out_store[%d]) * a.out_rs[%d] + myrow] = own_%d;"
+                         % (j, j, j, j, o))
+        L.append("    }")
+    for v, nv in pr.new_of_state.items():
+        L.append("    own_%d = own_%d;" % (v, nv))
+    L.append("  }")
+    # every workgroup read `base` before workgroup 0 can get here (it gathered, in its last
+    # step, a vector that every workgroup published after reading `base`; T >= 2)
+    L.append("  if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.ctl, base + (unsigned)a.T, %s);" % AG)
+    L.append("}")
+    return "\n".join(L) + "\n", (name,)
+
+
+def choose_rows(M, sumK, stage_floats, cu_count=256):
+    """Rows of every matrix per workgroup (R), wavefronts per workgroup, grid size.
+
+    The step time is the exchange latency, which grows with the number of workgroups that poll
+    the same granules (measured on MI355X, BASELINE config 4: 256 workgroups x 4 rows 6.1 us per
+    step, 128 x 8 rows 4.9 us), so the grid is HALF the CUs when the rows still fit in LDS, else
+    one workgroup per CU; ``AESARA_HIP_SCAN_ROWS`` overrides."""
+    nw = 4
+    env = os.environ.get("AESARA_HIP_SCAN_ROWS")
+    cands = [int(env)] if env else [-(-M // max(cu_count // 2, 1)), -(-M // cu_count)]
+    for R in cands:
+        R = -(-max(R, nw) // nw) * nw
+        G = -(-M // R)
+        if R * sumK * 4 + stage_floats * 4 <= LDS_BUDGET and G <= cu_count:
+            return R, nw, G
+    return None

@@ -991,6 +991,85 @@ case("cfg4_gru_b8_f32", rtol=1e-5, atol=1e-5)(_gru("float32", 16, 64, 8, 1e-5))
 case("gru_b1_f64", rtol=1e-11, atol=1e-11)(_gru("float64", 10, 24, 1, 1e-11))
 
 
+
+# ---------------------------------------------------------------------------------------
+# recurrent-vector Scans of the class the persistent one-kernel loop covers
+# (aesara_amd/scan_persist.py): circular output buffers (only the last state is read), two
+# states (LSTM), a nit-sot projection of the new state + invariant vectors, a state length
+# that is not a multiple of the wavefront; sizes modelled on tests/scan/test_basic.py
+# ---------------------------------------------------------------------------------------
+@case("sp_gru_last_f32", rtol=1e-5, atol=1e-5)
+def _():
+    x, h0 = at.fmatrix("x"), at.fvector("h0")
+    Ws = [at.fmatrix(n) for n in ("Wz", "Uz", "Wr", "Ur", "Wh", "Uh")]
+
+    def step(x_t, h, Wz, Uz, Wr, Ur, Wh, Uh):
+        z = at.sigmoid(at.dot(x_t, Wz) + at.dot(h, Uz))
+        r = at.sigmoid(at.dot(x_t, Wr) + at.dot(h, Ur))
+        hh = at.tanh(at.dot(x_t, Wh) + at.dot(r * h, Uh))
+        return (1 - z) * h + z * hh
+    hs, _ = ae.scan(step, sequences=[x], outputs_info=[h0], non_sequences=Ws)
+    H = 52
+    return [x, h0] + Ws, [hs[-1]], \
+        [N((21, H), "float32", 4, 0.3), N((H,), "float32", 3, 0.5)] + \
+        [N((H, H), "float32", 5 + k, 1.0 / np.sqrt(H)) for k in range(6)]
+
+
+@case("sp_lstm_vec_f32", rtol=2e-5, atol=2e-5)
+def _():
+    x, h0, c0 = at.fmatrix("x"), at.fvector("h0"), at.fvector("c0")
+    names = ("Wi", "Ui", "Wf", "Uf", "Wo", "Uo", "Wg", "Ug")
+    Ws = [at.fmatrix(n) for n in names]
+    bf = at.fvector("bf")
+
+    def step(x_t, h, c, Wi, Ui, Wf, Uf, Wo, Uo, Wg, Ug, bf):
+        i = at.sigmoid(at.dot(x_t, Wi) + at.dot(h, Ui))
+        f = at.sigmoid(at.dot(x_t, Wf) + at.dot(h, Uf) + bf)
+        o = at.sigmoid(at.dot(x_t, Wo) + at.dot(h, Uo))
+        g = at.tanh(at.dot(x_t, Wg) + at.dot(h, Ug))
+        c2 = f * c + i * g
+        return o * at.tanh(c2), c2
+    (hs, cs), _ = ae.scan(step, sequences=[x], outputs_info=[h0, c0], non_sequences=Ws + [bf])
+    H, D = 48, 20
+    shapes = [(D, H), (H, H)] * 4
+    return [x, h0, c0] + Ws + [bf], [hs, cs[-1]], \
+        [N((17, D), "float32", 4, 0.5), N((H,), "float32", 2, 0.3), N((H,), "float32", 3, 0.3)] + \
+        [N(sh, "float32", 5 + k, 1.0 / np.sqrt(sh[0])) for k, sh in enumerate(shapes)] + \
+        [N((H,), "float32", 20, 0.5, 1.0)]
+
+
+@case("sp_rnn_proj_f32", rtol=1e-5, atol=1e-5)
+def _():
+    x, h0 = at.fmatrix("x"), at.fvector("h0")
+    W, U_, V, b, c = at.fmatrix("W"), at.fmatrix("U"), at.fmatrix("V"), at.fvector("b"), at.fvector("c")
+
+    def step(x_t, h, W, U_, V, b, c):
+        h2 = at.tanh(at.dot(x_t, W) + at.dot(h, U_) + b)
+        return h2, at.dot(h2, V) + c
+    (hs, ys), _ = ae.scan(step, sequences=[x], outputs_info=[h0, None], non_sequences=[W, U_, V, b, c])
+    H, D = 32, 12
+    return [x, h0, W, U_, V, b, c], [hs, ys], \
+        [N((19, D), "float32", 4, 0.5), N((H,), "float32", 2, 0.3), N((D, H), "float32", 5, 0.3),
+         N((H, H), "float32", 6, 0.18), N((H, H), "float32", 7, 0.18), N((H,), "float32", 8, 0.1),
+         N((H,), "float32", 9, 0.1)]
+
+
+@case("sp_rnn_proj_narrow_f32", rtol=1e-5, atol=1e-5)
+def _():
+    # the projection is narrower than the state: outside the persistent class (launch-list path)
+    x, h0 = at.fmatrix("x"), at.fvector("h0")
+    W, U_, V = at.fmatrix("W"), at.fmatrix("U"), at.fmatrix("V")
+
+    def step(x_t, h, W, U_, V):
+        h2 = at.tanh(at.dot(x_t, W) + at.dot(h, U_))
+        return h2, at.dot(h2, V)
+    (hs, ys), _ = ae.scan(step, sequences=[x], outputs_info=[h0, None], non_sequences=[W, U_, V])
+    H, D, P = 32, 12, 8
+    return [x, h0, W, U_, V], [hs[-1], ys], \
+        [N((15, D), "float32", 4, 0.5), N((H,), "float32", 2, 0.3), N((D, H), "float32", 5, 0.3),
+         N((H, H), "float32", 6, 0.18), N((H, P), "float32", 7, 0.18)]
+
+
 # ---------------------------------------------------------------------------------------
 # Softmax family and Argmax (tests/tensor/test_special.py TestSoftmax/TestLogSoftmax/
 # TestSoftmaxGrad; tests/tensor/test_math.py TestMaxAndArgmax)

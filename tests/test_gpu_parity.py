@@ -45,7 +45,7 @@ def test_hip_matches_reference(c):
     ("cfg", "scan_", "gru", "softmax", "logsoftmax", "layernorm", "argmax", "gemv_", "advsub1",
      "lstm", "nll", "mlp", "cumop", "split", "advsub_nd", "advincsub_nd", "arange", "ifelse",
      "red_large", "reduce_all_t", "ew_transposed", "subtensor_3d", "blas_strides", "hierarchical",
-     "nnet_logreg", "sort_argsort", "rnn_lm"))],
+     "nnet_logreg", "sort_argsort", "rnn_lm", "sp_"))],
                          ids=lambda c: c["name"])
 def test_hip_graph_replay_matches_reference(c):
     """Same cases through hipGraph capture + replay (H1/K10 launch-list path)."""

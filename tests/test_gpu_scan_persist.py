@@ -1,0 +1,108 @@
+"""The Scan step loop as ONE persistent kernel (aesara_amd/scan_persist.py): parity with the
+reference's outputs, with the launch-list path and with an fp64 restatement at the BASELINE
+config-4 shape; replays (device-side tag epochs), workgroup geometries, fallbacks."""
+import os
+
+import numpy as np
+import pytest
+
+from golden_util import CASES, assert_matches, case_expected, case_inputs, case_plan
+
+pytestmark = pytest.mark.gpu
+
+PERSISTENT = ["cfg4_gru_b1_f32", "sp_gru_last_f32", "sp_lstm_vec_f32", "sp_rnn_proj_f32"]
+
+
+def _case(name):
+    return next(c for c in CASES if c["name"] == name)
+
+
+def _np(outs):
+    return [o.cpu().numpy() if hasattr(o, "cpu") else np.asarray(o) for o in outs]
+
+
+@pytest.mark.parametrize("name", PERSISTENT)
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_persistent_path_is_taken_and_matches(name, use_graph):
+    from aesara_amd import executor as E
+    c = _case(name)
+    ex = E.PlanExecutor(case_plan(c), use_graph=use_graph)
+    ins = case_inputs(c)
+    for it in range(4):                       # later calls: replay with advanced tag epochs
+        got = _np(ex(*ins))
+        assert_matches(c, got, case_expected(c), f"persistent call {it}")
+    assert list(ex.scan_modes.values()) == ["persistent"], ex.scan_modes
+    # identical to the launch-list path up to fp32 summation order
+    E.TUNE["scan_persist"] = 0
+    try:
+        ex2 = E.PlanExecutor(case_plan(c), use_graph=use_graph)
+        ref = _np(ex2(*ins))
+        assert all(v.startswith("launch-list") for v in ex2.scan_modes.values())
+    finally:
+        E.TUNE["scan_persist"] = 1
+    for g, r in zip(got, ref):
+        np.testing.assert_allclose(g, r, rtol=2e-5, atol=2e-5)
+
+
+def test_outside_the_class_falls_back():
+    from aesara_amd.executor import PlanExecutor
+    c = _case("sp_rnn_proj_narrow_f32")
+    ex = PlanExecutor(case_plan(c))
+    assert_matches(c, _np(ex(*case_inputs(c))), case_expected(c), "fallback")
+    assert all(v.startswith("launch-list") for v in ex.scan_modes.values()), ex.scan_modes
+
+
+def _gru_ref(x, h0, Ws):
+    import torch
+    Wz, Uz, Wr, Ur, Wh, Uh = [W.double() for W in Ws]
+    h = h0.double()
+    xd = x.double()
+    xz, xr, xh = xd @ Wz, xd @ Wr, xd @ Wh
+    hs = []
+    for t in range(x.shape[0]):
+        z = torch.sigmoid(xz[t] + h @ Uz)
+        r = torch.sigmoid(xr[t] + h @ Ur)
+        hh = torch.tanh(xh[t] + (r * h) @ Uh)
+        h = (1 - z) * h + z * hh
+        hs.append(h)
+    return torch.stack(hs)
+
+
+@pytest.mark.parametrize("T,H,rows", [(512, 1024, None), (512, 1024, 8), (64, 1000, None),
+                                      (33, 1024, 8), (7, 260, None), (2, 64, None)])
+def test_gru_full_size_all_steps_vs_fp64(T, H, rows, monkeypatch):
+    """BASELINE config 4 (T=512, H=1024, fp32, B=1) and ragged relatives: EVERY step's state
+    against an fp64 restatement (rel <= 1e-5 of the state's scale), eager and replayed."""
+    import torch
+    from aesara_amd.executor import PlanExecutor
+    if rows:
+        monkeypatch.setenv("AESARA_HIP_SCAN_ROWS", str(rows))
+    g = torch.Generator(device="cuda")
+    g.manual_seed(4)
+    x = torch.randn(T, H, dtype=torch.float32, device="cuda", generator=g) * 0.1
+    h0 = torch.randn(H, dtype=torch.float32, device="cuda", generator=g) * 0.5
+    Ws = [torch.randn(H, H, dtype=torch.float32, device="cuda", generator=g) / np.sqrt(H)
+          for _ in range(6)]
+    ref = _gru_ref(x, h0, Ws)
+    for use_graph in (False, True):
+        ex = PlanExecutor(case_plan(_case("cfg4_gru_b1_f32")), use_graph=use_graph)
+        for it in range(3):
+            hs, hT = ex(x, h0, *Ws)
+        assert list(ex.scan_modes.values()) == ["persistent"], ex.scan_modes
+        assert hs.shape == (T, H)
+        err = ((hs.double() - ref).abs().max() / ref.abs().max()).item()
+        assert err <= 1e-5, err
+        assert torch.equal(hT, hs[-1])
+
+
+def test_persistent_replays_are_deterministic():
+    import torch
+    from aesara_amd.executor import PlanExecutor
+    c = _case("sp_lstm_vec_f32")
+    ex = PlanExecutor(case_plan(c), use_graph=True)
+    ins = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in case_inputs(c)]
+    first = [o.clone() for o in ex(*ins)]
+    for _ in range(20):
+        outs = ex(*ins)
+        for a, b in zip(outs, first):
+            assert torch.equal(a, b)

@@ -258,7 +258,7 @@ def main():
         d, w = timeit(lambda: ex64(C64, A64, B64), 10)
         report("gemm f64 4096^3", d, w, 2 * 4096 ** 3, "TFLOP/s", 78.6)
 
-    if want("cfg4"):
+    if want("cfg4") or args.only == "gruB1":
         T, H = int(os.environ.get("AESARA_PROBE_T", 512)), 1024
         ex = PlanExecutor(plan_of("cfg4_gru_b1_f32"), use_graph=G)
         x = randn((T, H), f32, 4) * 0.1
@@ -270,7 +270,7 @@ def main():
         first = time.perf_counter() - t0
         d, w = timeit(lambda: ex(x, h0, *Ws), 5 if T > 64 else 1, warmup=1)
         report("cfg4 scan GRU T=%d H=1024 f32 B=1" % T, d, w, T * 6 * H * H * 4, "GB/s", 8000.0,
-               us_per_step=d * 1e3 / T, first_call_s=first)
+               us_per_step=d * 1e3 / T, first_call_s=first, scan_modes=list(ex.scan_modes.values()))
 
     if want("softmax"):
         Nr, Kc = 1 << 16, 1024
