@@ -438,15 +438,18 @@ class ShardedPlan:
     the next round's replay reading views of that buffer."""
 
     def __init__(self, plan: Plan, split_inputs: Dict[int, int], group=None, use_graph=False,
-                 executor_factory: Optional[Callable] = None, device=None):
+                 executor_factory: Optional[Callable] = None, device=None, borrow=False):
         self.spec = shard_plan(plan, split_inputs)
+        self.borrow = borrow or not use_graph
         self.group = group
         self.plan = plan
         if executor_factory is None:
             from .executor import PlanExecutor
 
             def executor_factory(p, use_graph=use_graph):
-                return PlanExecutor(p, use_graph=use_graph, device=device)
+                # rounds hand their results to the next round / the packed exchange buffer by
+                # pointer: borrowed internally, the final outputs are copied out below
+                return PlanExecutor(p, use_graph=use_graph, device=device, borrow=True)
         self.execs = [executor_factory(p) for p, _ in self.spec.rounds]
         self._packs: Dict[tuple, list] = {}
 
@@ -536,6 +539,8 @@ class ShardedPlan:
             for v, o in zip(p_k.outputs, outs):
                 carried_vals[v] = o
         final = [results[r][pos] for r, pos in spec.out_src]
+        if not self.borrow and not async_op:
+            final = [o.clone() if isinstance(o, torch.Tensor) else o for o in final]
         return (final, handles) if async_op else final
 
 
@@ -666,7 +671,7 @@ class PlacedPlan:
             sub = subplan_for_outputs(plan, self.mine)
             if executor_factory is None:
                 from .executor import PlanExecutor
-                self.exec = PlanExecutor(sub, use_graph=use_graph, device=device)
+                self.exec = PlanExecutor(sub, use_graph=use_graph, device=device)   # fresh outputs
             else:
                 self.exec = executor_factory(sub)
 

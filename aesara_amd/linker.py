@@ -49,10 +49,13 @@ class HipLinker(JITLinker):
     """A ``Linker`` that runs a whole ``FunctionGraph`` as HIP kernels on an MI355X."""
 
     def __init__(self, *args, return_numpy=False, use_graph=False, executor_factory=None,
-                 **kwargs):
+                 fast_call=True, **kwargs):
         super().__init__(*args, **kwargs)
         self.return_numpy = return_numpy
         self.use_graph = use_graph
+        # fast_call: the function's VM is one closure (bind cells -> executor -> store cells)
+        # instead of ``streamline`` over a one-thunk list (H0: the per-eval host protocol)
+        self.fast_call = fast_call
         # test hook: lets CPU-only tests substitute a checker for the device executor.
         self.executor_factory = executor_factory
         self.plan = None
@@ -94,7 +97,58 @@ class HipLinker(JITLinker):
         from .sharedvar import DeviceContainer
 
         fn, ins, outs, thunks, nodes = super().make_all(*args, **kwargs)
+        if self.fast_call and len(thunks) == 1:
+            fn = self._fast_vm(fn, thunks[0])
         return fn, [DeviceContainer.adopt(c) for c in ins], outs, thunks, nodes
+
+    def _fast_vm(self, slow_fn, thunk):
+        """What ``Function.__call__`` invokes as ``self.vm()`` (compile/function/types.py:967-973).
+
+        ``streamline`` (link/utils.py:150) wraps the single JIT thunk in a generic loop: clear the
+        no-recycling cells, iterate (thunk, node, old_storage) triples under a try block, clear
+        dead storage; the thunk itself (link/basic.py:663-678) rebuilds its argument list, walks
+        ``zip(fgraph.outputs, cells, values)`` and sets a compute-map flag per output.  With one
+        thunk that owns the whole graph none of that carries information: the closure below binds
+        the input cells to the executor call and stores the results, nothing else.  Attributes
+        the reference reads from the VM (``allow_gc``, ``storage_map``, ``jit_fn``, ``thunks``,
+        ``nodes``) are forwarded."""
+        jit = slow_fn.jit_fn
+        in_cells = list(thunk.inputs)
+        out_cells = list(thunk.outputs)
+        out_vars = list(self.fgraph.outputs)
+        plain = not self.return_numpy
+        ofilter = self.output_filter
+        n_in = len(in_cells)
+        if n_in == 1:
+            c0 = in_cells[0]
+            call = lambda: jit(c0[0])                                  # noqa: E731
+        elif n_in == 2:
+            c0, c1 = in_cells
+            call = lambda: jit(c0[0], c1[0])                           # noqa: E731
+        elif n_in == 3:
+            c0, c1, c2 = in_cells
+            call = lambda: jit(c0[0], c1[0], c2[0])                    # noqa: E731
+        else:
+            call = lambda: jit(*[c[0] for c in in_cells])              # noqa: E731
+
+        if plain and len(out_cells) == 1:
+            oc = out_cells[0]
+
+            def vm():
+                oc[0] = call()[0]
+        elif plain:
+            def vm():
+                for cell, val in zip(out_cells, call()):
+                    cell[0] = val
+        else:
+            def vm():
+                for var, cell, val in zip(out_vars, out_cells, call()):
+                    cell[0] = ofilter(var, val)
+        for attr in ("jit_fn", "allow_gc", "storage_map"):
+            setattr(vm, attr, getattr(slow_fn, attr))
+        vm.thunks, vm.nodes = [thunk], getattr(slow_fn, "nodes", None)
+        vm.slow_vm = slow_fn
+        return vm
 
     def create_thunk_inputs(self, storage_map):
         return [storage_map[n] for n in self.fgraph.inputs]

@@ -141,7 +141,7 @@ def main():
     timer = DevTimer(C, lib, check, torch)
     f64, f32 = torch.float64, torch.float32
 
-    ex = PlanExecutor(plan_of("cfg2_gauss_sum"), use_graph=G)
+    ex = PlanExecutor(plan_of("cfg2_gauss_sum"), use_graph=G, borrow=True)
 
     # synthetic input of the named shape, generated on device (rank-specific row block)
     x = randn((ROWS, COLS), f64, 1 + rank)
@@ -261,7 +261,8 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: fused Elemwise exp(-(x-mu)^2/2sigma^2).sum(), "
-                                   "fp64 4096x4096 per GPU, inputs resident in HBM, launch-list replay",
+                                   "fp64 4096x4096 per GPU, inputs resident in HBM, launch-list replay, "
+                                   "outputs borrowed (Out(borrow=True): function-owned buffers)",
                        "rows_per_gpu": ROWS, "cols": COLS,
                        "parallelism": "row-sharded x%d, bucketed async RCCL all-reduce of the CAReduce "
                                       "partials (8 evals per collective)" % world
@@ -289,7 +290,7 @@ def sec_cfg3b(c):
     """Gemm fp32 4096^3 through the plan the linker lowers for check_blas.py:54-57's update."""
     torch = c["torch"]
     f32 = torch.float32
-    ex = c["PlanExecutor"](c["plan_of"]("cfg3b_gemm_update"), use_graph=c["G"])
+    ex = c["PlanExecutor"](c["plan_of"]("cfg3b_gemm_update"), use_graph=c["G"], borrow=True)
     Cm = c["randn"]((4096, 4096), f32, 1)
     A, B = c["randn"]((4096, 4096), f32, 3), c["randn"]((4096, 4096), f32, 4)
     (out,) = ex(Cm, A, B)
@@ -312,7 +313,7 @@ def sec_cfg3a(c):
     torch = c["torch"]
     f64 = torch.float64
     plan = c["plan_of"]("gemv_beta_float64")        # beta*y + alpha*M.v (alpha, beta: plan constants)
-    ex = c["PlanExecutor"](plan, use_graph=c["G"])
+    ex = c["PlanExecutor"](plan, use_graph=c["G"], borrow=True)
     alpha, beta = (float(plan.vars[k].const["data"][0]) for k in (3, 4))
     M = c["randn"]((4096, 4096), f64, 2)
     v, y = c["randn"]((4096,), f64, 3), c["randn"]((4096,), f64, 4)
@@ -330,7 +331,7 @@ def sec_cfg3a(c):
 def sec_cfg1b(c):
     torch = c["torch"]
     f64 = torch.float64
-    ex = c["PlanExecutor"](c["plan_of"]("cfg1b_matrix_add"), use_graph=c["G"])
+    ex = c["PlanExecutor"](c["plan_of"]("cfg1b_matrix_add"), use_graph=c["G"], borrow=True)
     x, y = c["randn"]((4096, 4096), f64, 0), c["randn"]((4096, 4096), f64, 1)
     (out,) = ex(x, y)
     assert torch.equal(out, x + y)
@@ -360,7 +361,7 @@ def sec_cfg4(c):
     rows = []
     Ws = [c["randn"]((H, H), f32, 5 + k) / np.sqrt(H) for k in range(6)]
     for B, case in ((1, "cfg4_gru_b1_f32"), (64, "cfg4_gru_b8_f32")):
-        ex = c["PlanExecutor"](c["plan_of"](case), use_graph=c["G"])
+        ex = c["PlanExecutor"](c["plan_of"](case), use_graph=c["G"], borrow=True)
         shp = (T, H) if B == 1 else (T, B, H)
         x = c["randn"](shp, f32, 4) * 0.1
         h0 = torch.zeros((H,) if B == 1 else (B, H), dtype=f32, device="cuda")
@@ -411,7 +412,7 @@ def sec_cfg5(c):
     yv = (torch.rand(n_loc, device="cuda", generator=g) < 0.5).to(f32)
 
     from aesara_amd.dist import ShardedPlan
-    sp = ShardedPlan(c["plan_of"]("cfg5_logistic"), split_inputs={0: 0, 3: 0}, use_graph=c["G"],
+    sp = ShardedPlan(c["plan_of"]("cfg5_logistic"), split_inputs={0: 0, 3: 0}, use_graph=c["G"], borrow=True,
                      group=None if world == 1 else dist.group.WORLD)
     outs = sp(X, wv, b, yv)
     torch.cuda.synchronize()

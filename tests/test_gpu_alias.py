@@ -1,0 +1,114 @@
+"""Buffer ownership on the GPU: in-place updates never corrupt live views;
+replayed calls hand out fresh outputs unless borrowed and still raise on a bad index (medium)."""
+import numpy as np
+import pytest
+
+from test_host_logic import _alias_plan
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("view_is_output", [True, False])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_view_of_updated_alloc_keeps_its_values(view_is_output, use_graph):
+    from aesara_amd.executor import PlanExecutor
+    ex = PlanExecutor(_alias_plan(view_is_output), use_graph=use_graph)
+    y = np.array([7.0, 8.0, 9.0])
+    for _ in range(3):
+        a, r = [o.cpu().numpy() for o in ex(np.float64(1.5), np.int64(4), y)]
+        z = np.full((4, 3), 1.5)
+        want_r = z.copy()
+        want_r[0] = y
+        np.testing.assert_array_equal(r, want_r)
+        np.testing.assert_array_equal(a, z.T if view_is_output else z.T.sum(axis=0))
+
+
+def test_replay_outputs_are_fresh_unless_borrowed():
+    import torch
+    from golden_util import CASES, case_plan
+    from aesara_amd.executor import PlanExecutor
+    plan = case_plan(next(c for c in CASES if c["name"] == "cfg1b_matrix_add"))
+    x = torch.ones(64, 64, dtype=torch.float64, device="cuda")
+    for borrow in (False, True):
+        ex = PlanExecutor(plan, use_graph=True, borrow=borrow)
+        outs = []
+        for k in range(4):
+            y = torch.full((64, 64), float(k), dtype=torch.float64, device="cuda")
+            outs.append(ex(x, y)[0])
+        torch.cuda.synchronize()
+        if borrow:      # function-owned buffer: later calls overwrite what was handed out
+            assert len({o.data_ptr() for o in outs[1:]}) < 3
+        else:           # every call's result survives the following calls
+            for k, o in enumerate(outs):
+                assert float(o[0, 0]) == 1.0 + k, (k, float(o[0, 0]))
+
+
+def test_replayed_call_with_bad_index_raises():
+    import torch
+    from golden_util import CASES, case_inputs, case_plan
+    from aesara_amd.executor import PlanExecutor
+    c = next(c for c in CASES if c["name"] == "advsub1")
+    plan, ins = case_plan(c), case_inputs(c)
+    ipos = next(k for k, a in enumerate(ins) if np.asarray(a).dtype.kind == "i" and np.asarray(a).ndim == 1)
+    ex = PlanExecutor(plan, use_graph=True)
+    dev = [torch.from_numpy(np.ascontiguousarray(a)).cuda() if np.asarray(a).ndim else a for a in ins]
+    for _ in range(3):
+        ex(*dev)                                   # recorded, then replayed
+    bad = dev[ipos].clone()
+    bad[0] = 10 ** 6
+    good = dev[ipos].clone()
+    dev[ipos].copy_(bad)                            # same tensor, new values: the replay fast path
+    ex(*dev)                                        # the check is deferred (no pipeline stall) ...
+    with pytest.raises(IndexError):
+        ex.check()                                  # ... and reported once the flag has landed
+    dev[ipos].copy_(good)
+    ex(*dev)
+    ex.check()                                      # flag was reset
+    dev[ipos].copy_(bad)
+    ex(*dev)
+    torch.cuda.synchronize()
+    with pytest.raises(IndexError):                 # without check(): the next calls report it
+        for _ in range(3):
+            ex(*dev)
+            torch.cuda.synchronize()
+
+
+def test_replay_arena_is_packed_by_lifetimes():
+    """Static buffer plan: the replay arena of a many-intermediate plan is ONE
+    buffer whose size is the peak of the live set, smaller than the sum of all allocations, and
+    replays compute the same values in it call after call."""
+    from golden_util import CASES, assert_matches, case_expected, case_inputs, case_plan
+    from aesara_amd.executor import PlanExecutor
+    for name in ("nll_classifier_float32", "lstm_bptt_float32", "mlp_layers_float32"):
+        c = next(c for c in CASES if c["name"] == name)
+        ex = PlanExecutor(case_plan(c), use_graph=True)
+        ins = case_inputs(c)
+        for _ in range(4):
+            got = [o.cpu().numpy() if hasattr(o, "cpu") else np.asarray(o) for o in ex(*ins)]
+            assert_matches(c, got, case_expected(c), "packed arena")
+        total, naive = ex.arena_bytes
+        assert 0 < total <= naive, (name, total, naive)
+        if name != "mlp_layers_float32":      # (every intermediate of that plan is an output)
+            assert total < naive, (name, total, naive)
+
+
+def test_replayed_negative_stride_output_is_refreshed():
+    """An output that is a reversed view is materialised INSIDE the recorded launches: replays
+    with new input values return the new reversed data (not the first call's copy)."""
+    import torch
+    from aesara_amd.executor import PlanExecutor
+    from aesara_amd.plan import Node, Plan
+    p = Plan("rev", {}, [], [], [])
+    x = p.new_var("float64", [None], "x")
+    y = p.new_var("float64", [None])
+    o = p.new_var("float64", [None])
+    p.inputs, p.outputs = [x], [o]
+    sc = {"n_in": 1, "nodes": [{"op": "exp", "in": [["i", 0]], "dtype": "float64"}], "out": [["t", 0]]}
+    p.nodes = [Node("Elemwise", [x], [y], {"scalar": sc}),
+               Node("Subtensor", [y], [o], {"idx_list": [{"slice": [None, None, -1]}]})]
+    ex = PlanExecutor(p, use_graph=True)
+    xd = torch.zeros(100, dtype=torch.float64, device="cuda")
+    for k in range(4):
+        xd.copy_(torch.arange(100, dtype=torch.float64, device="cuda") * 0.01 * (k + 1))
+        (got,) = ex(xd)
+        np.testing.assert_allclose(got.cpu().numpy(), np.exp(xd.cpu().numpy())[::-1], rtol=1e-14)

@@ -186,3 +186,48 @@ def test_ifelse_runs_only_the_selected_branch():
     # the else-branch of the first output is outer(y, y) @ y - 1: Ger + Gemv chain
     assert any(n in t0 for n in ("ahip_ger", "ahip_gemv", "ahip_gemv_epilogue"))
     assert not any(n in t1 for n in ("ahip_ger", "ahip_gemv", "ahip_gemv_epilogue"))
+
+
+def _alias_plan(view_is_output):
+    """z = alloc(v, n, 3); zT = z.T; r = set_subtensor(z[0], y) — the update is the last reader
+    of z itself, but zT is a VIEW of the same buffer (executor.py _own_or_copy)."""
+    from aesara_amd.plan import Node
+    p = Plan("alias", {}, [], [], [])
+    v = p.new_var("float64", [], "v")
+    n = p.new_var("int64", [], "n")
+    y = p.new_var("float64", [None], "y")
+    c3 = p.add_const(np.int64(3))
+    c0 = p.add_const(np.int64(0))
+    z = p.new_var("float64", [None, None])
+    zt = p.new_var("float64", [None, None])
+    r = p.new_var("float64", [None, None])
+    s = p.new_var("float64", [None])
+    p.inputs = [v, n, y]
+    p.nodes = [Node("Alloc", [v, n, c3], [z], {}),
+               Node("DimShuffle", [z], [zt], {"new_order": [1, 0]})]
+    upd = Node("IncSubtensor", [z, y, c0], [r], {"idx_list": [{"index": "in"}],
+                                                  "set_instead_of_inc": True, "inplace": False})
+    red = Node("CAReduce", [zt], [s], {"scalar_op": "add", "axis": [0], "acc_dtype": "float64"})
+    if view_is_output:
+        p.nodes += [upd]
+        p.outputs = [zt, r]
+    else:
+        p.nodes += [upd, red]          # the view is READ after the update
+        p.outputs = [s, r]
+    return p
+
+
+@pytest.mark.parametrize("view_is_output", [True, False])
+def test_update_of_private_alloc_copies_when_a_view_is_still_live(view_is_output):
+    ex = PlanExecutor(_alias_plan(view_is_output), dry_run=True)
+    ex(np.float64(1.5), np.int64(4), np.arange(3.0))
+    # the IncSubtensor must not have written into the Alloc buffer: a copy precedes it
+    assert ex.trace.count("ahip_copy_strided") + ex.trace.count("ahip_copy") >= 2 or \
+        any("copy" in t for t in ex.trace), ex.trace
+    # without a live view the private buffer is still updated in place (no extra copy)
+    p = _alias_plan(True)
+    p.outputs = [p.outputs[1]]
+    p.nodes = [n for n in p.nodes if n.op != "DimShuffle"]
+    ex2 = PlanExecutor(p, dry_run=True)
+    ex2(np.float64(1.5), np.int64(4), np.arange(3.0))
+    assert len([t for t in ex2.trace if "copy" in t]) < len([t for t in ex.trace if "copy" in t])

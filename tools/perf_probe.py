@@ -74,19 +74,19 @@ def main():
     G = bool(args.graph)
 
     if want("cfg1b"):
-        ex = PlanExecutor(plan_of("cfg1b_matrix_add"), use_graph=G)
+        ex = PlanExecutor(plan_of("cfg1b_matrix_add"), use_graph=G, borrow=True)
         x, y = randn((4096, 4096), f64, 0), randn((4096, 4096), f64, 1)
         d, w = timeit(lambda: ex(x, y), 200)
         report("cfg1b add f64 4096^2", d, w, 3 * 4096 * 4096 * 8, "GB/s", 8000.0)
 
     if want("cfg2"):
-        ex = PlanExecutor(plan_of("cfg2_gauss_sum"), use_graph=G)
+        ex = PlanExecutor(plan_of("cfg2_gauss_sum"), use_graph=G, borrow=True)
         x = randn((4096, 4096), f64, 1)
         mu = torch.tensor(0.1, dtype=f64, device="cuda")
         sg = torch.tensor(1.3, dtype=f64, device="cuda")
         d, w = timeit(lambda: ex(x, mu, sg), 500)
         report("cfg2 fused exp-sum f64 4096^2", d, w, 4096 * 4096 * 8, "GB/s", 8000.0)
-        exu = PlanExecutor(plan_of("cfg2_gauss_sum"), use_graph=G, fuse=False)
+        exu = PlanExecutor(plan_of("cfg2_gauss_sum"), use_graph=G, fuse=False, borrow=True)
         d, w = timeit(lambda: exu(x, mu, sg), 100)
         report("cfg2 UNFUSED (reference node structure)", d, w, 4096 * 4096 * 8, "GB/s", 8000.0)
 
@@ -95,7 +95,7 @@ def main():
         pl = Plan("redsum", {0: Var(0, "float64", [None, None]), 1: Var(1, "float64", [])}, [0], [1],
                   [Node("CAReduce", [0], [1], {"scalar_op": "add", "axis": None,
                                                "acc_dtype": "float64"})])
-        ex = PlanExecutor(pl, use_graph=G)
+        ex = PlanExecutor(pl, use_graph=G, borrow=True)
         x = randn((4096, 4096), f64, 1)
         d, w = timeit(lambda: ex(x), 500)
         report("pure sum f64 4096^2 (streaming-read ceiling)", d, w, 4096 * 4096 * 8, "GB/s", 8000.0)
@@ -115,7 +115,7 @@ def main():
                 ("float32", f32, (4194304, 8), (0,), "add"), ("float32", f32, (8, 4194304), (1,), "add"),
                 ("float32", f32, (4194304, 8), (1,), "maximum"),
                 ("float32", f32, (256, 512, 256), (1,), "add"), ("float32", f32, (256, 512, 256), (0, 2), "add")):
-            ex = PlanExecutor(red_plan(dt, len(shape), axis, op), use_graph=G)
+            ex = PlanExecutor(red_plan(dt, len(shape), axis, op), use_graph=G, borrow=True)
             x = randn(shape, tdt, 3)
             d, w = timeit(lambda: ex(x), 50)
             report("%s axis=%s %s %s" % (op, axis, dt, "x".join(map(str, shape))), d, w,
@@ -148,17 +148,17 @@ def main():
                 ("argmax axis=1 f32 8192x4096", one("Argmax", [("float32", [None, None])], ("int64", [None]), {"axis": [1]}), (x,), nb),
                 ("argmax axis=0 f32 8192x4096", one("Argmax", [("float32", [None, None])], ("int64", [None]), {"axis": [0]}), (x,), nb),
         ):
-            ex = PlanExecutor(pl, use_graph=G)
+            ex = PlanExecutor(pl, use_graph=G, borrow=True)
             d, w = timeit(lambda: ex(*ins_), 10)
             report(name, d, w, byt, "GB/s", 8000.0)
-        exs = PlanExecutor(ew("mul", ["float32"] * 2, [[None, None], [1, 1]], "float32"), use_graph=G)
+        exs = PlanExecutor(ew("mul", ["float32"] * 2, [[None, None], [1, 1]], "float32"), use_graph=G, borrow=True)
         two = torch.full((1, 1), 2.0, dtype=f32, device="cuda")
         xs = DevArray.from_torch(x).view([4096, 2048], [8192, 2])
         d, w = timeit(lambda: exs(xs, two), 10)
         report("ew x[::2, ::2]*2 f32 (4096x2048 of 8192x4096)", d, w, 2 * 4096 * 2048 * 4, "GB/s", 8000.0)
         idx = torch.randint(0, 8192, (65536,), device="cuda")
         ext = PlanExecutor(one("AdvancedSubtensor1", [("float32", [None, None]), ("int64", [None])],
-                               ("float32", [None, None]), {}), use_graph=G)
+                               ("float32", [None, None]), {}), use_graph=G, borrow=True)
         d, w = timeit(lambda: ext(x, idx), 10)
         report("take 65536 rows of 4096 f32", d, w, 2 * 65536 * 4096 * 4, "GB/s", 8000.0)
 
@@ -186,14 +186,14 @@ def main():
                 ("join axis=1 2x(8192x4096 f32)", plan_n("Join", [("int64", []), ("float32", [None, None]), ("float32", [None, None])], ("float32", [None, None]), {}), (np.int64(1), x, x), 4 * nb),
                 ("alloc scalar -> 8192x4096 f32", plan_n("Alloc", [("float32", []), ("int64", []), ("int64", [])], ("float32", [None, None]), {}), (x[0, 0], np.int64(8192), np.int64(4096)), nb),
         ):
-            ex = PlanExecutor(pl, use_graph=G)
+            ex = PlanExecutor(pl, use_graph=G, borrow=True)
             d, w = timeit(lambda: ex(*ins_), 10)
             report(name, d, w, byt, "GB/s", 8000.0)
         idx = torch.randint(0, 8192, (65536,), device="cuda")
         y = randn((65536, 1024), f32, 2)
         z = randn((8192, 1024), f32, 3)
         exs = PlanExecutor(plan_n("AdvancedIncSubtensor1", [("float32", [None, None]), ("float32", [None, None]), ("int64", [None])],
-                                  ("float32", [None, None]), {"set_instead_of_inc": False, "inplace": False}), use_graph=G)
+                                  ("float32", [None, None]), {"set_instead_of_inc": False, "inplace": False}), use_graph=G, borrow=True)
         d, w = timeit(lambda: exs(z, y, idx), 10)
         report("scatter-add 65536 rows of 1024 f32 into 8192 rows", d, w, 2 * y.numel() * 4, "GB/s", 8000.0)
 
@@ -205,14 +205,14 @@ def main():
             vs = {i: Var(i, dt, [None] * nd) for i in range(3)}
             return Plan("dot", vs, [0, 1], [2], [Node(op, [0, 1], [2], {})])
         for dt, tdt, pk in (("float32", f32, 157.3), ("float64", f64, 78.6)):
-            exd = PlanExecutor(dot_plan("Dot22", dt, 2), use_graph=G)
+            exd = PlanExecutor(dot_plan("Dot22", dt, 2), use_graph=G, borrow=True)
             for M, N, K in ((8192, 8192, 512), (512, 512, 65536), (16384, 64, 1024), (64, 16384, 1024),
                             (2048, 2048, 2048), (4096, 4096, 64), (4000, 4000, 4000), (1024, 1024, 1024),
                             (65536, 256, 256), (256, 256, 256)):
                 A, B = randn((M, K), tdt, 1), randn((K, N), tdt, 2)
                 d, w = timeit(lambda: exd(A, B), 10)
                 report("dot22 %s %dx%dx%d" % (dt, M, N, K), d, w, 2 * M * N * K, "TFLOP/s", pk)
-            exb = PlanExecutor(dot_plan("BatchedDot", dt, 3), use_graph=G)
+            exb = PlanExecutor(dot_plan("BatchedDot", dt, 3), use_graph=G, borrow=True)
             for Bn, M, N, K in ((64, 512, 512, 512), (1024, 64, 64, 64), (16, 2048, 128, 2048)):
                 A, B = randn((Bn, M, K), tdt, 1), randn((Bn, K, N), tdt, 2)
                 d, w = timeit(lambda: exb(A, B), 10)
@@ -220,19 +220,19 @@ def main():
                        "TFLOP/s", pk)
 
     if want("cfg3a"):
-        ex = PlanExecutor(plan_of("gemv_small_float64"), use_graph=G)
+        ex = PlanExecutor(plan_of("gemv_small_float64"), use_graph=G, borrow=True)
         M = randn((4096, 4096), f64, 2)
         v = randn((4096,), f64, 3)
         y = randn((4096,), f64, 4)
         d, w = timeit(lambda: ex(y, M, v), 200)
         report("cfg3a gemv f64 4096^2", d, w, 4096 * 4096 * 8 + 2 * 4096 * 8, "GB/s", 8000.0)
-        ext = PlanExecutor(plan_of("gemv_T_float64"), use_graph=G)
+        ext = PlanExecutor(plan_of("gemv_T_float64"), use_graph=G, borrow=True)
         Mt = M.t()
         d, w = timeit(lambda: ext(y, Mt, v), 200)
         report("gemv f64 4096^2 (A.T view)", d, w, 4096 * 4096 * 8 + 2 * 4096 * 8, "GB/s", 8000.0)
 
     if args.only == "nn32":
-        ex = PlanExecutor(plan_of("cfg3b_gemm_update"), use_graph=G)
+        ex = PlanExecutor(plan_of("cfg3b_gemm_update"), use_graph=G, borrow=True)
         Cm = torch.zeros(4096, 4096, dtype=f32, device="cuda")
         A, B = randn((4096, 4096), f32, 3), randn((4096, 4096), f32, 4)
         d, w = timeit(lambda: ex(Cm, A, B), 30)
@@ -242,7 +242,7 @@ def main():
         report("gemm f32 4096^3 NT(B k-contig)", d, w, 2 * 4096 ** 3, "TFLOP/s", 157.3)
 
     if want("cfg3b"):
-        ex = PlanExecutor(plan_of("cfg3b_gemm_update"), use_graph=G)
+        ex = PlanExecutor(plan_of("cfg3b_gemm_update"), use_graph=G, borrow=True)
         Cm = torch.zeros(4096, 4096, dtype=f32, device="cuda")
         A, B = randn((4096, 4096), f32, 3), randn((4096, 4096), f32, 4)
         d, w = timeit(lambda: ex(Cm, A, B), 30)
@@ -252,7 +252,7 @@ def main():
             report(f"gemm f32 4096^3 {name}", d, w, 2 * 4096 ** 3, "TFLOP/s", 157.3)
         ex64 = PlanExecutor(plan_of("gemm_T000_float64") if any(
             c["name"] == "gemm_T000_float64" for c in CASES) else plan_of("gemm1_float64"),
-            use_graph=G)
+            use_graph=G, borrow=True)
         C64 = torch.zeros(4096, 4096, dtype=f64, device="cuda")
         A64, B64 = randn((4096, 4096), f64, 3), randn((4096, 4096), f64, 4)
         d, w = timeit(lambda: ex64(C64, A64, B64), 10)
@@ -260,7 +260,7 @@ def main():
 
     if want("cfg4") or args.only == "gruB1":
         T, H = int(os.environ.get("AESARA_PROBE_T", 512)), 1024
-        ex = PlanExecutor(plan_of("cfg4_gru_b1_f32"), use_graph=G)
+        ex = PlanExecutor(plan_of("cfg4_gru_b1_f32"), use_graph=G, borrow=True)
         x = randn((T, H), f32, 4) * 0.1
         h0 = torch.zeros(H, dtype=f32, device="cuda")
         Ws = [randn((H, H), f32, 5 + k) / np.sqrt(H) for k in range(6)]
@@ -277,11 +277,11 @@ def main():
         x = randn((Nr, Kc), f32, 11) * 3
         for label, kw in (("softmax rows f32 65536x1024 (row-chain kernel)", {}),
                           ("softmax rows f32 65536x1024 UNFUSED (3 passes)", {"fuse": False})):
-            ex = PlanExecutor(plan_of("softmax_rows_f32"), use_graph=G, **kw)
+            ex = PlanExecutor(plan_of("softmax_rows_f32"), use_graph=G, borrow=True, **kw)
             d, w = timeit(lambda: ex(x), 20, warmup=3)
             report(label, d, w, 2 * Nr * Kc * 4, "GB/s", 8000.0)
         xs = randn((1 << 20, 64), f32, 12)
-        ex = PlanExecutor(plan_of("softmax_rows_f32"), use_graph=G)
+        ex = PlanExecutor(plan_of("softmax_rows_f32"), use_graph=G, borrow=True)
         d, w = timeit(lambda: ex(xs), 20, warmup=3)
         report("softmax rows f32 1048576x64 (16 rows per wave)", d, w, 2 * (1 << 20) * 64 * 4,
                "GB/s", 8000.0)
@@ -291,7 +291,7 @@ def main():
         x = randn((Nr, Kc), f32, 31) * 3
         for label, kw in (("softmax rows f32 8192x50304 (long-row chain kernel)", {}),
                           ("softmax rows f32 8192x50304 UNFUSED (3 passes)", {"fuse": False})):
-            ex = PlanExecutor(plan_of("softmax_rows_f32"), use_graph=G, **kw)
+            ex = PlanExecutor(plan_of("softmax_rows_f32"), use_graph=G, borrow=True, **kw)
             d, w = timeit(lambda: ex(x), 10, warmup=2)
             report(label, d, w, 2 * Nr * Kc * 4, "GB/s", 8000.0)
 
@@ -300,13 +300,13 @@ def main():
         g, b = randn((1024,), f32, 14), randn((1024,), f32, 15)
         for label, kw in (("layernorm f32 64x1024x1024 (row-chain kernel)", {}),
                           ("layernorm f32 64x1024x1024 UNFUSED", {"fuse": False})):
-            ex = PlanExecutor(plan_of("layernorm_float32"), use_graph=G, **kw)
+            ex = PlanExecutor(plan_of("layernorm_float32"), use_graph=G, borrow=True, **kw)
             d, w = timeit(lambda: ex(x, g, b), 20, warmup=3)
             report(label, d, w, 2 * x.numel() * 4, "GB/s", 8000.0)
 
     if want("cfg4b64"):
         T, H, B = 512, 1024, 64
-        ex = PlanExecutor(plan_of("cfg4_gru_b8_f32"), use_graph=G)
+        ex = PlanExecutor(plan_of("cfg4_gru_b8_f32"), use_graph=G, borrow=True)
         x = randn((T, B, H), f32, 4) * 0.1
         h0 = torch.zeros((B, H), dtype=f32, device="cuda")
         Ws = [randn((H, H), f32, 5 + k) / np.sqrt(H) for k in range(6)]
@@ -324,7 +324,7 @@ def main():
             A, B = randn((M, K), f32, 3), randn((K, N), f32, 4)
             for tiles in (1, 100000):
                 check(_l.ahip_set_param(b"gemm_small_max_tiles", tiles))
-                exx = PlanExecutor(plan_of("cfg3b_gemm_update"), use_graph=G)
+                exx = PlanExecutor(plan_of("cfg3b_gemm_update"), use_graph=G, borrow=True)
                 d, w = timeit(lambda: exx(Cm, A, B), 20, warmup=3)
                 report("gemm f32 %dx%dx%d %s" % (M, N, K, "big-tile" if tiles == 1 else "small-tile"),
                        d, w, 2 * M * N * K, "TFLOP/s", 157.3)
@@ -332,7 +332,7 @@ def main():
 
     if want("nll"):
         Nb, Dd, Cc = 32768, 1024, 1000
-        ex = PlanExecutor(plan_of("nll_classifier_float32"), use_graph=G)
+        ex = PlanExecutor(plan_of("nll_classifier_float32"), use_graph=G, borrow=True)
         x = randn((Nb, Dd), f32, 21)
         W = randn((Dd, Cc), f32, 22) * 0.03
         b = randn((Cc,), f32, 23) * 0.1
@@ -343,7 +343,7 @@ def main():
                note="flops = forward GEMM + dW GEMM + dX-free; includes log-softmax, gather, scatter")
 
     if want("transposed"):
-        ex = PlanExecutor(plan_of("cfg1b_matrix_add"), use_graph=G)
+        ex = PlanExecutor(plan_of("cfg1b_matrix_add"), use_graph=G, borrow=True)
         x, y = randn((4096, 4096), f64, 0), randn((4096, 4096), f64, 1)
         d, w = timeit(lambda: ex(x, y.t()), 20)
         report("cfg1b add f64 4096^2 with y.T view (strided operand)", d, w, 3 * x.numel() * 8,
@@ -355,11 +355,11 @@ def main():
         report("materialise transpose f64 4096^2 (strided copy)", d, w, 2 * x.numel() * 8,
                "GB/s", 8000.0)
 
-        exr = PlanExecutor(plan_of("reduce_all_transposed_float64"), use_graph=G)
+        exr = PlanExecutor(plan_of("reduce_all_transposed_float64"), use_graph=G, borrow=True)
         d, w = timeit(lambda: exr(x, y), 20)
         report("(x*y.T).sum(), max(y.T-x), sum(sqr(x.T)+y) f64 4096^2 (3 tiled reduces)", d, w,
                3 * 2 * x.numel() * 8, "GB/s", 8000.0)
-        exf = PlanExecutor(plan_of("ew_transposed_float32_64x128"), use_graph=G)
+        exf = PlanExecutor(plan_of("ew_transposed_float32_64x128"), use_graph=G, borrow=True)
         xf, yf, vf = randn((8192, 4096), f32, 0), randn((4096, 8192), f32, 1), randn((4096,), f32, 2)
         d, w = timeit(lambda: exf(xf, yf, vf), 20)
         report("x+y.T, exp(y.T/4)*x-v, sqr(y.T) f32 8192x4096 (3 tiled kernels)", d, w,
@@ -367,7 +367,7 @@ def main():
 
     if want("bptt"):
         T, H = 512, 1024
-        ex = PlanExecutor(plan_of("scan_grad_last_state_f32"), use_graph=G)
+        ex = PlanExecutor(plan_of("scan_grad_last_state_f32"), use_graph=G, borrow=True)
         x = randn((T, H), f32, 41) * 0.1
         h0 = torch.zeros(H, dtype=f32, device="cuda")
         W = randn((H, H), f32, 42) / np.sqrt(H)
@@ -382,7 +382,7 @@ def main():
 
     if want("cfg5"):
         N, D = 1 << 22, 256
-        ex = PlanExecutor(plan_of("cfg5_logistic"), use_graph=G)
+        ex = PlanExecutor(plan_of("cfg5_logistic"), use_graph=G, borrow=True)
         X = randn((N, D), f32, 6)
         wv = randn((D,), f32, 7) / 16
         b = torch.tensor(0.1, dtype=f32, device="cuda")
