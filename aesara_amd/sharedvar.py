@@ -23,12 +23,9 @@ from aesara.link.basic import Container
 from aesara.tensor.sharedvar import TensorSharedVariable
 from aesara.tensor.type import TensorType
 
-_TORCH_DTYPES = {
-    "float32": torch.float32, "float64": torch.float64, "int8": torch.int8,
-    "int16": torch.int16, "int32": torch.int32, "int64": torch.int64,
-    "uint8": torch.uint8, "bool": torch.bool,
-}
-_DTYPE_NAMES = {v: k for k, v in _TORCH_DTYPES.items()}
+from .devcell import DTYPE_NAMES as _DTYPE_NAMES
+from .devcell import TORCH_DTYPES as _TORCH_DTYPES
+from .devcell import DeviceCellMixin, check_device_value  # noqa: F401  (re-exported)
 
 
 def _default_device():
@@ -38,40 +35,15 @@ def _default_device():
     return torch.device("cuda", torch.cuda.current_device())
 
 
-def check_device_value(typ, data):
-    """The checks of ``TensorType.filter`` (tensor/type.py:135-256) that apply to a value that
-    is already a typed, shaped device tensor: dtype, rank, static shape."""
-    want = _TORCH_DTYPES.get(typ.dtype)
-    if want is None or data.dtype != want:
-        raise TypeError(f"{typ}: device tensor has dtype {data.dtype}, expected {typ.dtype}")
-    if data.ndim != typ.ndim:
-        raise TypeError(f"Wrong number of dimensions: expected {typ.ndim}, "
-                        f"got {data.ndim} with shape {tuple(data.shape)}.")
-    if not all(s is None or s == ds for s, ds in zip(typ.shape, data.shape)):
-        raise TypeError(f"The type's shape ({typ.shape}) is not compatible with the "
-                        f"data's ({tuple(data.shape)})")
-    return data
+class DeviceContainer(DeviceCellMixin, Container):
+    """A storage cell (reference link/basic.py:39) that accepts device tensors as they are
+    (logic: ``devcell.DeviceCellMixin``; host values take the reference's own filter path)."""
 
-
-class DeviceContainer(Container):
-    """A storage cell (reference link/basic.py:39) that accepts device tensors as they are."""
-
-    device = None   # None: host values stay ndarrays (plain inputs); else upload target
+    def _host_set(self, value):
+        Container.__set__(self, value)
 
     def __set__(self, value):
-        if isinstance(value, torch.Tensor):
-            if self.readonly:
-                raise Exception(f"Cannot set readonly storage: {self.name}")
-            try:
-                self.storage[0] = check_device_value(self.type, value)
-            except Exception as e:
-                e.args = e.args + (f'Container name "{self.name}"',)
-                raise
-            return
-        Container.__set__(self, value)
-        if self.device is not None and isinstance(self.storage[0], np.ndarray):
-            self.storage[0] = torch.from_numpy(
-                np.ascontiguousarray(self.storage[0])).to(self.device)
+        self._device_set(value)
 
     data = property(Container.__get__, __set__)
     value = property(Container.__get__, __set__)

@@ -231,3 +231,20 @@ def test_update_of_private_alloc_copies_when_a_view_is_still_live(view_is_output
     ex2 = PlanExecutor(p, dry_run=True)
     ex2(np.float64(1.5), np.int64(4), np.arange(3.0))
     assert len([t for t in ex2.trace if "copy" in t]) < len([t for t in ex.trace if "copy" in t])
+
+
+def test_device_cell_checks_without_the_reference():
+    import torch
+    from aesara_amd.devcell import DeviceCell, PlainType
+    cell = DeviceCell(PlainType("float32", (None, 3)), name="w", device=torch.device("cpu"))
+    cell.value = np.ones((2, 3))                       # host value: filtered (cast) + "uploaded"
+    assert isinstance(cell.storage[0], torch.Tensor) and cell.storage[0].dtype == torch.float32
+    t = torch.zeros(5, 3)
+    cell.value = t
+    assert cell.storage[0] is t                        # device values are kept as they are
+    for bad in (torch.zeros(5, 4), torch.zeros(5, 3, dtype=torch.float64), torch.zeros(3)):
+        with pytest.raises(TypeError):
+            cell.value = bad
+    ro = DeviceCell(PlainType("float32", (None,)), readonly=True, storage=[None])
+    with pytest.raises(Exception):
+        ro.value = torch.zeros(3)
