@@ -16,10 +16,12 @@
 //     26 % (SQ_WAIT_ANY ~1900 of ~5500 cycles per wave-slab).  Four waves per SIMD plus a
 //     two-slab-deep register prefetch cover that latency.
 //   * both operands are staged through LDS in a [row][k] image with 144-byte rows (128 B + 16 B
-//     pad): fragments are fetched with one ds_read_b64 per lane (the rows of a fragment land on
-//     distinct banks; measured on the shipped kernel, rocprofv3 r02: SQ_LDS_BANK_CONFLICT /
-//     SQ_LDS_IDX_ACTIVE = 0.43 over reads + staging stores, the LDS array itself busy 34 % of the
-//     kernel's cycles — profiles/r02_gemm_pmc_summary.json).  Waves 0-3 stage
+//     pad) whose 8-byte units are swapped pairwise in rows with bit 3 set (Stage::swz): the
+//     compiler fetches fragments with ds_read2_b64 (16-lane groups over 32 banks), for which the
+//     plain image made rows i / i+8 collide (rocprofv3 r02: SQ_LDS_BANK_CONFLICT /
+//     SQ_LDS_IDX_ACTIVE = 0.43); with the swizzle the counter reads 0.00
+//     (profiles/r02b_gemm_pmc_summary_after_lds_swizzle.json; 4096^3 fp32 NN 115 -> 120, TN / TT
+//     123 -> 126 TFLOP/s: the LDS was 34 % busy, not the limiter).  Waves 0-3 stage
 //     A, waves 4-7 stage B (4 x 16-byte vectors per thread per slab) through per-thread 32-bit
 //     offsets from a wave-uniform base (SGPR base + VGPR offset addressing: no per-slab address
 //     arithmetic).  Operands whose contiguous axis is k go straight into the image; operands
@@ -53,7 +55,7 @@ template <> struct Traits<double> {
 };
 
 constexpr int BM = 128, BN = 128;
-constexpr int ROW_BYTES = 144;  // 128 B of k + 16 B pad -> conflict-free ds_read_b64 fragments
+constexpr int ROW_BYTES = 144;  // 128 B of k + 16 B pad (+ unit swizzle, Stage::swz) -> conflict-free fragments
 constexpr int THREADS = 512;    // 8 wavefronts
 constexpr int STG = 256;        // threads staging one operand (waves 0-3: A, waves 4-7: B)
 constexpr int NV = 4;           // 16-byte vectors per staging thread per slab (128*8/256)
@@ -163,6 +165,23 @@ struct Stage {
     }
   }
 
+  // 8-byte-unit swizzle: in rows with bit 3 set the two halves of every 16-byte vector trade
+  // places (unit u is stored at u ^ 1).  The fragment reads are emitted as ds_read2_b64, which
+  // the LDS serves in groups of 16 lanes over 32 banks: with the plain image rows i and i + 8
+  // of a fragment (pitch 36 dwords: 36 * 8 = 0 mod 32) hit the same bank pair — measured
+  // SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.43 (profiles/r02_gemm_pmc_summary.json); the
+  // readers apply the same XOR to their k-group (frag_off), so rows i and i + 8 now read
+  // different halves and the 16 lanes of a group cover 32 distinct banks.
+  static __device__ __forceinline__ vec_t swz(vec_t t, bool sw) {
+    vec_t u;
+    if constexpr (VEC == 4) {
+      u.x = sw ? t.z : t.x; u.y = sw ? t.w : t.y; u.z = sw ? t.x : t.z; u.w = sw ? t.y : t.w;
+    } else {
+      u.x = sw ? t.y : t.x; u.y = sw ? t.x : t.y;
+    }
+    return u;
+  }
+
   static __device__ __forceinline__ void store(const vec_t (&r)[NV], char* lds, int stid) {
     if constexpr (MODE == 1) {
 #pragma unroll
@@ -174,14 +193,16 @@ struct Stage {
           vec_t t;
 #pragma unroll
           for (int i = 0; i < VEC; ++i) t[i] = r[b * VEC + i][jj];
-          *reinterpret_cast<vec_t*>(lds + (nq * VEC + jj) * ROW_BYTES + kq * 16) = t;
+          const int row = nq * VEC + jj;
+          *reinterpret_cast<vec_t*>(lds + row * ROW_BYTES + kq * 16) = swz(t, (row & 8) != 0);
         }
       }
     } else {
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
         int v = stid + STG * j;
-        *reinterpret_cast<vec_t*>(lds + (v >> 3) * ROW_BYTES + (v & 7) * 16) = r[j];
+        *reinterpret_cast<vec_t*>(lds + (v >> 3) * ROW_BYTES + (v & 7) * 16) =
+            swz(r[j], ((v >> 3) & 8) != 0);
       }
     }
   }
@@ -306,7 +327,9 @@ __global__ __launch_bounds__(THREADS, 4) void gemm_kernel(GemmArgs g) {
 
   // per-lane fragment addressing: lane (i = l & 15, kg = l >> 4) reads 8 bytes at
   // row*144 + kstep*32 + kg*8  (f32: k = 8*kstep + 2*kg + {0,1}; f64: k = 4*kstep + kg)
-  const int frag_off = (lane & 15) * ROW_BYTES + (lane >> 4) * 8;
+  // (fragment base rows are multiples of 16, so bit 3 of the tile row is bit 3 of the lane:
+  // rows with that bit set hold their 8-byte units swapped pairwise, see Stage::swz)
+  const int frag_off = (lane & 15) * ROW_BYTES + ((lane >> 4) ^ ((lane >> 3) & 1)) * 8;
   const int pa_off = wm * 64 * ROW_BYTES + frag_off;
   const int pb_off = BM * ROW_BYTES + wn * 32 * ROW_BYTES + frag_off;
 
