@@ -158,6 +158,8 @@ SIGNATURES = {
     "ahip_list_end": (i32, [p_vp]),
     "ahip_list_length": (i32, [vp]),
     "ahip_list_run": (i32, [vp, vp]),
+    "ahip_list_bind_bases": (i32, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), i32]),
+    "ahip_list_run_rebased": (i32, [vp, C.POINTER(C.c_uint64), i32, vp]),
     "ahip_list_destroy": (i32, [vp]),
     "ahip_graph_begin": (i32, [vp]),
     "ahip_graph_end": (i32, [vp, p_vp]),

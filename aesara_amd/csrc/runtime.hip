@@ -40,7 +40,13 @@ struct LaunchRec {
   unsigned shmem;
   std::vector<char> arg; // by-value argument block
 };
-struct ahip_list_s { std::vector<LaunchRec> recs; };
+// relocation: 8-byte word `off` of launch `rec`'s argument block points into rebinding range `base`
+struct Reloc { uint32_t rec, off, base; };
+struct ahip_list_s {
+  std::vector<LaunchRec> recs;
+  std::vector<Reloc> relocs;
+  std::vector<uint64_t> cur;   // the base address each rebinding range is currently patched to
+};
 static thread_local ahip_list_s* g_recording = nullptr;
 
 static int issue(const LaunchRec& r, hipStream_t s) {
@@ -280,6 +286,53 @@ int ahip_list_run(ahip_list_t l, void* stream) {
     if (rc) return rc;
   }
   return AHIP_OK;
+}
+
+// Zero-copy replay for fresh buffers (a training loop hands over a NEW batch tensor on every
+// call): after recording, the caller names the address ranges of its rebindable buffers (plan
+// inputs, `out=` targets); every 8-byte word of every recorded argument block that points into
+// one of them becomes a relocation.  ahip_list_run_rebased patches those words by the distance
+// the buffers moved and re-issues the launches — one host call, no staging copy.
+int ahip_list_bind_bases(ahip_list_t l, const uint64_t* lo, const uint64_t* hi, int n) {
+  AHIP_REQUIRE(l != nullptr && (n == 0 || (lo && hi)), "null argument");
+  l->relocs.clear();
+  l->cur.assign(lo, lo + n);
+  for (int a = 0; a < n; ++a)
+    for (int b = 0; b < a; ++b)
+      AHIP_REQUIRE(hi[a] <= lo[b] || hi[b] <= lo[a] || lo[a] == hi[a] || lo[b] == hi[b],
+                   "rebinding ranges %d and %d overlap", a, b);
+  for (size_t r = 0; r < l->recs.size(); ++r) {
+    std::vector<char>& arg = l->recs[r].arg;
+    for (size_t off = 0; off + 8 <= arg.size(); off += 8) {
+      uint64_t v;
+      memcpy(&v, arg.data() + off, 8);
+      for (int k = 0; k < n; ++k)
+        if (v >= lo[k] && v < hi[k]) {
+          l->relocs.push_back(Reloc{(uint32_t)r, (uint32_t)off, (uint32_t)k});
+          break;
+        }
+    }
+  }
+  return (int)l->relocs.size();
+}
+
+int ahip_list_run_rebased(ahip_list_t l, const uint64_t* bases, int n, void* stream) {
+  AHIP_REQUIRE(l != nullptr && (size_t)n == l->cur.size(), "rebinding count mismatch");
+  bool moved = false;
+  for (int k = 0; k < n; ++k) moved |= (bases[k] != l->cur[k]);
+  if (moved) {
+    for (const Reloc& q : l->relocs) {
+      const uint64_t delta = bases[q.base] - l->cur[q.base];
+      if (!delta) continue;
+      uint64_t v;
+      char* p = l->recs[q.rec].arg.data() + q.off;
+      memcpy(&v, p, 8);
+      v += delta;
+      memcpy(p, &v, 8);
+    }
+    l->cur.assign(bases, bases + n);
+  }
+  return ahip_list_run(l, stream);
 }
 
 int ahip_list_destroy(ahip_list_t l) {

@@ -375,6 +375,14 @@ int ahip_list_begin(void);
 int ahip_list_end(ahip_list_t* out);
 int ahip_list_length(ahip_list_t l);
 int ahip_list_run(ahip_list_t l, void* stream);
+/* Zero-copy replay with rebound buffers (Function.__call__ binds NEW input arrays on every call,
+ * compile/function/types.py:835-843; the reference's thunks read them through storage cells).
+ * ahip_list_bind_bases: declare n address ranges [lo[k], hi[k]) (the plan inputs / output targets
+ * of the recorded call; must not overlap); every 8-byte word of a recorded argument block that
+ * points into a range becomes a relocation; returns their number (< 0: error).
+ * ahip_list_run_rebased: patch the relocations for the new base addresses and re-issue. */
+int ahip_list_bind_bases(ahip_list_t l, const uint64_t* lo, const uint64_t* hi, int n);
+int ahip_list_run_rebased(ahip_list_t l, const uint64_t* bases, int n, void* stream);
 int ahip_list_destroy(ahip_list_t l);
 int ahip_graph_begin(void* stream);
 int ahip_graph_end(void* stream, ahip_graph_t* out);

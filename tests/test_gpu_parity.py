@@ -92,7 +92,8 @@ def test_replay_with_fresh_input_tensors_and_host_arrays():
             got = [o.cpu().numpy() for o in replay(*ins)]
             for g, w in zip(got, want):
                 np.testing.assert_allclose(g, w, rtol=1e-6, atol=1e-7)
-    assert len(replay._stage) == 2 and len(replay._graphs) <= 4
+    # device batches are rebound in place (no staging); host batches go through ONE staging set
+    assert len(replay._stage) == 1 and len(replay._reloc) >= 1
     # CPU torch tensors are host buffers too: mutated in place between calls, same storage
     cpu = [torch.from_numpy(v) for v in batch(False)]
     for _ in range(3):
