@@ -40,7 +40,7 @@ SP_MAXSEQ = 12
 SP_MAXNSQ = 12
 SP_MAXOUT = 8
 SPIN_LIMIT = 1 << 21
-LDS_BUDGET = 150 * 1024
+LDS_BUDGET = 156 * 1024
 CTLS = []          # control words of live workspaces (error flags; debugging aid)
 
 
@@ -182,10 +182,11 @@ def analyze(inner, p, n_seqdots):
 class Spec:
     """Shape-specialised persistent kernel: M rows, K per matrix, R rows per workgroup."""
 
-    def __init__(self, prog: Program, plan, M, Ks, lens, R, nw):
+    def __init__(self, prog: Program, plan, M, Ks, lens, R, nw, place=None):
         self.prog, self.plan, self.M, self.Ks, self.lens, self.R, self.nw = \
             prog, plan, M, dict(Ks), dict(lens), R, nw
         assert R % nw == 0
+        self.place = dict(place or {})      # matrix var -> "reg" (rows in VGPRs) | "lds"
         # polling shape (measured defaults; environment overrides for sweeps)
         self.var = {"pollw": min(nw, int(os.environ.get("AESARA_HIP_SP_POLLW", 2))),
                     "sleep": int(os.environ.get("AESARA_HIP_SP_SLEEP", "1")),
@@ -193,7 +194,7 @@ class Spec:
 
     def key(self):
         pr = self.prog
-        blob = json.dumps(["sp4", sorted(self.var.items()), self.M, sorted(self.Ks.items()), sorted(self.lens.items()),
+        blob = json.dumps(["sp5", sorted(self.var.items()), sorted(self.place.items()), self.M, sorted(self.Ks.items()), sorted(self.lens.items()),
                            self.R, self.nw, sorted(pr.seq.items()), sorted(pr.state.items()),
                            sorted(pr.nsq.items()), sorted(pr.mats.items()),
                            [[ph["dots"], ph["ins"], ph["outs"], ph["scalar"], ph["out_refs"]]
@@ -221,7 +222,10 @@ def generate(spec: Spec):
 
     # ---- LDS: matrix rows of this workgroup + staged dot vectors (two step parities) ----------
     woff, wtot = {}, 0
+    in_reg = {a for a in pr.mats if spec.place.get(a) == "reg"}
     for a, slot in sorted(pr.mats.items(), key=lambda t: t[1]):
+        if a in in_reg:
+            continue
         woff[a] = wtot
         wtot += R * spec.Ks[a]
     # staged vectors: key (var, "prev" | "cur" | "glob"); invariant dot vectors are staged once
@@ -255,6 +259,16 @@ def generate(spec: Spec):
     for av, slot in sorted(pr.mats.items(), key=lambda t: t[1]):
         K = spec.Ks[av]
         K4 = K // 4
+        if av in in_reg:
+            # rows of this wavefront stay in VGPRs for the whole loop: lane l holds the 16-byte
+            # vectors l, l + 64, ... of each of its RPW rows (fully unrolled, static indices)
+            for i in range(RPW):
+                L.append("  const i64 wrow%d_%d = row0 + wave * %d + %d;" % (slot, i, RPW, i))
+                for q in range(K4 // 64):
+                    L.append("  const f4 wr%d_%d_%d = wrow%d_%d < %d ? *(const f4*)((const float*)a.mat[%d] + "
+                             "wrow%d_%d * a.mat_rs[%d] + 4 * (lane + %d)) : f4{0.f, 0.f, 0.f, 0.f};"
+                             % (slot, i, q, slot, i, M, slot, slot, i, slot, 64 * q))
+            continue
         L.append("  for (int idx = threadIdx.x; idx < %d; idx += %d) {" % (R * K4, BLOCK))
         L.append("    const int j = idx / %d, k4 = idx %% %d;" % (K4, K4))
         L.append("    const i64 r = row0 + j;")
@@ -388,6 +402,19 @@ def generate(spec: Spec):
                 vsrc = "Vl[par] + %d" % stage[(x, kind)]
             for i in range(RPW):
                 L.append("    float acc%d_%d_%d = 0.f;" % (pi, d, i))
+            if a_ in in_reg:
+                slot = pr.mats[a_]
+                L.append("    {")
+                L.append("      const float* vx = %s;" % vsrc)
+                for q in range(K4 // 64):
+                    L.append("      { const f4 xv = *(const f4*)(vx + 4 * (lane + %d));" % (64 * q))
+                    for i in range(RPW):
+                        L.append("        acc%d_%d_%d += wr%d_%d_%d.x * xv.x + wr%d_%d_%d.y * xv.y + "
+                                 "wr%d_%d_%d.z * xv.z + wr%d_%d_%d.w * xv.w;"
+                                 % ((pi, d, i) + (slot, i, q) * 4))
+                    L.append("      }")
+                L.append("    }")
+                continue
             L.append("    {")
             L.append("      const float* vx = %s;" % vsrc)
             L.append("      const float* wr = Wl + %d + (wave * %d) * %d;" % (woff[a_], RPW, K))
@@ -438,19 +465,40 @@ def generate(spec: Spec):
     return "\n".join(L) + "\n", (name,)
 
 
-def choose_rows(M, sumK, stage_floats, cu_count=256):
-    """Rows of every matrix per workgroup (R), wavefronts per workgroup, grid size.
+REG_BUDGET = 160      # VGPRs per lane that may hold matrix rows
 
-    The step time is the exchange latency, which grows with the number of workgroups that poll
-    the same granules (measured on MI355X, BASELINE config 4: 256 workgroups x 4 rows 6.1 us per
-    step, 128 x 8 rows 4.9 us), so the grid is HALF the CUs when the rows still fit in LDS, else
-    one workgroup per CU; ``AESARA_HIP_SCAN_ROWS`` overrides."""
-    nw = 4
+
+def choose_rows(M, Ks, stage_floats, cu_count=256):
+    """Geometry of the persistent kernel: rows of every matrix per workgroup (R), wavefronts per
+    workgroup, grid size and where each matrix's rows live ("lds" / "reg").
+
+    Measured on MI355X (BASELINE config 4, T = 512, H = 1024; ``tools/sp_sweep.sh``): 256
+    workgroups x 4 rows 6.1 us per step, **128 x 8 rows 4.6 us**, 64 x 16 rows (all rows in
+    VGPRs) 4.9 us, 32 x 32 rows 5.9 us — the exchange latency falls with the number of pollers
+    down to ~128 workgroups, below that the per-workgroup dot time grows faster.  So: half the CUs
+    when the rows fit, else one workgroup per CU, else fewer; rows go to LDS first and spill into
+    VGPRs (K % 256 == 0, REG_BUDGET per lane) — that is what lets H = 2048 (48 MiB of weights)
+    stay on chip.  ``AESARA_HIP_SCAN_ROWS`` / ``AESARA_HIP_SCAN_WAVES`` override."""
     env = os.environ.get("AESARA_HIP_SCAN_ROWS")
-    cands = [int(env)] if env else [-(-M // max(cu_count // 2, 1)), -(-M // cu_count)]
+    nw = int(os.environ.get("AESARA_HIP_SCAN_WAVES", "4"))
+    half = max(cu_count // 2, 1)
+    cands = [int(env)] if env else [-(-M // half), -(-M // cu_count), -(-M // (half // 2 or 1)),
+                                    -(-M // (half // 4 or 1))]
     for R in cands:
         R = -(-max(R, nw) // nw) * nw
         G = -(-M // R)
-        if R * sumK * 4 + stage_floats * 4 <= LDS_BUDGET and G <= cu_count:
-            return R, nw, G
+        if G > cu_count:
+            continue
+        rpw = R // nw
+        place, regs, lds = {}, 0, stage_floats * 4
+        for av, K in sorted(Ks.items(), key=lambda t: -t[1]):
+            if lds + R * K * 4 <= LDS_BUDGET:
+                place[av], lds = "lds", lds + R * K * 4
+            elif K % 256 == 0 and regs + rpw * (K // 64) <= REG_BUDGET:
+                place[av], regs = "reg", regs + rpw * (K // 64)
+            else:
+                place = None
+                break
+        if place is not None:
+            return R, nw, G, place
     return None

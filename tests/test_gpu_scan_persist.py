@@ -68,8 +68,10 @@ def _gru_ref(x, h0, Ws):
     return torch.stack(hs)
 
 
-@pytest.mark.parametrize("T,H,rows", [(512, 1024, None), (512, 1024, 8), (64, 1000, None),
-                                      (33, 1024, 8), (7, 260, None), (2, 64, None)])
+@pytest.mark.parametrize("T,H,rows", [(512, 1024, None), (512, 1024, 4), (64, 1000, None),
+                                      (33, 1024, 16),     # all matrix rows in VGPRs
+                                      (24, 2048, None),   # 48 MiB of weights: LDS + VGPRs
+                                      (7, 260, None), (2, 64, None)])
 def test_gru_full_size_all_steps_vs_fp64(T, H, rows, monkeypatch):
     """BASELINE config 4 (T=512, H=1024, fp32, B=1) and ragged relatives: EVERY step's state
     against an fp64 restatement (rel <= 1e-5 of the state's scale), eager and replayed."""
