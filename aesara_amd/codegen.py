@@ -310,6 +310,9 @@ def scalar_node_expr(op, ins, in_dts, dt):
     if op == "sgn":
         if _is_uint(dt) or dt == "bool":
             return "(%s)(%s != 0)" % (T, c[0])
+        if _is_float(dt):
+            # Sgn.c_code scalar/basic.py:2620: NaN stays NaN (np.sign does the same)
+            return "(%s)(%s > 0 ? 1 : (%s < 0 ? -1 : (%s != %s ? NAN : 0)))" % (T, c[0], c[0], c[0], c[0])
         return "(%s)((%s > 0) - (%s < 0))" % (T, c[0], c[0])
     if op == "sqr":
         return "(%s)(%s * %s)" % (T, c[0], c[0]) if dt != "bool" else c[0]

@@ -996,7 +996,6 @@ int ahip_gemm_batched(int dtype, int64_t batch, int64_t M, int64_t N, int64_t K,
   AHIP_REQUIRE(dtype == AHIP_F32 || dtype == AHIP_F64, "gemm supports float32/float64 only");
   AHIP_REQUIRE(M >= 0 && N >= 0 && K >= 0 && batch >= 0, "negative extent");
   AHIP_REQUIRE(alpha && beta, "null alpha/beta");
-  AHIP_REQUIRE(batch < 65536, "batch too large for grid.z");
   GemmArgs g;
   g.M = M; g.N = N; g.K = K;
   g.A = A; g.a_bs = a_bs; g.a_rs = a_rs; g.a_cs = a_cs;
@@ -1012,8 +1011,22 @@ int ahip_gemm_batched(int dtype, int64_t batch, int64_t M, int64_t N, int64_t K,
     AHIP_REQUIRE(K == 0 || (A && B), "null A/B");
     AHIP_REQUIRE(g.beta == 0.0 || Cin != nullptr, "beta != 0 needs Cin");
   }
-  return dtype == AHIP_F32 ? gemm_dispatch<float>(g, batch, as_stream(stream))
-                           : gemm_dispatch<double>(g, batch, as_stream(stream));
+  // grid.z carries the batch index: more than 65535 items (matmul over many small matrices)
+  // run as consecutive launches over slices of the batch
+  const int64_t isz = dtype == AHIP_F32 ? 4 : 8;
+  for (int64_t b0 = 0; b0 < batch || b0 == 0; b0 += 65535) {
+    const int64_t nb = (batch - b0) < 65535 ? (batch - b0) : 65535;
+    GemmArgs h = g;
+    h.A = static_cast<const char*>(g.A) + b0 * a_bs * isz;
+    h.B = static_cast<const char*>(g.B) + b0 * b_bs * isz;
+    h.Cin = static_cast<const char*>(g.Cin) + b0 * (g.beta != 0.0 ? ci_bs : c_bs) * isz;
+    h.C = static_cast<char*>(g.C) + b0 * c_bs * isz;
+    int rc = dtype == AHIP_F32 ? gemm_dispatch<float>(h, nb, as_stream(stream))
+                               : gemm_dispatch<double>(h, nb, as_stream(stream));
+    if (rc) return rc;
+    if (batch == 0) break;
+  }
+  return AHIP_OK;
 }
 
 int ahip_gemm(int dtype, int64_t M, int64_t N, int64_t K, const void* alpha, const void* A,

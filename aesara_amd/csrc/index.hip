@@ -4,6 +4,8 @@
 // :2128 AdvancedIncSubtensor1 (inc: np.add.at semantics, set: last write wins).
 // Index handling mirrors NumPy: a negative index wraps once (idx + nrows); anything still out
 // of range is reported through *bad_index and the row is skipped.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -11,6 +13,17 @@ namespace {
 template <typename I>
 __device__ __forceinline__ bool resolve(const I* idx, int64_t i, int64_t stride, int64_t nrows,
                                         int64_t* bad, int64_t* out) {
+  if constexpr (sizeof(I) == 8 && !std::is_signed<I>::value) {
+    // uint64 indices beyond int64 must not wrap into valid negative ones
+    const unsigned long long u = (unsigned long long)idx[i * stride];
+    if (u >= (unsigned long long)nrows) {
+      const unsigned long long code = (u < 0x7FFFFFFFFFFFFFFEULL ? u : 0x7FFFFFFFFFFFFFFEULL) + 1ULL;
+      atomicCAS(reinterpret_cast<unsigned long long*>(bad), 0ULL, code);
+      return false;
+    }
+    *out = (int64_t)u;
+    return true;
+  }
   int64_t v = (int64_t)idx[i * stride];
   int64_t w = v < 0 ? v + nrows : v;
   if (w < 0 || w >= nrows) {

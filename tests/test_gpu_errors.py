@@ -104,3 +104,53 @@ def test_scan_zero_steps_and_one_step():
     s0 = torch.randn(7, dtype=torch.float64, device="cuda")
     res, last = ex(x, s0)
     assert torch.allclose(res[0], s0 + x[0]) and torch.allclose(last, s0 + x[0])
+
+
+def _one_node_plan(op, in_vars, out_var, params):
+    from aesara_amd.plan import Node, Plan, Var
+    vs = {i: Var(i, dt, list(sh)) for i, (dt, sh) in enumerate(in_vars + [out_var])}
+    n = len(in_vars)
+    return Plan("one", vs, list(range(n)), [n], [Node(op, list(range(n)), [n], params)])
+
+
+def test_sgn_of_nan_is_nan_like_the_reference():
+    """Sgn.c_code (scalar/basic.py:2620) / np.sign: NaN stays NaN."""
+    import torch
+    from aesara_amd.executor import PlanExecutor
+    sc = {"n_in": 1, "nodes": [{"op": "sgn", "in": [["i", 0]], "dtype": "float32"}], "out": [["t", 0]]}
+    ex = PlanExecutor(_one_node_plan("Elemwise", [("float32", [None])], ("float32", [None]), {"scalar": sc}))
+    x = np.array([-2.5, 0.0, -0.0, 3.0, np.nan, np.inf, -np.inf], "float32")
+    (got,) = ex(_t(x))
+    np.testing.assert_array_equal(got.cpu().numpy(), np.sign(x))
+
+
+def test_batched_dot_with_more_than_65535_items():
+    """grid.z carries the batch index: a matmul over 70 000 small matrices runs as sliced
+    launches instead of failing."""
+    import torch
+    from aesara_amd.executor import PlanExecutor
+    ex = PlanExecutor(_one_node_plan("BatchedDot", [("float32", [None, None, None])] * 2,
+                                     ("float32", [None, None, None]), {}))
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0)
+    A = torch.randn(70000, 4, 5, dtype=torch.float32, device="cuda", generator=g)
+    B = torch.randn(70000, 5, 3, dtype=torch.float32, device="cuda", generator=g)
+    (got,) = ex(A, B)
+    ref = torch.einsum("bij,bjk->bik", A.double(), B.double())
+    assert got.shape == (70000, 4, 3)
+    assert (got.double() - ref).abs().max().item() < 1e-5
+
+
+def test_uint64_index_beyond_int64_is_out_of_bounds():
+    """An unsigned index >= 2**63 must not wrap into a valid negative one."""
+    import torch
+    from aesara_amd.executor import PlanExecutor
+    ex = PlanExecutor(_one_node_plan("AdvancedSubtensor1", [("float64", [None, None]), ("uint64", [None])],
+                                     ("float64", [None, None]), {}))
+    x = _t(np.arange(12.0).reshape(4, 3))
+    ok = torch.from_numpy(np.array([0, 3, 1], dtype=np.uint64).view(np.int64)).cuda().view(torch.uint64)
+    (got,) = ex(x, ok)
+    np.testing.assert_array_equal(got.cpu().numpy(), np.arange(12.0).reshape(4, 3)[[0, 3, 1]])
+    bad = torch.from_numpy(np.array([0, 2 ** 64 - 1, 1], dtype=np.uint64).view(np.int64)).cuda().view(torch.uint64)
+    with pytest.raises(IndexError):
+        ex(x, bad)
