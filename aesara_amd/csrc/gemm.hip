@@ -381,30 +381,42 @@ __global__ __launch_bounds__(THREADS, 4) void gemm_kernel(GemmArgs g) {
   auto slab = [&](int t, vec_t (&lr)[NV], const vec_t (&ur)[NV]) {
     const char* buf = smem + (t & 1) * SLAB;
     if (t + 2 < nslab) gload(lr, t + 2);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      frag_t fa[4], fb[2];
+    // fragment fetches run ONE k-step ahead of the MFMAs that consume them (two register sets,
+    // scheduling barriers pin the order): the ds_read latency of step ks+1 hides behind the 16
+    // MFMAs of step ks instead of stalling the wave at the top of every step pair
+    frag_t fa[2][4], fb[2][2];
+    auto fetch = [&](int set, int ks) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        fa[i] = *reinterpret_cast<const frag_t*>(buf + pa_off + i * 16 * ROW_BYTES + ks * 32);
+        fa[set][i] = *reinterpret_cast<const frag_t*>(buf + pa_off + i * 16 * ROW_BYTES + ks * 32);
 #pragma unroll
       for (int j = 0; j < 2; ++j)
-        fb[j] = *reinterpret_cast<const frag_t*>(buf + pb_off + j * 16 * ROW_BYTES + ks * 32);
+        fb[set][j] = *reinterpret_cast<const frag_t*>(buf + pb_off + j * 16 * ROW_BYTES + ks * 32);
+    };
+    auto mmas = [&](int set) {
       if constexpr (sizeof(T) == 4) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) mma(acc[i][j], fa[i].x, fb[j].x);
+          for (int j = 0; j < 2; ++j) mma(acc[i][j], fa[set][i].x, fb[set][j].x);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) mma(acc[i][j], fa[i].y, fb[j].y);
+          for (int j = 0; j < 2; ++j) mma(acc[i][j], fa[set][i].y, fb[set][j].y);
       } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) mma(acc[i][j], fa[i], fb[j]);
+          for (int j = 0; j < 2; ++j) mma(acc[i][j], fa[set][i], fb[set][j]);
       }
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks + 1 < 4) fetch((ks + 1) & 1, ks + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mmas(ks & 1);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (t + 1 < nslab) lstore(ur, t + 1);
     __syncthreads();

@@ -48,10 +48,14 @@ HIP_QUERY = RewriteDatabaseQuery(
 class HipLinker(JITLinker):
     """A ``Linker`` that runs a whole ``FunctionGraph`` as HIP kernels on an MI355X."""
 
-    def __init__(self, *args, return_numpy=False, use_graph=False, executor_factory=None,
+    def __init__(self, *args, return_numpy=False, use_graph=True, executor_factory=None,
                  fast_call=True, **kwargs):
         super().__init__(*args, **kwargs)
         self.return_numpy = return_numpy
+        # use_graph (default): the first call per input signature runs the host logic and records
+        # the launches; later calls of that signature replay them with one host call (new device
+        # buffers are rebound, host arrays staged) into a lifetime-packed arena and return fresh
+        # outputs.  Plans with data-dependent host control flow fall back to per-node launches.
         self.use_graph = use_graph
         # fast_call: the function's VM is one closure (bind cells -> executor -> store cells)
         # instead of ``streamline`` over a one-thunk list (H0: the per-eval host protocol)
