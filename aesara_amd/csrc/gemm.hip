@@ -20,7 +20,7 @@
 //     compiler fetches fragments with ds_read2_b64 (16-lane groups over 32 banks), for which the
 //     plain image made rows i / i+8 collide (rocprofv3 r02: SQ_LDS_BANK_CONFLICT /
 //     SQ_LDS_IDX_ACTIVE = 0.43); with the swizzle the counter reads 0.00
-//     (profiles/r02b_gemm_pmc_summary_after_lds_swizzle.json; 4096^3 fp32 NN 115 -> 120, TN / TT
+//     (profiles/r02_gemm_pmc_summary.json; 4096^3 fp32 NN 115 -> 120, TN / TT
 //     123 -> 126 TFLOP/s: the LDS was 34 % busy, not the limiter).  Waves 0-3 stage
 //     A, waves 4-7 stage B (4 x 16-byte vectors per thread per slab) through per-thread 32-bit
 //     offsets from a wave-uniform base (SGPR base + VGPR offset addressing: no per-slab address
@@ -169,7 +169,7 @@ struct Stage {
   // places (unit u is stored at u ^ 1).  The fragment reads are emitted as ds_read2_b64, which
   // the LDS serves in groups of 16 lanes over 32 banks: with the plain image rows i and i + 8
   // of a fragment (pitch 36 dwords: 36 * 8 = 0 mod 32) hit the same bank pair — measured
-  // SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.43 (profiles/r02_gemm_pmc_summary.json); the
+  // SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.43 (profiles/r02_gemm_pmc_before_lds_swizzle.json); the
   // readers apply the same XOR to their k-group (frag_off), so rows i and i + 8 now read
   // different halves and the 16 lanes of a group cover 32 distinct banks.
   static __device__ __forceinline__ vec_t swz(vec_t t, bool sw) {

@@ -108,3 +108,36 @@ def test_persistent_replays_are_deterministic():
         outs = ex(*ins)
         for a, b in zip(outs, first):
             assert torch.equal(a, b)
+
+
+def test_persistent_kernel_stress_many_replays_under_uneven_load():
+    """Hand-off protocol under load: 300 back-to-back replays of the config-4 loop (T = 64, 8192
+    exchanges each) while a second stream keeps streaming a large buffer through the memory
+    system; every evaluation must be bit-identical to the first (any stale / torn granule
+    changes h_T)."""
+    import torch
+    from aesara_amd.executor import PlanExecutor
+    T, H = 64, 1024
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    x = torch.randn(T, H, dtype=torch.float32, device="cuda", generator=g) * 0.1
+    h0 = torch.randn(H, dtype=torch.float32, device="cuda", generator=g) * 0.5
+    Ws = [torch.randn(H, H, dtype=torch.float32, device="cuda", generator=g) / np.sqrt(H)
+          for _ in range(6)]
+    ex = PlanExecutor(case_plan(_case("cfg4_gru_b1_f32")), use_graph=True)
+    hs0, _ = ex(x, h0, *Ws)
+    ref = _gru_ref(x, h0, Ws)
+    assert ((hs0.double() - ref).abs().max() / ref.abs().max()).item() <= 1e-5
+    first = hs0.clone()
+    side = torch.cuda.Stream()
+    big = torch.zeros(1 << 28, dtype=torch.float32, device="cuda")     # 1 GiB
+    bad = 0
+    for it in range(300):
+        if it % 3 == 0:
+            with torch.cuda.stream(side):
+                big.add_(1.0)                  # HBM traffic + CUs taken by another stream
+        hs, _ = ex(x, h0, *Ws)
+        bad += int(not torch.equal(hs, first))
+    torch.cuda.synchronize()
+    ex.check()
+    assert bad == 0, f"{bad} of 300 replays differ"
