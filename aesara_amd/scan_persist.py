@@ -94,6 +94,7 @@ class Program:
         self.phases, self.outs = [], []
         self.new_of_state = {}      # state var -> var holding its new value
         self.exchanged = []         # produced vars that some dot needs in full
+        self.mode = "vec"
 
 
 def analyze(inner, p, n_seqdots):
@@ -122,12 +123,19 @@ def analyze(inner, p, n_seqdots):
         return None, "too many sequence operands"
     inv_set = set(inv)
     produced = {}
+    # "vec": Gemv chains on vectors (state h[M]); "mat": small-M GEMM chains on a matrix state
+    # (h[B, N], batch of independent recurrences sharing the weights)
+    pr.mode = "mat" if any(st.kind == "gemm_epi" for st in inner.steps) else "vec"
+    nd = 2 if pr.mode == "mat" else 1
+    ok_kinds = ("gemm_epi", "elemwise") if pr.mode == "mat" else ("gemv_epi", "elemwise")
     for st in inner.steps:
-        if st.kind not in ("gemv_epi", "elemwise") or st.reduce is not None or st.post or \
-                st.fallback or st.extra.get("xprog"):
+        if st.kind not in ok_kinds or st.reduce is not None or st.post or \
+                (st.fallback and st.kind != "gemm_epi") or st.extra.get("xprog"):
             return None, f"step kind {st.kind} ({st.node.op if st.node else ''})"
         dots = []
-        for a, x in st.dots:
+        # (invariant matrix, loop operand): gemv_epi stores (A, x), gemm_epi (operand, weight)
+        pairs = [(b, a) for a, b in st.dots] if st.kind == "gemm_epi" else list(st.dots)
+        for a, x in pairs:
             if a not in inv_set or plan.vars[a].ndim != 2:
                 return None, "dot with a loop-varying matrix"
             if a not in pr.mats:
@@ -139,7 +147,7 @@ def analyze(inner, p, n_seqdots):
             dots.append((a, x))
         for v in st.inputs:
             if v in inv_set:
-                if plan.vars[v].ndim > 1:
+                if plan.vars[v].ndim > nd:
                     return None, "matrix used element-wise"
                 if v not in pr.nsq:
                     pr.nsq[v] = len(pr.nsq)
@@ -148,8 +156,8 @@ def analyze(inner, p, n_seqdots):
             if plan.vars[v].dtype != "float32":
                 return None, "non-float32 operand"
         for o in st.outputs:
-            if plan.vars[o].ndim != 1 or plan.vars[o].dtype != "float32":
-                return None, "step output is not a float32 vector"
+            if plan.vars[o].ndim != nd or plan.vars[o].dtype != "float32":
+                return None, "step output is not a float32 %s" % ("matrix" if nd == 2 else "vector")
             produced[o] = len(pr.phases)
         pr.phases.append({"dots": dots, "ins": list(st.inputs), "outs": list(st.outputs),
                           "scalar": st.scalar, "out_refs": list(st.out_refs)})

@@ -1,0 +1,343 @@
+"""K10p (matrix state) — the persistent one-kernel Scan loop for a BATCH of recurrences.
+
+Same boundary and exchange protocol as ``scan_persist`` (which see), for inner graphs whose fused
+steps are small-M GEMM chains + Elemwise (``gemm_epi``) on a float32 matrix state ``h[B, N]`` —
+BASELINE config 4 with B = 64: ``sigmoid(h @ Ur + xr) * h``, ``tanh((r*h) @ Uh + xh)`` … —
+instead of 2 launches per step that re-stream 12 MiB of weights from the memory-side cache:
+
+* workgroup (bi, nj) owns the 16 x 16 output tile of batch block ``bi`` (16 rows) and column
+  slice ``nj`` (16 columns); its 4 wavefronts split K, and each lane keeps ITS share of the
+  weight columns of every matrix in VGPRs in MFMA B-operand layout for the whole loop
+  (K / 16 registers per matrix: 192 for config 4) — weights are read from HBM once per eval;
+* the A operand (the 16 x K block of ``h`` or ``r*h`` that belongs to batch block ``bi``) is what
+  the 64 workgroups of that block exchange: every workgroup publishes its 256 tile values as
+  tagged 8-byte granules and polls the 16 x K block (chunks of 16 granules per thread) into a
+  padded LDS image (pitch K + 4: conflict-free ``ds_read_b128`` in MFMA A layout);
+* ``v_mfma_f32_16x16x4_f32`` over the wave's K quarter, partial tiles summed in wave order through
+  LDS, one thread per tile element runs the epilogue, keeps its state / sequence operands in
+  registers, publishes and stores;
+* products whose operand block is already staged (``h @ Uz`` in the second GRU phase) are issued
+  BEFORE the wait for the phase's new operand, so their MFMA time hides behind the hand-off.
+
+Batch blocks are independent recurrences: block -> workgroup mapping ``bi = blockIdx % NB`` puts
+the workgroups of one block on one or two XCDs (``blockIdx % 8``), so a block's granules are
+polled through two L2s only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import hashlib
+import json
+import os
+
+from . import codegen as cg
+from .scan_persist import SPIN_LIMIT
+
+SM_MAXMAT = 8
+SM_MAXSEQ = 12
+SM_MAXNSQ = 8
+SM_MAXOUT = 8
+
+
+class SmArgs(C.Structure):
+    _fields_ = [
+        ("T", C.c_int64),
+        ("mat", C.c_void_p * SM_MAXMAT), ("mat_rs", C.c_int64 * SM_MAXMAT),
+        ("seq", C.c_void_p * SM_MAXSEQ), ("seq_ts", C.c_int64 * SM_MAXSEQ),
+        ("seq_rs", C.c_int64 * SM_MAXSEQ), ("seq_cs", C.c_int64 * SM_MAXSEQ),
+        ("nsq", C.c_void_p * SM_MAXNSQ), ("nsq_rs", C.c_int64 * SM_MAXNSQ),
+        ("nsq_cs", C.c_int64 * SM_MAXNSQ),
+        ("out", C.c_void_p * SM_MAXOUT), ("out_ts", C.c_int64 * SM_MAXOUT),
+        ("out_rs", C.c_int64 * SM_MAXOUT), ("out_store", C.c_int64 * SM_MAXOUT),
+        ("out_pos0", C.c_int64 * SM_MAXOUT),
+        ("xch", C.c_void_p), ("ctl", C.c_void_p),
+    ]
+
+
+SM_STRUCT = r"""
+#define SM_MAXMAT %d
+#define SM_MAXSEQ %d
+#define SM_MAXNSQ %d
+#define SM_MAXOUT %d
+struct SmArgs {
+  i64 T;
+  const void* mat[SM_MAXMAT]; i64 mat_rs[SM_MAXMAT];
+  const void* seq[SM_MAXSEQ]; i64 seq_ts[SM_MAXSEQ]; i64 seq_rs[SM_MAXSEQ]; i64 seq_cs[SM_MAXSEQ];
+  const void* nsq[SM_MAXNSQ]; i64 nsq_rs[SM_MAXNSQ]; i64 nsq_cs[SM_MAXNSQ];
+  void* out[SM_MAXOUT]; i64 out_ts[SM_MAXOUT]; i64 out_rs[SM_MAXOUT]; i64 out_store[SM_MAXOUT];
+  i64 out_pos0[SM_MAXOUT];
+  unsigned long long* xch; unsigned* ctl;
+};
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64;
+""" % (SM_MAXMAT, SM_MAXSEQ, SM_MAXNSQ, SM_MAXOUT)
+
+
+class SpecMat:
+    """Shape-specialised kernel: B batch rows, N state columns, K per weight matrix."""
+
+    def __init__(self, prog, B, N, Ks):
+        self.prog, self.B, self.N, self.Ks = prog, B, N, dict(Ks)
+        self.NB = -(-B // 16)
+        self.NJ = N // 16
+        # granule loads a thread keeps in flight per polling pass (2 VGPRs each)
+        self.chunk = int(os.environ.get("AESARA_HIP_SM_CHUNK", "32"))
+        # exchange form: "flag" = untagged 8-byte float pairs + ONE tag word per producing
+        # workgroup (half the bytes, one polling pass); "granule" = {tag, value} per element
+        self.xmode = os.environ.get("AESARA_HIP_SM_XMODE", "flag")
+
+    def key(self):
+        pr = self.prog
+        blob = json.dumps(["sm4", self.chunk, self.xmode, self.B, self.N, sorted(self.Ks.items()), sorted(pr.seq.items()),
+                           sorted(pr.state.items()), sorted(pr.nsq.items()), sorted(pr.mats.items()),
+                           [[ph["dots"], ph["ins"], ph["outs"], ph["scalar"], ph["out_refs"]]
+                            for ph in pr.phases], pr.outs, pr.exchanged], sort_keys=True)
+        return hashlib.sha256(blob.encode()).hexdigest()[:24]
+
+
+def xch_layout(prog, NB, N, xmode="flag"):
+    """u64 offsets of the exchange buffer.  granule form: per exchanged matrix 4 slots of NB
+    blocks of 16 x N granules -> {var: (offset, slot length)}.  flag form: 4 slots of
+    NB x 16 x N/2 float pairs followed by 4 slots of NB x NJ tag words ->
+    {var: (payload offset, payload slot length, flag offset, flag slot length)}."""
+    off, total = {}, 0
+    if xmode == "granule":
+        lp = NB * 16 * N
+        for v in prog.exchanged:
+            off[v] = (total, lp)
+            total += 4 * lp
+        return off, total
+    lpp, lpf = NB * 16 * N // 2, NB * (N // 16)
+    for v in prog.exchanged:
+        off[v] = (total, lpp, total + 4 * lpp, lpf)
+        total += 4 * (lpp + lpf)
+    return off, total
+
+
+def generate(spec: SpecMat):
+    pr, B, N, NB, NJ = spec.prog, spec.B, spec.N, spec.NB, spec.NJ
+    name = "sm_" + spec.key()
+    AG = "__ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT"
+    L = [cg.PRELUDE, SM_STRUCT]
+    xoff, _tot = xch_layout(pr, NB, N, spec.xmode)
+    FLAG = spec.xmode == "flag"
+
+    # staged operand blocks (LDS images, pitch K + 4 floats)
+    stage, stot = {}, 0
+    for ph in pr.phases:
+        for a_, x in ph["dots"]:
+            K = spec.Ks[a_]
+            kind = "prev" if x in pr.state else "cur"
+            if (x, kind) not in stage:
+                stage[(x, kind)] = (stot, K)
+                stot += 16 * (K + 4)
+    ndots_max = max(len(ph["dots"]) for ph in pr.phases)
+    L.append('extern "C" __global__ __launch_bounds__(256) void %s(SmArgs a) {' % name)
+    L.append("  __shared__ __attribute__((aligned(16))) float Hl[%d];" % max(stot, 4))
+    L.append("  __shared__ float part[%d][4][256];" % max(ndots_max, 1))
+    L.append("  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;")
+    L.append("  const int r16 = lane & 15, grp = lane >> 4;")
+    L.append("  const int bi = blockIdx.x %% %d, nj = blockIdx.x / %d;" % (NB, NB))
+    L.append("  const int erow = tid >> 4, ecol = tid & 15;        // tile element owned by this thread")
+    L.append("  const i64 eb = (i64)bi * 16 + erow, en = (i64)nj * 16 + ecol;")
+    L.append("  const bool owner = eb < %d && en < %d;" % (B, N))
+    L.append("  const int vrows = (%d - bi * 16) < 16 ? (%d - bi * 16) : 16;   // valid rows of this batch block" % (B, B))
+    L.append("  const unsigned base = __hip_atomic_load(a.ctl, %s);" % AG)
+    L.append("  unsigned* errp = a.ctl + 1;")
+    # ---- weights -> registers, MFMA B layout: lane (r16, grp) of wave w holds
+    #      W[w*K/4 + grp*K/16 + s][nj*16 + r16], s = 0 .. K/16 - 1
+    for av, slot in sorted(pr.mats.items(), key=lambda t: t[1]):
+        K = spec.Ks[av]
+        L.append("  const i64 wk%d = (i64)wave * %d + grp * %d;" % (slot, K // 4, K // 16))
+        for s_ in range(K // 16):
+            L.append("  const float w%d_%d = ((const float*)a.mat[%d])[(wk%d + %d) * a.mat_rs[%d] + nj * 16 + r16];"
+                     % (slot, s_, slot, slot, s_, slot))
+    # ---- registers of the element owner
+    out_of = {}
+    for o, kind, j in pr.outs:
+        out_of.setdefault(o, []).append((kind, j))
+    for v, k in pr.state.items():
+        L.append("  float own_%d = 0.f;" % v)
+        L.append("  if (owner) own_%d = ((const float*)a.out[%d])[((a.out_pos0[%d] + a.out_store[%d] - 1) %% "
+                 "a.out_store[%d]) * a.out_ts[%d] + eb * a.out_rs[%d] + en];" % (v, k, k, k, k, k, k))
+    pw_nsq = sorted({v for ph in pr.phases for v in ph["ins"] if v in pr.nsq})
+    for v in pw_nsq:
+        s_ = pr.nsq[v]
+        L.append("  float own_%d = 0.f;" % v)
+        L.append("  if (owner) own_%d = ((const float*)a.nsq[%d])[eb * a.nsq_rs[%d] + en * a.nsq_cs[%d]];"
+                 % (v, s_, s_, s_))
+    pw_seq = sorted({v for ph in pr.phases for v in ph["ins"] if v in pr.seq})
+    for v in pw_seq:
+        s_ = pr.seq[v]
+        L.append("  float nxt_%d = 0.f, own_%d = 0.f;" % (v, v))
+        L.append("  if (owner && a.T > 0) nxt_%d = ((const float*)a.seq[%d])[eb * a.seq_rs[%d] + en * a.seq_cs[%d]];"
+                 % (v, s_, s_, s_))
+    for ph in pr.phases:
+        for o in ph["outs"]:
+            L.append("  float own_%d = 0.f;" % o)
+    L.append("  for (i64 t = 0; t < a.T; ++t) {")
+    for v in pw_seq:
+        s_ = pr.seq[v]
+        L.append("    own_%d = nxt_%d;" % (v, v))
+        L.append("    if (owner && t + 1 < a.T) nxt_%d = ((const float*)a.seq[%d])[(t + 1) * a.seq_ts[%d] + "
+                 "eb * a.seq_rs[%d] + en * a.seq_cs[%d]];" % (v, s_, s_, s_, s_))
+    staged_this_step = set()
+
+    def emit_mfma(pi, d, a_, x):
+        slot = pr.mats[a_]
+        K = spec.Ks[a_]
+        kind = "prev" if x in pr.state else "cur"
+        so, _k = stage[(x, kind)]
+        P = K + 4
+        L.append("    {")
+        L.append("      f4 acc = {0.f, 0.f, 0.f, 0.f};")
+        L.append("      const float* hp = Hl + %d + r16 * %d + wave * %d + grp * %d;" % (so, P, K // 4, K // 16))
+        for q in range(K // 64):
+            L.append("      { const f4 av = *(const f4*)(hp + %d);" % (4 * q))
+            for e, c in enumerate("xyzw"):
+                L.append("        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.%s, w%d_%d, acc, 0, 0, 0);"
+                         % (c, slot, 4 * q + e))
+            L.append("      }")
+        L.append("      for (int i = 0; i < 4; ++i) part[%d][wave][(4 * grp + i) * 16 + r16] = acc[i];" % d)
+        L.append("    }")
+
+    for pi, ph in enumerate(pr.phases):
+        L.append("    // ---- phase %d" % pi)
+        early, late = [], []
+        for d, (a_, x) in enumerate(ph["dots"]):
+            kind = "prev" if x in pr.state else "cur"
+            (early if (x, kind) in staged_this_step else late).append((d, a_, x))
+        # products on blocks that are already staged run before the wait for the new operand
+        # (after a barrier: the previous phase's epilogue threads may still be reading `part`)
+        if early:
+            L.append("    __syncthreads();")
+        for d, a_, x in early:
+            emit_mfma(pi, d, a_, x)
+        newly = []
+        for d, a_, x in late:
+            kind = "prev" if x in pr.state else "cur"
+            if (x, kind) in staged_this_step:
+                continue
+            staged_this_step.add((x, kind))
+            newly.append((x, kind))
+            so, K = stage[(x, kind)]
+            P = K + 4
+            per_thread = 16 * K // 256          # granules per thread (K % 64 == 0)
+            nchunk = max(1, per_thread // spec.chunk)
+            cl = per_thread // nchunk           # loads per thread per chunk
+            src = pr.new_of_state.get(x, x)
+            if kind == "prev":
+                k_out = pr.state[x]
+                L.append("    if (t == 0) {")
+                L.append("      const float* ini = (const float*)a.out[%d] + ((a.out_pos0[%d] + a.out_store[%d] - 1) %% "
+                         "a.out_store[%d]) * a.out_ts[%d];" % (k_out, k_out, k_out, k_out, k_out))
+                L.append("      for (int idx = tid; idx < %d; idx += 256) {" % (16 * K))
+                L.append("        const int rr = idx / %d, cc = idx %% %d;" % (K, K))
+                L.append("        Hl[%d + rr * %d + cc] = rr < vrows ? ini[((i64)bi * 16 + rr) * a.out_rs[%d] + cc] : 0.f;"
+                         % (so, P, k_out))
+                L.append("      }")
+                L.append("    } else {")
+                step_expr = "(t - 1)"
+            else:
+                L.append("    {")
+                step_expr = "t"
+            ind = "      "
+            if FLAG:
+                po_, lpp, fo_, lpf = xoff[src]
+                PT = 16 * K // 2 // 256          # float pairs per thread
+                L.append(ind + "const unsigned long long want64 = (unsigned long long)(base + (unsigned)%s + 1u);" % step_expr)
+                L.append(ind + "if (wave == 0) {")
+                L.append(ind + "  const u64* fl = a.xch + %d + (%s & 3) * %d + (i64)bi * %d;" % (fo_, step_expr, lpf, NJ))
+                L.append(ind + "  for (int spin = 0;; ++spin) {")
+                L.append(ind + "    bool ok = true;")
+                L.append(ind + "    for (int j = lane; j < %d; j += 64) ok = ok && (__hip_atomic_load(fl + j, %s) == want64);" % (NJ, AG))
+                L.append(ind + "    if (__all(ok)) break;")
+                L.append(ind + "    if (spin > %d || ((spin & 255) == 255 && __hip_atomic_load(errp, %s) != 0u)) "
+                         "{ __hip_atomic_store(errp, 1u, %s); break; }" % (SPIN_LIMIT, AG, AG))
+                L.append(ind + "    __builtin_amdgcn_s_sleep(1);")
+                L.append(ind + "  }")
+                L.append(ind + "}")
+                L.append(ind + "__syncthreads();")
+                L.append(ind + "const u64* src = a.xch + %d + (%s & 3) * %d + (i64)bi * %d;" % (po_, step_expr, lpp, 16 * K // 2))
+                L.append(ind + "u64 g[%d];" % PT)
+                for u in range(PT):
+                    L.append(ind + "{ const int idx = %d * 256 + tid; g[%d] = (idx / %d < vrows) ? "
+                             "__hip_atomic_load(src + idx, %s) : 0ull; }" % (u, u, K // 2, AG))
+                for u in range(PT):
+                    L.append(ind + "{ const int idx = %d * 256 + tid; "
+                             "*(u64*)(Hl + %d + (idx / %d) * %d + 2 * (idx %% %d)) = g[%d]; }"
+                             % (u, so, K // 2, P, K // 2, u))
+                L.append("    }")
+                continue
+            xo, lp = xoff[src]
+            L.append(ind + "const u64* src = a.xch + %d + (%s & 3) * %d + (i64)bi * %d;" % (xo, step_expr, lp, 16 * K))
+            L.append(ind + "const unsigned want = base + (unsigned)%s + 1u;" % step_expr)
+            L.append(ind + "for (int ch = 0; ch < %d; ++ch) {" % nchunk)
+            L.append(ind + "  u64 g[%d];" % cl)
+            L.append(ind + "  for (int spin = 0;; ++spin) {")
+            L.append(ind + "    bool ok = true;")
+            for u in range(cl):
+                L.append(ind + "    { const int idx = (ch * %d + %d) * 256 + tid; "
+                         "if (idx / %d < vrows) { g[%d] = __hip_atomic_load(src + idx, %s); "
+                         "ok = ok && ((unsigned)(g[%d] >> 32) == want); } else g[%d] = 0; }"
+                         % (cl, u, K, u, AG, u, u))
+            L.append(ind + "    if (ok) break;")
+            L.append(ind + "    if (spin > %d || ((spin & 255) == 255 && __hip_atomic_load(errp, %s) != 0u)) "
+                     "{ __hip_atomic_store(errp, 1u, %s); break; }" % (SPIN_LIMIT, AG, AG))
+            L.append(ind + "    __builtin_amdgcn_s_sleep(1);")
+            L.append(ind + "  }")
+            for u in range(cl):
+                L.append(ind + "  { const int idx = (ch * %d + %d) * 256 + tid; "
+                         "Hl[%d + (idx / %d) * %d + idx %% %d] = __uint_as_float((unsigned)g[%d]); }"
+                         % (cl, u, so, K, P, K, u))
+            L.append(ind + "}")
+            L.append("    }")
+        if newly or not early:
+            L.append("    __syncthreads();")
+        for d, a_, x in late:
+            emit_mfma(pi, d, a_, x)
+        L.append("    __syncthreads();")
+        D = len(ph["dots"])
+        for d in range(D):
+            L.append("    const float dot_%d_%d = part[%d][0][tid] + part[%d][1][tid] + part[%d][2][tid] + part[%d][3][tid];"
+                     % (pi, d, d, d, d, d))
+        L.append("    if (owner) {")
+        ins = ["dot_%d_%d" % (pi, d) for d in range(D)] + ["own_%d" % v for v in ph["ins"]]
+        lines, outs, odts = cg.emit_scalar_body(ph["scalar"], ins, ["float32"] * len(ins),
+                                                indent="      ", suffix="_p%d" % pi)
+        L.extend(lines)
+        for o, ri in zip(ph["outs"], ph["out_refs"]):
+            L.append("      own_%d = %s;" % (o, cg._cast(outs[ri], odts[ri], "float32")))
+            if o in xoff and not FLAG:
+                xo, lp = xoff[o]
+                L.append("      __hip_atomic_store(a.xch + %d + (t & 3) * %d + (i64)bi * %d + erow * %d + en, "
+                         "((u64)(base + (unsigned)t + 1u) << 32) | (u64)__float_as_uint(own_%d), %s);"
+                         % (xo, lp, 16 * N, N, o, AG))
+            for _kind, j in out_of.get(o, []):
+                L.append("      ((float*)a.out[%d])[((a.out_pos0[%d] + t) %% a.out_store[%d]) * a.out_ts[%d] + "
+                         "eb * a.out_rs[%d] + en] = own_%d;" % (j, j, j, j, j, o))
+        L.append("    }")
+        if FLAG:
+            pub = [o for o in ph["outs"] if o in xoff]
+            for o in pub:
+                po_, lpp, fo_, lpf = xoff[o]
+                L.append("    { const float nb_ = __shfl_down(own_%d, 1, 64);" % o)
+                L.append("      if (owner && (ecol & 1) == 0) {")
+                L.append("        union { float f[2]; u64 u; } pk; pk.f[0] = own_%d; pk.f[1] = nb_;" % o)
+                L.append("        __hip_atomic_store(a.xch + %d + (t & 3) * %d + (i64)bi * %d + erow * %d + (en >> 1), pk.u, %s);"
+                         % (po_, lpp, 16 * N // 2, N // 2, AG))
+                L.append("      } }")
+            if pub:
+                # payload complete (write-through stores acknowledged) before the tag is raised
+                L.append('    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");')
+                L.append("    __syncthreads();")
+                for o in pub:
+                    po_, lpp, fo_, lpf = xoff[o]
+                    L.append("    if (tid == 0) __hip_atomic_store(a.xch + %d + (t & 3) * %d + (i64)bi * %d + nj, "
+                             "(unsigned long long)(base + (unsigned)t + 1u), %s);" % (fo_, lpf, NJ, AG))
+    for v, nv in pr.new_of_state.items():
+        L.append("    own_%d = own_%d;" % (v, nv))
+    L.append("  }")
+    L.append("  if (blockIdx.x == 0 && tid == 0) __hip_atomic_store(a.ctl, base + (unsigned)a.T, %s);" % AG)
+    L.append("}")
+    return "\n".join(L) + "\n", (name,)

@@ -10,7 +10,8 @@ from golden_util import CASES, assert_matches, case_expected, case_inputs, case_
 
 pytestmark = pytest.mark.gpu
 
-PERSISTENT = ["cfg4_gru_b1_f32", "sp_gru_last_f32", "sp_lstm_vec_f32", "sp_rnn_proj_f32"]
+PERSISTENT = ["cfg4_gru_b1_f32", "sp_gru_last_f32", "sp_lstm_vec_f32", "sp_rnn_proj_f32",
+              "cfg4_gru_b8_f32"]
 
 
 def _case(name):
@@ -110,7 +111,8 @@ def test_persistent_replays_are_deterministic():
             assert torch.equal(a, b)
 
 
-def test_persistent_kernel_stress_many_replays_under_uneven_load():
+@pytest.mark.parametrize("batch", [0, 64])
+def test_persistent_kernel_stress_many_replays_under_uneven_load(batch):
     """Hand-off protocol under load: 300 back-to-back replays of the config-4 loop (T = 64, 8192
     exchanges each) while a second stream keeps streaming a large buffer through the memory
     system; every evaluation must be bit-identical to the first (any stale / torn granule
@@ -120,14 +122,18 @@ def test_persistent_kernel_stress_many_replays_under_uneven_load():
     T, H = 64, 1024
     g = torch.Generator(device="cuda")
     g.manual_seed(7)
-    x = torch.randn(T, H, dtype=torch.float32, device="cuda", generator=g) * 0.1
-    h0 = torch.randn(H, dtype=torch.float32, device="cuda", generator=g) * 0.5
+    shp = (T, H) if not batch else (T, batch, H)
+    x = torch.randn(*shp, dtype=torch.float32, device="cuda", generator=g) * 0.1
+    h0 = torch.randn(*shp[1:], dtype=torch.float32, device="cuda", generator=g) * 0.5
     Ws = [torch.randn(H, H, dtype=torch.float32, device="cuda", generator=g) / np.sqrt(H)
           for _ in range(6)]
-    ex = PlanExecutor(case_plan(_case("cfg4_gru_b1_f32")), use_graph=True)
+    ex = PlanExecutor(case_plan(_case("cfg4_gru_b8_f32" if batch else "cfg4_gru_b1_f32")),
+                      use_graph=True)
     hs0, _ = ex(x, h0, *Ws)
-    ref = _gru_ref(x, h0, Ws)
-    assert ((hs0.double() - ref).abs().max() / ref.abs().max()).item() <= 1e-5
+    assert list(ex.scan_modes.values()) == ["persistent"]
+    if not batch:
+        ref = _gru_ref(x, h0, Ws)
+        assert ((hs0.double() - ref).abs().max() / ref.abs().max()).item() <= 1e-5
     first = hs0.clone()
     side = torch.cuda.Stream()
     big = torch.zeros(1 << 28, dtype=torch.float32, device="cuda")     # 1 GiB
@@ -141,3 +147,38 @@ def test_persistent_kernel_stress_many_replays_under_uneven_load():
     torch.cuda.synchronize()
     ex.check()
     assert bad == 0, f"{bad} of 300 replays differ"
+
+
+@pytest.mark.parametrize("T,H,B", [(512, 1024, 64), (40, 1024, 40), (9, 256, 5), (3, 64, 16)])
+def test_gru_matrix_state_all_steps_vs_fp64(T, H, B):
+    """The batch (matrix-state) class: BASELINE config 4 with B = 64 and ragged relatives (a last
+    batch block with fewer than 16 rows) through the MFMA persistent kernel, EVERY step against
+    an fp64 restatement, eager and replayed."""
+    import torch
+    from aesara_amd.executor import PlanExecutor
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    x = torch.randn(T, B, H, dtype=torch.float32, device="cuda", generator=g) * 0.1
+    h0 = torch.randn(B, H, dtype=torch.float32, device="cuda", generator=g) * 0.5
+    Ws = [torch.randn(H, H, dtype=torch.float32, device="cuda", generator=g) / np.sqrt(H)
+          for _ in range(6)]
+    Wz, Uz, Wr, Ur, Wh, Uh = [W.double() for W in Ws]
+    h = h0.double()
+    ref = []
+    for t in range(T):
+        xt = x[t].double()
+        z = torch.sigmoid(xt @ Wz + h @ Uz)
+        r = torch.sigmoid(xt @ Wr + h @ Ur)
+        hh = torch.tanh(xt @ Wh + (r * h) @ Uh)
+        h = (1 - z) * h + z * hh
+        ref.append(h)
+    ref = torch.stack(ref)
+    for use_graph in (False, True):
+        ex = PlanExecutor(case_plan(_case("cfg4_gru_b8_f32")), use_graph=use_graph)
+        for it in range(3):
+            hs, hT = ex(x, h0, *Ws)
+        assert list(ex.scan_modes.values()) == ["persistent"], ex.scan_modes
+        assert hs.shape == (T, B, H)
+        err = ((hs.double() - ref).abs().max() / ref.abs().max()).item()
+        assert err <= 1e-5, err
+        assert torch.equal(hT, hs[-1])
