@@ -95,6 +95,7 @@ class Program:
         self.new_of_state = {}      # state var -> var holding its new value
         self.exchanged = []         # produced vars that some dot needs in full
         self.mode = "vec"
+        self.dtype = "float32"
 
 
 def analyze(inner, p, n_seqdots):
@@ -126,6 +127,10 @@ def analyze(inner, p, n_seqdots):
     # "vec": Gemv chains on vectors (state h[M]); "mat": small-M GEMM chains on a matrix state
     # (h[B, N], batch of independent recurrences sharing the weights)
     pr.mode = "mat" if any(st.kind == "gemm_epi" for st in inner.steps) else "vec"
+    # one floating dtype throughout (the state's): float32 always, float64 for the vector class
+    pr.dtype = plan.vars[plan.outputs[0]].dtype
+    if pr.dtype not in (("float32",) if pr.mode == "mat" else ("float32", "float64")):
+        return None, "state dtype %s" % pr.dtype
     nd = 2 if pr.mode == "mat" else 1
     ok_kinds = ("gemm_epi", "elemwise") if pr.mode == "mat" else ("gemv_epi", "elemwise")
     for st in inner.steps:
@@ -153,11 +158,11 @@ def analyze(inner, p, n_seqdots):
                     pr.nsq[v] = len(pr.nsq)
             elif not (v in pr.seq or v in pr.state or v in produced):
                 return None, "operand of unknown origin"
-            if plan.vars[v].dtype != "float32":
-                return None, "non-float32 operand"
+            if plan.vars[v].dtype != pr.dtype:
+                return None, "operand dtype differs from the state's"
         for o in st.outputs:
-            if plan.vars[o].ndim != nd or plan.vars[o].dtype != "float32":
-                return None, "step output is not a float32 %s" % ("matrix" if nd == 2 else "vector")
+            if plan.vars[o].ndim != nd or plan.vars[o].dtype != pr.dtype:
+                return None, "step output is not a %s %s" % (pr.dtype, "matrix" if nd == 2 else "vector")
             produced[o] = len(pr.phases)
         pr.phases.append({"dots": dots, "ins": list(st.inputs), "outs": list(st.outputs),
                           "scalar": st.scalar, "out_refs": list(st.out_refs)})
@@ -190,7 +195,8 @@ def analyze(inner, p, n_seqdots):
 class Spec:
     """Shape-specialised persistent kernel: M rows, K per matrix, R rows per workgroup."""
 
-    def __init__(self, prog: Program, plan, M, Ks, lens, R, nw, place=None):
+    def __init__(self, prog: Program, plan, M, Ks, lens, R, nw, place=None, dtype="float32"):
+        self.dtype = dtype
         self.prog, self.plan, self.M, self.Ks, self.lens, self.R, self.nw = \
             prog, plan, M, dict(Ks), dict(lens), R, nw
         assert R % nw == 0
@@ -202,7 +208,7 @@ class Spec:
 
     def key(self):
         pr = self.prog
-        blob = json.dumps(["sp5", sorted(self.var.items()), sorted(self.place.items()), self.M, sorted(self.Ks.items()), sorted(self.lens.items()),
+        blob = json.dumps(["sp6", self.dtype, sorted(self.var.items()), sorted(self.place.items()), self.M, sorted(self.Ks.items()), sorted(self.lens.items()),
                            self.R, self.nw, sorted(pr.seq.items()), sorted(pr.state.items()),
                            sorted(pr.nsq.items()), sorted(pr.mats.items()),
                            [[ph["dots"], ph["ins"], ph["outs"], ph["scalar"], ph["out_refs"]]
@@ -210,11 +216,12 @@ class Spec:
         return hashlib.sha256(blob.encode()).hexdigest()[:24]
 
 
-def xch_layout(prog, lens):
-    """granule offsets of the exchange buffer: per exchanged vector 4 slots of padded length."""
+def xch_layout(prog, lens, gpv=1):
+    """granule offsets of the exchange buffer: per exchanged vector 4 slots of padded length
+    (``gpv`` 8-byte granules per value: 2 for float64 — high and low word, each tagged)."""
     off, total = {}, 0
     for v in prog.exchanged:
-        lp = (lens[v] + 15) // 16 * 16
+        lp = (gpv * lens[v] + 15) // 16 * 16
         off[v] = (total, lp)
         total += 4 * lp
     return off, total
@@ -225,8 +232,16 @@ def generate(spec: Spec):
     BLOCK = 64 * NW
     RPW = R // NW                         # rows per wavefront = lanes that run the epilogue
     name = "sp_" + spec.key()
-    L = [cg.PRELUDE, SP_STRUCT]
+    F64 = spec.dtype == "float64"
+    T = "double" if F64 else "float"
+    VEC = 2 if F64 else 4                 # elements per 16-byte vector
+    GPV = 2 if F64 else 1                 # 8-byte granules per exchanged value
+    comps = "xyzw"[:VEC]
+    L = [cg.PRELUDE, SP_STRUCT, "typedef %s TV __attribute__((ext_vector_type(%d)));" % (T, VEC)]
     AG = "__ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT"
+
+    def vdot(w, x):
+        return " + ".join("%s.%s * %s.%s" % (w, c, x, c) for c in comps)
 
     # ---- LDS: matrix rows of this workgroup + staged dot vectors (two step parities) ----------
     woff, wtot = {}, 0
@@ -251,12 +266,12 @@ def generate(spec: Spec):
                 if (x, kind) not in stage:
                     stage[(x, kind)] = stot
                     stot += K
-    xoff, _xtot = xch_layout(pr, spec.lens)
+    xoff, _xtot = xch_layout(pr, spec.lens, GPV)
     L.append('extern "C" __global__ __launch_bounds__(%d) void %s(SpArgs a) {' % (BLOCK, name))
-    L.append("  __shared__ __attribute__((aligned(16))) float Wl[%d];" % max(wtot, 4))
-    L.append("  __shared__ __attribute__((aligned(16))) float Vl[2][%d];" % max(stot, 4))
+    L.append("  __shared__ __attribute__((aligned(16))) %s Wl[%d];" % (T, max(wtot, 4)))
+    L.append("  __shared__ __attribute__((aligned(16))) %s Vl[2][%d];" % (T, max(stot, 4)))
     if itot:
-        L.append("  __shared__ __attribute__((aligned(16))) float Il[%d];" % itot)
+        L.append("  __shared__ __attribute__((aligned(16))) %s Il[%d];" % (T, itot))
     L.append("  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;")
     L.append("  const i64 row0 = (i64)blockIdx.x * %d;" % R)
     L.append("  const i64 myrow = row0 + wave * %d + lane;     // row owned by this lane (lane < %d)" % (RPW, RPW))
@@ -266,53 +281,53 @@ def generate(spec: Spec):
     # ---- matrix rows -> LDS ------------------------------------------------------------------
     for av, slot in sorted(pr.mats.items(), key=lambda t: t[1]):
         K = spec.Ks[av]
-        K4 = K // 4
+        K4 = K // VEC
         if av in in_reg:
             # rows of this wavefront stay in VGPRs for the whole loop: lane l holds the 16-byte
             # vectors l, l + 64, ... of each of its RPW rows (fully unrolled, static indices)
             for i in range(RPW):
                 L.append("  const i64 wrow%d_%d = row0 + wave * %d + %d;" % (slot, i, RPW, i))
                 for q in range(K4 // 64):
-                    L.append("  const f4 wr%d_%d_%d = wrow%d_%d < %d ? *(const f4*)((const float*)a.mat[%d] + "
-                             "wrow%d_%d * a.mat_rs[%d] + 4 * (lane + %d)) : f4{0.f, 0.f, 0.f, 0.f};"
-                             % (slot, i, q, slot, i, M, slot, slot, i, slot, 64 * q))
+                    L.append("  const TV wr%d_%d_%d = wrow%d_%d < %d ? *(const TV*)((const %s*)a.mat[%d] + "
+                             "wrow%d_%d * a.mat_rs[%d] + %d * (lane + %d)) : TV(0);"
+                             % (slot, i, q, slot, i, M, T, slot, slot, i, slot, VEC, 64 * q))
             continue
         L.append("  for (int idx = threadIdx.x; idx < %d; idx += %d) {" % (R * K4, BLOCK))
         L.append("    const int j = idx / %d, k4 = idx %% %d;" % (K4, K4))
         L.append("    const i64 r = row0 + j;")
-        L.append("    f4 v = {0.f, 0.f, 0.f, 0.f};")
-        L.append("    if (r < %d) v = *(const f4*)((const float*)a.mat[%d] + r * a.mat_rs[%d] + 4 * k4);"
-                 % (M, slot, slot))
-        L.append("    *(f4*)(Wl + %d + j * %d + 4 * k4) = v;" % (woff[av], K))
+        L.append("    TV v = TV(0);")
+        L.append("    if (r < %d) v = *(const TV*)((const %s*)a.mat[%d] + r * a.mat_rs[%d] + %d * k4);"
+                 % (M, T, slot, slot, VEC))
+        L.append("    *(TV*)(Wl + %d + j * %d + %d * k4) = v;" % (woff[av], K, VEC))
         L.append("  }")
     for x, off in inv_stage.items():
         K = spec.lens[x]
         L.append("  for (int k = threadIdx.x; k < %d; k += %d) Il[%d + k] = "
-                 "((const float*)a.nsq[%d])[k * a.nsq_es[%d]];" % (K, BLOCK, off, pr.nsq[x], pr.nsq[x]))
+                 "((const %s*)a.nsq[%d])[k * a.nsq_es[%d]];" % (K, BLOCK, off, T, pr.nsq[x], pr.nsq[x]))
     # ---- registers of the row owner --------------------------------------------------------------
     out_of = {}
     for o, kind, j in pr.outs:
         out_of.setdefault(o, []).append((kind, j))
     for v, k in pr.state.items():
         # value of the previous step: row (pos0 - 1) of the output buffer holds the initial state
-        L.append("  float own_%d = 0.f;" % v)
-        L.append("  if (owner) own_%d = ((const float*)a.out[%d])[((a.out_pos0[%d] + a.out_store[%d] - 1) %% "
-                 "a.out_store[%d]) * a.out_rs[%d] + myrow];" % (v, k, k, k, k, k))
+        L.append("  %s own_%d = 0;" % (T, v))
+        L.append("  if (owner) own_%d = ((const %s*)a.out[%d])[((a.out_pos0[%d] + a.out_store[%d] - 1) %% "
+                 "a.out_store[%d]) * a.out_rs[%d] + myrow];" % (v, T, k, k, k, k, k))
     pw_nsq = sorted({v for ph in pr.phases for v in ph["ins"] if v in pr.nsq})
     for v in pw_nsq:
         es_one = spec.lens[v] == 1
-        L.append("  float own_%d = 0.f;" % v)
-        L.append("  if (owner) own_%d = ((const float*)a.nsq[%d])[%s];"
-                 % (v, pr.nsq[v], "0" if es_one else "myrow * a.nsq_es[%d]" % pr.nsq[v]))
+        L.append("  %s own_%d = 0;" % (T, v))
+        L.append("  if (owner) own_%d = ((const %s*)a.nsq[%d])[%s];"
+                 % (v, T, pr.nsq[v], "0" if es_one else "myrow * a.nsq_es[%d]" % pr.nsq[v]))
     pw_seq = sorted({v for ph in pr.phases for v in ph["ins"] if v in pr.seq})
     for v in pw_seq:
         s = pr.seq[v]
         idx = "0" if spec.lens[v] == 1 else "myrow * a.seq_es[%d]" % s
-        L.append("  float nxt_%d = 0.f, own_%d = 0.f;" % (v, v))
-        L.append("  if (owner && a.T > 0) nxt_%d = ((const float*)a.seq[%d])[%s];" % (v, s, idx))
+        L.append("  %s nxt_%d = 0, own_%d = 0;" % (T, v, v))
+        L.append("  if (owner && a.T > 0) nxt_%d = ((const %s*)a.seq[%d])[%s];" % (v, T, s, idx))
     for ph in pr.phases:
         for o in ph["outs"]:
-            L.append("  float own_%d = 0.f;" % o)
+            L.append("  %s own_%d = 0;" % (T, o))
     L.append("  __syncthreads();")
     L.append("  for (i64 t = 0; t < a.T; ++t) {")
     L.append("    const int par = (int)(t & 1);")
@@ -320,8 +335,8 @@ def generate(spec: Spec):
         s = pr.seq[v]
         idx = "0" if spec.lens[v] == 1 else "myrow * a.seq_es[%d]" % s
         L.append("    own_%d = nxt_%d;" % (v, v))
-        L.append("    if (owner && t + 1 < a.T) nxt_%d = ((const float*)a.seq[%d])[(t + 1) * a.seq_ts[%d] + %s];"
-                 % (v, s, s, idx))
+        L.append("    if (owner && t + 1 < a.T) nxt_%d = ((const %s*)a.seq[%d])[(t + 1) * a.seq_ts[%d] + %s];"
+                 % (v, T, s, s, idx))
     staged_this_step = set()
     for pi, ph in enumerate(pr.phases):
         L.append("    // ---- phase %d" % pi)
@@ -341,16 +356,16 @@ def generate(spec: Spec):
             if kind == "glob":
                 s = pr.seq[x]
                 L.append("    for (int k = threadIdx.x; k < %d; k += %d) Vl[par][%d + k] = "
-                         "((const float*)a.seq[%d])[t * a.seq_ts[%d] + k * a.seq_es[%d]];"
-                         % (K, BLOCK, so, s, s, s))
+                         "((const %s*)a.seq[%d])[t * a.seq_ts[%d] + k * a.seq_es[%d]];"
+                         % (K, BLOCK, so, T, s, s, s))
                 continue
             src = pr.new_of_state.get(x, x)
             xo, lp = xoff[src]
             if kind == "prev":
                 k_out = pr.state[x]
                 L.append("    if (t == 0) {")
-                L.append("      const float* ini = (const float*)a.out[%d] + ((a.out_pos0[%d] + a.out_store[%d] - 1) %% "
-                         "a.out_store[%d]) * a.out_rs[%d];" % (k_out, k_out, k_out, k_out, k_out))
+                L.append("      const %s* ini = (const %s*)a.out[%d] + ((a.out_pos0[%d] + a.out_store[%d] - 1) %% "
+                         "a.out_store[%d]) * a.out_rs[%d];" % (T, T, k_out, k_out, k_out, k_out, k_out))
                 L.append("      for (int k = threadIdx.x; k < %d; k += %d) Vl[par][%d + k] = ini[k];" % (K, BLOCK, so))
                 L.append("    } else {")
                 step_expr, ind = "(t - 1)", "      "
@@ -358,7 +373,8 @@ def generate(spec: Spec):
                 L.append("    {")
                 step_expr, ind = "t", "      "
             PT = 64 * spec.var["pollw"]
-            NGp = (K + PT - 1) // PT
+            KG = GPV * K                   # granules of this vector (float64: hi / lo halves)
+            NGp = (KG + PT - 1) // PT
             pg = "" if PT == BLOCK else "if (threadIdx.x < %d) " % PT
             L.append(ind + "const u64* src = a.xch + %d + (%s & 3) * %d;" % (xo, step_expr, lp))
             L.append(ind + "const unsigned want = base + (unsigned)%s + 1u;" % step_expr)
@@ -367,8 +383,8 @@ def generate(spec: Spec):
             if spec.var["repoll"]:
                 L.append(ind + "bool have[%d];" % NGp)
                 for q in range(NGp):
-                    L.append(ind + "have[%d] = %s;" % (q, "false" if (q + 1) * PT <= K else
-                                                      "!(threadIdx.x + %d < %d)" % (q * PT, K)))
+                    L.append(ind + "have[%d] = %s;" % (q, "false" if (q + 1) * PT <= KG else
+                                                      "!(threadIdx.x + %d < %d)" % (q * PT, KG)))
             L.append(ind + "for (int spin = 0;; ++spin) {")
             L.append(ind + "  bool ok = true;")
             for q in range(NGp):
@@ -376,7 +392,7 @@ def generate(spec: Spec):
                     L.append(ind + "  if (!have[%d]) { g[%d] = __hip_atomic_load(src + threadIdx.x + %d, %s); }"
                              % (q, q, q * PT, AG))
                 else:
-                    guard = "" if (q + 1) * PT <= K else "if (threadIdx.x + %d < %d) " % (q * PT, K)
+                    guard = "" if (q + 1) * PT <= KG else "if (threadIdx.x + %d < %d) " % (q * PT, KG)
                     L.append(ind + "  %s{ g[%d] = __hip_atomic_load(src + threadIdx.x + %d, %s); "
                              "ok = ok && ((unsigned)(g[%d] >> 32) == want); }" % (guard, q, q * PT, AG, q))
             if spec.var["repoll"]:
@@ -391,9 +407,15 @@ def generate(spec: Spec):
                 L.append(ind + "  __builtin_amdgcn_s_sleep(%d);" % spec.var["sleep"])
             L.append(ind + "}")
             for q in range(NGp):
-                guard = "" if (q + 1) * PT <= K else "if (threadIdx.x + %d < %d) " % (q * PT, K)
-                L.append(ind + "%sVl[par][%d + threadIdx.x + %d] = __uint_as_float((unsigned)g[%d]);"
-                         % (guard, so, q * PT, q))
+                guard = "" if (q + 1) * PT <= KG else "if (threadIdx.x + %d < %d) " % (q * PT, KG)
+                if F64:
+                    # granule 2k = {tag, high word}, 2k + 1 = {tag, low word}: two 4-byte LDS stores
+                    # rebuild the double in place (little endian: low word first)
+                    L.append(ind + "%s((unsigned*)(Vl[par] + %d))[(threadIdx.x + %d) ^ 1] = (unsigned)g[%d];"
+                             % (guard, so, q * PT, q))
+                else:
+                    L.append(ind + "%sVl[par][%d + threadIdx.x + %d] = __uint_as_float((unsigned)g[%d]);"
+                             % (guard, so, q * PT, q))
             L.append(ind + "}")
             L.append("    }")
         if need_sync:
@@ -402,66 +424,68 @@ def generate(spec: Spec):
         D = len(ph["dots"])
         for d, (a_, x) in enumerate(ph["dots"]):
             K = spec.Ks[a_]
-            K4 = K // 4
+            K4 = K // VEC
             if x in pr.nsq:
                 vsrc = "Il + %d" % inv_stage[x]
             else:
                 kind = "prev" if x in pr.state else ("cur" if x not in pr.seq else "glob")
                 vsrc = "Vl[par] + %d" % stage[(x, kind)]
             for i in range(RPW):
-                L.append("    float acc%d_%d_%d = 0.f;" % (pi, d, i))
+                L.append("    %s acc%d_%d_%d = 0;" % (T, pi, d, i))
             if a_ in in_reg:
                 slot = pr.mats[a_]
                 L.append("    {")
-                L.append("      const float* vx = %s;" % vsrc)
+                L.append("      const %s* vx = %s;" % (T, vsrc))
                 for q in range(K4 // 64):
-                    L.append("      { const f4 xv = *(const f4*)(vx + 4 * (lane + %d));" % (64 * q))
+                    L.append("      { const TV xv = *(const TV*)(vx + %d * (lane + %d));" % (VEC, 64 * q))
                     for i in range(RPW):
-                        L.append("        acc%d_%d_%d += wr%d_%d_%d.x * xv.x + wr%d_%d_%d.y * xv.y + "
-                                 "wr%d_%d_%d.z * xv.z + wr%d_%d_%d.w * xv.w;"
-                                 % ((pi, d, i) + (slot, i, q) * 4))
+                        L.append("        acc%d_%d_%d += %s;" % (pi, d, i, vdot("wr%d_%d_%d" % (slot, i, q), "xv")))
                     L.append("      }")
                 L.append("    }")
                 continue
             L.append("    {")
-            L.append("      const float* vx = %s;" % vsrc)
-            L.append("      const float* wr = Wl + %d + (wave * %d) * %d;" % (woff[a_], RPW, K))
+            L.append("      const %s* vx = %s;" % (T, vsrc))
+            L.append("      const %s* wr = Wl + %d + (wave * %d) * %d;" % (T, woff[a_], RPW, K))
             L.append("#pragma unroll")
             L.append("      for (int k4 = lane; k4 < %d; k4 += 64) {" % K4)
-            L.append("        const f4 xv = *(const f4*)(vx + 4 * k4);")
+            L.append("        const TV xv = *(const TV*)(vx + %d * k4);" % VEC)
             for i in range(RPW):
-                L.append("        { const f4 wv = *(const f4*)(wr + %d + 4 * k4); "
-                         "acc%d_%d_%d += wv.x * xv.x + wv.y * xv.y + wv.z * xv.z + wv.w * xv.w; }"
-                         % (i * K, pi, d, i))
+                L.append("        { const TV wv = *(const TV*)(wr + %d + %d * k4); acc%d_%d_%d += %s; }"
+                         % (i * K, VEC, pi, d, i, vdot("wv", "xv")))
             L.append("      }")
             L.append("    }")
         if D:
             L.append("    for (int s = 32; s > 0; s >>= 1) {")
             for d in range(D):
                 for i in range(RPW):
-                    L.append("      acc%d_%d_%d += shfl_xor_<float>(acc%d_%d_%d, s);" % (pi, d, i, pi, d, i))
+                    L.append("      acc%d_%d_%d += shfl_xor_<%s>(acc%d_%d_%d, s);" % (pi, d, i, T, pi, d, i))
             L.append("    }")
         for d in range(D):
             sel = "acc%d_%d_%d" % (pi, d, RPW - 1)
             for i in range(RPW - 2, -1, -1):
                 sel = "(lane == %d ? acc%d_%d_%d : %s)" % (i, pi, d, i, sel)
-            L.append("    const float dot_%d_%d = %s;" % (pi, d, sel))
+            L.append("    const %s dot_%d_%d = %s;" % (T, pi, d, sel))
         # -- epilogue on the row owners
         L.append("    if (owner) {")
         ins = ["dot_%d_%d" % (pi, d) for d in range(D)] + ["own_%d" % v for v in ph["ins"]]
-        lines, outs, odts = cg.emit_scalar_body(ph["scalar"], ins, ["float32"] * len(ins),
+        lines, outs, odts = cg.emit_scalar_body(ph["scalar"], ins, [spec.dtype] * len(ins),
                                                 indent="      ", suffix="_p%d" % pi)
         L.extend(lines)
         for k, (o, ri) in enumerate(zip(ph["outs"], ph["out_refs"])):
-            L.append("      own_%d = %s;" % (o, cg._cast(outs[ri], odts[ri], "float32")))
+            L.append("      own_%d = %s;" % (o, cg._cast(outs[ri], odts[ri], spec.dtype)))
             if o in xoff:
                 xo, lp = xoff[o]
-                L.append("      __hip_atomic_store(a.xch + %d + (t & 3) * %d + myrow, "
-                         "((u64)(base + (unsigned)t + 1u) << 32) | (u64)__float_as_uint(own_%d), %s);"
-                         % (xo, lp, o, AG))
+                if F64:
+                    L.append("      { const u64 bits = (u64)__double_as_longlong(own_%d), tg = (u64)(base + (unsigned)t + 1u) << 32;" % o)
+                    L.append("        __hip_atomic_store(a.xch + %d + (t & 3) * %d + 2 * myrow, tg | (bits >> 32), %s);" % (xo, lp, AG))
+                    L.append("        __hip_atomic_store(a.xch + %d + (t & 3) * %d + 2 * myrow + 1, tg | (bits & 0xFFFFFFFFull), %s); }" % (xo, lp, AG))
+                else:
+                    L.append("      __hip_atomic_store(a.xch + %d + (t & 3) * %d + myrow, "
+                             "((u64)(base + (unsigned)t + 1u) << 32) | (u64)__float_as_uint(own_%d), %s);"
+                             % (xo, lp, o, AG))
             for kind, j in out_of.get(o, []):
-                L.append("      ((float*)a.out[%d])[((a.out_pos0[%d] + t) %% a.out_store[%d]) * a.out_rs[%d] + myrow] = own_%d;"
-                         % (j, j, j, j, o))
+                L.append("      ((%s*)a.out[%d])[((a.out_pos0[%d] + t) %% a.out_store[%d]) * a.out_rs[%d] + myrow] = own_%d;"
+                         % (T, j, j, j, j, o))
         L.append("    }")
     for v, nv in pr.new_of_state.items():
         L.append("    own_%d = own_%d;" % (v, nv))
@@ -476,7 +500,7 @@ def generate(spec: Spec):
 REG_BUDGET = 160      # VGPRs per lane that may hold matrix rows
 
 
-def choose_rows(M, Ks, stage_floats, cu_count=256):
+def choose_rows(M, Ks, stage_floats, cu_count=256, itemsize=4):
     """Geometry of the persistent kernel: rows of every matrix per workgroup (R), wavefronts per
     workgroup, grid size and where each matrix's rows live ("lds" / "reg").
 
@@ -498,12 +522,12 @@ def choose_rows(M, Ks, stage_floats, cu_count=256):
         if G > cu_count:
             continue
         rpw = R // nw
-        place, regs, lds = {}, 0, stage_floats * 4
+        place, regs, lds = {}, 0, stage_floats * itemsize
         for av, K in sorted(Ks.items(), key=lambda t: -t[1]):
-            if lds + R * K * 4 <= LDS_BUDGET:
-                place[av], lds = "lds", lds + R * K * 4
-            elif K % 256 == 0 and regs + rpw * (K // 64) <= REG_BUDGET:
-                place[av], regs = "reg", regs + rpw * (K // 64)
+            if lds + R * K * itemsize <= LDS_BUDGET:
+                place[av], lds = "lds", lds + R * K * itemsize
+            elif K % 256 == 0 and regs + rpw * (K // 64) * (itemsize // 4) <= REG_BUDGET:
+                place[av], regs = "reg", regs + rpw * (K // 64) * (itemsize // 4)
             else:
                 place = None
                 break

@@ -11,7 +11,7 @@ from golden_util import CASES, assert_matches, case_expected, case_inputs, case_
 pytestmark = pytest.mark.gpu
 
 PERSISTENT = ["cfg4_gru_b1_f32", "sp_gru_last_f32", "sp_lstm_vec_f32", "sp_rnn_proj_f32",
-              "cfg4_gru_b8_f32"]
+              "cfg4_gru_b8_f32", "gru_b1_f64"]
 
 
 def _case(name):
@@ -41,8 +41,9 @@ def test_persistent_path_is_taken_and_matches(name, use_graph):
         assert all(v.startswith("launch-list") for v in ex2.scan_modes.values())
     finally:
         E.TUNE["scan_persist"] = 1
+    tol = 1e-11 if name.endswith("f64") else 2e-5
     for g, r in zip(got, ref):
-        np.testing.assert_allclose(g, r, rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(g, r, rtol=tol, atol=tol)
 
 
 def test_outside_the_class_falls_back():
@@ -182,3 +183,25 @@ def test_gru_matrix_state_all_steps_vs_fp64(T, H, B):
         err = ((hs.double() - ref).abs().max() / ref.abs().max()).item()
         assert err <= 1e-5, err
         assert torch.equal(hT, hs[-1])
+
+
+@pytest.mark.parametrize("T,H", [(64, 512), (17, 1024), (5, 26)])
+def test_gru_float64_all_steps(T, H):
+    """float64 state (Aesara's default floatX): values travel as two tagged granules (high / low
+    word) and the loop runs in double — every step within 1e-12 of a torch fp64 restatement."""
+    import torch
+    from aesara_amd.executor import PlanExecutor
+    g = torch.Generator(device="cuda")
+    g.manual_seed(9)
+    x = torch.randn(T, H, dtype=torch.float64, device="cuda", generator=g) * 0.1
+    h0 = torch.randn(H, dtype=torch.float64, device="cuda", generator=g) * 0.5
+    Ws = [torch.randn(H, H, dtype=torch.float64, device="cuda", generator=g) / np.sqrt(H)
+          for _ in range(6)]
+    ref = _gru_ref(x, h0, Ws)
+    for use_graph in (False, True):
+        ex = PlanExecutor(case_plan(_case("gru_b1_f64")), use_graph=use_graph)
+        for it in range(3):
+            hs, hT = ex(x, h0, *Ws)
+        assert list(ex.scan_modes.values()) == ["persistent"], ex.scan_modes
+        err = ((hs - ref).abs().max() / ref.abs().max()).item()
+        assert err <= 1e-12, err
