@@ -133,13 +133,24 @@ def analyze(inner, p, n_seqdots):
         return None, "state dtype %s" % pr.dtype
     nd = 2 if pr.mode == "mat" else 1
     ok_kinds = ("gemm_epi", "elemwise") if pr.mode == "mat" else ("gemv_epi", "elemwise")
+    alias = {}
+
+    def res(v):
+        while v in alias:
+            v = alias[v]
+        return v
     for st in inner.steps:
+        if st.kind == "node" and st.node.op in ("SpecifyShape", "ViewOp"):
+            alias[st.outputs[0]] = st.inputs[0]      # value-preserving views: same vector / matrix
+            continue
         if st.kind not in ok_kinds or st.reduce is not None or st.post or \
                 (st.fallback and st.kind != "gemm_epi") or st.extra.get("xprog"):
             return None, f"step kind {st.kind} ({st.node.op if st.node else ''})"
         dots = []
         # (invariant matrix, loop operand): gemv_epi stores (A, x), gemm_epi (operand, weight)
         pairs = [(b, a) for a, b in st.dots] if st.kind == "gemm_epi" else list(st.dots)
+        pairs = [(a, res(x)) for a, x in pairs]
+        st_inputs = [res(v) for v in st.inputs]
         for a, x in pairs:
             if a not in inv_set or plan.vars[a].ndim != 2:
                 return None, "dot with a loop-varying matrix"
@@ -150,7 +161,7 @@ def analyze(inner, p, n_seqdots):
             if x in inv_set and x not in pr.nsq:
                 pr.nsq[x] = len(pr.nsq)
             dots.append((a, x))
-        for v in st.inputs:
+        for v in st_inputs:
             if v in inv_set:
                 if plan.vars[v].ndim > nd:
                     return None, "matrix used element-wise"
@@ -164,18 +175,18 @@ def analyze(inner, p, n_seqdots):
             if plan.vars[o].ndim != nd or plan.vars[o].dtype != pr.dtype:
                 return None, "step output is not a %s %s" % (pr.dtype, "matrix" if nd == 2 else "vector")
             produced[o] = len(pr.phases)
-        pr.phases.append({"dots": dots, "ins": list(st.inputs), "outs": list(st.outputs),
+        pr.phases.append({"dots": dots, "ins": list(st_inputs), "outs": list(st.outputs),
                           "scalar": st.scalar, "out_refs": list(st.out_refs)})
     if len(pr.mats) > SP_MAXMAT or len(pr.nsq) > SP_MAXNSQ or not pr.mats:
         return None, "no / too many matrices"
     if len(plan.outputs) != n_rec + n_nit or len(plan.outputs) > SP_MAXOUT:
         return None, "output count"
     for j, o in enumerate(plan.outputs):
-        if o not in produced:
+        if res(o) not in produced:
             return None, "a step output is not computed by a fused step"
-        pr.outs.append((o, "rec" if j < n_rec else "nit", j))
+        pr.outs.append((res(o), "rec" if j < n_rec else "nit", j))
     for v, k in pr.state.items():
-        pr.new_of_state[v] = plan.outputs[k]
+        pr.new_of_state[v] = res(plan.outputs[k])
     # which produced vectors have to be exchanged (some dot reads them in full)
     need = []
     for ph in pr.phases:
