@@ -63,6 +63,18 @@ template <typename T, int N> __device__ __forceinline__ Pack<T, N> nt_load(const
   return r;
 }
 
+template <typename T, int N> __device__ __forceinline__ void nt_store(Pack<T, N>* p, const Pack<T, N>& r) {
+  if constexpr (sizeof(T) * N >= 16) {
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    u4* q = (u4*)p;
+    const u4* d = (const u4*)&r;
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) * N / 16; ++i) __builtin_nontemporal_store(d[i], q + i);
+  } else {
+    *p = r;
+  }
+}
+
 // ---- scalar helpers (reference: aesara/scalar/basic.py, scalar/math.py c_code) ----
 template <typename T> __device__ __forceinline__ T idiv_floor(T x, T y) {  // FloorDivide :2039
   if (y == 0) return 0;
@@ -836,7 +848,7 @@ def generate(spec: KernelSpec):
                 continue
             if cls == "c" and V > 1:
                 ptr = "(const Pack<%s, %d>*)(p%d + %s)" % (ct, V, k, elem_off_exprs[k])
-                if spec.nt:
+                if int(spec.nt) & 1:
                     B.append("      const Pack<%s, %d> x%d%s = nt_load(%s);" % (ct, V, k, sfx, ptr))
                 else:
                     B.append("      const Pack<%s, %d> x%d%s = *%s;" % (ct, V, k, sfx, ptr))
@@ -879,8 +891,12 @@ def generate(spec: KernelSpec):
                 B.append("      %s = %s;" % (accs[v], red_combine(red["op"], red["acc"], accs[v], val)))
         if V > 1:
             for k in range(nout):
-                B.append("      *(Pack<%s, %d>*)(p%d + %s) = y%d%s;" %
-                         (CTYPE[spec.out_dtypes[k]], V, nin + k, elem_off_exprs[nin + k], k, sfx))
+                if int(spec.nt) & 2:
+                    B.append("      nt_store((Pack<%s, %d>*)(p%d + %s), y%d%s);" %
+                             (CTYPE[spec.out_dtypes[k]], V, nin + k, elem_off_exprs[nin + k], k, sfx))
+                else:
+                    B.append("      *(Pack<%s, %d>*)(p%d + %s) = y%d%s;" %
+                             (CTYPE[spec.out_dtypes[k]], V, nin + k, elem_off_exprs[nin + k], k, sfx))
         return B
 
     def elem_offsets(inner="inner", off_sfx=""):
