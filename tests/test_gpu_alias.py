@@ -41,6 +41,12 @@ def test_replay_outputs_are_fresh_unless_borrowed():
         else:           # every call's result survives the following calls
             for k, o in enumerate(outs):
                 assert float(o[0, 0]) == 1.0 + k, (k, float(o[0, 0]))
+            # ... and without a device copy: the recorded launch is re-pointed at a newly
+            # allocated tensor (the output is a rebindable range of the launch list)
+            ents = list(ex._graphs.values())
+            assert ents and all(e[8] for e in ents), [e[8] for e in ents]
+            arena_ptr = ents[0][2][0].data_ptr()
+            assert all(o.data_ptr() != arena_ptr for o in outs[1:])
 
 
 def test_replayed_call_with_bad_index_raises():
