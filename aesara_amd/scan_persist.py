@@ -41,7 +41,6 @@ SP_MAXNSQ = 12
 SP_MAXOUT = 8
 SPIN_LIMIT = 1 << 21
 LDS_BUDGET = 156 * 1024
-CTLS = []          # control words of live workspaces (error flags; debugging aid)
 
 
 class SpArgs(C.Structure):
