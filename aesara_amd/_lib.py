@@ -8,6 +8,12 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# PyTorch-ROCm bundles its own libamdhip64 and must load it BEFORE libaesara_hip.so pulls in the
+# system copy: the process then has ONE HIP runtime (the dynamic loader resolves our dependency
+# to the already loaded SONAME).  Loaded the other way round there are two runtimes, and a static
+# kernel of this library launched on one of torch's streams fails with "no ROCm-capable device".
+import torch  # noqa: F401,E402
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AESARA_HIP_LIB", os.path.join(_HERE, "libaesara_hip.so"))
 
