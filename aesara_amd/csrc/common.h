@@ -48,6 +48,7 @@ void ahip_gemm_set_skinny_nf(int64_t v);  // gemm.hip tuning knob (ahip_set_para
 void ahip_gemv_set_col_blocks_per_cu(int64_t v);  // gemv.hip tuning knobs (ahip_set_param)
 void ahip_gemv_set_col_strip_lanes(int64_t v);
 void ahip_index_set_argmax_max_slices(int64_t v);
+void ahip_gemm_set_group(int64_t v);
 
 // Every kernel launch of the library goes through these two helpers so that a launch list
 // (ahip_list_*: the CVM analogue) can record the launches instead of executing them.

@@ -61,6 +61,7 @@ int ahip_set_param(const char* name, int64_t value) {
   else if (!strcmp(name, "gemv_col_blocks_per_cu")) ahip_gemv_set_col_blocks_per_cu(value);
   else if (!strcmp(name, "gemv_col_strip_lanes")) ahip_gemv_set_col_strip_lanes(value);
   else if (!strcmp(name, "argmax_max_slices")) ahip_index_set_argmax_max_slices(value);
+  else if (!strcmp(name, "gemm_group")) ahip_gemm_set_group(value);
   else { ahip_set_error("unknown parameter %s", name); return AHIP_EINVAL; }
   return AHIP_OK;
 }

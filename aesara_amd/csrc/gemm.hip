@@ -68,6 +68,7 @@ struct GemmArgs {
   void* C; int64_t c_bs, c_rs, c_cs;
   double alpha, beta;
   int tiles_m, tiles_n;
+  int group;             // tile-rows per group of the workgroup walk (L2 reuse of the B panels)
   int64_t a_lim, b_lim;  // bytes from A / B (per batch item) to the end of their valid extent
 };
 
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(THREADS, 4) void gemm_kernel(GemmArgs g) {
     int base = (xcd < rr) ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q;
     bid = base + bid / AHIP_NUM_XCD;
   }
-  constexpr int GROUP = 8;
+  const int GROUP = g.group;
   int group_sz = GROUP * g.tiles_n;
   int gid = bid / group_sz;
   int first_m = gid * GROUP;
@@ -460,6 +461,7 @@ __global__ void scale_kernel(GemmArgs g) {
 // wavefront runs the MFMA chain over a quarter of K straight from global memory (the operands are
 // L2-resident at these sizes; fragments are loaded in MFMA layout, no LDS staging), and the four
 // partial tiles are summed in wave order through LDS (deterministic).  Arbitrary strides.
+int64_t g_gemm_group = 8;          // tile-rows per walk group (ahip_set_param "gemm_group")
 int64_t g_small_max_tiles = 64;    // scalar-load form: below this many 128x128 tiles (x4 for the
                                    // vector-load form, see gemm_dispatch)
 
@@ -893,6 +895,7 @@ int gemm_dispatch(GemmArgs& g, int64_t batch, hipStream_t s) {
     return AHIP_OK;
   }
   g.tiles_m = (int)((g.M + BM - 1) / BM);
+  g.group = (int)g_gemm_group;
   g.tiles_n = (int)((g.N + BN - 1) / BN);
   AHIP_REQUIRE((int64_t)g.tiles_m * g.tiles_n < (1LL << 31), "too many tiles");
   // below one 128x128 tile per CU the 16-row kernels win when their vector-load form applies
@@ -965,6 +968,7 @@ int gemm_splitk(const GemmArgs& g, int64_t S, void* ws, hipStream_t s) {
   p.alpha = 1.0; p.beta = 0.0;
   set_limits(p, (int64_t)sizeof(T));
   p.tiles_m = (int)((g.M + BM - 1) / BM);
+  p.group = (int)g_gemm_group;
   p.tiles_n = (int)((g.N + BN - 1) / BN);
   int am = operand_mode<T>(p.A, p.a_rs, p.a_cs, p.M, p.K, p.a_bs, S);
   int bm = operand_mode<T>(p.B, p.b_cs, p.b_rs, p.N, p.K, p.b_bs, S);
@@ -996,6 +1000,7 @@ double host_scalar(int dtype, const void* p) {
 }  // namespace
 
 void ahip_gemm_set_small_max_tiles(int64_t v) { g_small_max_tiles = v; }
+void ahip_gemm_set_group(int64_t v) { g_gemm_group = v; }
 void ahip_gemm_set_skinny_nf(int64_t v) { g_skinny_nf = v; }
 
 extern "C" {
