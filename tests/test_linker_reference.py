@@ -294,3 +294,59 @@ def test_rnn_language_model_adam_step_matches_reference(ae):
         np.testing.assert_allclose(a.get_value(), b.get_value(), rtol=1e-8, atol=1e-10)
     from aesara_amd.executor import PlanExecutor
     PlanExecutor(f_hip.maker.linker.plan, dry_run=True)     # every step has a kernel / launch plan
+
+
+def test_function_drives_the_real_executor_host_path(ae):
+    """`aesara.function(..., mode=HIP)` over the REAL `PlanExecutor` in dry-run mode (no device:
+    every C-ABI call is recorded instead of issued): `Function.__call__` -> fast VM -> executor
+    host logic (binding, shapes, fusion, kernel generation + hiprtc compilation, launch
+    recording), for BASELINE configs 2, 3b, 4 and 5; slow (`streamline`) and fast VMs agree."""
+    import aesara.tensor as at
+    from aesara.compile.mode import Mode
+    from aesara_amd.device import DevArray
+    from aesara_amd.executor import PlanExecutor
+    from aesara_amd.linker import HIP_QUERY, HipLinker
+
+    execs = []
+
+    def factory(plan):
+        ex = PlanExecutor(plan, dry_run=True)
+        execs.append(ex)
+        return ex
+
+    x, mu, sg = at.dmatrix("x"), at.dscalar("mu"), at.dscalar("sigma")
+    A, B = at.fmatrix("A"), at.fmatrix("B")
+    X, w, b, yv = at.fmatrix("X"), at.fvector("w"), at.fscalar("b"), at.fvector("y")
+    z = at.dot(X, w) + b
+    logp = -(yv * at.softplus(-z) + (1 - yv) * at.softplus(z)).sum()
+    xs, h0, U = at.fmatrix("xs"), at.fvector("h0"), at.fmatrix("U")
+    hs, _ = ae.scan(lambda x_t, h, U: at.tanh(x_t + at.dot(h, U)), sequences=[xs],
+                    outputs_info=[h0], non_sequences=[U])
+    rng = np.random.default_rng(0)
+    f32 = "float32"
+    cases = [
+        ([x, mu, sg], [at.exp(-(x - mu) ** 2 / (2 * sg ** 2)).sum()],
+         [rng.standard_normal((64, 48)), np.asarray(0.1), np.asarray(1.3)], [()]),
+        ([A, B], [at.dot(A, B)], [rng.standard_normal((32, 16)).astype(f32),
+                                  rng.standard_normal((16, 24)).astype(f32)], [(32, 24)]),
+        ([X, w, b, yv], [logp] + ae.grad(logp, [w, b]),
+         [rng.standard_normal((128, 64)).astype(f32), rng.standard_normal(64).astype(f32),
+          np.asarray(0.1, f32), (rng.random(128) < 0.5).astype(f32)], [(), (64,), ()]),
+        ([xs, h0, U], [hs], [rng.standard_normal((12, 64)).astype(f32), np.zeros(64, f32),
+                             (rng.standard_normal((64, 64)) * 0.1).astype(f32)], [(12, 64)]),
+    ]
+    for fast in (True, False):
+        for ins, outs, vals, shapes in cases:
+            f = ae.function(ins, outs, mode=Mode(HipLinker(executor_factory=factory, fast_call=fast),
+                                                 HIP_QUERY))
+            f.trust_input = True
+            for _ in range(2):
+                res = f(*vals)
+            res = res if isinstance(res, list) else [res]
+            assert hasattr(f.vm, "slow_vm") == fast
+            for r, shp, o in zip(res, shapes, outs):
+                assert isinstance(r, DevArray) and r.shape == shp and r.dtype == o.dtype, (r, shp)
+            trace = execs[-1].trace
+            assert trace, "no C-ABI entry point was reached"
+    # the Scan of the last case went through the persistent one-kernel loop
+    assert list(execs[-1].scan_modes.values()) == ["persistent"], execs[-1].scan_modes
