@@ -99,7 +99,12 @@ int ahip_elemwise_reduce_all(ahip_fn_t k, int nd, const int64_t* shape, int nops
     // one partial per workgroup; a few workgroups of 256 threads per CU keep enough 16-byte
     // loads in flight (HBM-bound) while the in-kernel finalize stays tiny.
     want = (items + block - 1) / block;
-    int64_t cap = (int64_t)ahip_cu_count() * g_reduce_blocks_per_cu;
+    // reduce_blocks_per_cu counts 256-thread blocks: the resident thread count per CU stays
+    // the same for larger workgroups (1024 threads -> 2 per CU -> 512 partials, which ONE
+    // workgroup folds in a single level of the in-kernel finalize)
+    int64_t per_cu = g_reduce_blocks_per_cu * 256 / block;
+    if (per_cu < 1) per_cu = 1;
+    int64_t cap = (int64_t)ahip_cu_count() * per_cu;
     if (cap > AHIP_MAX_PARTIALS) cap = AHIP_MAX_PARTIALS;
     if (want > cap) want = cap;
     if (want < 1) want = 1;
