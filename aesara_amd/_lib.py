@@ -150,6 +150,9 @@ SIGNATURES = {
     "ahip_take_rows": (i32, [i32, vp, i64, i64, i64, vp, i32, i64, i64, vp, i64, vp, vp]),
     "ahip_scatter_rows": (i32, [i32, vp, i64, i64, i64, vp, i32, i64, i64, vp, i64, i32, vp,
                                 vp]),
+    "ahip_scatter_add_ws_bytes": (sz, [i64, i64]),
+    "ahip_scatter_add_rows_ordered": (i32, [i32, vp, i64, i64, i64, vp, i32, i64, i64, vp, i64, vp,
+                                            sz, vp, vp]),
     "ahip_sort_max_row": (i32, [i32]),
     "ahip_sort_rows": (i32, [i32, vp, i64, i64, i64, i64, vp, vp, vp]),
     "ahip_nonzero_write": (i32, [vp, i64, i32, p_i64, p_vp, vp]),

@@ -39,7 +39,14 @@ struct IdxArgs {
   const void* src; void* dst; const void* idx;
   int64_t nrows, src_rs, dst_rs, row_elems, nidx, idx_stride;
   int64_t* bad;
+  const int* hot_off;   // scatter-add only: when set, rows with <= ORDERED_MAX entries are skipped
+  const int* nhot;      // with hot_off: number of such rows left (0: the kernel returns at once)
 };
+
+constexpr int ORDERED_MAX = 64;   // entries per destination row the ordered form sums in index order
+__device__ __forceinline__ bool cold_row(const int* off, int64_t r) {
+  return off != nullptr && off[r + 1] - off[r] <= ORDERED_MAX;
+}
 
 template <typename T, typename I>
 __global__ __launch_bounds__(256) void take_rows_kernel(IdxArgs a) {
@@ -88,11 +95,13 @@ template <typename T, typename I>
 __global__ __launch_bounds__(256) void scatter_add_kernel(IdxArgs a) {
   const T* __restrict__ src = static_cast<const T*>(a.src);
   T* dst = static_cast<T*>(a.dst);
+  if (a.nhot != nullptr && *a.nhot == 0) return;
   const int64_t total = a.nidx * a.row_elems;
   for (int64_t f = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; f < total;
        f += (int64_t)gridDim.x * blockDim.x) {
     int64_t i = f / a.row_elems, e = f - i * a.row_elems, r;
-    if (resolve(static_cast<const I*>(a.idx), i, a.idx_stride, a.nrows, a.bad, &r))
+    if (resolve(static_cast<const I*>(a.idx), i, a.idx_stride, a.nrows, a.bad, &r) &&
+        !cold_row(a.hot_off, r))
       atomic_acc<T>(dst + r * a.dst_rs + e, src[i * a.src_rs + e]);
   }
 }
@@ -157,6 +166,7 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(IdxVecArgs w) {
   const IdxArgs& a = w.a;
   const T* __restrict__ src = static_cast<const T*>(a.src);
   T* dst = static_cast<T*>(a.dst);
+  if (a.nhot != nullptr && *a.nhot == 0) return;
   const int lane = threadIdx.x & 63;
   const int lg = w.g.lg;
   const int G = 1 << lg, sub = lane >> lg, l = lane & (G - 1), rpw = 64 >> lg;
@@ -165,7 +175,8 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(IdxVecArgs w) {
        i0 < a.nidx; i0 += nwaves * rpw) {
     const int64_t i = i0 + sub;
     int64_t r;
-    if (i >= a.nidx || !resolve(static_cast<const I*>(a.idx), i, a.idx_stride, a.nrows, a.bad, &r))
+    if (i >= a.nidx || !resolve(static_cast<const I*>(a.idx), i, a.idx_stride, a.nrows, a.bad, &r) ||
+        cold_row(a.hot_off, r))
       continue;
     const T* s = src + i * a.src_rs;
     T* d = dst + r * a.dst_rs;
@@ -176,6 +187,178 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(IdxVecArgs w) {
       atomic_acc<T>(d + e + 2 * G, v2); atomic_acc<T>(d + e + 3 * G, v3);
     }
     for (; e < a.row_elems; e += G) atomic_acc<T>(d + e, s[e]);
+  }
+}
+
+
+// ---- ordered float scatter-add ------------------------------------------------------------
+// np.add.at (AdvancedIncSubtensor1.perform, tensor/subtensor.py:2128) walks the index list in
+// order, so x[r] receives its contributions in increasing list position; floating-point atomics
+// deliver them in any order (a rounding-level, run-to-run varying difference) and serialise on
+// hot cache lines.  The ordered form buckets the list by destination row
+//   count (hist) -> exclusive offsets (ahip_cumulative) -> place (atomic cursor per row)
+// and then lets ONE wavefront own each destination row: it sorts the row's bucket by list
+// position in registers (rank by 64 shuffles) and adds the source rows in that order — plain
+// loads, one read-modify-write of the destination row, bit-exact with the reference.  Rows that
+// collect more than ORDERED_MAX entries ("hot" rows) are left to the atomic kernel, which skips
+// every other row (hot_off).
+struct OrdArgs {
+  IdxArgs a;
+  int* cnt;      // [nrows + 1], zeroed; hist counts into cnt[r + 1]
+  int* off;      // [nrows + 1] inclusive scan of cnt: off[r] = first bucket slot of row r
+  int* cursor;   // [nrows], zeroed
+  int* bucket;   // [nidx] list positions grouped by destination row
+  int* nhot;     // [1] number of rows left to the atomic form (zeroed with cnt)
+};
+
+__global__ __launch_bounds__(256) void ord_zero_kernel(OrdArgs o) {   // cnt and cursor
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i <= o.a.nrows;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    o.cnt[i] = 0;
+    if (i < o.a.nrows) o.cursor[i] = 0;
+    if (i == 0) *o.nhot = 0;
+  }
+}
+
+// inclusive scan of cnt[0..n) into off by ONE workgroup (n <= ORD_SCAN_MAX): thread t owns a
+// contiguous chunk, the chunk totals are scanned through LDS
+constexpr int ORD_SCAN_MAX = 1 << 17;
+__global__ __launch_bounds__(1024) void ord_scan_kernel(OrdArgs o) {
+  __shared__ int tot[1024];
+  const int n = (int)o.a.nrows + 1, t = threadIdx.x;
+  const int c = (n + 1023) / 1024, lo = t * c, hi = min(lo + c, n);
+  int sum = 0;
+  for (int i = lo; i < hi; ++i) sum += o.cnt[i];
+  tot[t] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const int v = t >= d ? tot[t - d] : 0;
+    __syncthreads();
+    tot[t] += v;
+    __syncthreads();
+  }
+  int run = tot[t] - sum;
+  int hot = 0;
+  for (int i = lo; i < hi; ++i) {
+    hot += o.cnt[i] > ORDERED_MAX;
+    run += o.cnt[i];
+    o.off[i] = run;
+  }
+  if (hot) atomicAdd(o.nhot, hot);
+}
+
+__global__ __launch_bounds__(256) void ord_count_hot_kernel(OrdArgs o) {   // large nrows only
+  int hot = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < o.a.nrows;
+       i += (int64_t)gridDim.x * blockDim.x)
+    hot += o.cnt[i + 1] > ORDERED_MAX;
+  if (hot) atomicAdd(o.nhot, hot);
+}
+
+template <typename I>
+__global__ __launch_bounds__(256) void ord_hist_kernel(OrdArgs o) {
+  const IdxArgs& a = o.a;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.nidx;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r;
+    if (resolve(static_cast<const I*>(a.idx), i, a.idx_stride, a.nrows, a.bad, &r))
+      atomicAdd(o.cnt + r + 1, 1);
+  }
+}
+
+template <typename I>
+__global__ __launch_bounds__(256) void ord_place_kernel(OrdArgs o) {
+  const IdxArgs& a = o.a;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.nidx;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r;
+    if (resolve(static_cast<const I*>(a.idx), i, a.idx_stride, a.nrows, a.bad, &r))   // (reported by hist already)
+      o.bucket[o.off[r] + atomicAdd(o.cursor + r, 1)] = (int)i;
+  }
+}
+
+// wide rows: one wavefront per (destination row, tile of 64 * V elements); the waves of a row sort
+// the same (L1-resident) bucket.  Four source rows are in flight per lane; the adds stay in list
+// order.  Tiles rather than whole rows keep the work items short, so a row with many entries does
+// not leave the chip idle behind it (measured r02, 65536 x 1024 fp32 into 8192 rows: row-per-wave
+// 65 us).
+template <typename T, int V>
+__global__ __launch_bounds__(256) void ord_sum_wide_kernel(OrdArgs o) {
+  const IdxArgs& a = o.a;
+  typedef T TV __attribute__((ext_vector_type(V)));
+  const T* __restrict__ src = static_cast<const T*>(a.src);
+  T* dst = static_cast<T*>(a.dst);
+  const int lane = threadIdx.x & 63;
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  const int64_t span = 64 * V;
+  const int64_t ntiles = (a.row_elems + span - 1) / span, items = a.nrows * ntiles;
+  const int wave0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  for (int64_t it = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave0; it < items; it += nwaves) {
+    const int64_t r = it / ntiles, tile = it - r * ntiles;
+    const int b0 = __builtin_amdgcn_readfirstlane(o.off[r]);
+    const int s = __builtin_amdgcn_readfirstlane(o.off[r + 1]) - b0;
+    if (s == 0 || s > ORDERED_MAX) continue;
+    const int pos = lane < s ? o.bucket[b0 + lane] : 0x7FFFFFFF;
+    int rank = 0;
+    for (int m = 0; m < s; ++m) rank += __builtin_amdgcn_readlane(pos, m) < pos;
+    int sorted = 0;                                   // lane k: the k-th smallest list position
+    for (int k = 0; k < s; ++k) {
+      const int from = __ffsll((unsigned long long)__ballot(rank == k)) - 1;
+      const int v = __shfl(pos, from);
+      sorted = lane == k ? v : sorted;
+    }
+    const int64_t e0 = tile * span + (int64_t)lane * V;
+    const bool on = e0 < a.row_elems;                 // every lane stays in the loops below
+    T* d = dst + r * a.dst_rs + e0;
+    const T* sb = src + e0;
+    TV acc;
+    if (on) acc = *reinterpret_cast<const TV*>(d);
+    int k = 0;
+    for (; k + 3 < s; k += 4) {
+      const int64_t p0 = __builtin_amdgcn_readlane(sorted, k), p1 = __builtin_amdgcn_readlane(sorted, k + 1);
+      const int64_t p2 = __builtin_amdgcn_readlane(sorted, k + 2), p3 = __builtin_amdgcn_readlane(sorted, k + 3);
+      if (on) {
+        const TV v0 = *reinterpret_cast<const TV*>(sb + p0 * a.src_rs);
+        const TV v1 = *reinterpret_cast<const TV*>(sb + p1 * a.src_rs);
+        const TV v2 = *reinterpret_cast<const TV*>(sb + p2 * a.src_rs);
+        const TV v3 = *reinterpret_cast<const TV*>(sb + p3 * a.src_rs);
+        acc += v0; acc += v1; acc += v2; acc += v3;
+      }
+    }
+    for (; k < s; ++k) {
+      const int64_t p = __builtin_amdgcn_readlane(sorted, k);
+      if (on) acc += *reinterpret_cast<const TV*>(sb + p * a.src_rs);
+    }
+    if (on) *reinterpret_cast<TV*>(d) = acc;
+  }
+}
+
+// narrow rows: one thread per destination element; the row's (short) bucket is walked by
+// repeated selection of the next larger list position (every lane of a row reads the same
+// bucket words: broadcast loads).
+template <typename T>
+__global__ __launch_bounds__(256) void ord_sum_narrow_kernel(OrdArgs o) {
+  const IdxArgs& a = o.a;
+  const T* __restrict__ src = static_cast<const T*>(a.src);
+  T* dst = static_cast<T*>(a.dst);
+  const int64_t total = a.nrows * a.row_elems;
+  for (int64_t f = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; f < total;
+       f += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = f / a.row_elems, e = f - r * a.row_elems;
+    const int b0 = o.off[r], s = o.off[r + 1] - b0;
+    if (s == 0 || s > ORDERED_MAX) continue;
+    T acc = dst[r * a.dst_rs + e];
+    int last = -1;
+    for (int k = 0; k < s; ++k) {
+      int next = 0x7FFFFFFF;
+      for (int m = 0; m < s; ++m) {
+        const int p = o.bucket[b0 + m];
+        next = (p > last && p < next) ? p : next;
+      }
+      acc += src[(int64_t)next * a.src_rs + e];
+      last = next;
+    }
+    dst[r * a.dst_rs + e] = acc;
   }
 }
 
@@ -269,6 +452,70 @@ int dispatch(int which, int dtype, int idx_dtype, IdxArgs& a, hipStream_t s) {
     case AHIP_F64: return by_index<double>(which, idx_dtype, a, s);
     default: ahip_set_error("scatter-add unsupported for dtype %d", dtype); return AHIP_ENOSUP;
   }
+}
+
+
+// ---- ordered scatter-add: host side ----
+struct OrdLayout { size_t cnt, off, cursor, bucket, nhot, scan_ws, total; };
+inline size_t up16(size_t v) { return (v + 15) & ~size_t(15); }
+OrdLayout ord_layout(int64_t nrows, int64_t nidx) {
+  OrdLayout L;
+  L.cnt = 0;
+  L.cursor = up16((size_t)(nrows + 1) * 4);                 // cnt and cursor are zeroed together
+  L.off = L.cursor + up16((size_t)nrows * 4);
+  L.bucket = L.off + up16((size_t)(nrows + 1) * 4);
+  L.nhot = L.bucket + up16((size_t)nidx * 4);
+  L.scan_ws = L.nhot + 16;
+  L.total = L.scan_ws + up16(ahip_cumulative_ws_bytes(AHIP_I32, 1, nrows + 1, 1));
+  return L;
+}
+
+template <template <typename> class F>
+int by_index_only(int idx_dtype, OrdArgs& o, hipStream_t s) {
+  switch (idx_dtype) {
+    case AHIP_I8: return F<int8_t>::go(o, s);
+    case AHIP_I16: return F<int16_t>::go(o, s);
+    case AHIP_I32: return F<int32_t>::go(o, s);
+    case AHIP_I64: return F<int64_t>::go(o, s);
+    case AHIP_U8: return F<uint8_t>::go(o, s);
+    case AHIP_U16: return F<uint16_t>::go(o, s);
+    case AHIP_U32: return F<uint32_t>::go(o, s);
+    case AHIP_U64: return F<uint64_t>::go(o, s);
+    default: ahip_set_error("index dtype %d is not an integer type", idx_dtype); return AHIP_EINVAL;
+  }
+}
+template <typename I> struct HistGo {
+  static int go(OrdArgs& o, hipStream_t s) {
+    AHIP_LAUNCH((ord_hist_kernel<I>), dim3(grid_for(o.a.nidx)), dim3(256), 0, s, o);
+    return AHIP_OK;
+  }
+};
+template <typename I> struct PlaceGo {
+  static int go(OrdArgs& o, hipStream_t s) {
+    AHIP_LAUNCH((ord_place_kernel<I>), dim3(grid_for(o.a.nidx)), dim3(256), 0, s, o);
+    return AHIP_OK;
+  }
+};
+
+template <typename T>
+int run_ord_sum(OrdArgs& o, hipStream_t s) {
+  const IdxArgs& a = o.a;
+  constexpr int V = 16 / sizeof(T);
+  if (a.row_elems < 32) {
+    AHIP_LAUNCH((ord_sum_narrow_kernel<T>), dim3(grid_for(a.nrows * a.row_elems)), dim3(256), 0, s, o);
+    return AHIP_OK;
+  }
+  VecGeom g;
+  const bool vec = vec_geom<T>(a, &g);
+  const int64_t span = 64 * (vec ? V : 1);
+  int64_t want = (a.nrows * ((a.row_elems + span - 1) / span) + 3) / 4;
+  const int64_t cap = (int64_t)ahip_cu_count() * 32;
+  if (want > cap) want = cap;
+  if (vec)
+    AHIP_LAUNCH((ord_sum_wide_kernel<T, V>), dim3((unsigned)want), dim3(256), 0, s, o);
+  else
+    AHIP_LAUNCH((ord_sum_wide_kernel<T, 1>), dim3((unsigned)want), dim3(256), 0, s, o);
+  return AHIP_OK;
 }
 
 // ---- row argmax (np.argmax semantics: first maximum; a NaN is the maximum; first NaN wins) ----
@@ -550,6 +797,56 @@ int ahip_scatter_rows(int dtype, void* dst, int64_t nrows, int64_t dst_rs, int64
   AHIP_REQUIRE(dst != nullptr || nrows == 0, "null dst");
   IdxArgs a{src, dst, idx, nrows, src_rs, dst_rs, row_elems, nidx, idx_stride, bad_index};
   return dispatch(accumulate ? 1 : 2, dtype, idx_dtype, a, as_stream(stream));
+}
+
+size_t ahip_scatter_add_ws_bytes(int64_t nrows, int64_t nidx) {
+  if (nrows <= 0 || nidx <= 0 || nrows >= 0x7FFFFFF0LL || nidx >= 0x7FFFFFF0LL) return 0;
+  return ord_layout(nrows, nidx).total;
+}
+
+int ahip_scatter_add_rows_ordered(int dtype, void* dst, int64_t nrows, int64_t dst_rs,
+                                  int64_t row_elems, const void* idx, int idx_dtype, int64_t nidx,
+                                  int64_t idx_stride, const void* src, int64_t src_rs, void* ws,
+                                  size_t ws_bytes, int64_t* bad_index, void* stream) {
+  AHIP_REQUIRE(nrows >= 0 && row_elems >= 0 && nidx >= 0, "negative extent");
+  if (nidx == 0 || row_elems == 0) return AHIP_OK;
+  AHIP_REQUIRE(idx && src && bad_index, "null argument");
+  AHIP_REQUIRE(dst != nullptr || nrows == 0, "null dst");
+  AHIP_REQUIRE(dtype == AHIP_F32 || dtype == AHIP_F64, "ordered scatter-add is the floating-point form");
+  if (nrows == 0) {   // every index is out of range: let the plain form report it
+    IdxArgs a{src, dst, idx, nrows, src_rs, dst_rs, row_elems, nidx, idx_stride, bad_index};
+    return dispatch(1, dtype, idx_dtype, a, as_stream(stream));
+  }
+  const size_t need = ahip_scatter_add_ws_bytes(nrows, nidx);
+  AHIP_REQUIRE(need != 0, "ordered scatter-add: more than 2^31 rows or indices");
+  AHIP_REQUIRE(ws != nullptr && ws_bytes >= need && reinterpret_cast<uintptr_t>(ws) % 16 == 0,
+               "ordered scatter-add: workspace too small or misaligned");
+  hipStream_t s = as_stream(stream);
+  const OrdLayout L = ord_layout(nrows, nidx);
+  char* w = static_cast<char*>(ws);
+  OrdArgs o{{src, dst, idx, nrows, src_rs, dst_rs, row_elems, nidx, idx_stride, bad_index},
+            reinterpret_cast<int*>(w + L.cnt), reinterpret_cast<int*>(w + L.off),
+            reinterpret_cast<int*>(w + L.cursor), reinterpret_cast<int*>(w + L.bucket),
+            reinterpret_cast<int*>(w + L.nhot)};
+  AHIP_LAUNCH(ord_zero_kernel, dim3(grid_for(nrows + 1)), dim3(256), 0, s, o);
+  int rc = by_index_only<HistGo>(idx_dtype, o, s);
+  if (rc != AHIP_OK) return rc;
+  if (nrows + 1 <= ORD_SCAN_MAX) {
+    AHIP_LAUNCH(ord_scan_kernel, dim3(1), dim3(1024), 0, s, o);
+  } else {
+    rc = ahip_cumulative(AHIP_I32, 0, o.cnt, 1, nrows + 1, 1, 0, 1, 1, o.off, w + L.scan_ws,
+                         L.total - L.scan_ws, stream);
+    if (rc != AHIP_OK) return rc;
+    AHIP_LAUNCH(ord_count_hot_kernel, dim3(grid_for(nrows)), dim3(256), 0, s, o);
+  }
+  rc = by_index_only<PlaceGo>(idx_dtype, o, s);
+  if (rc != AHIP_OK) return rc;
+  rc = dtype == AHIP_F32 ? run_ord_sum<float>(o, s) : run_ord_sum<double>(o, s);
+  if (rc != AHIP_OK) return rc;
+  IdxArgs hot = o.a;            // rows with more than ORDERED_MAX entries: atomics
+  hot.hot_off = o.off;
+  hot.nhot = o.nhot;
+  return dispatch(1, dtype, idx_dtype, hot, s);
 }
 
 size_t ahip_argmax_ws_bytes(int dtype, int64_t nrows, int64_t k, int64_t x_rs, int64_t x_cs) {

@@ -320,6 +320,18 @@ int ahip_scatter_rows(int dtype, void* dst, int64_t nrows, int64_t dst_rs, int64
                       const void* idx, int idx_dtype, int64_t nidx, int64_t idx_stride,
                       const void* src, int64_t src_rs, int accumulate, int64_t* bad_index,
                       void* stream);
+/* Ordered floating-point scatter-add (float32 / float64): the same result as walking the index
+ * list in order (np.add.at, AdvancedIncSubtensor1.perform tensor/subtensor.py:2128), bit for bit,
+ * for every destination row that receives at most 64 contributions; rows receiving more are
+ * accumulated with atomics (any order).  The list is bucketed by destination row (count, scan,
+ * place) and one wavefront per row adds its sources in list order.  `ws` is a 16-byte aligned
+ * workspace of ahip_scatter_add_ws_bytes(nrows, nidx) bytes (0 = extents beyond 2^31: use
+ * ahip_scatter_rows).  Index and error handling as above.                                        */
+size_t ahip_scatter_add_ws_bytes(int64_t nrows, int64_t nidx);
+int ahip_scatter_add_rows_ordered(int dtype, void* dst, int64_t nrows, int64_t dst_rs,
+                                  int64_t row_elems, const void* idx, int idx_dtype, int64_t nidx,
+                                  int64_t idx_stride, const void* src, int64_t src_rs, void* ws,
+                                  size_t ws_bytes, int64_t* bad_index, void* stream);
 /* ---- K13: sort / argsort of rows ----------------------------------------------------------------
  * replaces: tensor/sort.py:29 SortOp (perform :48 np.sort) / :150 ArgSortOp (perform :184
  * np.argsort) along the last axis.  x is viewed as [rows, n] with element strides x_rs / x_cs;

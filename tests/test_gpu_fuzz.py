@@ -380,3 +380,97 @@ def test_row_chains_and_gemm_epilogues_on_operand_views():
         for u, w_ in zip(got, want):
             u = u.cpu().numpy() if hasattr(u, "cpu") else np.asarray(u)
             np.testing.assert_allclose(u, w_, rtol=5e-5, atol=2e-3, err_msg=str((n, d)))
+
+
+def _scatter_plan(dtype, idx_dtype, nd):
+    from aesara_amd.plan import Node, Plan, Var
+    vs = {0: Var(0, dtype, [None] * nd), 1: Var(1, dtype, [None] * nd), 2: Var(2, idx_dtype, [None]),
+          3: Var(3, dtype, [None] * nd)}
+    return Plan("fuzz_addat", vs, [0, 1, 2], [3],
+                [Node("AdvancedIncSubtensor1", [0, 1, 2], [3], {"set_instead_of_inc": False, "inplace": False})])
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_float_scatter_add_is_bit_exact_in_list_order(dtype):
+    """AdvancedIncSubtensor1 (inc) on floats: np.add.at adds the contributions of a row in the order
+    of the index list (tensor/subtensor.py:2128); the ordered kernel must reproduce that sum bit for
+    bit whenever no row receives more than 64 entries — wide vector rows, ragged rows, narrow rows
+    and vectors, negative / strided / small-dtype indices, eagerly and replayed."""
+    import torch
+    from aesara_amd.executor import PlanExecutor
+    rng = np.random.default_rng(77)
+    cases = [(8192, 1024, 65536), (1000, 1000, 9000), (513, 257, 4000), (300, 36, 2500), (64, 33, 700),
+             (4096, 5, 20000), (50000, 1, 200000), (150000, 2, 100000), (97, 64, 97 * 40), (2, 4096, 100), (1, 128, 64)]
+    for rows, width, n in cases:
+        shape = (rows, width) if width > 1 else (rows,)
+        x = (rng.standard_normal(shape) * 100).astype(dtype)
+        y = (rng.standard_normal((n,) + shape[1:]) * 100).astype(dtype)
+        if rows * 64 < n:
+            n = rows * 64
+            y = y[:n]
+        # at most 64 hits per row: a random multiset drawn without exceeding the cap
+        pool = np.repeat(np.arange(rows), 64)
+        idx = rng.permutation(pool)[:n].astype("int64")
+        idx = np.where(rng.random(n) < 0.3, idx - rows, idx)          # some negative spellings
+        want = x.copy()
+        np.add.at(want, idx, y)
+        for idt in ("int64", "int32"):
+            for use_graph in (False, True):
+                ex = PlanExecutor(_scatter_plan(dtype, idt, len(shape)), use_graph=use_graph)
+                for _ in range(2 if use_graph else 1):
+                    (got,) = ex(_to_dev(x), _to_dev(y), _to_dev(idx.astype(idt)))
+                assert np.array_equal(got.cpu().numpy(), want), (rows, width, n, idt, use_graph)
+        # a strided index vector (every other entry of a longer one)
+        long_idx = np.zeros(2 * n, "int64")
+        long_idx[::2] = idx
+        (got,) = PlanExecutor(_scatter_plan(dtype, "int64", len(shape)))(
+            _to_dev(x), _to_dev(y), torch.from_numpy(long_idx).cuda()[::2])
+        assert np.array_equal(got.cpu().numpy(), want), (rows, width, "strided")
+
+
+def test_float_scatter_add_hot_rows_and_errors():
+    """Rows that collect more than 64 entries take the atomic form (close, not bit-exact); the rest
+    of the same call stays exact; an out-of-range index raises IndexError like NumPy."""
+    import torch
+    from aesara_amd.executor import PlanExecutor
+    rng = np.random.default_rng(78)
+    rows, width, n = 512, 256, 40000
+    x = rng.standard_normal((rows, width)).astype("float32")
+    y = rng.standard_normal((n, width)).astype("float32")
+    idx = rng.integers(8, rows, n).astype("int64")
+    idx[rng.random(n) < 0.3] = 3                                       # one very hot row
+    idx[:5000][rng.random(5000) < 0.5] = 5
+    want = x.copy()
+    np.add.at(want, idx, y)
+    ex = PlanExecutor(_scatter_plan("float32", "int64", 2))
+    (got,) = ex(_to_dev(x), _to_dev(y), _to_dev(idx))
+    got = got.cpu().numpy()
+    counts = np.bincount(idx, minlength=rows)
+    cold = counts <= 64
+    assert cold.sum() > 100 and (~cold).sum() >= 2
+    assert np.array_equal(got[cold], want[cold])
+    assert np.allclose(got[~cold], want[~cold], rtol=1e-4, atol=1e-2)
+    # all entries on one row, and a single-row destination
+    one = np.zeros(n, "int64")
+    w1 = x[:1].copy()
+    np.add.at(w1, one, y)
+    (g1,) = ex(_to_dev(x[:1]), _to_dev(y), _to_dev(one))
+    assert np.allclose(g1.cpu().numpy(), w1, rtol=1e-4, atol=5e-2)
+    # more destination rows than the one-workgroup offset scan takes (ahip_cumulative + hot count)
+    big = 140000
+    xb = rng.standard_normal((big, 4)).astype("float32")
+    ib = rng.integers(100, big, 30000).astype("int64")
+    ib[:200] = 7
+    yb = rng.standard_normal((30000, 4)).astype("float32")
+    wb = xb.copy()
+    np.add.at(wb, ib, yb)
+    (gb,) = ex(_to_dev(xb), _to_dev(yb), _to_dev(ib))
+    gb = gb.cpu().numpy()
+    assert np.array_equal(np.delete(gb, 7, 0), np.delete(wb, 7, 0))
+    assert np.allclose(gb[7], wb[7], rtol=1e-4, atol=1e-3)
+    bad = idx.copy()
+    bad[1234] = rows
+    with pytest.raises(IndexError):
+        (g,) = ex(_to_dev(x), _to_dev(y), _to_dev(bad))
+        torch.cuda.synchronize()
+        ex.check()
