@@ -170,3 +170,35 @@ def test_replay_rebinds_to_fresh_device_tensors_without_staging():
     assert float(r2(c3, b2)[0][0, 0]) == 7.0          # rebound
     assert float(r2(c3, c3)[0][0, 0]) == 10.0         # aliased inputs: safe path
     assert float(r2(a, c3)[0][0, 0]) == 6.0
+
+
+@pytest.mark.parametrize("borrow", [False, True])
+def test_replay_output_fed_back_as_input(borrow):
+    """An iteration h = f(h, W) hands each result straight back as the next call's input.  With
+    borrowed outputs that input IS the function-owned output buffer of the recorded launches (and
+    with fresh outputs it is a buffer the list once wrote): the replay must notice the overlap and
+    still compute tanh(h @ W) of the OLD h — checked against the eager executor, 12 rounds."""
+    import torch
+    from aesara_amd.executor import PlanExecutor
+    from aesara_amd.plan import Node, Plan, Var
+    tanh = {"n_in": 1, "nodes": [{"op": "tanh", "in": [["i", 0]], "dtype": "float32"}], "out": [["t", 0]]}
+    vs = {0: Var(0, "float32", [None, None]), 1: Var(1, "float32", [None, None]),
+          2: Var(2, "float32", [None, None]), 3: Var(3, "float32", [None, None])}
+    plan = Plan("feedback", vs, [0, 1], [3], [Node("Dot22", [0, 1], [2], {}),
+                                              Node("Elemwise", [2], [3], {"scalar": tanh})])
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    W = torch.randn(96, 96, device="cuda", generator=g) * 0.3
+    h0 = torch.randn(64, 96, device="cuda", generator=g)
+    eager = PlanExecutor(plan)
+    replay = PlanExecutor(plan, use_graph=True, borrow=borrow)
+    he, hr = h0.clone(), h0.clone()
+    for k in range(12):
+        (he,) = eager(he, W)
+        (hr,) = replay(hr, W)
+        assert torch.allclose(hr, he, rtol=1e-5, atol=1e-6), k
+    # the transposed result fed back (a view of the previous output with other strides)
+    Wt = W.t().contiguous()
+    (a,) = eager(he.t().contiguous().t(), Wt)
+    (b,) = replay(hr.t().contiguous().t(), Wt)
+    assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
