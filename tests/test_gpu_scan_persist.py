@@ -205,3 +205,37 @@ def test_gru_float64_all_steps(T, H):
         assert list(ex.scan_modes.values()) == ["persistent"], ex.scan_modes
         err = ((hs - ref).abs().max() / ref.abs().max()).item()
         assert err <= 1e-12, err
+
+
+@pytest.mark.parametrize("borrow", [False, True])
+@pytest.mark.parametrize("batch", [0, 48])
+def test_stateful_chunks_feed_the_last_state_back(borrow, batch):
+    """A long sequence run as chunks, each call starting from the previous call's last state (a
+    stateful RNN): the replayed persistent kernel sees a new ``x`` chunk and an ``h0`` that is the
+    function's own previous result (borrowed: a range of its arena) on every call.  The chunked
+    states must equal the one-shot run: exactly for the vector state (same kernel, same
+    arithmetic), to fp32 round-off for the matrix state (the hoisted ``x @ W`` GEMMs pick their
+    tiling by the row count, so the summation order differs between 768 and 4608 rows)."""
+    import torch
+    from aesara_amd.executor import PlanExecutor
+    T, H, CH = 96, 512, 16
+    g = torch.Generator(device="cuda")
+    g.manual_seed(21)
+    shp = (T, batch, H) if batch else (T, H)
+    x = torch.randn(*shp, dtype=torch.float32, device="cuda", generator=g) * 0.1
+    h0 = torch.randn(*shp[1:], dtype=torch.float32, device="cuda", generator=g) * 0.5
+    Ws = [torch.randn(H, H, dtype=torch.float32, device="cuda", generator=g) / np.sqrt(H)
+          for _ in range(6)]
+    name = "cfg4_gru_b8_f32" if batch else "cfg4_gru_b1_f32"
+    whole, _ = PlanExecutor(case_plan(_case(name)))(x, h0, *Ws)
+    ex = PlanExecutor(case_plan(_case(name)), use_graph=True, borrow=borrow)
+    h, got = h0, []
+    for c in range(T // CH):
+        hs, h = ex(x[c * CH:(c + 1) * CH], h, *Ws)
+        got.append(hs.clone())
+    assert list(ex.scan_modes.values()) == ["persistent"], ex.scan_modes
+    ex.check()
+    if batch:
+        assert torch.allclose(torch.cat(got), whole, rtol=1e-4, atol=2e-6)
+    else:
+        assert torch.equal(torch.cat(got), whole)
