@@ -474,3 +474,117 @@ def test_float_scatter_add_hot_rows_and_errors():
         (g,) = ex(_to_dev(x), _to_dev(y), _to_dev(bad))
         torch.cuda.synchronize()
         ex.check()
+
+
+def _rand_dag(rng, R, C, n_ops):
+    """A random multi-node plan over float64 matrices holding small integers (every op below is
+    exact in fp64, so results compare bit for bit): Elemwise, transposes, row-slice views,
+    IncSubtensor set / inc, row gathers and scatter-set / -add, axis sums, Dot22.  Views, values
+    read after an update of their base, duplicated and passed-through outputs are all likely."""
+    from aesara_amd.plan import Node, Plan, Var
+    vs, nodes, shapes = {}, [], {}
+
+    def new(shape, dtype="float64", const=None):
+        vid = len(vs)
+        vs[vid] = Var(vid, dtype, [None] * len(shape) if const is None else list(shape), None, const)
+        shapes[vid] = tuple(shape)
+        return vid
+
+    def ew(op, ins):
+        nd = {"n_in": len(ins), "nodes": [{"op": op, "in": [["i", k] for k in range(len(ins))],
+                                            "dtype": "float64"}], "out": [["t", 0]]}
+        o = new(shapes[ins[0]])
+        nodes.append(Node("Elemwise", list(ins), [o], {"scalar": nd}))
+        return o
+
+    def cint(v):
+        return new((), "int64", {"shape": [], "data": [int(v)]})
+
+    ins = [new((R, C)), new((R, C)), new((C, R))]
+    idx_in = new((5,), "int64")
+    inputs = ins + [idx_in]
+    for _ in range(n_ops):
+        mats = [v for v, s in shapes.items() if len(s) == 2 and vs[v].dtype == "float64" and min(s) > 0]
+        a = int(rng.choice(mats))
+        kind = rng.choice(["add", "neg", "T", "rows", "inc", "take", "scat", "sum", "dot", "sub"])
+        same = [v for v in mats if shapes[v] == shapes[a]]
+        if kind in ("add", "sub"):
+            ew(kind, [a, int(rng.choice(same))])
+        elif kind == "neg":
+            ew("neg", [a])
+        elif kind == "T":
+            o = new(shapes[a][::-1])
+            nodes.append(Node("DimShuffle", [a], [o], {"new_order": [1, 0]}))
+        elif kind == "rows":
+            n = shapes[a][0]
+            lo, hi = sorted(int(v) for v in rng.integers(0, n + 1, 2))
+            st = int(rng.choice([1, 1, 2, -1]))
+            sl = slice(lo, hi, st) if st > 0 else slice(hi - 1 if hi else None, lo - 1 if lo else None, st)
+            m = len(range(*sl.indices(n)))
+            o = new((m, shapes[a][1]))
+            nodes.append(Node("Subtensor", [a], [o], {"idx_list": [{"slice": [sl.start, sl.stop, sl.step]}]}))
+        elif kind == "inc":
+            n = shapes[a][0]
+            lo, hi = sorted(int(v) for v in rng.integers(0, n + 1, 2))
+            enc = {"idx_list": [{"slice": [lo, hi, None]}]}
+            b = int(rng.choice(same))
+            y = new((hi - lo, shapes[a][1]))
+            nodes.append(Node("Subtensor", [b], [y], dict(enc)))
+            o = new(shapes[a])
+            nodes.append(Node("IncSubtensor", [a, y], [o], dict(enc, set_instead_of_inc=bool(rng.random() < 0.5),
+                                                               inplace=False)))
+        elif kind == "take" and shapes[a][0] == R:      # the index vector is drawn for R rows
+            o = new((5, shapes[a][1]))
+            nodes.append(Node("AdvancedSubtensor1", [a, idx_in], [o], {}))
+        elif kind == "scat" and shapes[a][0] == R:
+            src = [v for v in mats if shapes[v] == (5, shapes[a][1])]
+            if not src:
+                continue
+            o = new(shapes[a])
+            nodes.append(Node("AdvancedIncSubtensor1", [a, int(rng.choice(src)), idx_in], [o],
+                              {"set_instead_of_inc": bool(rng.random() < 0.4), "inplace": False}))
+        elif kind == "sum":
+            ax = int(rng.integers(0, 2))
+            o = new((shapes[a][1 - ax],))
+            nodes.append(Node("CAReduce", [a], [o], {"scalar_op": "add", "axis": [ax], "acc_dtype": "float64"}))
+        elif kind == "dot":
+            bs = [v for v in mats if shapes[v][0] == shapes[a][1]]
+            if not bs or len([n_ for n_ in nodes if n_.op == "Dot22"]) >= 3:
+                continue
+            b = int(rng.choice(bs))
+            o = new((shapes[a][0], shapes[b][1]))
+            nodes.append(Node("Dot22", [a, b], [o], {}))
+    cand = [v for v in vs if vs[v].const is None and vs[v].dtype == "float64"]
+    outs = [int(v) for v in rng.choice(cand, size=int(rng.integers(1, 4)))]
+    return Plan("fuzz_dag", vs, inputs, outs, nodes), shapes, idx_in
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("AESARA_FUZZ_SEEDS", "8"))))
+def test_random_multi_node_plans_eager_and_replay(seed):
+    """Buffer planning under fire: random DAGs (``_rand_dag``) evaluated eagerly, replayed with
+    fresh outputs and replayed with borrowed outputs, three calls each with NEW input tensors —
+    every output of every call bit-equal to the oracle.  Catches an in-place update of a value that
+    is still read, an arena range reused while a view of it is alive, a stale rebinding."""
+    import interp
+    import torch
+    from aesara_amd.executor import PlanExecutor
+    rng = np.random.default_rng(4000 + seed)
+    for trial in range(25):
+        R, C = int(rng.integers(1, 9)), int(rng.integers(1, 9))
+        plan, shapes, idx_in = _rand_dag(rng, R, C, int(rng.integers(3, 16)))
+        exs = [PlanExecutor(plan), PlanExecutor(plan, use_graph=True),
+               PlanExecutor(plan, use_graph=True, borrow=True)]
+        for call in range(3):
+            args = []
+            for vid in plan.inputs:
+                if vid == idx_in:
+                    args.append(rng.integers(-R, R, 5).astype("int64"))
+                else:
+                    args.append(rng.integers(-3, 4, shapes[vid]).astype("float64"))
+            want = interp.run_plan(plan, args)
+            for k, ex in enumerate(exs):
+                got = ex(*[torch.from_numpy(a).cuda() for a in args])
+                for g, w in zip(got, want):
+                    g = g.cpu().numpy()
+                    assert g.shape == w.shape and np.array_equal(g, w), \
+                        (seed, trial, call, ("eager", "replay", "borrow")[k], plan.pretty())
