@@ -202,3 +202,46 @@ def test_shard_rows_partition():
             assert blocks[0][0] == 0 and blocks[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
             assert max(h - l for l, h in blocks) - min(h - l for l, h in blocks) <= 1
+
+
+def test_random_plans_shard_soundly():
+    """Soundness of the sharding analysis on random multi-node plans (the generator of the GPU
+    DAG fuzz: Elemwise, transposes, row slices, IncSubtensor, gathers / scatters, axis sums, row
+    chains, Dot22 on integer-valued float64 — exact arithmetic): with the (R, C) inputs split by
+    rows and the (C, R) input by columns, ``shard_plan`` either refuses (ShardingError) or every
+    logical shard's result equals the unsharded value bit for bit (its own block where the output
+    stays split)."""
+    import interp
+    from aesara_amd.dist import ShardingError, run_local_shards, shard_rows
+    from test_gpu_fuzz import _rand_dag
+    accepted = refused = 0
+    for seed in range(6):
+        rng = np.random.default_rng(9000 + seed)
+        for trial in range(40):
+            R, C = (int(v) for v in rng.choice([4, 6, 7, 8, 9], 2, replace=False))
+            plan, shapes, idx_in = _rand_dag(rng, R, C, int(rng.integers(2, 10)))
+            args = [rng.integers(-R, R, 5).astype("int64") if v == idx_in
+                    else rng.integers(-3, 4, shapes[v]).astype("float64") for v in plan.inputs]
+            want = interp.run_plan(plan, args)
+            k = int(rng.integers(2, 4))
+            split = {0: 0, 1: 0, 2: 1}
+            shards = []
+            for r in range(k):
+                lo, hi = shard_rows(R, k, r)
+                shards.append([args[0][lo:hi], args[1][lo:hi], args[2][:, lo:hi], args[3]])
+            try:
+                outs, spec = run_local_shards(plan, split, shards, executor_factory=oracle_factory)
+            except ShardingError:
+                refused += 1
+                continue
+            accepted += 1
+            for r in range(k):
+                lo, hi = shard_rows(R, k, r)
+                for o, w, st in zip(outs[r], want, spec.out_state):
+                    o = np.asarray(o)
+                    if st[0] == "split":
+                        sl = [slice(None)] * w.ndim
+                        sl[st[1]] = slice(lo, hi)
+                        w = w[tuple(sl)]
+                    assert o.shape == w.shape and np.array_equal(o, w), (seed, trial, r, st, plan.pretty())
+    assert accepted >= 40 and refused >= 20, (accepted, refused)
