@@ -239,3 +239,51 @@ def test_stateful_chunks_feed_the_last_state_back(borrow, batch):
         assert torch.allclose(torch.cat(got), whole, rtol=1e-4, atol=2e-6)
     else:
         assert torch.equal(torch.cat(got), whole)
+
+
+@pytest.mark.parametrize("name,dims", [("sp_lstm_vec_f32", {17: "T", 20: "D", 48: "H"}),
+                                        ("sp_rnn_proj_f32", {19: "T", 12: "D", 32: "H"}),
+                                        ("sp_gru_last_f32", {21: "T", 52: "H"}),
+                                        ("gru_b1_f64", None)])
+def test_persistent_scans_on_random_extents(name, dims):
+    """The golden recurrences (LSTM with two states, RNN with a per-step projection output, GRU
+    that returns only the last state, float64 GRU) at random extents — ragged state sizes (12,
+    68, 100, 260, 516 ...), odd ones that fall outside the class (31, 7), single steps, inputs
+    wider than the state: the one-kernel loop against the launch-list path (same arithmetic up to
+    summation order)."""
+    import torch
+    from aesara_amd import executor as E
+    c = _case(name)
+    base = case_inputs(c)
+    if dims is None:
+        dims = {base[0].shape[0]: "T", base[1].shape[0]: "H"}
+    rng = np.random.default_rng(31)
+    f64 = name.endswith("f64")
+    for trial in range(10):
+        val = {"T": int(rng.choice([1, 2, 3, 9, 30])), "D": int(rng.choice([4, 7, 36, 72])),
+               "H": int(rng.choice([4, 12, 31, 68, 100, 260, 384, 516]))}
+        ins = []
+        for a in base:
+            shp = tuple(val[dims[n]] for n in a.shape)
+            scale = 0.5 if len(shp) == 1 else 1.0 / np.sqrt(shp[0])
+            ins.append((rng.standard_normal(shp) * scale).astype(a.dtype))
+        dev = [torch.from_numpy(a).cuda() for a in ins]
+        ex = E.PlanExecutor(case_plan(c), use_graph=True)
+        for _ in range(2):
+            got = _np(ex(*dev))
+        # weight rows are read as 16-byte vectors: contraction lengths that are not a multiple of
+        # 4 (float32) / 2 (float64) elements stay on the launch list (and must still be right)
+        vec_ok = all(val[k] % (2 if f64 else 4) == 0 for k in set(dims.values()) - {"T"})
+        if vec_ok and val["T"] >= 2:
+            assert list(ex.scan_modes.values()) == ["persistent"], (val, ex.scan_modes)
+        ex.check()
+        E.TUNE["scan_persist"] = 0
+        try:
+            ref = _np(E.PlanExecutor(case_plan(c))(*dev))
+        finally:
+            E.TUNE["scan_persist"] = 1
+        tol = 1e-11 if f64 else 3e-5
+        for g, r in zip(got, ref):
+            assert g.shape == r.shape, (val, g.shape, r.shape)
+            np.testing.assert_allclose(g, r, rtol=tol, atol=tol * max(1.0, float(np.abs(r).max(initial=0))),
+                                       err_msg=str(val))
