@@ -55,9 +55,17 @@ template <> struct Traits<double> {
 };
 
 constexpr int BM = 128, BN = 128;
+// tile shapes: H = 0 the 128x128 / 8-wave tile described above; H = 1 its half-size sibling
+// (64x64, 4 wavefronts as 2x2, 32x32 = 2x2 fragments per wave, waves 0-1 stage A, 2-3 stage B)
+// for problems that give the big tile fewer workgroups than the chip has CUs
+template <int H> struct Cfg {
+  static constexpr int BM = H ? 64 : 128, BN = H ? 64 : 128;
+  static constexpr int THREADS = H ? 256 : 512;
+  static constexpr int STG = THREADS / 2;                    // threads staging one operand
+  static constexpr int WN = H ? 2 : 4;                       // waves along n (2 along m)
+  static constexpr int FM = BM / 2 / 16, FN = BN / WN / 16;  // 16x16 fragments per wave
+};
 constexpr int ROW_BYTES = 144;  // 128 B of k + 16 B pad (+ unit swizzle, Stage::swz) -> conflict-free fragments
-constexpr int THREADS = 512;    // 8 wavefronts
-constexpr int STG = 256;        // threads staging one operand (waves 0-3: A, waves 4-7: B)
 constexpr int NV = 4;           // 16-byte vectors per staging thread per slab (128*8/256)
 
 struct GemmArgs {
@@ -82,7 +90,7 @@ void set_limits(GemmArgs& g, int64_t isz);
 // `rs` = element stride between rows of the operand (m for A, n for B), `ks` = stride along k.
 // A staging thread (stid in [0,256)) owns NV vectors per slab; their byte offsets from the
 // wave-uniform slab base are loop invariant and kept as 32-bit VGPRs.
-template <typename T, int MODE>
+template <typename T, int MODE, int STG = 256>
 struct Stage {
   using Tr = Traits<T>;
   using vec_t = typename Tr::vec_t;
@@ -226,9 +234,13 @@ template <> __device__ __forceinline__ int frag_row<double>(int lane, int r) {
   return (lane >> 4) + 4 * r;
 }
 
-template <typename T, int AMODE, int BMODE, int EM>
-__global__ __launch_bounds__(THREADS, 4) void gemm_kernel(GemmArgs g) {
+template <typename T, int AMODE, int BMODE, int EM, int H = 0>
+__global__ __launch_bounds__(Cfg<H>::THREADS, 4) void gemm_kernel(GemmArgs g) {
   constexpr bool EDGE = (EM != 0);
+  constexpr int BM = Cfg<H>::BM, BN = Cfg<H>::BN, STG = Cfg<H>::STG, WN = Cfg<H>::WN;
+  constexpr int FM = Cfg<H>::FM, FN = Cfg<H>::FN;
+  using StA = Stage<T, AMODE, STG>;
+  using StB = Stage<T, BMODE, STG>;
   using Tr = Traits<T>;
   using acc_t = typename Tr::acc_t;
   using vec_t = typename Tr::vec_t;
@@ -240,8 +252,8 @@ __global__ __launch_bounds__(THREADS, 4) void gemm_kernel(GemmArgs g) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;  // 2x4 waves, 64x32 each
-  const bool stage_a = wave < 4;            // wave-uniform: which operand this wave stages
+  const int wm = wave / WN, wn = wave % WN;  // 2 x WN waves, (16 FM) x (16 FN) outputs each
+  const bool stage_a = wave < WN;           // wave-uniform: which operand this wave stages
   const int stid = tid & (STG - 1);
 
   // XCD-aware bijective remap of the linear workgroup id (speed only), then a grouped
@@ -280,14 +292,14 @@ __global__ __launch_bounds__(THREADS, 4) void gemm_kernel(GemmArgs g) {
       ? reinterpret_cast<const char*>(static_cast<const T*>(g.A) + z * g.a_bs) + g.a_lim
       : reinterpret_cast<const char*>(static_cast<const T*>(g.B) + z * g.b_bs) + g.b_lim;
   unsigned off[NV];
-  if (stage_a) Stage<T, AMODE>::offsets(off, stid, s_rs, s_ks);
-  else Stage<T, BMODE>::offsets(off, stid, s_rs, s_ks);
+  if (stage_a) StA::offsets(off, stid, s_rs, s_ks);
+  else StB::offsets(off, stid, s_rs, s_ks);
 
-  acc_t acc[4][2];
+  acc_t acc[FM][FN];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = 0;
+    for (int j = 0; j < FN; ++j) acc[i][j] = 0;
 
   // two register staging sets (slab parity): loads of slab t+2 are issued at the start of slab
   // t and stored to LDS at the end of slab t+1 (load-to-use distance: two slabs)
@@ -303,9 +315,9 @@ __global__ __launch_bounds__(THREADS, 4) void gemm_kernel(GemmArgs g) {
       records = rem <= 0 ? 0 : (rem > 0x7FFFFFFF ? 0x7FFFFFFF : (int)rem);
     }
     if (stage_a)
-      Stage<T, AMODE>::template load<EM>(r, base, off, stid, s_rs, s_ks, s_rows, krem, records);
+      StA::template load<EM>(r, base, off, stid, s_rs, s_ks, s_rows, krem, records);
     else
-      Stage<T, BMODE>::template load<EM>(r, base, off, stid, s_rs, s_ks, s_rows, krem, records);
+      StB::template load<EM>(r, base, off, stid, s_rs, s_ks, s_rows, krem, records);
   };
   auto lstore = [&](const vec_t (&r)[NV], int t) {
     char* nb = smem + (t & 1) * SLAB;
@@ -315,13 +327,13 @@ __global__ __launch_bounds__(THREADS, 4) void gemm_kernel(GemmArgs g) {
     // drains the two-slab-deep prefetch)
     int s2 = stid;
     asm volatile("" : "+v"(s2));
-    if (stage_a) Stage<T, AMODE>::store(r, nb, s2);
-    else Stage<T, BMODE>::store(r, nb + BM * ROW_BYTES, s2);
+    if (stage_a) StA::store(r, nb, s2);
+    else StB::store(r, nb + BM * ROW_BYTES, s2);
   };
 
   if (nslab > 0) {
     gload(r0, 0);
-    if (nslab > 1) gload(r1, 1);
+    gload(r1, nslab > 1 ? 1 : 0);   // unconditional, like the prefetch in slab()
     lstore(r0, 0);
   }
   __syncthreads();
@@ -331,8 +343,8 @@ __global__ __launch_bounds__(THREADS, 4) void gemm_kernel(GemmArgs g) {
   // (fragment base rows are multiples of 16, so bit 3 of the tile row is bit 3 of the lane:
   // rows with that bit set hold their 8-byte units swapped pairwise, see Stage::swz)
   const int frag_off = (lane & 15) * ROW_BYTES + ((lane >> 4) ^ ((lane >> 3) & 1)) * 8;
-  const int pa_off = wm * 64 * ROW_BYTES + frag_off;
-  const int pb_off = BM * ROW_BYTES + wn * 32 * ROW_BYTES + frag_off;
+  const int pa_off = wm * (16 * FM) * ROW_BYTES + frag_off;
+  const int pb_off = BM * ROW_BYTES + wn * (16 * FN) * ROW_BYTES + frag_off;
 
   // fp32 only: chunked summation.  A 4096-long fp32 fma chain has a Frobenius error of 1.15e-6
   // against an fp64 product — outside the 1e-6 parity bar (the reference's OpenBLAS sgemm sums in
@@ -356,13 +368,13 @@ __global__ __launch_bounds__(THREADS, 4) void gemm_kernel(GemmArgs g) {
     int l2 = lane;
     asm volatile("" : "+v"(l2));
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int64_t col = n0 + wn * 32 + j * 16 + (l2 & 15);
+      for (int j = 0; j < FN; ++j) {
+        const int64_t col = n0 + wn * (16 * FN) + j * 16 + (l2 & 15);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int64_t row = m0 + wm * 64 + i * 16 + frag_row<T>(l2, r);
+          const int64_t row = m0 + wm * (16 * FM) + i * 16 + frag_row<T>(l2, r);
           if (!EDGE || (row < g.M && col < g.N)) {
             T v = alpha * acc[i][j][r];
             if (first) {
@@ -381,34 +393,37 @@ __global__ __launch_bounds__(THREADS, 4) void gemm_kernel(GemmArgs g) {
   // the other LDS buffer, one barrier
   auto slab = [&](int t, vec_t (&lr)[NV], const vec_t (&ur)[NV]) {
     const char* buf = smem + (t & 1) * SLAB;
-    if (t + 2 < nslab) gload(lr, t + 2);
+    // always issued (the last two slabs re-read the final slab): a prefetch inside a branch
+    // makes the compiler's s_waitcnt at the LDS stores below count only the loads it is sure of,
+    // i.e. wait for vmcnt(3..0) — the just-issued prefetch included — instead of vmcnt(7..4)
+    gload(lr, t + 2 < nslab ? t + 2 : nslab - 1);
     // fragment fetches run ONE k-step ahead of the MFMAs that consume them (two register sets,
     // scheduling barriers pin the order): the ds_read latency of step ks+1 hides behind the 16
     // MFMAs of step ks instead of stalling the wave at the top of every step pair
-    frag_t fa[2][4], fb[2][2];
+    frag_t fa[2][FM], fb[2][FN];
     auto fetch = [&](int set, int ks) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < FM; ++i)
         fa[set][i] = *reinterpret_cast<const frag_t*>(buf + pa_off + i * 16 * ROW_BYTES + ks * 32);
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < FN; ++j)
         fb[set][j] = *reinterpret_cast<const frag_t*>(buf + pb_off + j * 16 * ROW_BYTES + ks * 32);
     };
     auto mmas = [&](int set) {
       if constexpr (sizeof(T) == 4) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < FM; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) mma(acc[i][j], fa[set][i].x, fb[set][j].x);
+          for (int j = 0; j < FN; ++j) mma(acc[i][j], fa[set][i].x, fb[set][j].x);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < FM; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) mma(acc[i][j], fa[set][i].y, fb[set][j].y);
+          for (int j = 0; j < FN; ++j) mma(acc[i][j], fa[set][i].y, fb[set][j].y);
       } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < FM; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) mma(acc[i][j], fa[set][i], fb[set][j]);
+          for (int j = 0; j < FN; ++j) mma(acc[i][j], fa[set][i], fb[set][j]);
       }
     };
     fetch(0, 0);
@@ -462,6 +477,12 @@ __global__ void scale_kernel(GemmArgs g) {
 // L2-resident at these sizes; fragments are loaded in MFMA layout, no LDS staging), and the four
 // partial tiles are summed in wave order through LDS (deterministic).  Arbitrary strides.
 int64_t g_gemm_group = 8;          // tile-rows per walk group (ahip_set_param "gemm_group")
+// 64x64 tile (Cfg<1>) window, measured r02 fp32 (default -> half tile): 1024^3 36.8 -> 32.1 us,
+// 2048x1024x1024 64.2 -> 48.4, 3072x1024x1024 91.6 -> 65.6, 3072x2048x1024 (384 big tiles:
+// 1.5 rounds of the chip) 144 -> 123; it loses below ~48 big tiles (768^2x1024: 26 -> 33 us, the
+// 16-row kernels win) and from two full rounds of big tiles on (4096x2048x1024: 148 -> 157)
+int64_t g_half_max_tiles = 448;    // used below this many 128x128 tiles ...
+int64_t g_half_min_tiles = 192;    // ... when the problem has at least this many 64x64 tiles
 int64_t g_small_max_tiles = 64;    // scalar-load form: below this many 128x128 tiles (x4 for the
                                    // vector-load form, see gemm_dispatch)
 
@@ -828,13 +849,13 @@ int operand_mode(const void* p, int64_t rs, int64_t ks, int64_t rows, int64_t K,
   return 2;
 }
 
-template <typename T, int AM, int BMd, int EDGE>
+template <typename T, int AM, int BMd, int EDGE, int H = 0>
 int launch_gemm(const GemmArgs& g, int64_t batch, hipStream_t s) {
-  constexpr size_t lds = 2 * (BM + BN) * ROW_BYTES;
+  constexpr size_t lds = 2 * (Cfg<H>::BM + Cfg<H>::BN) * ROW_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(gemm_kernel<T, AM, BMd, EDGE>),
+        reinterpret_cast<const void*>(gemm_kernel<T, AM, BMd, EDGE, H>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       ahip_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -843,7 +864,7 @@ int launch_gemm(const GemmArgs& g, int64_t batch, hipStream_t s) {
     attr_set = true;
   }
   dim3 grid((unsigned)(g.tiles_m * g.tiles_n), 1, (unsigned)batch);
-  AHIP_LAUNCH((gemm_kernel<T, AM, BMd, EDGE>), grid, dim3(THREADS), lds, s, g);
+  AHIP_LAUNCH((gemm_kernel<T, AM, BMd, EDGE, H>), grid, dim3(Cfg<H>::THREADS), lds, s, g);
   return AHIP_OK;
 }
 
@@ -870,10 +891,22 @@ int dispatch_modes(const GemmArgs& g, int am, int bm, int64_t batch, hipStream_t
 // which instantiation: 0 interior, 2 ragged M / N with K a multiple of BK (bounded descriptors,
 // predicated stores only), 1 fully predicated
 template <typename T>
-int edge_mode(const GemmArgs& g) {
+int edge_mode(const GemmArgs& g, int bm_ = BM, int bn_ = BN) {
   const bool kfull = g.K % Traits<T>::BK == 0;
-  if (kfull && g.M % BM == 0 && g.N % BN == 0) return 0;
+  if (kfull && g.M % bm_ == 0 && g.N % bn_ == 0) return 0;
   return kfull ? 2 : 1;
+}
+
+// the 64x64 tile: vector-staged operands and K a multiple of the slab only (everything else
+// keeps the 128x128 / 16-row kernels)
+template <typename T, int EDGE>
+int dispatch_half(const GemmArgs& g, int am, int bm, int64_t batch, hipStream_t s) {
+  switch (am * 3 + bm) {
+    case 0: return launch_gemm<T, 0, 0, EDGE, 1>(g, batch, s);
+    case 1: return launch_gemm<T, 0, 1, EDGE, 1>(g, batch, s);
+    case 3: return launch_gemm<T, 1, 0, EDGE, 1>(g, batch, s);
+    default: return launch_gemm<T, 1, 1, EDGE, 1>(g, batch, s);
+  }
 }
 
 template <typename T>
@@ -898,6 +931,20 @@ int gemm_dispatch(GemmArgs& g, int64_t batch, hipStream_t s) {
   g.group = (int)g_gemm_group;
   g.tiles_n = (int)((g.N + BN - 1) / BN);
   AHIP_REQUIRE((int64_t)g.tiles_m * g.tiles_n < (1LL << 31), "too many tiles");
+  int am = operand_mode<T>(g.A, g.a_rs, g.a_cs, g.M, g.K, g.a_bs, batch);
+  int bm = operand_mode<T>(g.B, g.b_cs, g.b_rs, g.N, g.K, g.b_bs, batch);
+  {
+    // mid-size problems: fewer 128x128 tiles than CUs, but enough 64x64 tiles to fill the chip
+    const int64_t t128 = (int64_t)g.tiles_m * g.tiles_n * batch;
+    const int64_t tm64 = (g.M + 63) / 64, tn64 = (g.N + 63) / 64;
+    if (am < 2 && bm < 2 && g.K % Traits<T>::BK == 0 && t128 < g_half_max_tiles &&
+        tm64 * tn64 * batch >= g_half_min_tiles && tm64 * tn64 < (1LL << 31)) {
+      g.tiles_m = (int)tm64;
+      g.tiles_n = (int)tn64;
+      return edge_mode<T>(g, 64, 64) == 0 ? dispatch_half<T, 0>(g, am, bm, batch, s)
+                                          : dispatch_half<T, 2>(g, am, bm, batch, s);
+    }
+  }
   // below one 128x128 tile per CU the 16-row kernels win when their vector-load form applies
   // (measured fp32: 1024^3 = 64 tiles 86 -> 36 us, 2048x1024x1024 = 128 tiles 88 -> 65 us,
   // 2048x2048x512 = 256 tiles: big 53 vs 64 us); the scalar-load form only below 64 tiles
@@ -919,8 +966,6 @@ int gemm_dispatch(GemmArgs& g, int64_t batch, hipStream_t s) {
     if ((int64_t)g.tiles_m * g.tiles_n * batch < limit && (g.M + 15) / 16 < 65536 && batch < 65536)
       return launch_small<T>(g, batch, s);
   }
-  int am = operand_mode<T>(g.A, g.a_rs, g.a_cs, g.M, g.K, g.a_bs, batch);
-  int bm = operand_mode<T>(g.B, g.b_cs, g.b_rs, g.N, g.K, g.b_bs, batch);
   return run_big<T>(g, am, bm, batch, s);
 }
 
@@ -1000,6 +1045,8 @@ double host_scalar(int dtype, const void* p) {
 }  // namespace
 
 void ahip_gemm_set_small_max_tiles(int64_t v) { g_small_max_tiles = v; }
+void ahip_gemm_set_half_max_tiles(int64_t v) { g_half_max_tiles = v; }
+void ahip_gemm_set_half_min_tiles(int64_t v) { g_half_min_tiles = v; }
 void ahip_gemm_set_group(int64_t v) { g_gemm_group = v; }
 void ahip_gemm_set_skinny_nf(int64_t v) { g_skinny_nf = v; }
 

@@ -610,3 +610,51 @@ def test_random_multi_node_plans_eager_and_replay(seed):
                     g = g.cpu().numpy()
                     assert g.shape == w.shape and np.array_equal(g, w), \
                         (seed, trial, call, ("eager", "replay", "borrow")[k], plan.pretty())
+
+
+def test_half_tile_gemm_all_layouts_and_ragged_extents():
+    """The 64x64-tile instantiation of the MFMA GEMM (mid-size problems) forced for every
+    vector-staged problem: 4 layouts (A / B row-major or transposed views), M / N ragged around
+    64 and 128, K a multiple of the slab, alpha / beta, fp32 and fp64, batched — against fp64
+    NumPy at the bars of the big tile (Frobenius 2e-6 fp32, 1e-13 fp64)."""
+    import torch
+    from aesara_amd._lib import check, lib
+    from aesara_amd.executor import PlanExecutor
+    from aesara_amd.plan import Node, Plan, Var
+    rng = np.random.default_rng(77)
+    check(lib.ahip_set_param(b"gemm_half_max_tiles", 1 << 40))
+    check(lib.ahip_set_param(b"gemm_half_min_tiles", 1))
+    try:
+        for dt in ("float32", "float64"):
+            bk = 32 if dt == "float32" else 16
+            vs = [Var(0, dt, [None, None]), Var(1, dt, []), Var(2, dt, [None, None]), Var(3, dt, [None, None]),
+                  Var(4, dt, []), Var(5, dt, [None, None])]
+            plan = Plan("half_gemm", {v.id: v for v in vs}, [0, 1, 2, 3, 4], [5],
+                        [Node("Gemm", [0, 1, 2, 3, 4], [5], {"inplace": False})])
+            ex = PlanExecutor(plan)
+            for M, N, K in [(64, 64, bk), (128, 192, 4 * bk), (256, 320, 2 * bk), (100, 68, 3 * bk), (4, 260, bk),
+                            (1024, 1024, 1024), (136, 72, 2112), (512, 640, 4096 + bk)]:
+                for ta in (False, True):
+                    for tb in (False, True):
+                        x = rng.standard_normal((K, M) if ta else (M, K)).astype(dt)
+                        y = rng.standard_normal((N, K) if tb else (K, N)).astype(dt)
+                        z = rng.standard_normal((M, N)).astype(dt)
+                        al, be = float(rng.choice([1.0, 0.8])), float(rng.choice([0.0, 0.4]))
+                        xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+                        (got,) = ex(torch.from_numpy(z).cuda(), np.asarray(al, dt), xd.t() if ta else xd,
+                                    yd.t() if tb else yd, np.asarray(be, dt))
+                        want = be * z.astype("float64") + al * ((x.T if ta else x).astype("float64")
+                                                                 @ (y.T if tb else y).astype("float64"))
+                        err = np.linalg.norm(got.cpu().numpy() - want) / np.linalg.norm(want)
+                        assert err <= (2e-6 if dt == "float32" else 1e-13), (dt, M, N, K, ta, tb, err)
+            vb = [Var(0, dt, [None] * 3), Var(1, dt, [None] * 3), Var(2, dt, [None] * 3)]
+            bplan = Plan("half_bdot", {v.id: v for v in vb}, [0, 1], [2], [Node("BatchedDot", [0, 1], [2], {})])
+            a3 = rng.standard_normal((3, 96, 4 * bk)).astype(dt)
+            b3 = rng.standard_normal((3, 4 * bk, 160)).astype(dt)
+            (got,) = PlanExecutor(bplan)(torch.from_numpy(a3).cuda(), torch.from_numpy(b3).cuda())
+            want = a3.astype("float64") @ b3.astype("float64")
+            err = np.linalg.norm(got.cpu().numpy() - want) / np.linalg.norm(want)
+            assert err <= (2e-6 if dt == "float32" else 1e-13), (dt, "batched", err)
+    finally:
+        check(lib.ahip_set_param(b"gemm_half_max_tiles", 448))
+        check(lib.ahip_set_param(b"gemm_half_min_tiles", 192))
