@@ -937,7 +937,8 @@ int gemm_dispatch(GemmArgs& g, int64_t batch, hipStream_t s) {
     // mid-size problems: fewer 128x128 tiles than CUs, but enough 64x64 tiles to fill the chip
     const int64_t t128 = (int64_t)g.tiles_m * g.tiles_n * batch;
     const int64_t tm64 = (g.M + 63) / 64, tn64 = (g.N + 63) / 64;
-    if (am < 2 && bm < 2 && g.K % Traits<T>::BK == 0 && t128 < g_half_max_tiles &&
+    // (exactly one big tile per CU is one full round of the chip: the big tile keeps it)
+    if (am < 2 && bm < 2 && g.K % Traits<T>::BK == 0 && t128 < g_half_max_tiles && t128 != 256 &&
         tm64 * tn64 * batch >= g_half_min_tiles && tm64 * tn64 < (1LL << 31)) {
       g.tiles_m = (int)tm64;
       g.tiles_n = (int)tn64;

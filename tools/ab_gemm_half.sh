@@ -5,7 +5,7 @@ sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"]); sys.path.insert(0, os.path.jo
 from golden_util import CASES, case_plan
 from aesara_amd.executor import PlanExecutor
 from aesara_amd._lib import lib, check
-plan = case_plan(next(c for c in CASES if c["name"] == "cfg3b_gemm_update"))
+plan = case_plan(next(c for c in CASES if c["name"] == ("gemm0_float64" if os.environ.get("F64") else "cfg3b_gemm_update")))
 def timeit(f, n=30):
     for _ in range(5): f()
     torch.cuda.synchronize()
@@ -17,7 +17,8 @@ def timeit(f, n=30):
 shapes = [(512,512,512),(768,768,1024),(1024,1024,1024),(1024,1024,4096),(1536,1024,1024),(2048,1024,1024),(2048,2048,512),
           (2048,2048,2048),(3072,1024,1024),(4096,1024,1024),(1024,4096,1024),(3072,2048,1024),(4096,2048,1024),(4096,4096,1024), (1000,1000,1024), (2500, 1100, 512)]
 for (M,N,K) in shapes:
-    A = torch.randn(M, K, device="cuda"); B = torch.randn(K, N, device="cuda"); Cm = torch.zeros(M, N, device="cuda")
+    dt = torch.float64 if os.environ.get("F64") else torch.float32
+    A = torch.randn(M, K, device="cuda", dtype=dt); B = torch.randn(K, N, device="cuda", dtype=dt); Cm = torch.zeros(M, N, device="cuda", dtype=dt)
     res = {}
     for label, mx in (("default", 1), ("half", 1 << 40)):
         check(lib.ahip_set_param(b"gemm_half_max_tiles", mx))
