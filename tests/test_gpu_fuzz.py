@@ -584,7 +584,10 @@ def test_random_multi_node_plans_eager_and_replay(seed):
     from aesara_amd.executor import PlanExecutor
     rng = np.random.default_rng(4000 + seed)
     for trial in range(25):
-        R, C = (int(v) for v in rng.choice([1, 2, 3, 4, 6, 7, 8, 9], 2, replace=False))
+        # small extents by default; every fourth trial uses extents that reach the 16-byte-vector,
+        # LDS-tiled and MFMA-tile code paths (values stay small integers: still exact)
+        dims = [1, 2, 3, 4, 6, 7, 8, 9] if trial % 4 else [16, 24, 33, 48, 64, 66, 100, 128, 130]
+        R, C = (int(v) for v in rng.choice(dims, 2, replace=False))
         plan, shapes, idx_in = _rand_dag(rng, R, C, int(rng.integers(3, 16)))
         exs = [PlanExecutor(plan), PlanExecutor(plan, use_graph=True),
                PlanExecutor(plan, use_graph=True, borrow=True)]
