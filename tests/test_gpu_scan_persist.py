@@ -287,3 +287,38 @@ def test_persistent_scans_on_random_extents(name, dims):
             assert g.shape == r.shape, (val, g.shape, r.shape)
             np.testing.assert_allclose(g, r, rtol=tol, atol=tol * max(1.0, float(np.abs(r).max(initial=0))),
                                        err_msg=str(val))
+
+
+@pytest.mark.parametrize("batch", [0, 32])
+def test_varying_chunk_lengths_share_one_exchange_workspace(batch):
+    """Calls with different step counts (16, 20, 16, 7, 2, 33 ...) are different replay signatures
+    of the SAME persistent kernel and exchange workspace (the tag epoch advances by each call's
+    step count): the chained states must equal the one-shot run."""
+    import torch
+    from aesara_amd.executor import PlanExecutor
+    H = 256
+    lens = [16, 20, 16, 7, 2, 33, 20, 2]
+    T = sum(lens)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(22)
+    shp = (T, batch, H) if batch else (T, H)
+    x = torch.randn(*shp, dtype=torch.float32, device="cuda", generator=g) * 0.1
+    h0 = torch.randn(*shp[1:], dtype=torch.float32, device="cuda", generator=g) * 0.5
+    Ws = [torch.randn(H, H, dtype=torch.float32, device="cuda", generator=g) / np.sqrt(H)
+          for _ in range(6)]
+    name = "cfg4_gru_b8_f32" if batch else "cfg4_gru_b1_f32"
+    whole, _ = PlanExecutor(case_plan(_case(name)))(x, h0, *Ws)
+    ex = PlanExecutor(case_plan(_case(name)), use_graph=True)
+    for rep in range(2):
+        h, got, t0 = h0, [], 0
+        for n in lens:
+            hs, h = ex(x[t0:t0 + n], h, *Ws)
+            got.append(hs)
+            t0 += n
+        ex.check()
+        cat = torch.cat(got)
+        if batch:
+            assert torch.allclose(cat, whole, rtol=1e-4, atol=2e-6), rep
+        else:
+            assert torch.equal(cat, whole), rep
+    assert set(ex.scan_modes.values()) == {"persistent"}, ex.scan_modes
