@@ -297,6 +297,125 @@ def split_invariant(plan: Plan, invariant_inputs: List[int]):
     return pre, loop, hoisted
 
 
+def hoist_sequence_only(plan: Plan, seq_inputs: List[int], invariant: set):
+    """Everything in a Scan step that depends only on *sequence* rows and loop invariants does not
+    take part in the recurrence: it is computed for ALL steps before the loop and the step reads
+    row t of the result.  Covers the vector class: ``Elemwise`` on per-step vectors and ``Gemv``
+    chains with invariant matrices (``W1 x_t + W2 h_t`` of a gate — a gradient Scan recomputes the
+    forward gates from stored states this way, scan/op.py:2379 ``Scan.L_op``); the lifted plan runs
+    them as ``[T, n]`` Elemwise kernels and GEMMs (T x K @ K x M fills the chip; T separate GEMVs
+    cannot).  The reference's ``scan_pushout_seqs_ops`` (scan/rewriting.py) has the same aim but
+    leaves the dots, and whatever depends on them, inside.
+
+    Returns ``(loop_plan, lifted)``; ``lifted`` = None or ``{"plan": Plan over whole sequences,
+    "seq_in": step-plan ids of the sequences it reads, "inv_in": ids of the invariants it reads,
+    "outs": step-plan ids of its results (appended to the loop plan's inputs, in this order)}``."""
+    V = plan.vars
+    floats = ("float32", "float64")
+
+    def cval(vid):
+        v = V[vid]
+        if v.const is not None and len(v.const.get("data", ())) == 1:
+            return float(v.const["data"][0])
+        return None
+
+    Q = {v for v in seq_inputs if V[v].ndim == 1 and V[v].dtype in floats}
+    seq_set = set(seq_inputs)
+    hoisted, keep = [], []
+    for n in plan.nodes:
+        ok = False
+        if n.op == "Elemwise" and n.inputs and any(i in Q for i in n.inputs):
+            ok = all(i in Q or ((i in invariant or V[i].const is not None) and V[i].ndim == 1)
+                     for i in n.inputs) and \
+                all(V[o].ndim == 1 and V[o].dtype in floats for o in n.outputs)
+        elif n.op == "Gemv":
+            y, alpha, A, x, beta = n.inputs
+            ok = A in invariant and V[A].ndim == 2 and x in Q and cval(alpha) is not None and \
+                cval(beta) is not None and (cval(beta) == 0.0 or y in Q) and \
+                V[n.outputs[0]].dtype in floats
+        if ok:
+            hoisted.append(n)
+            Q.update(n.outputs)
+        else:
+            keep.append(n)
+    used_later = {i for n in keep for i in n.inputs} | set(plan.outputs)
+    outs = [o for n in hoisted for o in n.outputs if o in used_later]
+    if not outs:
+        return plan, None
+    # keep only the hoisted nodes the results depend on
+    need, live = set(outs), []
+    for n in reversed(hoisted):
+        if any(o in need for o in n.outputs):
+            live.append(n)
+            need.update(n.inputs)
+    live.reverse()
+    dropped = [n for n in hoisted if n not in live]
+    if dropped:        # (they fed nothing that is kept: leave them where they were)
+        live_ids = {id(n) for n in live}
+        keep = [n for n in plan.nodes if id(n) not in live_ids]
+
+    # what only fed the hoisted nodes (the AllocEmpty "y" of a beta = 0 Gemv and its shape
+    # arithmetic) is dead in the loop now
+    pure = {"AllocEmpty", "Shape_i", "Shape", "DimShuffle", "Elemwise", "ScalarFromTensor",
+            "TensorFromScalar", "MakeVector", "Alloc", "ViewOp"}
+    while True:
+        read = {i for n in keep for i in n.inputs} | set(plan.outputs)
+        dead = [n for n in keep if n.op in pure and not any(o in read for o in n.outputs)]
+        if not dead:
+            break
+        dead_ids = {id(n) for n in dead}
+        keep = [n for n in keep if id(n) not in dead_ids]
+
+    lp = Plan(plan.name + "_allsteps", {}, [], [], [])
+    m, seq_in, inv_in = {}, [], []
+
+    def same(v):                      # invariant / constant operand: the same variable
+        if ("s", v) not in m:
+            src = V[v]
+            m[("s", v)] = lp.new_var(src.dtype, list(src.shape), src.name, src.const)
+            if src.const is None:
+                inv_in.append(v)
+        return m[("s", v)]
+
+    def rows(v):                      # per-step vector -> [T, n]
+        if ("r", v) not in m:
+            m[("r", v)] = lp.new_var(V[v].dtype, [None, V[v].shape[0]])
+            if v in seq_set:
+                seq_in.append(v)
+        return m[("r", v)]
+
+    def as_row(v):                    # invariant vector next to [T, n] operands: [1, n]
+        if ("b", v) not in m:
+            src = V[v]
+            if src.const is not None:
+                c = dict(src.const)
+                c["shape"] = [1] + list(c["shape"])
+                m[("b", v)] = lp.new_var(src.dtype, [1] + list(src.shape), None, c)
+            else:
+                o = lp.new_var(src.dtype, [1] + list(src.shape))
+                lp.nodes.append(Node("DimShuffle", [same(v)], [o], {"new_order": ["x", 0]}))
+                m[("b", v)] = o
+        return m[("b", v)]
+
+    for n in live:
+        if n.op == "Elemwise":
+            ins = [rows(i) if i in Q else as_row(i) for i in n.inputs]
+            lp.nodes.append(Node("Elemwise", ins, [rows(o) for o in n.outputs], dict(n.params)))
+        else:
+            y, alpha, A, x, beta = n.inputs
+            at_ = lp.new_var(V[A].dtype, [V[A].shape[1], V[A].shape[0]])
+            lp.nodes.append(Node("DimShuffle", [same(A)], [at_], {"new_order": [1, 0]}))
+            if cval(beta) == 0.0:
+                lp.nodes.append(Node("Dot22Scalar", [rows(x), at_, same(alpha)], [rows(n.outputs[0])], {}))
+            else:
+                lp.nodes.append(Node("Gemm", [rows(y), same(alpha), rows(x), at_, same(beta)],
+                                     [rows(n.outputs[0])], {"inplace": False}))
+    lp.inputs = [m[("r", v)] for v in seq_in] + [m[("s", v)] for v in inv_in]
+    lp.outputs = [m[("r", o)] for o in outs]
+    loop = Plan(plan.name + "_seqonly", plan.vars, list(plan.inputs) + outs, list(plan.outputs), keep)
+    return loop, {"plan": lp, "seq_in": seq_in, "inv_in": inv_in, "outs": outs}
+
+
 def hoist_sequence_dots(plan: Plan, seq_inputs: List[int], invariant: set):
     """Matrix products of a Scan step that involve only a *sequence* row and loop-invariant
     matrices (``x_t @ W`` of an RNN gate) do not depend on the recurrence: they are removed from
@@ -318,10 +437,15 @@ def hoist_sequence_dots(plan: Plan, seq_inputs: List[int], invariant: set):
     for n in plan.nodes:
         h = None
         if n.op == "Gemv":
-            _y, alpha, A, x, beta = n.inputs
-            if A in invariant and x in seqs and const_value(beta) == 0.0 \
-                    and const_value(alpha) is not None:
-                h = {"kind": "gemv", "seq": x, "mat": A, "alpha": const_value(alpha)}
+            y, alpha, A, x, beta = n.inputs
+            if A in invariant and x in seqs and const_value(alpha) is not None:
+                if const_value(beta) == 0.0:
+                    h = {"kind": "gemv", "seq": x, "mat": A, "alpha": const_value(alpha)}
+                elif const_value(beta) is not None and y in seqs:
+                    # a chain  W1 x_t + W2 h_t  (the gate pre-activations a gradient Scan
+                    # recomputes from stored states): accumulates onto an earlier hoisted product
+                    h = {"kind": "gemv", "seq": x, "mat": A, "alpha": const_value(alpha),
+                         "beta": const_value(beta), "acc": y}
         elif n.op in ("Dot22", "Dot"):
             a, b = n.inputs
             if a in seqs and b in invariant and plan.vars[b].ndim == 2:
@@ -332,6 +456,7 @@ def hoist_sequence_dots(plan: Plan, seq_inputs: List[int], invariant: set):
         if h is not None and plan.vars[n.outputs[0]].dtype in ("float32", "float64"):
             h["out"] = n.outputs[0]
             hoists.append(h)
+            seqs.add(n.outputs[0])       # row t of the result is a sequence operand from here on
         else:
             keep.append(n)
     if not hoists:

@@ -92,6 +92,8 @@ class Program:
         self.seq, self.state, self.nsq, self.mats = {}, {}, {}, {}
         self.phases, self.outs = [], []
         self.new_of_state = {}      # state var -> var holding its new value
+        self.tap_seq = {}           # mit-mot tap-1 var -> recurrent output whose buffer holds its rows
+        self.passthru = {}          # nit-sot output index -> sequence var it hands out unchanged
         self.exchanged = []         # produced vars that some dot needs in full
         self.mode = "vec"
         self.dtype = "float32"
@@ -101,12 +103,22 @@ def analyze(inner, p, n_seqdots):
     """Returns (Program, None) or (None, reason)."""
     plan = inner.plan
     n_seqs = p["n_seqs"]
-    if p.get("mit_mot_in_slices") or p.get("n_shared_outs", 0) or p.get("as_while", False):
-        return None, "mit-mot / shared outputs / do-while"
+    if p.get("n_shared_outs", 0) or p.get("as_while", False):
+        return None, "shared outputs / do-while"
+    # mit-mot groups of the form a gradient Scan uses for the state it propagates (Scan.L_op,
+    # scan/op.py:2379): input taps [0, 1], output tap [1] — step i reads rows i and i + 1 of the
+    # buffer and overwrites row i + 1.  Row i is what step i - 1 wrote (the running value: a
+    # state with its initial value in row 0), row i + 1 still holds what the caller put there
+    # (the incoming gradient of that step): a sequence that happens to live in the output buffer.
+    mm_in = [list(t) for t in p.get("mit_mot_in_slices", [])]
+    mm_out = [list(t) for t in p.get("mit_mot_out_slices", [])]
+    if any(t != [0, 1] for t in mm_in) or any(t != [1] for t in mm_out):
+        return None, "mit-mot taps other than [0, 1] -> [1]"
+    n_mm = len(mm_in)
     taps = [list(t) for t in p["mit_sot_in_slices"]] + [list(t) for t in p["sit_sot_in_slices"]]
     if any(t != [-1] for t in taps):
         return None, "taps other than [-1]"
-    n_rec, n_nit = len(taps), p["n_nit_sot"]
+    n_rec, n_nit = n_mm + len(taps), p["n_nit_sot"]
     if n_rec == 0:
         return None, "no recurrent state"
     pr = Program()
@@ -114,12 +126,19 @@ def analyze(inner, p, n_seqdots):
     n_fixed = len(ins) - n_seqdots
     for s, v in enumerate(ins[:n_seqs]):
         pr.seq[v] = s
-    for k, v in enumerate(ins[n_seqs:n_seqs + n_rec]):
-        pr.state[v] = k
-    inv = ins[n_seqs + n_rec:n_fixed]
+    idx = n_seqs
+    for g in range(n_mm):
+        pr.state[ins[idx]] = g
+        pr.seq[ins[idx + 1]] = n_seqs + n_seqdots + g     # slot of the buffer-resident sequence
+        pr.tap_seq[ins[idx + 1]] = g
+        idx += 2
+    for k in range(len(taps)):
+        pr.state[ins[idx]] = n_mm + k
+        idx += 1
+    inv = ins[idx:n_fixed]
     for j, v in enumerate(ins[n_fixed:]):
         pr.seq[v] = n_seqs + j
-    if len(pr.seq) > SP_MAXSEQ:
+    if n_seqs + n_seqdots + n_mm > SP_MAXSEQ:
         return None, "too many sequence operands"
     inv_set = set(inv)
     produced = {}
@@ -130,6 +149,8 @@ def analyze(inner, p, n_seqdots):
     pr.dtype = plan.vars[plan.outputs[0]].dtype
     if pr.dtype not in (("float32",) if pr.mode == "mat" else ("float32", "float64")):
         return None, "state dtype %s" % pr.dtype
+    if n_mm and pr.mode == "mat":
+        return None, "mit-mot with a matrix state"
     nd = 2 if pr.mode == "mat" else 1
     ok_kinds = ("gemm_epi", "elemwise") if pr.mode == "mat" else ("gemv_epi", "elemwise")
     alias = {}
@@ -138,12 +159,29 @@ def analyze(inner, p, n_seqdots):
         while v in alias:
             v = alias[v]
         return v
+    # a GEMV step that evaluates its vector on the fly (fusion._fuse_xprologue) is taken apart
+    # again: here the vector is a phase of its own (computed by the row owners, then exchanged)
+    steps = []
     for st in inner.steps:
+        for _d, xp in sorted(st.extra.get("xprog", {}).items()):
+            steps.append(xp["step"])
+        steps.append(st)
+    readers = {}
+    for st in steps:
+        for v in list(st.inputs) + [x for d in st.dots for x in d]:
+            readers[v] = readers.get(v, 0) + 1
+    for st in steps:
         if st.kind == "node" and st.node.op in ("SpecifyShape", "ViewOp"):
             alias[st.outputs[0]] = st.inputs[0]      # value-preserving views: same vector / matrix
             continue
+        if st.kind == "node" and st.node.op == "DimShuffle" and pr.mode == "vec" and \
+                [d for d in st.node.params["new_order"] if d != "x"] == [0] and \
+                plan.vars[st.inputs[0]].ndim == 1 and not readers.get(st.outputs[0]) and \
+                st.outputs[0] in plan.outputs:
+            alias[st.outputs[0]] = st.inputs[0]      # a step output handed out as a row / column
+            continue
         if st.kind not in ok_kinds or st.reduce is not None or st.post or \
-                (st.fallback and st.kind != "gemm_epi") or st.extra.get("xprog"):
+                (st.fallback and st.kind != "gemm_epi"):
             return None, f"step kind {st.kind} ({st.node.op if st.node else ''})"
         dots = []
         # (invariant matrix, loop operand): gemv_epi stores (A, x), gemm_epi (operand, weight)
@@ -157,6 +195,8 @@ def analyze(inner, p, n_seqdots):
                 pr.mats[a] = len(pr.mats)
             if not (x in pr.seq or x in pr.state or x in produced or x in inv_set):
                 return None, "dot vector of unknown origin"
+            if x in pr.tap_seq:
+                return None, "dot with a mit-mot tap"
             if x in inv_set and x not in pr.nsq:
                 pr.nsq[x] = len(pr.nsq)
             dots.append((a, x))
@@ -182,6 +222,9 @@ def analyze(inner, p, n_seqdots):
         return None, "output count"
     for j, o in enumerate(plan.outputs):
         if res(o) not in produced:
+            if j >= n_rec and res(o) in pr.seq and res(o) not in pr.tap_seq:
+                pr.passthru[j] = res(o)      # a nit-sot output that is a row of a sequence
+                continue
             return None, "a step output is not computed by a fused step"
         pr.outs.append((res(o), "rec" if j < n_rec else "nit", j))
     for v, k in pr.state.items():
@@ -222,7 +265,8 @@ class Spec:
                            self.R, self.nw, sorted(pr.seq.items()), sorted(pr.state.items()),
                            sorted(pr.nsq.items()), sorted(pr.mats.items()),
                            [[ph["dots"], ph["ins"], ph["outs"], ph["scalar"], ph["out_refs"]]
-                            for ph in pr.phases], pr.outs, pr.exchanged], sort_keys=True)
+                            for ph in pr.phases], pr.outs, pr.exchanged, sorted(pr.tap_seq.items())],
+                          sort_keys=True)
         return hashlib.sha256(blob.encode()).hexdigest()[:24]
 
 

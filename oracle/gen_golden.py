@@ -986,6 +986,33 @@ def _gru(dt, T_, H, B_, tol):
     return mk
 
 
+def _gru_bptt(dt, T_, H, B_):
+    """BASELINE config 4's recurrence under aesara.grad: loss = sum(h_T ** 2) + mean(hs), gradients
+    wrt the six weight matrices and h0 — the forward Scan keeps every state, the gradient Scan
+    (mit-mot accumulators, reversed sequences) runs behind it (scan/op.py:2379 Scan.L_op)."""
+    def mk():
+        x = T(dt, (2, 2) if B_ == 1 else (2, 2, 2), "x")
+        h0 = T(dt, (2,) if B_ == 1 else (2, 2), "h0")
+        Ws = [T(dt, (2, 2), n) for n in ("Wz", "Uz", "Wr", "Ur", "Wh", "Uh")]
+
+        def step(x_t, h, Wz, Uz, Wr, Ur, Wh, Uh):
+            z = at.sigmoid(at.dot(x_t, Wz) + at.dot(h, Uz))
+            r = at.sigmoid(at.dot(x_t, Wr) + at.dot(h, Ur))
+            hh = at.tanh(at.dot(x_t, Wh) + at.dot(r * h, Uh))
+            return (1 - z) * h + z * hh
+        hs, _ = ae.scan(step, sequences=[x], outputs_info=[h0], non_sequences=Ws)
+        loss = (hs[-1] ** 2).sum() + hs.mean()
+        grads = ae.grad(loss, Ws + [h0])
+        xs = (T_, H) if B_ == 1 else (T_, B_, H)
+        hsz = (H,) if B_ == 1 else (B_, H)
+        return [x, h0] + Ws, [loss] + grads, \
+            [N(xs, dt, 4, 0.3), N(hsz, dt, 3, 0.5)] + \
+            [N((H, H), dt, 5 + k, 1.0 / np.sqrt(H)) for k in range(6)]
+    return mk
+
+
+case("gru_bptt_b1_f32", rtol=2e-4, atol=2e-5)(_gru_bptt("float32", 12, 20, 1))
+case("gru_bptt_b4_f64", rtol=1e-9, atol=1e-10)(_gru_bptt("float64", 9, 12, 4))
 case("cfg4_gru_b1_f32", rtol=1e-5, atol=1e-5)(_gru("float32", 32, 64, 1, 1e-5))
 case("cfg4_gru_b8_f32", rtol=1e-5, atol=1e-5)(_gru("float32", 16, 64, 8, 1e-5))
 case("gru_b1_f64", rtol=1e-11, atol=1e-11)(_gru("float64", 10, 24, 1, 1e-11))

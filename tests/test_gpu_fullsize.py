@@ -531,3 +531,45 @@ def test_sort_and_argsort_rows_against_torch_stable_sort():
     ps, _ = plans("float64", 2)
     with pytest.raises(NotImplementedError):
         PlanExecutor(ps)(_randn((2, 5000), torch.float64, 1), np.int64(1))
+
+
+@pytest.mark.parametrize("T,H,B,name", [(64, 256, 1, "gru_bptt_b1_f32"), (24, 128, 16, "gru_bptt_b4_f64")])
+def test_gru_bptt_against_torch_autograd(T, H, B, name):
+    """SURVEY §8(f3) at a real shape: loss and gradients of the GRU recurrence (forward Scan +
+    gradient Scan with mit-mot accumulators, lowered from aesara.grad) against torch.autograd of an
+    fp64 restatement — eager and replayed."""
+    import torch
+    from aesara_amd.executor import PlanExecutor
+    dt = torch.float32 if name.endswith("f32") else torch.float64
+    g = torch.Generator(device="cuda")
+    g.manual_seed(13)
+    shp = (T, H) if B == 1 else (T, B, H)
+    x = torch.randn(*shp, dtype=dt, device="cuda", generator=g) * 0.3
+    h0 = torch.randn(*shp[1:], dtype=dt, device="cuda", generator=g) * 0.5
+    Ws = [torch.randn(H, H, dtype=dt, device="cuda", generator=g) / np.sqrt(H) for _ in range(6)]
+    leaves = [w.double().requires_grad_(True) for w in Ws] + [h0.double().requires_grad_(True)]
+    Wz, Uz, Wr, Ur, Wh, Uh, h = leaves
+    hs = []
+    for t in range(T):
+        xt = x[t].double()
+        z = torch.sigmoid(xt @ Wz + h @ Uz)
+        r = torch.sigmoid(xt @ Wr + h @ Ur)
+        hh = torch.tanh(xt @ Wh + (r * h) @ Uh)
+        h = (1 - z) * h + z * hh
+        hs.append(h)
+    loss = (hs[-1] ** 2).sum() + torch.stack(hs).mean()
+    grads = torch.autograd.grad(loss, leaves)
+    want = [loss.detach()] + [gr.detach() for gr in grads]
+    tol = 2e-4 if dt == torch.float32 else 1e-9
+    for use_graph in (False, True):
+        ex = PlanExecutor(_plan(name), use_graph=use_graph)
+        for _ in range(2):
+            got = ex(x, h0, *Ws)
+        assert len(got) == len(want)
+        for k, (gv, wv) in enumerate(zip(got, want)):
+            err = ((gv.double() - wv).abs().max() / wv.abs().max().clamp_min(1e-30)).item()
+            assert gv.shape == wv.shape and err <= tol, (use_graph, k, err)
+        if B == 1:
+            # vector state: the forward Scan AND the gradient Scan (mit-mot [0, 1] -> [1], gate
+            # recomputation hoisted over the whole sequence) run as one persistent kernel each
+            assert list(ex.scan_modes.values()) == ["persistent", "persistent"], ex.scan_modes
