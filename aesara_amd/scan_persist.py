@@ -35,10 +35,10 @@ import os
 
 from . import codegen as cg
 
-SP_MAXMAT = 8
-SP_MAXSEQ = 12
+SP_MAXMAT = 12
+SP_MAXSEQ = 28
 SP_MAXNSQ = 12
-SP_MAXOUT = 8
+SP_MAXOUT = 16
 SPIN_LIMIT = 1 << 21
 LDS_BUDGET = 156 * 1024
 
@@ -261,7 +261,7 @@ class Spec:
 
     def key(self):
         pr = self.prog
-        blob = json.dumps(["sp6", self.dtype, sorted(self.var.items()), sorted(self.place.items()), self.M, sorted(self.Ks.items()), sorted(self.lens.items()),
+        blob = json.dumps(["sp7", self.dtype, sorted(self.var.items()), sorted(self.place.items()), self.M, sorted(self.Ks.items()), sorted(self.lens.items()),
                            self.R, self.nw, sorted(pr.seq.items()), sorted(pr.state.items()),
                            sorted(pr.nsq.items()), sorted(pr.mats.items()),
                            [[ph["dots"], ph["ins"], ph["outs"], ph["scalar"], ph["out_refs"]]

@@ -1011,6 +1011,32 @@ def _gru_bptt(dt, T_, H, B_):
     return mk
 
 
+@case("lstm_bptt_vec_f32", rtol=3e-4, atol=3e-5)
+def _():
+    """LSTM with a vector state under aesara.grad (two recurrent states -> two mit-mot groups in
+    the gradient Scan), separate weight matrices per gate, loss on the last hidden state."""
+    x, h0, c0 = at.fmatrix("x"), at.fvector("h0"), at.fvector("c0")
+    names = ("Wi", "Ui", "Wf", "Uf", "Wo", "Uo", "Wg", "Ug")
+    Ws = [at.fmatrix(n) for n in names]
+    bf = at.fvector("bf")
+
+    def step(x_t, h, c, Wi, Ui, Wf, Uf, Wo, Uo, Wg, Ug, bf):
+        i = at.sigmoid(at.dot(x_t, Wi) + at.dot(h, Ui))
+        f = at.sigmoid(at.dot(x_t, Wf) + at.dot(h, Uf) + bf)
+        o = at.sigmoid(at.dot(x_t, Wo) + at.dot(h, Uo))
+        g = at.tanh(at.dot(x_t, Wg) + at.dot(h, Ug))
+        c2 = f * c + i * g
+        return o * at.tanh(c2), c2
+    (hs, cs), _ = ae.scan(step, sequences=[x], outputs_info=[h0, c0], non_sequences=Ws + [bf])
+    loss = (hs[-1] ** 2).sum() + cs.mean()
+    grads = ae.grad(loss, Ws + [bf, h0])
+    D, H = 12, 16
+    return [x, h0, c0] + Ws + [bf], [loss] + grads, \
+        [N((9, D), "float32", 4, 0.5), N((H,), "float32", 3, 0.5), N((H,), "float32", 2, 0.5)] + \
+        [N((D if k % 2 == 0 else H, H), "float32", 5 + k, 1.0 / np.sqrt(D if k % 2 == 0 else H))
+         for k in range(8)] + [N((H,), "float32", 20, 0.2)]
+
+
 case("gru_bptt_b1_f32", rtol=2e-4, atol=2e-5)(_gru_bptt("float32", 12, 20, 1))
 case("gru_bptt_b4_f64", rtol=1e-9, atol=1e-10)(_gru_bptt("float64", 9, 12, 4))
 case("cfg4_gru_b1_f32", rtol=1e-5, atol=1e-5)(_gru("float32", 32, 64, 1, 1e-5))

@@ -322,3 +322,27 @@ def test_varying_chunk_lengths_share_one_exchange_workspace(batch):
         else:
             assert torch.equal(cat, whole), rep
     assert set(ex.scan_modes.values()) == {"persistent"}, ex.scan_modes
+
+
+@pytest.mark.parametrize("name", ["gru_bptt_b1_f32", "lstm_bptt_vec_f32", "scan_grad_last_state_f32"])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_gradient_scans_run_persistent_and_match(name, use_graph):
+    """aesara.grad through a recurrence: the forward Scan and the gradient Scan (mit-mot groups
+    [0, 1] -> [1] for every propagated state; the gate recomputation from stored states lifted
+    out of the step as whole-sequence Elemwise kernels and GEMMs) both take the one-kernel loop;
+    loss and gradients against the reference's outputs, and against the launch-list path."""
+    from aesara_amd import executor as E
+    c = _case(name)
+    ex = E.PlanExecutor(case_plan(c), use_graph=use_graph)
+    ins = case_inputs(c)
+    for it in range(3):
+        got = _np(ex(*ins))
+        assert_matches(c, got, case_expected(c), f"persistent gradient call {it}")
+    assert set(ex.scan_modes.values()) == {"persistent"} and len(ex.scan_modes) == 2, ex.scan_modes
+    E.TUNE["scan_persist"] = 0
+    try:
+        ref = _np(E.PlanExecutor(case_plan(c))(*ins))
+    finally:
+        E.TUNE["scan_persist"] = 1
+    for g, r in zip(got, ref):
+        np.testing.assert_allclose(g, r, rtol=2e-4, atol=2e-5)
