@@ -297,6 +297,91 @@ def split_invariant(plan: Plan, invariant_inputs: List[int]):
     return pre, loop, hoisted
 
 
+def _prune_dead(plan: Plan, keep: List[Node]) -> List[Node]:
+    pure = {"AllocEmpty", "Shape_i", "Shape", "DimShuffle", "Elemwise", "ScalarFromTensor",
+            "TensorFromScalar", "MakeVector", "Alloc", "ViewOp"}
+    while True:
+        read = {i for n in keep for i in n.inputs} | set(plan.outputs)
+        dead = [n for n in keep if n.op in pure and not any(o in read for o in n.outputs)]
+        if not dead:
+            return keep
+        dead_ids = {id(n) for n in dead}
+        keep = [n for n in keep if id(n) not in dead_ids]
+
+
+def _hoist_sequence_only_stacked(plan: Plan, seq_inputs: List[int], invariant: set):
+    """The matrix-state class of :func:`hoist_sequence_only` (a batch of recurrences: per-step
+    values are ``[B, n]`` matrices).  The steps are stacked along the rows — a sequence ``[T, B, n]``
+    is read as ``[T * B, n]`` — so the hoisted nodes run unchanged on the stacked operands:
+    ``Elemwise`` (invariant operands must broadcast along the rows: static leading extent 1),
+    ``Dot22`` / ``Dot22Scalar`` / ``Gemm`` with an invariant right-hand matrix.  ``lifted["stacked"]``
+    tells the executor to fold / unfold the two leading axes."""
+    V = plan.vars
+    floats = ("float32", "float64")
+
+    def is_const_scalar(vid):
+        v = V[vid]
+        return v.const is not None and len(v.const.get("data", ())) == 1
+
+    Q = {v for v in seq_inputs if V[v].ndim == 2 and V[v].dtype in floats}
+    seq_set = set(seq_inputs)
+    hoisted, keep = [], []
+    for n in plan.nodes:
+        ok = False
+        if n.op == "Elemwise" and n.inputs and any(i in Q for i in n.inputs):
+            ok = all(i in Q or ((i in invariant or V[i].const is not None) and V[i].ndim == 2
+                                and V[i].shape[0] == 1) for i in n.inputs) and \
+                all(V[o].ndim == 2 and V[o].dtype in floats for o in n.outputs)
+        elif n.op in ("Dot22", "Dot") and len(n.inputs) == 2:
+            a, b = n.inputs
+            ok = a in Q and b in invariant and V[b].ndim == 2 and V[n.outputs[0]].dtype in floats
+        elif n.op == "Dot22Scalar":
+            a, b, sc = n.inputs
+            ok = a in Q and b in invariant and V[b].ndim == 2 and is_const_scalar(sc)
+        elif n.op == "Gemm":
+            z, al, a, b, be = n.inputs
+            ok = z in Q and a in Q and b in invariant and V[b].ndim == 2 and \
+                is_const_scalar(al) and is_const_scalar(be)
+        if ok:
+            hoisted.append(n)
+            Q.update(n.outputs)
+        else:
+            keep.append(n)
+    used_later = {i for n in keep for i in n.inputs} | set(plan.outputs)
+    outs = [o for n in hoisted for o in n.outputs if o in used_later]
+    if not outs:
+        return plan, None
+    need, live = set(outs), []
+    for n in reversed(hoisted):
+        if any(o in need for o in n.outputs):
+            live.append(n)
+            need.update(n.inputs)
+    live.reverse()
+    live_ids = {id(n) for n in live}
+    keep = _prune_dead(plan, [n for n in plan.nodes if id(n) not in live_ids])
+    lp = Plan(plan.name + "_allsteps", {}, [], [], [])
+    m, seq_in, inv_in = {}, [], []
+
+    def var(v):
+        if v not in m:
+            src = V[v]
+            m[v] = lp.new_var(src.dtype, list(src.shape), src.name, src.const)
+            if src.const is None:
+                if v in seq_set:
+                    seq_in.append(v)
+                elif v in invariant:
+                    inv_in.append(v)
+        return m[v]
+
+    for n in live:
+        lp.nodes.append(Node("Dot22" if n.op == "Dot" else n.op, [var(i) for i in n.inputs],
+                             [var(o) for o in n.outputs], dict(n.params)))
+    lp.inputs = [m[v] for v in seq_in] + [m[v] for v in inv_in]
+    lp.outputs = [m[o] for o in outs]
+    loop = Plan(plan.name + "_seqonly", plan.vars, list(plan.inputs) + outs, list(plan.outputs), keep)
+    return loop, {"plan": lp, "seq_in": seq_in, "inv_in": inv_in, "outs": outs, "stacked": True}
+
+
 def hoist_sequence_only(plan: Plan, seq_inputs: List[int], invariant: set):
     """Everything in a Scan step that depends only on *sequence* rows and loop invariants does not
     take part in the recurrence: it is computed for ALL steps before the loop and the step reads
@@ -321,6 +406,8 @@ def hoist_sequence_only(plan: Plan, seq_inputs: List[int], invariant: set):
 
     Q = {v for v in seq_inputs if V[v].ndim == 1 and V[v].dtype in floats}
     seq_set = set(seq_inputs)
+    if not Q and any(V[v].ndim == 2 and V[v].dtype in floats for v in seq_inputs):
+        return _hoist_sequence_only_stacked(plan, seq_inputs, invariant)
     hoisted, keep = [], []
     for n in plan.nodes:
         ok = False
