@@ -94,9 +94,23 @@ class Program:
         self.new_of_state = {}      # state var -> var holding its new value
         self.tap_seq = {}           # mit-mot tap-1 var -> recurrent output whose buffer holds its rows
         self.passthru = {}          # nit-sot output index -> sequence var it hands out unchanged
+        self.passthru_t = set()     # inner output vars that are such a sequence TRANSPOSED per step
+        self.passthru_tj = set()    # ... as nit-sot output indices
         self.exchanged = []         # produced vars that some dot needs in full
         self.mode = "vec"
         self.dtype = "float32"
+
+
+class _DotPhase:
+    """Stand-in step for a plain ``Dot22(operand, invariant matrix)`` node of a matrix-state loop."""
+    kind, reduce, post, fallback, extra = "gemm_epi", None, (), (), {}
+
+    def __init__(self, operand, weight, out):
+        self.dots = [[operand, weight]]
+        self.inputs, self.outputs = [], [out]
+        self.scalar = {"n_in": 1, "nodes": [], "out": [["i", 0]]}
+        self.out_refs = [0]
+        self.node = None
 
 
 def analyze(inner, p, n_seqdots):
@@ -144,13 +158,13 @@ def analyze(inner, p, n_seqdots):
     produced = {}
     # "vec": Gemv chains on vectors (state h[M]); "mat": small-M GEMM chains on a matrix state
     # (h[B, N], batch of independent recurrences sharing the weights)
-    pr.mode = "mat" if any(st.kind == "gemm_epi" for st in inner.steps) else "vec"
+    pr.mode = "mat" if any(st.kind == "gemm_epi" or (st.kind == "node" and st.node.op in ("Dot22", "Dot")
+                                                    and plan.vars[st.outputs[0]].ndim == 2)
+                           for st in inner.steps) else "vec"
     # one floating dtype throughout (the state's): float32 always, float64 for the vector class
     pr.dtype = plan.vars[plan.outputs[0]].dtype
     if pr.dtype not in (("float32",) if pr.mode == "mat" else ("float32", "float64")):
         return None, "state dtype %s" % pr.dtype
-    if n_mm and pr.mode == "mat":
-        return None, "mit-mot with a matrix state"
     nd = 2 if pr.mode == "mat" else 1
     ok_kinds = ("gemm_epi", "elemwise") if pr.mode == "mat" else ("gemv_epi", "elemwise")
     alias = {}
@@ -174,6 +188,18 @@ def analyze(inner, p, n_seqdots):
         if st.kind == "node" and st.node.op in ("SpecifyShape", "ViewOp"):
             alias[st.outputs[0]] = st.inputs[0]      # value-preserving views: same vector / matrix
             continue
+        if st.kind == "node" and st.node.op == "DimShuffle" and pr.mode == "mat" and \
+                st.node.params["new_order"] == [1, 0] and st.inputs[0] in pr.seq and \
+                st.inputs[0] not in pr.tap_seq and not readers.get(st.outputs[0]) and \
+                st.outputs[0] in plan.outputs:
+            pr.passthru_t.add(st.outputs[0])         # a sequence-only matrix handed out transposed
+            alias[st.outputs[0]] = st.inputs[0]
+            continue
+        if st.kind == "node" and st.node.op in ("Dot22", "Dot") and pr.mode == "mat" and \
+                len(st.inputs) == 2 and st.inputs[1] in inv_set:
+            # a product that feeds several Elemwise steps (no single epilogue to fuse with): a
+            # phase whose "epilogue" hands the dot through
+            st = _DotPhase(st.inputs[0], st.inputs[1], st.outputs[0])
         if st.kind == "node" and st.node.op == "DimShuffle" and pr.mode == "vec" and \
                 [d for d in st.node.params["new_order"] if d != "x"] == [0] and \
                 plan.vars[st.inputs[0]].ndim == 1 and not readers.get(st.outputs[0]) and \
@@ -224,6 +250,8 @@ def analyze(inner, p, n_seqdots):
         if res(o) not in produced:
             if j >= n_rec and res(o) in pr.seq and res(o) not in pr.tap_seq:
                 pr.passthru[j] = res(o)      # a nit-sot output that is a row of a sequence
+                if o in pr.passthru_t:
+                    pr.passthru_tj.add(j)
                 continue
             return None, "a step output is not computed by a fused step"
         pr.outs.append((res(o), "rec" if j < n_rec else "nit", j))

@@ -34,9 +34,9 @@ from . import codegen as cg
 from .scan_persist import SPIN_LIMIT
 
 SM_MAXMAT = 8
-SM_MAXSEQ = 12
+SM_MAXSEQ = 28
 SM_MAXNSQ = 8
-SM_MAXOUT = 8
+SM_MAXOUT = 16
 
 
 class SmArgs(C.Structure):
@@ -88,10 +88,11 @@ class SpecMat:
 
     def key(self):
         pr = self.prog
-        blob = json.dumps(["sm4", self.chunk, self.xmode, self.B, self.N, sorted(self.Ks.items()), sorted(pr.seq.items()),
+        blob = json.dumps(["sm5", self.chunk, self.xmode, self.B, self.N, sorted(self.Ks.items()), sorted(pr.seq.items()),
                            sorted(pr.state.items()), sorted(pr.nsq.items()), sorted(pr.mats.items()),
                            [[ph["dots"], ph["ins"], ph["outs"], ph["scalar"], ph["out_refs"]]
-                            for ph in pr.phases], pr.outs, pr.exchanged], sort_keys=True)
+                            for ph in pr.phases], pr.outs, pr.exchanged, sorted(pr.tap_seq.items())],
+                          sort_keys=True)
         return hashlib.sha256(blob.encode()).hexdigest()[:24]
 
 
@@ -114,6 +115,36 @@ def xch_layout(prog, NB, N, xmode="flag"):
     return off, total
 
 
+def stage_slots(prog, Ks):
+    """LDS images of the staged operand blocks (16 x (K + 4) floats each): {(var, kind): (float
+    offset, K)} and the total.  A block whose last product lies before another block's first one
+    lends it its space (a gradient step stages three operands, two at a time)."""
+    first, last, order = {}, {}, []
+    for pi, ph in enumerate(prog.phases):
+        for a_, x in ph["dots"]:
+            key = (x, "prev" if x in prog.state else "cur")
+            if key not in first:
+                first[key] = pi
+                order.append((key, Ks[a_]))
+            last[key] = pi
+    stage, free, stot = {}, [], 0
+    live = []                                   # (last phase, offset, K)
+    for key, K in order:
+        for ent in [e for e in live if e[0] < first[key]]:
+            live.remove(ent)
+            free.append((ent[1], ent[2]))
+        slot = next((f for f in free if f[1] == K), None)
+        if slot is not None and key[1] == "cur":
+            free.remove(slot)
+            off = slot[0]
+        else:
+            off = stot
+            stot += 16 * (K + 4)
+        stage[key] = (off, K)
+        live.append((last[key], off, K))
+    return stage, stot
+
+
 def generate(spec: SpecMat):
     pr, B, N, NB, NJ = spec.prog, spec.B, spec.N, spec.NB, spec.NJ
     name = "sm_" + spec.key()
@@ -123,14 +154,7 @@ def generate(spec: SpecMat):
     FLAG = spec.xmode == "flag"
 
     # staged operand blocks (LDS images, pitch K + 4 floats)
-    stage, stot = {}, 0
-    for ph in pr.phases:
-        for a_, x in ph["dots"]:
-            K = spec.Ks[a_]
-            kind = "prev" if x in pr.state else "cur"
-            if (x, kind) not in stage:
-                stage[(x, kind)] = (stot, K)
-                stot += 16 * (K + 4)
+    stage, stot = stage_slots(pr, spec.Ks)
     ndots_max = max(len(ph["dots"]) for ph in pr.phases)
     L.append('extern "C" __global__ __launch_bounds__(256) void %s(SmArgs a) {' % name)
     L.append("  __shared__ __attribute__((aligned(16))) float Hl[%d];" % max(stot, 4))
@@ -218,9 +242,11 @@ def generate(spec: SpecMat):
             kind = "prev" if x in pr.state else "cur"
             if (x, kind) in staged_this_step:
                 continue
+            so, K = stage[(x, kind)]
+            # a block staged into a lent slot replaces whatever lived there
+            staged_this_step -= {q for q in staged_this_step if stage[q][0] == so}
             staged_this_step.add((x, kind))
             newly.append((x, kind))
-            so, K = stage[(x, kind)]
             P = K + 4
             per_thread = 16 * K // 256          # granules per thread (K % 64 == 0)
             nchunk = max(1, per_thread // spec.chunk)
