@@ -225,6 +225,7 @@ def generate(spec: SpecMat):
         L.append("      for (int i = 0; i < 4; ++i) part[%d][wave][(4 * grp + i) * 16 + r16] = acc[i];" % d)
         L.append("    }")
 
+    pending_pub = []
     for pi, ph in enumerate(pr.phases):
         L.append("    // ---- phase %d" % pi)
         early, late = [], []
@@ -238,6 +239,66 @@ def generate(spec: SpecMat):
         for d, a_, x in early:
             emit_mfma(pi, d, a_, x)
         newly = []
+        fresh = []
+        for d, a_, x in late:
+            kind = "prev" if x in pr.state else "cur"
+            if (x, kind) not in staged_this_step and (x, kind) not in fresh:
+                fresh.append((x, kind))
+        if FLAG and len(fresh) >= 2 and all(k_ == "cur" for _x, k_ in fresh):
+            # several operands published by the same epilogue (the two last-phase products of a
+            # gradient step): ONE polling pass over all their tags, all bulk loads in flight
+            # together, then per operand  LDS image -> barrier -> its products, so the MFMAs of
+            # the first hide the arrival of the second
+            for x, kind in fresh:
+                so = stage[(x, kind)][0]
+                staged_this_step -= {q for q in staged_this_step if stage[q][0] == so}
+                staged_this_step.add((x, kind))
+            ind = "    "
+            L.append(ind + "const unsigned long long want64_p%d = (unsigned long long)(base + (unsigned)t + 1u);" % pi)
+            L.append(ind + "if (wave == 0) {")
+            L.append(ind + "  for (int spin = 0;; ++spin) {")
+            L.append(ind + "    bool ok = true;")
+            for x, kind in fresh:
+                po_, lpp, fo_, lpf = xoff[pr.new_of_state.get(x, x)]
+                L.append(ind + "    for (int j = lane; j < %d; j += 64) ok = ok && (__hip_atomic_load("
+                         "a.xch + %d + (t & 3) * %d + (i64)bi * %d + j, %s) == want64_p%d);"
+                         % (NJ, fo_, lpf, NJ, AG, pi))
+            L.append(ind + "    if (__all(ok)) break;")
+            L.append(ind + "    if (spin > %d || ((spin & 255) == 255 && __hip_atomic_load(errp, %s) != 0u)) "
+                     "{ __hip_atomic_store(errp, 1u, %s); break; }" % (SPIN_LIMIT, AG, AG))
+            L.append(ind + "    __builtin_amdgcn_s_sleep(1);")
+            L.append(ind + "  }")
+            L.append(ind + "}")
+            L.append(ind + "__syncthreads();")
+            for q, (x, kind) in enumerate(fresh):
+                so, K = stage[(x, kind)]
+                po_, lpp, fo_, lpf = xoff[pr.new_of_state.get(x, x)]
+                PT = 16 * K // 2 // 256
+                L.append(ind + "const u64* src%d_%d = a.xch + %d + (t & 3) * %d + (i64)bi * %d;"
+                         % (pi, q, po_, lpp, 16 * K // 2))
+                L.append(ind + "u64 g%d_%d[%d];" % (pi, q, PT))
+                for u in range(PT):
+                    L.append(ind + "{ const int idx = %d * 256 + tid; g%d_%d[%d] = (idx / %d < vrows) ? "
+                             "__hip_atomic_load(src%d_%d + idx, %s) : 0ull; }" % (u, pi, q, u, K // 2, pi, q, AG))
+            done = set()
+            for q, (x, kind) in enumerate(fresh):
+                so, K = stage[(x, kind)]
+                P = K + 4
+                PT = 16 * K // 2 // 256
+                for u in range(PT):
+                    L.append(ind + "{ const int idx = %d * 256 + tid; "
+                             "*(u64*)(Hl + %d + (idx / %d) * %d + 2 * (idx %% %d)) = g%d_%d[%d]; }"
+                             % (u, so, K // 2, P, K // 2, pi, q, u))
+                L.append(ind + "__syncthreads();")
+                for d, a_, x2 in late:
+                    if x2 == x and d not in done:
+                        done.add(d)
+                        emit_mfma(pi, d, a_, x2)
+            for d, a_, x2 in late:
+                if d not in done:
+                    emit_mfma(pi, d, a_, x2)
+            late = []
+            newly = list(fresh)
         for d, a_, x in late:
             kind = "prev" if x in pr.state else "cur"
             if (x, kind) in staged_this_step:
@@ -318,12 +379,13 @@ def generate(spec: SpecMat):
                          % (cl, u, so, K, P, K, u))
             L.append(ind + "}")
             L.append("    }")
-        if newly or not early:
-            L.append("    __syncthreads();")
-        for d, a_, x in late:
-            emit_mfma(pi, d, a_, x)
-        L.append("    __syncthreads();")
         D = len(ph["dots"])
+        if D:
+            if newly or not early:
+                L.append("    __syncthreads();")
+            for d, a_, x in late:
+                emit_mfma(pi, d, a_, x)
+            L.append("    __syncthreads();")
         for d in range(D):
             L.append("    const float dot_%d_%d = part[%d][0][tid] + part[%d][1][tid] + part[%d][2][tid] + part[%d][3][tid];"
                      % (pi, d, d, d, d, d))
@@ -344,7 +406,14 @@ def generate(spec: SpecMat):
                          "eb * a.out_rs[%d] + en] = own_%d;" % (j, j, j, j, j, o))
         L.append("    }")
         if FLAG:
-            pub = [o for o in ph["outs"] if o in xoff]
+            # Elemwise-only phases run back to back in the element owner's registers: what they
+            # have to publish goes out with ONE store-acknowledge wait and barrier, right before
+            # the next phase that stages an operand (or at the end of the step)
+            pending_pub.extend(o for o in ph["outs"] if o in xoff)
+            nxt_has_dots = pi + 1 < len(pr.phases) and bool(pr.phases[pi + 1]["dots"])
+            pub = pending_pub if (nxt_has_dots or pi + 1 == len(pr.phases)) else []
+            if pub:
+                pending_pub = []
             for o in pub:
                 po_, lpp, fo_, lpf = xoff[o]
                 L.append("    { const float nb_ = __shfl_down(own_%d, 1, 64);" % o)
