@@ -343,18 +343,21 @@ def sec_cfg1b(c):
             "roofline": roof("hbm", 3 * 4096 * 4096 * 8, d, HBM_PEAK_GBS), "check": {"exact": True}}
 
 
-def _gru_ref(torch, x, h0, Ws):
+def _gru_ref(torch, x, h0, Ws, all_steps=False):
     """fp64 restatement of the GRU step of tests/golden cfg4 (oracle/gen_golden.py), all T steps."""
     Wz, Uz, Wr, Ur, Wh, Uh = [W.double() for W in Ws]
     h = h0.double()
     xd = x.double()
     xz, xr, xh = xd @ Wz, xd @ Wr, xd @ Wh
+    hs = []
     for t in range(x.shape[0]):
         z = torch.sigmoid(xz[t] + h @ Uz)
         r = torch.sigmoid(xr[t] + h @ Ur)
         hh = torch.tanh(xh[t] + (r * h) @ Uh)
         h = (1 - z) * h + z * hh
-    return h
+        if all_steps:
+            hs.append(h)
+    return torch.stack(hs) if all_steps else h
 
 
 def sec_cfg4(c):
@@ -389,6 +392,33 @@ def sec_cfg4(c):
         rows.append({"config": "cfg4 Scan GRU T=512 H=1024 fp32 B=%d" % B, "dtype": "f32",
                      "evals_per_s": 1e3 / max(d, w), "first_call_s": first, "scan_path": kind,
                      "roofline": rl, "check": {"hT_max_rel_err_vs_fp64_all_steps": err, "bar": 1e-5}})
+        del ex
+    # the same recurrence under aesara.grad (not a BASELINE config, reported next to
+    # config 4 because it is the Scan gradient path on the same kernels): loss + 7 gradients
+    for B, case in ((1, "gru_bptt_b1_f32"), (64, "gru_bptt_b4_f32")):
+        ex = c["PlanExecutor"](c["plan_of"](case), use_graph=c["G"], borrow=True)
+        shp = (T, H) if B == 1 else (T, B, H)
+        x = c["randn"](shp, f32, 4) * 0.1
+        h0 = torch.zeros((H,) if B == 1 else (B, H), dtype=f32, device="cuda")
+        outs = ex(x, h0, *Ws)
+        hs = _gru_ref(torch, x, h0, Ws, all_steps=True)
+        ref = ((hs[-1] ** 2).sum() + hs.mean()).item()
+        err = abs(outs[0].item() - ref) / abs(ref)
+        assert err <= 1e-4, f"cfg4 training step B={B}: loss rel err {err}"
+        d, w = c["timer"].time(lambda: ex(x, h0, *Ws), 5, warmup=1)
+        rows.append({"config": "cfg4 + aesara.grad: GRU training step T=512 H=1024 fp32 B=%d "
+                               "(loss + 7 gradients; extra, not a BASELINE config)" % B,
+                     "dtype": "f32", "evals_per_s": 1e3 / max(d, w), "ms_per_eval": d,
+                     "scan_path": getattr(ex, "scan_modes", None),
+                     "roofline": (roof("mfma", 3 * T * 6 * 2 * B * H * H, d, MFMA_F32_PEAK,
+                                       us_per_step=d * 1e3 / T,
+                                       note="flops = forward + gate recomputation + backward / weight-"
+                                            "gradient products (3 x the forward count)") if B > 1 else
+                                  roof("hbm", 3 * T * 6 * H * H * 4, d, HBM_PEAK_GBS, us_per_step=d * 1e3 / T,
+                                       note="algorithmic = the matrices of forward, recomputation and "
+                                            "backward re-streamed every step (3 x config 4's bound)")),
+                     "check": {"loss_rel_err_vs_fp64": err, "bar": 1e-4,
+                               "gradients": "tests/test_gpu_fullsize.py::test_gru_bptt_against_torch_autograd"}})
         del ex
     return rows
 
