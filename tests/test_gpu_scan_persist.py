@@ -244,7 +244,11 @@ def test_stateful_chunks_feed_the_last_state_back(borrow, batch):
 @pytest.mark.parametrize("name,dims", [("sp_lstm_vec_f32", {17: "T", 20: "D", 48: "H"}),
                                         ("sp_rnn_proj_f32", {19: "T", 12: "D", 32: "H"}),
                                         ("sp_gru_last_f32", {21: "T", 52: "H"}),
-                                        ("gru_b1_f64", None)])
+                                        ("gru_b1_f64", None),
+                                        ("gru_bptt_b1_f32", {12: "T", 20: "H"}),
+                                        ("lstm_bptt_vec_f32", {9: "T", 12: "D", 16: "H"}),
+                                        ("gru_bptt_b4_f32", {10: "T", 4: "B", 16: "H"}),
+                                        ("cfg4_gru_b8_f32", {16: "T", 8: "B", 64: "H"})])
 def test_persistent_scans_on_random_extents(name, dims):
     """The golden recurrences (LSTM with two states, RNN with a per-step projection output, GRU
     that returns only the last state, float64 GRU) at random extents — ragged state sizes (12,
@@ -260,8 +264,10 @@ def test_persistent_scans_on_random_extents(name, dims):
     rng = np.random.default_rng(31)
     f64 = name.endswith("f64")
     for trial in range(10):
+        batched = "B" in dims.values()
         val = {"T": int(rng.choice([1, 2, 3, 9, 30])), "D": int(rng.choice([4, 7, 36, 72])),
-               "H": int(rng.choice([4, 12, 31, 68, 100, 260, 384, 516]))}
+               "H": int(rng.choice([64, 100, 128, 320] if batched else [4, 12, 31, 68, 100, 260, 384, 516])),
+               "B": int(rng.choice([1, 5, 16, 40]))}
         ins = []
         for a in base:
             shp = tuple(val[dims[n]] for n in a.shape)
@@ -273,16 +279,18 @@ def test_persistent_scans_on_random_extents(name, dims):
             got = _np(ex(*dev))
         # weight rows are read as 16-byte vectors: contraction lengths that are not a multiple of
         # 4 (float32) / 2 (float64) elements stay on the launch list (and must still be right)
-        vec_ok = all(val[k] % (2 if f64 else 4) == 0 for k in set(dims.values()) - {"T"})
+        vec_ok = all(val[k] % (2 if f64 else 4) == 0 for k in set(dims.values()) - {"T", "B"})
+        if batched:       # matrix state: weights in MFMA layout (K % 64 = 0), one 16 x 16 tile per CU
+            vec_ok = val["H"] % 64 == 0 and -(-val["B"] // 16) * (val["H"] // 16) <= 256
         if vec_ok and val["T"] >= 2:
-            assert list(ex.scan_modes.values()) == ["persistent"], (val, ex.scan_modes)
+            assert set(ex.scan_modes.values()) == {"persistent"}, (val, ex.scan_modes)
         ex.check()
         E.TUNE["scan_persist"] = 0
         try:
             ref = _np(E.PlanExecutor(case_plan(c))(*dev))
         finally:
             E.TUNE["scan_persist"] = 1
-        tol = 1e-11 if f64 else 3e-5
+        tol = 1e-11 if f64 else (3e-4 if "bptt" in name else 3e-5)
         for g, r in zip(got, ref):
             assert g.shape == r.shape, (val, g.shape, r.shape)
             np.testing.assert_allclose(g, r, rtol=tol, atol=tol * max(1.0, float(np.abs(r).max(initial=0))),
