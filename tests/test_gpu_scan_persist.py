@@ -354,3 +354,36 @@ def test_gradient_scans_run_persistent_and_match(name, use_graph):
         E.TUNE["scan_persist"] = 1
     for g, r in zip(got, ref):
         np.testing.assert_allclose(g, r, rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("batch", [0, 16])
+def test_sgd_loop_over_bptt_plan_replay_equals_eager(batch):
+    """Five SGD steps on the GRU weights through the loss-and-gradients plan: every call gets NEW
+    weight tensors (the replayed launch lists — two persistent kernels, whole-sequence GEMMs —
+    are rebound to them); the loss trajectory and the final weights of the replayed executor
+    equal the eager executor's to fp32 round-off."""
+    import torch
+    from aesara_amd.executor import PlanExecutor
+    T, H = 24, 128
+    name = "gru_bptt_b4_f32" if batch else "gru_bptt_b1_f32"
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    shp = (T, batch, H) if batch else (T, H)
+    x = torch.randn(*shp, device="cuda", generator=g) * 0.3
+    h0 = torch.randn(*shp[1:], device="cuda", generator=g) * 0.5
+    W0 = [torch.randn(H, H, device="cuda", generator=g) / np.sqrt(H) for _ in range(6)]
+    traj = {}
+    for mode in (False, True):
+        ex = PlanExecutor(case_plan(_case(name)), use_graph=mode)
+        Ws, losses = [w.clone() for w in W0], []
+        for it in range(5):
+            outs = ex(x, h0, *Ws)
+            losses.append(outs[0].item())
+            Ws = [w - 0.05 * gw for w, gw in zip(Ws, outs[1:7])]     # new tensors every step
+        ex.check()
+        assert set(ex.scan_modes.values()) == {"persistent"}, ex.scan_modes
+        traj[mode] = (losses, Ws)
+    assert traj[False][0][-1] < traj[False][0][0]          # the loss goes down
+    np.testing.assert_allclose(traj[True][0], traj[False][0], rtol=2e-5)
+    for a, b in zip(traj[True][1], traj[False][1]):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
