@@ -443,15 +443,7 @@ def hoist_sequence_only(plan: Plan, seq_inputs: List[int], invariant: set):
 
     # what only fed the hoisted nodes (the AllocEmpty "y" of a beta = 0 Gemv and its shape
     # arithmetic) is dead in the loop now
-    pure = {"AllocEmpty", "Shape_i", "Shape", "DimShuffle", "Elemwise", "ScalarFromTensor",
-            "TensorFromScalar", "MakeVector", "Alloc", "ViewOp"}
-    while True:
-        read = {i for n in keep for i in n.inputs} | set(plan.outputs)
-        dead = [n for n in keep if n.op in pure and not any(o in read for o in n.outputs)]
-        if not dead:
-            break
-        dead_ids = {id(n) for n in dead}
-        keep = [n for n in keep if id(n) not in dead_ids]
+    keep = _prune_dead(plan, keep)
 
     lp = Plan(plan.name + "_allsteps", {}, [], [], [])
     m, seq_in, inv_in = {}, [], []
