@@ -248,3 +248,56 @@ def test_device_cell_checks_without_the_reference():
     ro = DeviceCell(PlainType("float32", (None,)), readonly=True, storage=[None])
     with pytest.raises(Exception):
         ro.value = torch.zeros(3)
+
+
+@pytest.mark.parametrize("name", ["gru_bptt_b1_f32", "gru_bptt_b4_f32", "lstm_bptt_vec_f32", "cfg4_gru_b1_f32"])
+def test_sequence_only_hoisting_preserves_the_step(name):
+    """fusion.hoist_sequence_only on the Scan inner plans of the golden recurrences and their
+    gradient Scans: the lifted plan evaluated ONCE over whole sequences plus the reduced step plan
+    must give, for every step, what the original step plan gives (all three through the oracle)."""
+    import interp
+    from golden_util import CASES, case_plan
+    from aesara_amd.fusion import hoist_sequence_only, split_invariant
+    plan = case_plan(next(c for c in CASES if c["name"] == name))
+    rng = np.random.default_rng(5)
+    T, B, H = 6, 3, 8
+    checked = 0
+    for node in plan.nodes:
+        if node.op != "Scan":
+            continue
+        p, inner = node.params, node.params["inner"]
+        n_seqs = p["n_seqs"]
+        n_var = len(inner.inputs) - p["n_non_seqs"]
+        pre, loop, hoisted = split_invariant(inner, inner.inputs[n_var:])
+        loop2, lifted = hoist_sequence_only(loop, list(loop.inputs[:n_seqs]), set(loop.inputs[n_var:]))
+        if lifted is None:
+            continue
+
+        def rand(v, lead=()):
+            shp = tuple((1 if s == 1 else (B if k == 0 and inner.vars[v].ndim == 2 and name.endswith("b4_f32") else H))
+                        for k, s in enumerate(inner.vars[v].shape))
+            return rng.standard_normal(lead + shp).astype(inner.vars[v].dtype)
+        seqs = [rand(v, (T,)) for v in inner.inputs[:n_seqs]]
+        taps = [rand(v) for v in inner.inputs[n_seqs:n_var]]
+        invs = [rand(v) for v in inner.inputs[n_var:]]
+        if name.endswith("b4_f32"):          # invariant matrices are H x H, not B x H
+            invs = [rng.standard_normal((H, H)).astype("float32") if a.ndim == 2 else a for a in invs]
+        hv = interp.run_plan(pre, invs) if pre is not None else []
+        inv_all = dict(zip(list(inner.inputs[n_var:]) + list(hoisted), invs + list(hv)))
+        stacked = lifted.get("stacked", False)
+        largs = []
+        for v in lifted["seq_in"]:
+            S = seqs[list(inner.inputs[:n_seqs]).index(v)]
+            largs.append(S.reshape(T * S.shape[1], S.shape[2]) if stacked else S)
+        largs += [inv_all[v] for v in lifted["inv_in"]]
+        rows = interp.run_plan(lifted["plan"], largs)
+        if stacked:
+            rows = [r.reshape(T, -1, r.shape[1]) for r in rows]
+        for t in range(T):
+            step_in = [s[t] for s in seqs] + taps + invs
+            want = interp.run_plan(inner, step_in)
+            got = interp.run_plan(loop2, step_in + list(hv) + [r[t] for r in rows])
+            for g, w in zip(got, want):
+                np.testing.assert_allclose(g, w, rtol=2e-5, atol=2e-6)
+        checked += 1
+    assert checked >= 1
