@@ -21,10 +21,11 @@ weight matrix from L2 / HBM on every step; here one launch runs all T steps:
   the next step) stays in registers: lane i of a wavefront owns one output row.
 
 Eligibility (anything else runs the launch-list path, and ``PlanExecutor.scan_modes`` says which
-was taken): no mit-mot / shared outputs / do-while, every recurrent output has the single tap -1,
-the fused inner steps are Gemv chains + Elemwise on float32 vectors of one length M, matrices are
-loop invariant and row-contiguous with K % 4 == 0, at least one exchanged vector, T >= 2, and the
-matrix rows of a workgroup fit in LDS.
+was taken): no shared outputs / do-while, every sit-sot output has the single tap -1, mit-mot
+groups only of the gradient form ([0, 1] -> [1], see ``analyze``), the fused inner steps are Gemv
+chains + Elemwise on float32 / float64 vectors of one length M, matrices are loop invariant (rows
+that are not whole 16-byte vectors are zero-padded by the executor), at least one exchanged
+vector, T >= 2, and the matrix rows of a workgroup fit on chip (LDS + VGPRs).
 """
 from __future__ import annotations
 
@@ -382,6 +383,13 @@ def generate(spec: Spec):
                  % (M, T, slot, slot, VEC))
         L.append("    *(TV*)(Wl + %d + j * %d + %d * k4) = v;" % (woff[av], K, VEC))
         L.append("  }")
+    if any(spec.lens.get(x, spec.Ks[a]) != spec.Ks[a] for ph in pr.phases for a, x in ph["dots"]):
+        # some contraction length is padded: the tails of the staged images must read as zeros
+        L.append("  for (int k = threadIdx.x; k < %d; k += %d) { Vl[0][k] = 0; Vl[1][k] = 0; }"
+                 % (max(stot, 4), BLOCK))
+        if itot:
+            L.append("  for (int k = threadIdx.x; k < %d; k += %d) Il[k] = 0;" % (itot, BLOCK))
+        L.append("  __syncthreads();")
     for x, off in inv_stage.items():
         K = spec.lens[x]
         L.append("  for (int k = threadIdx.x; k < %d; k += %d) Il[%d + k] = "
@@ -432,7 +440,9 @@ def generate(spec: Spec):
                 continue
             staged_this_step.add((x, kind))
             need_sync = True
-            K = spec.Ks[a_]
+            # the vector's TRUE length (the LDS image is Ks[a_] long: zero-padded to whole 16-byte
+            # vectors when the contraction length is not a multiple of them, see _scan_persist)
+            K = spec.lens[x]
             so = stage[(x, kind)]
             NG = (K + BLOCK - 1) // BLOCK
             if kind == "glob":

@@ -252,7 +252,7 @@ def test_stateful_chunks_feed_the_last_state_back(borrow, batch):
 def test_persistent_scans_on_random_extents(name, dims):
     """The golden recurrences (LSTM with two states, RNN with a per-step projection output, GRU
     that returns only the last state, float64 GRU) at random extents — ragged state sizes (12,
-    68, 100, 260, 516 ...), odd ones that fall outside the class (31, 7), single steps, inputs
+    68, 100, 260, 516 ...), odd ones whose weight rows are zero-padded (31, 7), single steps, inputs
     wider than the state: the one-kernel loop against the launch-list path (same arithmetic up to
     summation order)."""
     import torch
@@ -278,8 +278,8 @@ def test_persistent_scans_on_random_extents(name, dims):
         for _ in range(2):
             got = _np(ex(*dev))
         # weight rows are read as 16-byte vectors: contraction lengths that are not a multiple of
-        # 4 (float32) / 2 (float64) elements stay on the launch list (and must still be right)
-        vec_ok = all(val[k] % (2 if f64 else 4) == 0 for k in set(dims.values()) - {"T", "B"})
+        # 4 (float32) / 2 (float64) elements get zero-padded copies (still the one-kernel loop)
+        vec_ok = True
         if batched:       # matrix state: weights in MFMA layout (K % 64 = 0), one 16 x 16 tile per CU
             vec_ok = val["H"] % 64 == 0 and -(-val["B"] // 16) * (val["H"] // 16) <= 256
         if vec_ok and val["T"] >= 2:
