@@ -76,8 +76,12 @@ typedef unsigned long long u64;
 class SpecMat:
     """Shape-specialised kernel: B batch rows, N state columns, K per weight matrix."""
 
-    def __init__(self, prog, B, N, Ks):
+    def __init__(self, prog, B, N, Ks, Nt=None):
+        # N: state width the tiles cover (a multiple of 64); Nt: the true width (<= N) when the
+        # executor zero-padded the weights — columns Nt .. N-1 are never owned, never published
+        # (they read as the zeros the exchange buffer starts with) and hit zero weight rows
         self.prog, self.B, self.N, self.Ks = prog, B, N, dict(Ks)
+        self.Nt = N if Nt is None else Nt
         self.NB = -(-B // 16)
         self.NJ = N // 16
         # granule loads a thread keeps in flight per polling pass (2 VGPRs each)
@@ -88,7 +92,7 @@ class SpecMat:
 
     def key(self):
         pr = self.prog
-        blob = json.dumps(["sm5", self.chunk, self.xmode, self.B, self.N, sorted(self.Ks.items()), sorted(pr.seq.items()),
+        blob = json.dumps(["sm6", self.chunk, self.xmode, self.B, self.N, self.Nt, sorted(self.Ks.items()), sorted(pr.seq.items()),
                            sorted(pr.state.items()), sorted(pr.nsq.items()), sorted(pr.mats.items()),
                            [[ph["dots"], ph["ins"], ph["outs"], ph["scalar"], ph["out_refs"]]
                             for ph in pr.phases], pr.outs, pr.exchanged, sorted(pr.tap_seq.items())],
@@ -164,7 +168,7 @@ def generate(spec: SpecMat):
     L.append("  const int bi = blockIdx.x %% %d, nj = blockIdx.x / %d;" % (NB, NB))
     L.append("  const int erow = tid >> 4, ecol = tid & 15;        // tile element owned by this thread")
     L.append("  const i64 eb = (i64)bi * 16 + erow, en = (i64)nj * 16 + ecol;")
-    L.append("  const bool owner = eb < %d && en < %d;" % (B, N))
+    L.append("  const bool owner = eb < %d && en < %d;" % (B, spec.Nt))
     L.append("  const int vrows = (%d - bi * 16) < 16 ? (%d - bi * 16) : 16;   // valid rows of this batch block" % (B, B))
     L.append("  const unsigned base = __hip_atomic_load(a.ctl, %s);" % AG)
     L.append("  unsigned* errp = a.ctl + 1;")
@@ -320,8 +324,8 @@ def generate(spec: SpecMat):
                          "a.out_store[%d]) * a.out_ts[%d];" % (k_out, k_out, k_out, k_out, k_out))
                 L.append("      for (int idx = tid; idx < %d; idx += 256) {" % (16 * K))
                 L.append("        const int rr = idx / %d, cc = idx %% %d;" % (K, K))
-                L.append("        Hl[%d + rr * %d + cc] = rr < vrows ? ini[((i64)bi * 16 + rr) * a.out_rs[%d] + cc] : 0.f;"
-                         % (so, P, k_out))
+                L.append("        Hl[%d + rr * %d + cc] = (rr < vrows && cc < %d) ? ini[((i64)bi * 16 + rr) * a.out_rs[%d] + cc] : 0.f;"
+                         % (so, P, spec.Nt, k_out))
                 L.append("      }")
                 L.append("    } else {")
                 step_expr = "(t - 1)"
