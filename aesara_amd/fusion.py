@@ -297,6 +297,142 @@ def split_invariant(plan: Plan, invariant_inputs: List[int]):
     return pre, loop, hoisted
 
 
+def split_column_slices(plan: Plan, invariant: set) -> Plan:
+    """Fused-gate recurrences compute ONE product for all gates and slice it by columns::
+
+        pre = b + x_t @ Wx + h @ Wh          # [B, 4H]
+        i, f, o, g = pre[:, 0:H], pre[:, H:2H], ...
+
+    (the usual Theano / Aesara LSTM step).  Every consumer sees only its slice, so the chain is
+    split per slice with column views of the invariant operands — ``x_t @ Wx[:, kH:(k+1)H]`` … —
+    which leaves H-wide products with H-wide epilogues: the shape the sequence hoisting and the
+    persistent kernels work on.  Handles a chain of ``Dot22`` / ``Gemm`` (invariant right-hand
+    matrix) / ``Elemwise`` (chain operands and invariant rows ``[1, N]``) whose every value is
+    read only inside the chain or by ``Subtensor`` nodes ``[:, a:b]`` with constant bounds.
+    Returns the plan unchanged when nothing matches."""
+    V = plan.vars
+    clients = plan.clients()
+
+    def cint(vid):
+        v = V[vid]
+        if v.const is not None and len(v.const.get("data", ())) == 1 and v.dtype.startswith("int"):
+            return int(v.const["data"][0])
+        return None
+
+    def col_slice(n):
+        """(a, b) when node n is Subtensor [:, a:b] with constant bounds, else None"""
+        if n.op != "Subtensor" or V[n.inputs[0]].ndim != 2:
+            return None
+        idx = n.params["idx_list"]
+        if len(idx) != 2 or "slice" not in idx[0] or "slice" not in idx[1]:
+            return None
+        if idx[0]["slice"] != [None, None, None] or idx[1]["slice"][2] not in (None, 1):
+            return None
+        extra = list(n.inputs[1:])
+        ab = []
+        for e in idx[1]["slice"][:2]:
+            if e == "in":
+                c = cint(extra.pop(0)) if extra else None
+                if c is None:
+                    return None
+                ab.append(c)
+            elif isinstance(e, int):
+                ab.append(e)
+            else:
+                return None
+        return (ab[0], ab[1]) if 0 <= ab[0] < ab[1] else None
+
+    producer = {o: (ni, n) for ni, n in enumerate(plan.nodes) for o in n.outputs}
+
+    def chain_of(root):
+        """node indices of the chain ending in `root`, or None"""
+        chain, todo = set(), [root]
+        while todo:
+            v = todo.pop()
+            if v not in producer:
+                return None
+            ni, n = producer[v]
+            if ni in chain:
+                continue
+            if n.op in ("Dot22", "Dot") and len(n.inputs) == 2 and n.inputs[1] in invariant \
+                    and V[n.inputs[1]].ndim == 2 and V[n.outputs[0]].ndim == 2:
+                chain.add(ni)
+            elif n.op == "Gemm" and n.inputs[3] in invariant and V[n.inputs[3]].ndim == 2:
+                chain.add(ni)
+                todo.append(n.inputs[0])
+            elif n.op == "Elemwise" and len(n.outputs) == 1 and V[n.outputs[0]].ndim == 2:
+                chain.add(ni)
+                for i in n.inputs:
+                    if (i in invariant or V[i].const is not None) and V[i].ndim == 2 and V[i].shape[0] == 1:
+                        continue
+                    todo.append(i)
+            else:
+                return None
+        return chain
+
+    new_nodes, replaced, removed = {}, {}, set()
+    work = Plan(plan.name, dict(plan.vars), list(plan.inputs), list(plan.outputs), [])
+    for root, (rni, rn) in list(producer.items()):
+        cl = clients.get(root, [])
+        if not cl or any(c[0] == "out" for c in cl):
+            continue
+        slices = [col_slice(plan.nodes[c[0]]) if c[1] == 0 else None for c in cl]
+        if any(sl is None for sl in slices) or len(cl) < 2:
+            continue
+        chain = chain_of(root)
+        if not chain:
+            continue
+        chain_vars = {o for ni in chain for o in plan.nodes[ni].outputs}
+        ok = all(all(c[0] in chain or (v == root and col_slice(plan.nodes[c[0]]) is not None)
+                     for c in clients[v] if c[0] != "out") and
+                 not any(c[0] == "out" for c in clients[v]) for v in chain_vars)
+        if not ok or chain & removed:
+            continue
+        order = sorted(chain)
+        for (cni, _pos), (a, b) in zip(cl, slices):
+            m = {}
+
+            def inv_cols(v, a=a, b=b):
+                key = ("inv", v)
+                if key not in m:
+                    src = V[v]
+                    o = work.new_var(src.dtype, [src.shape[0], None])
+                    new_nodes.setdefault(cni, []).append(
+                        Node("Subtensor", [v], [o], {"idx_list": [{"slice": [None, None, None]},
+                                                                  {"slice": [a, b, None]}]}))
+                    m[key] = o
+                return m[key]
+            for ni in order:
+                n = plan.nodes[ni]
+                out = work.new_var(V[n.outputs[0]].dtype, [V[n.outputs[0]].shape[0], None])
+                if n.op in ("Dot22", "Dot"):
+                    nn = Node("Dot22", [n.inputs[0], inv_cols(n.inputs[1])], [out], {})
+                elif n.op == "Gemm":
+                    nn = Node("Gemm", [m[n.inputs[0]], n.inputs[1], n.inputs[2], inv_cols(n.inputs[3]),
+                                       n.inputs[4]], [out], dict(n.params))
+                else:
+                    nn = Node("Elemwise", [m[i] if i in m else inv_cols(i) for i in n.inputs], [out],
+                              copy.deepcopy(n.params))
+                m[n.outputs[0]] = out
+                new_nodes.setdefault(cni, []).append(nn)
+            replaced[plan.nodes[cni].outputs[0]] = m[root]
+            removed.add(cni)
+        removed |= chain
+    if not replaced:
+        return plan
+    nodes = []
+    for ni, n in enumerate(plan.nodes):
+        nodes.extend(new_nodes.get(ni, []))
+        if ni in removed:
+            continue
+        nodes.append(Node(n.op, [replaced.get(i, i) for i in n.inputs], list(n.outputs), n.params))
+    # the slice nodes' new values keep the old variable ids' consumers: rewrite the inserted nodes too
+    work.nodes = [Node(n.op, [replaced.get(i, i) for i in n.inputs], list(n.outputs), n.params) for n in nodes]
+    work.outputs = [replaced.get(o, o) for o in plan.outputs]
+    work.name = plan.name + "_cols"
+    return work
+
+
 def _prune_dead(plan: Plan, keep: List[Node]) -> List[Node]:
     pure = {"AllocEmpty", "Shape_i", "Shape", "DimShuffle", "Elemwise", "ScalarFromTensor",
             "TensorFromScalar", "MakeVector", "Alloc", "ViewOp"}

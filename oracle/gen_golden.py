@@ -1274,6 +1274,25 @@ for _dt, _tol in (("float64", 1e-10), ("float32", 5e-5)):
     case(f"lstm_bptt_{_dt}", rtol=_tol, atol=_tol)(_mklstm)
 
 
+@case("lstm_fused_fwd_f32", rtol=2e-5, atol=2e-5)
+def _():
+    """The usual fused-gate LSTM step (ONE product for the four gates, sliced by columns) as a
+    forward Scan with a matrix state, H = 64: all hidden states and the last cell state."""
+    H = 64
+    x, h0, c0 = at.ftensor3("x"), at.fmatrix("h0"), at.fmatrix("c0")
+    W, U_, b = at.fmatrix("W"), at.fmatrix("U"), at.fvector("b")
+
+    def step(x_t, h, c, W, U_, b):
+        g = at.dot(x_t, W) + at.dot(h, U_) + b
+        i, f, o, gg = (g[:, k * H:(k + 1) * H] for k in range(4))
+        c2 = at.sigmoid(f) * c + at.sigmoid(i) * at.tanh(gg)
+        return at.sigmoid(o) * at.tanh(c2), c2
+    (hs, cs), _ = ae.scan(step, sequences=[x], outputs_info=[h0, c0], non_sequences=[W, U_, b])
+    return [x, h0, c0, W, U_, b], [hs, cs[-1]], \
+        [N((6, 3, 20), "float32", 1, 0.5), N((3, H), "float32", 2, 0.5), N((3, H), "float32", 6, 0.5),
+         N((20, 4 * H), "float32", 3, 0.2), N((H, 4 * H), "float32", 4, 0.12), N((4 * H,), "float32", 5, 0.1)]
+
+
 @case("rowchain_integer", exact=True)
 def _():
     # last-axis reduction chains on integer / bool data go through the same row-chain kernels

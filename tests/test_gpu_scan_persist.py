@@ -387,3 +387,39 @@ def test_sgd_loop_over_bptt_plan_replay_equals_eager(batch):
     np.testing.assert_allclose(traj[True][0], traj[False][0], rtol=2e-5)
     for a, b in zip(traj[True][1], traj[False][1]):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("T,B,D", [(48, 64, 96), (7, 5, 20)])
+def test_fused_gate_lstm_runs_persistent(T, B, D):
+    """The usual LSTM step — one product for the four gates, sliced by columns — is split per gate
+    (fusion.split_column_slices: column views of W / U / b) and runs as the matrix-state persistent
+    kernel with ONE hand-off per step (h; the cell state stays in the element owners' registers).
+    Every hidden state and the last cell state against an fp64 restatement."""
+    import torch
+    from aesara_amd.executor import PlanExecutor
+    H = 64
+    g = torch.Generator(device="cuda")
+    g.manual_seed(17)
+    x = torch.randn(T, B, D, device="cuda", generator=g) * 0.5
+    h0 = torch.randn(B, H, device="cuda", generator=g) * 0.5
+    c0 = torch.randn(B, H, device="cuda", generator=g) * 0.5
+    W = torch.randn(D, 4 * H, device="cuda", generator=g) / np.sqrt(D)
+    U = torch.randn(H, 4 * H, device="cuda", generator=g) / np.sqrt(H)
+    b = torch.randn(4 * H, device="cuda", generator=g) * 0.1
+    h, c, hs = h0.double(), c0.double(), []
+    for t in range(T):
+        gates = x[t].double() @ W.double() + h @ U.double() + b.double()
+        i, f, o, gg = (gates[:, k * H:(k + 1) * H] for k in range(4))
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        hs.append(h)
+    want_hs, want_c = torch.stack(hs), c
+    for use_graph in (False, True):
+        ex = PlanExecutor(case_plan(_case("lstm_fused_fwd_f32")), use_graph=use_graph)
+        for _ in range(2):
+            got_hs, got_c = ex(x, h0, c0, W, U, b)
+        assert list(ex.scan_modes.values()) == ["persistent"], ex.scan_modes
+        ex.check()
+        for gv, wv in ((got_hs, want_hs), (got_c, want_c)):
+            err = ((gv.double() - wv).abs().max() / wv.abs().max()).item()
+            assert gv.shape == wv.shape and err <= 2e-5, (use_graph, err)

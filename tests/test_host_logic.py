@@ -301,3 +301,36 @@ def test_sequence_only_hoisting_preserves_the_step(name):
                 np.testing.assert_allclose(g, w, rtol=2e-5, atol=2e-6)
         checked += 1
     assert checked >= 1
+
+
+@pytest.mark.parametrize("name", ["lstm_bptt_float32", "lstm_fused_fwd_f32", "lstm_bptt_float64"])
+def test_column_slice_splitting_preserves_the_step(name):
+    """fusion.split_column_slices on fused-gate LSTM steps (forward and gradient inner plans): the
+    rewritten step (one product chain per gate, column views of the invariant operands) gives the
+    same outputs as the original one, through the oracle; the forward step must actually change."""
+    import interp
+    from golden_util import CASES, case_plan
+    from aesara_amd.fusion import split_column_slices
+    plan = case_plan(next(c for c in CASES if c["name"] == name))
+    changed = 0
+    for node in plan.nodes:
+        if node.op == "Scan":
+            inner, p = node.params["inner"], node.params
+            n_var = len(inner.inputs) - p["n_non_seqs"]
+            changed += split_column_slices(inner, set(inner.inputs[n_var:])) is not inner
+    assert changed >= 1
+    # end-to-end through the oracle: the whole plan with every Scan inner plan rewritten
+    import copy
+    from golden_util import case_inputs
+    c = next(c for c in CASES if c["name"] == name)
+    ins = case_inputs(c)
+    want = interp.run_plan(plan, ins)
+    plan2 = copy.deepcopy(plan)
+    for node in plan2.nodes:
+        if node.op == "Scan":
+            inner = node.params["inner"]
+            n_var = len(inner.inputs) - node.params["n_non_seqs"]
+            node.params["inner"] = split_column_slices(inner, set(inner.inputs[n_var:]))
+    got = interp.run_plan(plan2, ins)
+    for g, w in zip(got, want):
+        np.testing.assert_allclose(g, w, rtol=1e-5 if "32" in name else 1e-12, atol=1e-6 if "32" in name else 1e-13)
