@@ -298,20 +298,26 @@ def split_invariant(plan: Plan, invariant_inputs: List[int]):
 
 
 def split_column_slices(plan: Plan, invariant: set) -> Plan:
-    """Fused-gate recurrences compute ONE product for all gates and slice it by columns::
+    """Fused-gate recurrences compute ONE product for all gates and slice it along its last axis::
 
-        pre = b + x_t @ Wx + h @ Wh          # [B, 4H]
+        pre = b + x_t @ Wx + h @ Wh          # [B, 4H]   (or a vector of length 4H)
         i, f, o, g = pre[:, 0:H], pre[:, H:2H], ...
 
     (the usual Theano / Aesara LSTM step).  Every consumer sees only its slice, so the chain is
-    split per slice with column views of the invariant operands — ``x_t @ Wx[:, kH:(k+1)H]`` … —
-    which leaves H-wide products with H-wide epilogues: the shape the sequence hoisting and the
-    persistent kernels work on.  Handles a chain of ``Dot22`` / ``Gemm`` (invariant right-hand
-    matrix) / ``Elemwise`` (chain operands and invariant rows ``[1, N]``) whose every value is
-    read only inside the chain or by ``Subtensor`` nodes ``[:, a:b]`` with constant bounds.
-    Returns the plan unchanged when nothing matches."""
+    split per slice with views of the invariant operands — ``x_t @ Wx[:, kH:(k+1)H]`` … — which
+    leaves H-wide products with H-wide epilogues: the shape the sequence hoisting and the
+    persistent kernels work on.  Handles a chain of ``Dot22`` / ``Gemm`` (matrix state) or ``Gemv``
+    (vector state; the slice selects rows of the matrix) with an invariant matrix operand and
+    ``Elemwise`` nodes (chain operands and invariant rows ``[1, N]`` / vectors), every value of
+    which is read only inside the chain or by ``Subtensor`` nodes ``[..., a:b]`` with constant
+    bounds.  Returns the plan unchanged when nothing matches."""
     V = plan.vars
     clients = plan.clients()
+    # invariants and views of them computed in the step (the W.T of every Gemv)
+    inv = set(invariant)
+    for n in plan.nodes:
+        if n.op in ("DimShuffle", "ViewOp") and all(i in inv for i in n.inputs):
+            inv.update(n.outputs)
 
     def cint(vid):
         v = V[vid]
@@ -319,18 +325,20 @@ def split_column_slices(plan: Plan, invariant: set) -> Plan:
             return int(v.const["data"][0])
         return None
 
-    def col_slice(n):
-        """(a, b) when node n is Subtensor [:, a:b] with constant bounds, else None"""
-        if n.op != "Subtensor" or V[n.inputs[0]].ndim != 2:
+    def last_slice(n):
+        """(a, b) when node n is Subtensor [..., a:b] on the last axis with constant bounds"""
+        if n.op != "Subtensor":
             return None
+        nd = V[n.inputs[0]].ndim
         idx = n.params["idx_list"]
-        if len(idx) != 2 or "slice" not in idx[0] or "slice" not in idx[1]:
+        if nd not in (1, 2) or len(idx) != nd or any("slice" not in e for e in idx):
             return None
-        if idx[0]["slice"] != [None, None, None] or idx[1]["slice"][2] not in (None, 1):
+        if nd == 2 and idx[0]["slice"] != [None, None, None]:
             return None
-        extra = list(n.inputs[1:])
-        ab = []
-        for e in idx[1]["slice"][:2]:
+        if idx[-1]["slice"][2] not in (None, 1):
+            return None
+        extra, ab = list(n.inputs[1:]), []
+        for e in idx[-1]["slice"][:2]:
             if e == "in":
                 c = cint(extra.pop(0)) if extra else None
                 if c is None:
@@ -340,12 +348,13 @@ def split_column_slices(plan: Plan, invariant: set) -> Plan:
                 ab.append(e)
             else:
                 return None
-        return (ab[0], ab[1]) if 0 <= ab[0] < ab[1] else None
+        return (ab[0], ab[1]) if 0 <= ab[0] < ab[1] and not extra else None
 
     producer = {o: (ni, n) for ni, n in enumerate(plan.nodes) for o in n.outputs}
 
     def chain_of(root):
         """node indices of the chain ending in `root`, or None"""
+        nd = V[root].ndim
         chain, todo = set(), [root]
         while todo:
             v = todo.pop()
@@ -354,16 +363,22 @@ def split_column_slices(plan: Plan, invariant: set) -> Plan:
             ni, n = producer[v]
             if ni in chain:
                 continue
-            if n.op in ("Dot22", "Dot") and len(n.inputs) == 2 and n.inputs[1] in invariant \
+            if nd == 2 and n.op in ("Dot22", "Dot") and len(n.inputs) == 2 and n.inputs[1] in inv \
                     and V[n.inputs[1]].ndim == 2 and V[n.outputs[0]].ndim == 2:
                 chain.add(ni)
-            elif n.op == "Gemm" and n.inputs[3] in invariant and V[n.inputs[3]].ndim == 2:
+            elif nd == 2 and n.op == "Gemm" and n.inputs[3] in inv and V[n.inputs[3]].ndim == 2:
                 chain.add(ni)
                 todo.append(n.inputs[0])
-            elif n.op == "Elemwise" and len(n.outputs) == 1 and V[n.outputs[0]].ndim == 2:
+            elif nd == 1 and n.op == "Gemv" and n.inputs[2] in inv and V[n.inputs[2]].ndim == 2:
+                chain.add(ni)
+                y = n.inputs[0]
+                if not (y in producer and producer[y][1].op == "AllocEmpty"):
+                    todo.append(y)                 # beta != 0: accumulates onto a chain value
+            elif n.op == "Elemwise" and len(n.outputs) == 1 and V[n.outputs[0]].ndim == nd:
                 chain.add(ni)
                 for i in n.inputs:
-                    if (i in invariant or V[i].const is not None) and V[i].ndim == 2 and V[i].shape[0] == 1:
+                    if (i in inv or V[i].const is not None) and V[i].ndim == nd and \
+                            (nd == 1 or V[i].shape[0] == 1):
                         continue
                     todo.append(i)
             else:
@@ -374,47 +389,56 @@ def split_column_slices(plan: Plan, invariant: set) -> Plan:
     work = Plan(plan.name, dict(plan.vars), list(plan.inputs), list(plan.outputs), [])
     for root, (rni, rn) in list(producer.items()):
         cl = clients.get(root, [])
-        if not cl or any(c[0] == "out" for c in cl):
+        if len(cl) < 2 or any(c[0] == "out" for c in cl):
             continue
-        slices = [col_slice(plan.nodes[c[0]]) if c[1] == 0 else None for c in cl]
-        if any(sl is None for sl in slices) or len(cl) < 2:
+        slices = [last_slice(plan.nodes[c[0]]) if c[1] == 0 else None for c in cl]
+        if any(sl is None for sl in slices):
             continue
         chain = chain_of(root)
-        if not chain:
+        if not chain or chain & removed:
             continue
+        nd = V[root].ndim
         chain_vars = {o for ni in chain for o in plan.nodes[ni].outputs}
-        ok = all(all(c[0] in chain or (v == root and col_slice(plan.nodes[c[0]]) is not None)
-                     for c in clients[v] if c[0] != "out") and
-                 not any(c[0] == "out" for c in clients[v]) for v in chain_vars)
-        if not ok or chain & removed:
+        if not all(all(c[0] != "out" and (c[0] in chain or (v == root and last_slice(plan.nodes[c[0]])))
+                       for c in clients[v]) for v in chain_vars):
             continue
         order = sorted(chain)
         for (cni, _pos), (a, b) in zip(cl, slices):
             m = {}
+            sink = new_nodes.setdefault(cni, [])
 
-            def inv_cols(v, a=a, b=b):
-                key = ("inv", v)
+            def part(v, axis, a=a, b=b, m=m, sink=sink):
+                """v[..., a:b] (axis = -1) or v[a:b] (axis = 0: rows of a Gemv matrix, the y of a
+                beta = 0 Gemv) of an operand that is not a chain value"""
+                key = ("p", v, axis)
                 if key not in m:
                     src = V[v]
-                    o = work.new_var(src.dtype, [src.shape[0], None])
-                    new_nodes.setdefault(cni, []).append(
-                        Node("Subtensor", [v], [o], {"idx_list": [{"slice": [None, None, None]},
-                                                                  {"slice": [a, b, None]}]}))
+                    shp = list(src.shape)
+                    shp[axis] = None
+                    o = work.new_var(src.dtype, shp)
+                    idx = [{"slice": [a, b, None]}] if axis == 0 else \
+                        [{"slice": [None, None, None]}] * (src.ndim - 1) + [{"slice": [a, b, None]}]
+                    sink.append(Node("Subtensor", [v], [o], {"idx_list": idx}))
                     m[key] = o
                 return m[key]
             for ni in order:
                 n = plan.nodes[ni]
-                out = work.new_var(V[n.outputs[0]].dtype, [V[n.outputs[0]].shape[0], None])
+                ov = V[n.outputs[0]]
+                out = work.new_var(ov.dtype, list(ov.shape[:-1]) + [None])
                 if n.op in ("Dot22", "Dot"):
-                    nn = Node("Dot22", [n.inputs[0], inv_cols(n.inputs[1])], [out], {})
+                    nn = Node("Dot22", [n.inputs[0], part(n.inputs[1], -1)], [out], {})
                 elif n.op == "Gemm":
-                    nn = Node("Gemm", [m[n.inputs[0]], n.inputs[1], n.inputs[2], inv_cols(n.inputs[3]),
+                    nn = Node("Gemm", [m[n.inputs[0]], n.inputs[1], n.inputs[2], part(n.inputs[3], -1),
                                        n.inputs[4]], [out], dict(n.params))
+                elif n.op == "Gemv":
+                    y = n.inputs[0]
+                    nn = Node("Gemv", [m[y] if y in m else part(y, 0), n.inputs[1], part(n.inputs[2], 0),
+                                       n.inputs[3], n.inputs[4]], [out], dict(n.params))
                 else:
-                    nn = Node("Elemwise", [m[i] if i in m else inv_cols(i) for i in n.inputs], [out],
+                    nn = Node("Elemwise", [m[i] if i in m else part(i, -1) for i in n.inputs], [out],
                               copy.deepcopy(n.params))
                 m[n.outputs[0]] = out
-                new_nodes.setdefault(cni, []).append(nn)
+                sink.append(nn)
             replaced[plan.nodes[cni].outputs[0]] = m[root]
             removed.add(cni)
         removed |= chain
@@ -423,14 +447,17 @@ def split_column_slices(plan: Plan, invariant: set) -> Plan:
     nodes = []
     for ni, n in enumerate(plan.nodes):
         nodes.extend(new_nodes.get(ni, []))
-        if ni in removed:
-            continue
-        nodes.append(Node(n.op, [replaced.get(i, i) for i in n.inputs], list(n.outputs), n.params))
-    # the slice nodes' new values keep the old variable ids' consumers: rewrite the inserted nodes too
+        if ni not in removed:
+            nodes.append(n)
     work.nodes = [Node(n.op, [replaced.get(i, i) for i in n.inputs], list(n.outputs), n.params) for n in nodes]
     work.outputs = [replaced.get(o, o) for o in plan.outputs]
     work.name = plan.name + "_cols"
-    return work
+    return _prune_dead_plan(work)
+
+
+def _prune_dead_plan(plan: Plan) -> Plan:
+    plan.nodes = _prune_dead(plan, list(plan.nodes))
+    return plan
 
 
 def _prune_dead(plan: Plan, keep: List[Node]) -> List[Node]:

@@ -423,3 +423,39 @@ def test_fused_gate_lstm_runs_persistent(T, B, D):
         for gv, wv in ((got_hs, want_hs), (got_c, want_c)):
             err = ((gv.double() - wv).abs().max() / wv.abs().max()).item()
             assert gv.shape == wv.shape and err <= 2e-5, (use_graph, err)
+
+
+@pytest.mark.parametrize("T,D", [(64, 40), (3, 7)])
+def test_fused_gate_lstm_vector_state_runs_persistent(T, D):
+    """The fused-gate LSTM step on a vector state (one sequence): the 4H-long ``Gemv`` chain is
+    split per gate (row blocks of W.T / U.T), the ``x_t`` products are lifted over the sequence,
+    the loop exchanges only h — all states against an fp64 restatement."""
+    import torch
+    from aesara_amd.executor import PlanExecutor
+    H = 48
+    g = torch.Generator(device="cuda")
+    g.manual_seed(19)
+    x = torch.randn(T, D, device="cuda", generator=g) * 0.5
+    h0 = torch.randn(H, device="cuda", generator=g) * 0.5
+    c0 = torch.randn(H, device="cuda", generator=g) * 0.5
+    W = torch.randn(D, 4 * H, device="cuda", generator=g) / np.sqrt(D)
+    U = torch.randn(H, 4 * H, device="cuda", generator=g) / np.sqrt(H)
+    b = torch.randn(4 * H, device="cuda", generator=g) * 0.1
+    h, c, hs = h0.double(), c0.double(), []
+    for t in range(T):
+        gates = x[t].double() @ W.double() + h @ U.double() + b.double()
+        i, f, o, gg = (gates[k * H:(k + 1) * H] for k in range(4))
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        hs.append(h)
+    want_hs, want_c = torch.stack(hs), c
+    for use_graph in (False, True):
+        ex = PlanExecutor(case_plan(_case("lstm_fused_vec_f32")), use_graph=use_graph)
+        for _ in range(2):
+            got_hs, got_c = ex(x, h0, c0, W, U, b)
+        if T >= 2:
+            assert list(ex.scan_modes.values()) == ["persistent"], ex.scan_modes
+        ex.check()
+        for gv, wv in ((got_hs, want_hs), (got_c, want_c)):
+            err = ((gv.double() - wv).abs().max() / wv.abs().max()).item()
+            assert gv.shape == wv.shape and err <= 2e-5, (use_graph, err)

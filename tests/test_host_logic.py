@@ -303,7 +303,8 @@ def test_sequence_only_hoisting_preserves_the_step(name):
     assert checked >= 1
 
 
-@pytest.mark.parametrize("name", ["lstm_bptt_float32", "lstm_fused_fwd_f32", "lstm_bptt_float64"])
+@pytest.mark.parametrize("name", ["lstm_bptt_float32", "lstm_fused_fwd_f32", "lstm_bptt_float64",
+                                  "lstm_fused_vec_f32"])
 def test_column_slice_splitting_preserves_the_step(name):
     """fusion.split_column_slices on fused-gate LSTM steps (forward and gradient inner plans): the
     rewritten step (one product chain per gate, column views of the invariant operands) gives the
