@@ -159,9 +159,9 @@ def analyze(inner, p, n_seqdots):
     produced = {}
     # "vec": Gemv chains on vectors (state h[M]); "mat": small-M GEMM chains on a matrix state
     # (h[B, N], batch of independent recurrences sharing the weights)
-    pr.mode = "mat" if any(st.kind == "gemm_epi" or (st.kind == "node" and st.node.op in ("Dot22", "Dot")
-                                                    and plan.vars[st.outputs[0]].ndim == 2)
-                           for st in inner.steps) else "vec"
+    pr.mode = "mat" if plan.vars[plan.outputs[0]].ndim == 2 or any(
+        st.kind == "gemm_epi" or (st.kind == "node" and st.node.op in ("Dot22", "Dot")
+                                  and plan.vars[st.outputs[0]].ndim == 2) for st in inner.steps) else "vec"
     # one floating dtype throughout (the state's): float32 always, float64 for the vector class
     pr.dtype = plan.vars[plan.outputs[0]].dtype
     if pr.dtype not in (("float32",) if pr.mode == "mat" else ("float32", "float64")):

@@ -1312,6 +1312,26 @@ def _():
          N((20, 4 * H), "float32", 3, 0.2), N((H, 4 * H), "float32", 4, 0.12), N((4 * H,), "float32", 5, 0.1)]
 
 
+@case("lstm_fused_bptt_h64_f32", rtol=3e-4, atol=3e-5)
+def _():
+    """Fused-gate LSTM (matrix state, H = 64) under aesara.grad: loss and gradients wrt W, U, b
+    (the step of lstm_fused_fwd_f32; a width the GPU probes can run at a realistic T and B)."""
+    H = 64
+    x, h0, c0 = at.ftensor3("x"), at.fmatrix("h0"), at.fmatrix("c0")
+    W, U_, b = at.fmatrix("W"), at.fmatrix("U"), at.fvector("b")
+
+    def step(x_t, h, c, W, U_, b):
+        g = at.dot(x_t, W) + at.dot(h, U_) + b
+        i, f, o, gg = (g[:, k * H:(k + 1) * H] for k in range(4))
+        c2 = at.sigmoid(f) * c + at.sigmoid(i) * at.tanh(gg)
+        return at.sigmoid(o) * at.tanh(c2), c2
+    (hs, cs), _ = ae.scan(step, sequences=[x], outputs_info=[h0, c0], non_sequences=[W, U_, b])
+    loss = (hs[-1] ** 2).sum() + cs.mean()
+    return [x, h0, c0, W, U_, b], [loss] + list(ae.grad(loss, [W, U_, b])), \
+        [N((5, 3, 20), "float32", 1, 0.5), N((3, H), "float32", 2, 0.5), N((3, H), "float32", 6, 0.5),
+         N((20, 4 * H), "float32", 3, 0.2), N((H, 4 * H), "float32", 4, 0.12), N((4 * H,), "float32", 5, 0.1)]
+
+
 @case("lstm_fused_vec_bptt_f32", rtol=3e-4, atol=3e-5)
 def _():
     """Fused-gate LSTM on a vector state under aesara.grad: loss and the gradients wrt W, U, b."""
