@@ -460,9 +460,124 @@ def _prune_dead_plan(plan: Plan) -> Plan:
     return plan
 
 
+def push_out_accumulators(plan: Plan) -> Plan:
+    """A gradient Scan sums what it computes for every step into sit-sot accumulators —
+    ``acc_t = acc_{t-1} + g_t`` for the gradient of a non-sequence such as a bias, with
+    ``g_t = sum(delta_t, axis=0)`` for a batch (Scan.L_op, scan/op.py:2379) — although ``delta_t`` is
+    a nit-sot output of the same Scan anyway (the weight gradients are GEMMs over it after the loop).
+    Such an accumulator is taken out of the loop: its whole buffer is rebuilt after the Scan as
+    ``init + cumsum_t(reduce(delta))`` (the same additions in the same order, one CAReduce + one
+    CumOp over [T, H]), cut to the buffer length the caller allocated, so every use of the old output
+    — whatever row it reads — sees the same values.  The step loses its batch reduction, which is
+    what kept batched recurrences with biases off the persistent gradient kernel."""
+    def is_add(sc):
+        return (sc.get("n_in") == 2 and len(sc["nodes"]) == 1 and sc["nodes"][0]["op"] == "add"
+                and sorted(map(tuple, sc["nodes"][0]["in"])) == [("i", 0), ("i", 1)] and sc["out"] == [["t", 0]])
+
+    out_nodes, changed = [], False
+    orig = plan
+    plan = Plan(plan.name, dict(plan.vars), list(plan.inputs), list(plan.outputs), list(plan.nodes))
+    replaced = {}
+    for node in plan.nodes:
+        if node.op != "Scan" or node.params.get("as_while") or not node.params.get("sit_sot_in_slices"):
+            out_nodes.append(node)
+            continue
+        p = dict(node.params)
+        inner = p["inner"]
+        n_seqs = p["n_seqs"]
+        mm_in = [list(t) for t in p.get("mit_mot_in_slices", [])]
+        mm_out = [list(t) for t in p.get("mit_mot_out_slices", [])]
+        ms = [list(t) for t in p["mit_sot_in_slices"]]
+        ss = [list(t) for t in p["sit_sot_in_slices"]]
+        n_mm, n_ms, n_ss, n_nit = len(mm_in), len(ms), len(ss), p["n_nit_sot"]
+        n_sh = p.get("n_shared_outs", 0)
+        tap0 = n_seqs + sum(len(t) for t in mm_in) + sum(len(t) for t in ms)      # first sit-sot tap
+        out0 = sum(len(t) for t in mm_out) + n_ms                                  # first sit-sot output
+        nit0 = out0 + n_ss
+        iprod = {o: n_ for n_ in inner.nodes for o in n_.outputs}
+        iclients = inner.clients()
+        drop = []          # (q, nit index j, reduce params or None)
+        for q in range(n_ss):
+            if ss[q] != [-1]:
+                continue
+            tq, oq = inner.inputs[tap0 + q], inner.outputs[out0 + q]
+            upd = iprod.get(oq)
+            if upd is None or upd.op != "Elemwise" or not is_add(upd.params["scalar"]) or tq not in upd.inputs:
+                continue
+            if [c for c in iclients[tq]] != [c for c in iclients[tq] if c[0] != "out" and inner.nodes[c[0]] is upd] \
+                    or len(iclients[tq]) != 1 or len(iclients[oq]) != 1:
+                continue
+            a = [i for i in upd.inputs if i != tq]
+            if len(a) != 1:
+                continue
+            a, red = a[0], None
+            an = iprod.get(a)
+            if an is not None and an.op == "CAReduce" and an.params["scalar_op"] == "add" and \
+                    an.params["axis"] == [0] and inner.vars[an.inputs[0]].ndim == 2:
+                red, a = dict(an.params), an.inputs[0]
+            if a not in inner.outputs[nit0:nit0 + n_nit] or inner.vars[a].ndim != (2 if red else 1):
+                continue
+            if inner.vars[a].dtype != inner.vars[oq].dtype:
+                continue
+            drop.append((q, inner.outputs[nit0:nit0 + n_nit].index(a), red))
+        if not drop:
+            out_nodes.append(node)
+            continue
+        changed = True
+        dq = {q for q, _j, _r in drop}
+        base_in = 1 + n_seqs + n_mm + n_ms            # position of the first sit-sot init in node.inputs
+        new_inputs = [v for k, v in enumerate(node.inputs) if not (base_in <= k < base_in + n_ss and k - base_in in dq)]
+        base_out = n_mm + n_ms
+        new_outputs = [v for k, v in enumerate(node.outputs) if not (base_out <= k < base_out + n_ss and k - base_out in dq)]
+        in_keep = [v for k, v in enumerate(inner.inputs) if not (tap0 <= k < tap0 + n_ss and k - tap0 in dq)]
+        out_keep = [v for k, v in enumerate(inner.outputs) if not (out0 <= k < out0 + n_ss and k - out0 in dq)]
+        new_inner = Plan(inner.name + "_noacc", inner.vars, in_keep, out_keep, list(inner.nodes))
+        new_inner.nodes = _prune_dead(new_inner, list(new_inner.nodes))
+        p["inner"] = new_inner
+        p["sit_sot_in_slices"] = [t for q, t in enumerate(ss) if q not in dq]
+        out_nodes.append(Node("Scan", new_inputs, new_outputs, p))
+        V = plan.vars
+        for q, j, red in drop:
+            old = node.outputs[base_out + q]
+            init_buf = node.inputs[base_in + q]
+            vall = node.outputs[n_mm + n_ms + n_ss + j]
+            dt = V[old].dtype
+            width = V[init_buf].shape[1:]
+            r = vall
+            if red is not None:
+                r = plan.new_var(dt, [None] + list(width))
+                out_nodes.append(Node("CAReduce", [vall], [r], dict(red, axis=[1])))
+            cs = plan.new_var(dt, [None] + list(width))
+            out_nodes.append(Node("CumOp", [r], [cs], {"axis": 0, "mode": "add"}))
+            row = plan.new_var(dt, [1] + list(width))
+            out_nodes.append(Node("Subtensor", [init_buf], [row], {"idx_list": [{"slice": [0, 1, None]}]}))
+            add2 = {"n_in": 2, "nodes": [{"op": "add", "in": [["i", 0], ["i", 1]], "dtype": dt}], "out": [["t", 0]]}
+            rows = plan.new_var(dt, [None] + list(width))
+            out_nodes.append(Node("Elemwise", [cs, row], [rows], {"scalar": add2}))
+            ax = plan.add_const(0, "int8")
+            full = plan.new_var(dt, [None] + list(width))
+            out_nodes.append(Node("Join", [ax, row, rows], [full], {}))
+            # keep the last `store` rows (the caller's buffer may be shorter than T + 1)
+            nfull = plan.new_var("int64", [])
+            out_nodes.append(Node("Shape_i", [full], [nfull], {"i": 0}))
+            store = plan.new_var("int64", [])
+            out_nodes.append(Node("Shape_i", [init_buf], [store], {"i": 0}))
+            start = plan.new_var("int64", [])
+            sub2 = {"n_in": 2, "nodes": [{"op": "sub", "in": [["i", 0], ["i", 1]], "dtype": "int64"}], "out": [["t", 0]]}
+            out_nodes.append(Node("Elemwise", [nfull, store], [start], {"scalar": sub2}))
+            new = plan.new_var(dt, list(V[old].shape))
+            out_nodes.append(Node("Subtensor", [full, start], [new], {"idx_list": [{"slice": ["in", None, None]}]}))
+            replaced[old] = new
+    if not changed:
+        return orig
+    plan.nodes = [Node(n_.op, [replaced.get(i, i) for i in n_.inputs], list(n_.outputs), n_.params) for n_ in out_nodes]
+    plan.outputs = [replaced.get(o, o) for o in plan.outputs]
+    return plan
+
+
 def _prune_dead(plan: Plan, keep: List[Node]) -> List[Node]:
     pure = {"AllocEmpty", "Shape_i", "Shape", "DimShuffle", "Elemwise", "ScalarFromTensor",
-            "TensorFromScalar", "MakeVector", "Alloc", "ViewOp"}
+            "TensorFromScalar", "MakeVector", "Alloc", "ViewOp", "CAReduce", "Subtensor"}
     while True:
         read = {i for n in keep for i in n.inputs} | set(plan.outputs)
         dead = [n for n in keep if n.op in pure and not any(o in read for o in n.outputs)]

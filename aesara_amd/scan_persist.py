@@ -106,12 +106,19 @@ class _DotPhase:
     """Stand-in step for a plain ``Dot22(operand, invariant matrix)`` node of a matrix-state loop."""
     kind, reduce, post, fallback, extra = "gemm_epi", None, (), (), {}
 
-    def __init__(self, operand, weight, out):
+    def __init__(self, operand, weight, out, add=None):
         self.dots = [[operand, weight]]
-        self.inputs, self.outputs = [], [out]
-        self.scalar = {"n_in": 1, "nodes": [], "out": [["i", 0]]}
+        self.inputs, self.outputs = ([] if add is None else [add]), [out]
+        self.scalar = {"n_in": 1, "nodes": [], "out": [["i", 0]]} if add is None else \
+            {"n_in": 2, "nodes": [{"op": "add", "in": [["i", 0], ["i", 1]], "dtype": "float32"}],
+             "out": [["t", 0]]}
         self.out_refs = [0]
         self.node = None
+
+
+def _const1(plan, vid):
+    v = plan.vars[vid]
+    return v.const is not None and len(v.const.get("data", ())) == 1 and float(v.const["data"][0]) == 1.0
 
 
 def analyze(inner, p, n_seqdots):
@@ -201,6 +208,11 @@ def analyze(inner, p, n_seqdots):
             # a product that feeds several Elemwise steps (no single epilogue to fuse with): a
             # phase whose "epilogue" hands the dot through
             st = _DotPhase(st.inputs[0], st.inputs[1], st.outputs[0])
+        if st.kind == "node" and st.node.op == "Gemm" and pr.mode == "mat" and \
+                st.inputs[3] in inv_set and _const1(plan, st.inputs[1]) and _const1(plan, st.inputs[4]):
+            # z + x @ W with nothing fused behind it (the state update of a plain RNN's gradient
+            # step): a product phase whose epilogue adds z
+            st = _DotPhase(st.inputs[2], st.inputs[3], st.outputs[0], add=st.inputs[0])
         if st.kind == "node" and st.node.op == "DimShuffle" and pr.mode == "vec" and \
                 [d for d in st.node.params["new_order"] if d != "x"] == [0] and \
                 plan.vars[st.inputs[0]].ndim == 1 and not readers.get(st.outputs[0]) and \

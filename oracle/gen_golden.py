@@ -1312,6 +1312,23 @@ def _():
          N((20, 4 * H), "float32", 3, 0.2), N((H, 4 * H), "float32", 4, 0.12), N((4 * H,), "float32", 5, 0.1)]
 
 
+@case("rnn_bias_bptt_b4_f32", rtol=3e-4, atol=3e-5)
+def _():
+    """A batched tanh RNN WITH a bias under aesara.grad: the bias gradient is a sum over the batch
+    accumulated inside the gradient Scan (a sit-sot ``acc + sum(delta, axis=0)``)."""
+    x, h0 = at.ftensor3("x"), at.fmatrix("h0")
+    W, U_, b = at.fmatrix("W"), at.fmatrix("U"), at.fvector("b")
+
+    def step(x_t, h, W, U_, b):
+        return at.tanh(at.dot(x_t, W) + at.dot(h, U_) + b)
+    hs, _ = ae.scan(step, sequences=[x], outputs_info=[h0], non_sequences=[W, U_, b])
+    loss = (hs[-1] ** 2).sum() + hs.mean()
+    H = 16
+    return [x, h0, W, U_, b], [loss] + list(ae.grad(loss, [W, U_, b, h0])), \
+        [N((7, 4, 12), "float32", 1, 0.5), N((4, H), "float32", 2, 0.5),
+         N((12, H), "float32", 3, 0.3), N((H, H), "float32", 4, 0.25), N((H,), "float32", 5, 0.1)]
+
+
 @case("lstm_fused_bptt_h64_f32", rtol=3e-4, atol=3e-5)
 def _():
     """Fused-gate LSTM (matrix state, H = 64) under aesara.grad: loss and gradients wrt W, U, b

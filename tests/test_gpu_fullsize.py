@@ -575,3 +575,35 @@ def test_gru_bptt_against_torch_autograd(T, H, B, name):
             # [0, 1] -> [1], gate recomputation hoisted over the whole sequence) run as one
             # persistent kernel each
             assert list(ex.scan_modes.values()) == ["persistent", "persistent"], ex.scan_modes
+
+
+def test_biased_rnn_bptt_against_torch_autograd():
+    """A batched tanh RNN with a bias under aesara.grad at a real shape: the bias accumulator is
+    rebuilt after the loop (fusion.push_out_accumulators), both Scans run persistent; loss and the
+    gradients wrt W, U, b, h0 against torch.autograd of an fp64 restatement."""
+    import torch
+    from aesara_amd.executor import PlanExecutor
+    T, B, D, H = 32, 48, 96, 128
+    g = torch.Generator(device="cuda")
+    g.manual_seed(23)
+    x = torch.randn(T, B, D, device="cuda", generator=g) * 0.4
+    h0 = torch.randn(B, H, device="cuda", generator=g) * 0.5
+    W = torch.randn(D, H, device="cuda", generator=g) / np.sqrt(D)
+    U = torch.randn(H, H, device="cuda", generator=g) / np.sqrt(H)
+    b = torch.randn(H, device="cuda", generator=g) * 0.1
+    leaves = [t.double().requires_grad_(True) for t in (W, U, b, h0)]
+    Wd, Ud, bd, h = leaves
+    hs = []
+    for t in range(T):
+        h = torch.tanh(x[t].double() @ Wd + h @ Ud + bd)
+        hs.append(h)
+    loss = (hs[-1] ** 2).sum() + torch.stack(hs).mean()
+    want = [loss.detach()] + [gr.detach() for gr in torch.autograd.grad(loss, leaves)]
+    for use_graph in (False, True):
+        ex = PlanExecutor(_plan("rnn_bias_bptt_b4_f32"), use_graph=use_graph)
+        for _ in range(2):
+            got = ex(x, h0, W, U, b)
+        assert list(ex.scan_modes.values()) == ["persistent", "persistent"], ex.scan_modes
+        for k, (gv, wv) in enumerate(zip(got, want)):
+            err = ((gv.double() - wv).abs().max() / wv.abs().max().clamp_min(1e-30)).item()
+            assert gv.shape == wv.shape and err <= 2e-4, (use_graph, k, err)

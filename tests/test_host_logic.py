@@ -335,3 +335,27 @@ def test_column_slice_splitting_preserves_the_step(name):
     got = interp.run_plan(plan2, ins)
     for g, w in zip(got, want):
         np.testing.assert_allclose(g, w, rtol=1e-5 if "32" in name else 1e-12, atol=1e-6 if "32" in name else 1e-13)
+
+
+def test_accumulator_push_out_preserves_every_golden_scan_plan():
+    """fusion.push_out_accumulators on every golden plan with a Scan: where a sit-sot accumulator
+    (bias gradients of batched recurrences, summed inside the gradient Scan) is rebuilt after the
+    loop, the rewritten plan gives the same outputs through the oracle — whatever row of the
+    accumulator buffer the outer graph reads."""
+    import interp
+    from golden_util import CASES, case_inputs, case_plan
+    from aesara_amd.fusion import push_out_accumulators
+    changed = []
+    for c in CASES:
+        plan = case_plan(c)
+        if not any(n.op == "Scan" for n in plan.nodes):
+            continue
+        new = push_out_accumulators(plan)
+        if new is plan:
+            continue
+        changed.append(c["name"])
+        ins = case_inputs(c)
+        for g, w in zip(interp.run_plan(new, ins), interp.run_plan(plan, ins)):
+            np.testing.assert_allclose(np.asarray(g, dtype="float64"), np.asarray(w, dtype="float64"),
+                                       rtol=1e-6, atol=1e-7, err_msg=c["name"])
+    assert {"rnn_bias_bptt_b4_f32", "lstm_fused_bptt_h64_f32"} <= set(changed), changed
