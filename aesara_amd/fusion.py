@@ -575,9 +575,126 @@ def push_out_accumulators(plan: Plan) -> Plan:
     return plan
 
 
+def split_assembled_columns(plan: Plan) -> Plan:
+    """The gradient step of a fused-gate recurrence assembles the gate gradients into ONE wide
+    matrix — ``X = zeros(B, 4H); X[:, 0:H] = p_i; X[:, H:2H] = p_f; ...`` — only to multiply it with
+    the (transposed) fused weight matrix and to hand it out as a nit-sot output.  The product is a
+    sum over the blocks, ``z + X @ W = z + sum_k p_k @ W[a_k:b_k, :]``, and the output is the blocks
+    side by side, so the assembly leaves the step: the Scan returns the blocks as separate nit-sot
+    outputs (H-wide, what the persistent matrix kernel writes) and ONE ``Join`` after the loop
+    rebuilds ``[T, B, 4H]`` for the weight-gradient GEMMs."""
+    def cint(pl, vid):
+        v = pl.vars[vid]
+        if v.const is not None and len(v.const.get("data", ())) == 1 and v.dtype.startswith("int"):
+            return int(v.const["data"][0])
+        return None
+
+    orig, out_nodes, replaced, changed = plan, [], {}, False
+    plan = Plan(plan.name, dict(plan.vars), list(plan.inputs), list(plan.outputs), list(plan.nodes))
+    for node in plan.nodes:
+        if node.op != "Scan" or node.params.get("as_while") or not node.params.get("n_nit_sot"):
+            out_nodes.append(node)
+            continue
+        p = dict(node.params)
+        inner = p["inner"]
+        n_seqs, n_nit, n_sh = p["n_seqs"], p["n_nit_sot"], p.get("n_shared_outs", 0)
+        mm_in = [list(t) for t in p.get("mit_mot_in_slices", [])]
+        mm_out = [list(t) for t in p.get("mit_mot_out_slices", [])]
+        n_mm, n_ms, n_ss = len(mm_in), len(p["mit_sot_in_slices"]), len(p["sit_sot_in_slices"])
+        nit0 = sum(len(t) for t in mm_out) + n_ms + n_ss
+        n_var = len(inner.inputs) - p["n_non_seqs"]
+        inv = set(inner.inputs[n_var:])
+        for n_ in inner.nodes:
+            if n_.op in ("DimShuffle", "ViewOp") and all(i in inv for i in n_.inputs):
+                inv.update(n_.outputs)
+        iprod = {o: n_ for n_ in inner.nodes for o in n_.outputs}
+        icl = inner.clients()
+        found = None
+        for j in range(n_nit):
+            X = inner.outputs[nit0 + j]
+            if inner.vars[X].ndim != 2 or inner.outputs.count(X) != 1:
+                continue
+            parts, v = [], X
+            while v in iprod and iprod[v].op == "IncSubtensor":
+                n_ = iprod[v]
+                idx = n_.params["idx_list"]
+                if len(idx) != 2 or idx[0].get("slice") != [None, None, None] or \
+                        idx[1].get("slice", [0, 0, 0])[2] not in (None, 1):
+                    parts = None
+                    break
+                extra, ab = list(n_.inputs[2:]), []
+                for e in idx[1]["slice"][:2]:
+                    ab.append(cint(inner, extra.pop(0)) if e == "in" and extra else (e if isinstance(e, int) else None))
+                if None in ab or extra:
+                    parts = None
+                    break
+                parts.append((ab[0], ab[1], n_.inputs[1]))
+                v = n_.inputs[0]
+                if v != X and len(icl[v]) != 1:
+                    parts = None
+                    break
+            if not parts or v not in iprod or iprod[v].op != "Alloc":
+                continue
+            fill = inner.vars[iprod[v].inputs[0]]
+            if fill.const is None or any(float(d) != 0.0 for d in fill.const.get("data", [1])):
+                continue
+            parts.sort()
+            if parts[0][0] != 0 or any(parts[k][1] != parts[k + 1][0] for k in range(len(parts) - 1)):
+                continue
+            uses = [c for c in icl[X] if c[0] != "out"]
+            gemms = [inner.nodes[c[0]] for c in uses]
+            if len(uses) != 1 or uses[0][1] != 2 or gemms[0].op != "Gemm" or gemms[0].inputs[3] not in inv:
+                continue
+            found = (j, X, parts, gemms[0])
+            break
+        if found is None:
+            out_nodes.append(node)
+            continue
+        changed = True
+        j, X, parts, gm = found
+        work = Plan(inner.name + "_blocks", dict(inner.vars), list(inner.inputs), list(inner.outputs), [])
+        z, al, _x, W, be = gm.inputs
+        one = work.add_const(1.0, inner.vars[al].dtype)
+        nodes = []
+        for n_ in inner.nodes:
+            if n_ is not gm:
+                nodes.append(n_)
+                continue
+            acc = z
+            for k, (a, b, pk) in enumerate(parts):
+                wk = work.new_var(inner.vars[W].dtype, [None, inner.vars[W].shape[1]])
+                nodes.append(Node("Subtensor", [W], [wk], {"idx_list": [{"slice": [a, b, None]}]}))
+                out = gm.outputs[0] if k == len(parts) - 1 else \
+                    work.new_var(inner.vars[gm.outputs[0]].dtype, list(inner.vars[gm.outputs[0]].shape))
+                nodes.append(Node("Gemm", [acc, al, pk, wk, be if k == 0 else one], [out], dict(gm.params)))
+                acc = out
+        work.outputs = inner.outputs[:nit0 + j] + [pk for _a, _b, pk in parts] + inner.outputs[nit0 + j + 1:]
+        work.nodes = _prune_dead(work, nodes)
+        p["inner"] = work
+        p["n_nit_sot"] = n_nit + len(parts) - 1
+        len0 = 1 + n_seqs + n_mm + n_ms + n_ss + n_sh
+        new_inputs = list(node.inputs[:len0 + j]) + [node.inputs[len0 + j]] * len(parts) + list(node.inputs[len0 + j + 1:])
+        o0 = n_mm + n_ms + n_ss
+        old = node.outputs[o0 + j]
+        ov = plan.vars[old]
+        pouts = [plan.new_var(ov.dtype, list(ov.shape[:-1]) + [None]) for _ in parts]
+        new_outputs = list(node.outputs[:o0 + j]) + pouts + list(node.outputs[o0 + j + 1:])
+        out_nodes.append(Node("Scan", new_inputs, new_outputs, p))
+        ax = plan.add_const(ov.ndim - 1, "int8")
+        whole = plan.new_var(ov.dtype, list(ov.shape))
+        out_nodes.append(Node("Join", [ax] + pouts, [whole], {}))
+        replaced[old] = whole
+    if not changed:
+        return orig
+    plan.nodes = [Node(n_.op, [replaced.get(i, i) for i in n_.inputs], list(n_.outputs), n_.params) for n_ in out_nodes]
+    plan.outputs = [replaced.get(o, o) for o in plan.outputs]
+    return plan
+
+
 def _prune_dead(plan: Plan, keep: List[Node]) -> List[Node]:
     pure = {"AllocEmpty", "Shape_i", "Shape", "DimShuffle", "Elemwise", "ScalarFromTensor",
-            "TensorFromScalar", "MakeVector", "Alloc", "ViewOp", "CAReduce", "Subtensor"}
+            "TensorFromScalar", "MakeVector", "Alloc", "ViewOp", "CAReduce", "Subtensor", "IncSubtensor",
+            "Assert"}      # (an Assert nobody reads guards nothing that is still computed)
     while True:
         read = {i for n in keep for i in n.inputs} | set(plan.outputs)
         dead = [n for n in keep if n.op in pure and not any(o in read for o in n.outputs)]

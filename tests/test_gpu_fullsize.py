@@ -607,3 +607,41 @@ def test_biased_rnn_bptt_against_torch_autograd():
         for k, (gv, wv) in enumerate(zip(got, want)):
             err = ((gv.double() - wv).abs().max() / wv.abs().max().clamp_min(1e-30)).item()
             assert gv.shape == wv.shape and err <= 2e-4, (use_graph, k, err)
+
+
+def test_fused_gate_lstm_bptt_against_torch_autograd():
+    """The usual fused-gate LSTM under aesara.grad at a real T and B (H = 64 is baked into the
+    golden's gate slices): forward AND gradient Scan on the persistent matrix kernel (column-slice
+    splitting, accumulator push-out, block-wise gate gradients); loss and the gradients wrt W, U, b
+    against torch.autograd of an fp64 restatement."""
+    import torch
+    from aesara_amd.executor import PlanExecutor
+    T, B, D, H = 24, 40, 48, 64
+    g = torch.Generator(device="cuda")
+    g.manual_seed(29)
+    x = torch.randn(T, B, D, device="cuda", generator=g) * 0.4
+    h0 = torch.randn(B, H, device="cuda", generator=g) * 0.5
+    c0 = torch.randn(B, H, device="cuda", generator=g) * 0.5
+    W = torch.randn(D, 4 * H, device="cuda", generator=g) / np.sqrt(D)
+    U = torch.randn(H, 4 * H, device="cuda", generator=g) / np.sqrt(H)
+    b = torch.randn(4 * H, device="cuda", generator=g) * 0.1
+    leaves = [t.double().requires_grad_(True) for t in (W, U, b)]
+    Wd, Ud, bd = leaves
+    h, c, hs, cs = h0.double(), c0.double(), [], []
+    for t in range(T):
+        gates = x[t].double() @ Wd + h @ Ud + bd
+        i, f, o, gg = (gates[:, k * H:(k + 1) * H] for k in range(4))
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        hs.append(h)
+        cs.append(c)
+    loss = (hs[-1] ** 2).sum() + torch.stack(cs).mean()
+    want = [loss.detach()] + [gr.detach() for gr in torch.autograd.grad(loss, leaves)]
+    for use_graph in (False, True):
+        ex = PlanExecutor(_plan("lstm_fused_bptt_h64_f32"), use_graph=use_graph)
+        for _ in range(2):
+            got = ex(x, h0, c0, W, U, b)
+        assert list(ex.scan_modes.values()) == ["persistent", "persistent"], ex.scan_modes
+        for k, (gv, wv) in enumerate(zip(got, want)):
+            err = ((gv.double() - wv).abs().max() / wv.abs().max().clamp_min(1e-30)).item()
+            assert gv.shape == wv.shape and err <= 2e-4, (use_graph, k, err)

@@ -359,3 +359,24 @@ def test_accumulator_push_out_preserves_every_golden_scan_plan():
             np.testing.assert_allclose(np.asarray(g, dtype="float64"), np.asarray(w, dtype="float64"),
                                        rtol=1e-6, atol=1e-7, err_msg=c["name"])
     assert {"rnn_bias_bptt_b4_f32", "lstm_fused_bptt_h64_f32"} <= set(changed), changed
+
+
+@pytest.mark.parametrize("name", ["lstm_fused_bptt_h64_f32", "lstm_bptt_float32", "lstm_bptt_float64"])
+def test_assembled_gate_gradients_leave_the_step(name):
+    """fusion.split_assembled_columns (after push_out_accumulators) on fused-gate LSTM gradient
+    Scans: the 4H-wide assembled gate gradient becomes per-gate nit-sot outputs + one Join after the
+    loop, its product a sum over row blocks of the weight matrix — same outputs through the oracle."""
+    import interp
+    from golden_util import CASES, case_inputs, case_plan
+    from aesara_amd.fusion import push_out_accumulators, split_assembled_columns
+    c = next(c for c in CASES if c["name"] == name)
+    plan, ins = case_plan(c), case_inputs(c)
+    p1 = push_out_accumulators(plan)
+    p2 = split_assembled_columns(p1)
+    assert p2 is not p1
+    scans = [n for n in p2.nodes if n.op == "Scan"]
+    assert scans[1].params["n_nit_sot"] == 4 and not any(
+        m.op in ("IncSubtensor", "Alloc", "Assert", "CAReduce") for m in scans[1].params["inner"].nodes)
+    tol = 1e-6 if "32" in name else 1e-13
+    for g, w in zip(interp.run_plan(p2, ins), interp.run_plan(plan, ins)):
+        np.testing.assert_allclose(np.asarray(g, "float64"), np.asarray(w, "float64"), rtol=tol, atol=tol)
