@@ -515,11 +515,19 @@ def push_out_accumulators(plan: Plan) -> Plan:
             if an is not None and an.op == "CAReduce" and an.params["scalar_op"] == "add" and \
                     an.params["axis"] == [0] and inner.vars[an.inputs[0]].ndim == 2:
                 red, a = dict(an.params), an.inputs[0]
-            if a not in inner.outputs[nit0:nit0 + n_nit] or inner.vars[a].ndim != (2 if red else 1):
+            nits = inner.outputs[nit0:nit0 + n_nit]
+            if inner.vars[a].ndim != (2 if red else 1) or inner.vars[a].dtype != inner.vars[oq].dtype:
                 continue
-            if inner.vars[a].dtype != inner.vars[oq].dtype:
+            if a in nits:
+                drop.append((q, nits.index(a), red))
                 continue
-            drop.append((q, inner.outputs[nit0:nit0 + n_nit].index(a), red))
+            # a vector handed out as a row ([1, n]: DimShuffle 'x', 0): summing the size-1 axis of
+            # the [T, 1, n] output gives the [T, n] addends back
+            via = [o for o in nits if o in iprod and iprod[o].op == "DimShuffle" and iprod[o].inputs[0] == a
+                   and iprod[o].params["new_order"] == ["x", 0]]
+            if red is None and via:
+                drop.append((q, nits.index(via[0]), {"scalar_op": "add", "axis": [0],
+                                                     "acc_dtype": inner.vars[a].dtype}))
         if not drop:
             out_nodes.append(node)
             continue
@@ -577,12 +585,13 @@ def push_out_accumulators(plan: Plan) -> Plan:
 
 def split_assembled_columns(plan: Plan) -> Plan:
     """The gradient step of a fused-gate recurrence assembles the gate gradients into ONE wide
-    matrix — ``X = zeros(B, 4H); X[:, 0:H] = p_i; X[:, H:2H] = p_f; ...`` — only to multiply it with
-    the (transposed) fused weight matrix and to hand it out as a nit-sot output.  The product is a
-    sum over the blocks, ``z + X @ W = z + sum_k p_k @ W[a_k:b_k, :]``, and the output is the blocks
-    side by side, so the assembly leaves the step: the Scan returns the blocks as separate nit-sot
-    outputs (H-wide, what the persistent matrix kernel writes) and ONE ``Join`` after the loop
-    rebuilds ``[T, B, 4H]`` for the weight-gradient GEMMs."""
+    value — ``X = zeros(B, 4H); X[:, 0:H] = p_i; X[:, H:2H] = p_f; ...`` (a vector of length 4H for
+    a vector state) — only to multiply it with the (transposed) fused weight matrix and to hand it
+    out as a nit-sot output.  The product is a sum over the blocks, ``z + X @ W = z + sum_k p_k @
+    W[a_k:b_k, :]`` (``z + A x = z + sum_k A[:, a_k:b_k] p_k`` for a Gemv), and the output is the
+    blocks side by side, so the assembly leaves the step: the Scan returns the blocks as separate
+    nit-sot outputs (H-wide, what the persistent kernels write) and ONE ``Join`` after the loop
+    rebuilds the wide array for the weight-gradient GEMMs."""
     def cint(pl, vid):
         v = pl.vars[vid]
         if v.const is not None and len(v.const.get("data", ())) == 1 and v.dtype.startswith("int"):
@@ -598,9 +607,8 @@ def split_assembled_columns(plan: Plan) -> Plan:
         p = dict(node.params)
         inner = p["inner"]
         n_seqs, n_nit, n_sh = p["n_seqs"], p["n_nit_sot"], p.get("n_shared_outs", 0)
-        mm_in = [list(t) for t in p.get("mit_mot_in_slices", [])]
         mm_out = [list(t) for t in p.get("mit_mot_out_slices", [])]
-        n_mm, n_ms, n_ss = len(mm_in), len(p["mit_sot_in_slices"]), len(p["sit_sot_in_slices"])
+        n_mm, n_ms, n_ss = len(mm_out), len(p["mit_sot_in_slices"]), len(p["sit_sot_in_slices"])
         nit0 = sum(len(t) for t in mm_out) + n_ms + n_ss
         n_var = len(inner.inputs) - p["n_non_seqs"]
         inv = set(inner.inputs[n_var:])
@@ -611,26 +619,31 @@ def split_assembled_columns(plan: Plan) -> Plan:
         icl = inner.clients()
         found = None
         for j in range(n_nit):
-            X = inner.outputs[nit0 + j]
-            if inner.vars[X].ndim != 2 or inner.outputs.count(X) != 1:
+            o = inner.outputs[nit0 + j]
+            X, view = o, None
+            if o in iprod and iprod[o].op == "DimShuffle" and \
+                    [d for d in iprod[o].params["new_order"] if d != "x"] == list(range(inner.vars[iprod[o].inputs[0]].ndim)):
+                X, view = iprod[o].inputs[0], iprod[o]       # handed out with broadcast axes added
+            nd = inner.vars[X].ndim
+            if nd not in (1, 2) or inner.outputs.count(o) != 1 or (view is not None and len(icl[o]) != 1):
                 continue
             parts, v = [], X
             while v in iprod and iprod[v].op == "IncSubtensor":
                 n_ = iprod[v]
                 idx = n_.params["idx_list"]
-                if len(idx) != 2 or idx[0].get("slice") != [None, None, None] or \
-                        idx[1].get("slice", [0, 0, 0])[2] not in (None, 1):
+                if len(idx) != nd or any("slice" not in e for e in idx) or \
+                        (nd == 2 and idx[0]["slice"] != [None, None, None]) or idx[-1]["slice"][2] not in (None, 1):
                     parts = None
                     break
                 extra, ab = list(n_.inputs[2:]), []
-                for e in idx[1]["slice"][:2]:
+                for e in idx[-1]["slice"][:2]:
                     ab.append(cint(inner, extra.pop(0)) if e == "in" and extra else (e if isinstance(e, int) else None))
                 if None in ab or extra:
                     parts = None
                     break
                 parts.append((ab[0], ab[1], n_.inputs[1]))
                 v = n_.inputs[0]
-                if v != X and len(icl[v]) != 1:
+                if len(icl[v]) != 1:
                     parts = None
                     break
             if not parts or v not in iprod or iprod[v].op != "Alloc":
@@ -641,32 +654,47 @@ def split_assembled_columns(plan: Plan) -> Plan:
             parts.sort()
             if parts[0][0] != 0 or any(parts[k][1] != parts[k + 1][0] for k in range(len(parts) - 1)):
                 continue
-            uses = [c for c in icl[X] if c[0] != "out"]
-            gemms = [inner.nodes[c[0]] for c in uses]
-            if len(uses) != 1 or uses[0][1] != 2 or gemms[0].op != "Gemm" or gemms[0].inputs[3] not in inv:
+            # X is read by exactly two things: the product and the output (or the view handed out)
+            uses = [c for c in icl[X] if c[0] != "out" and inner.nodes[c[0]] is not view]
+            if len(uses) != 1 or len(icl[X]) != 2:
                 continue
-            found = (j, X, parts, gemms[0])
+            un = inner.nodes[uses[0][0]]
+            if not ((nd == 2 and un.op == "Gemm" and uses[0][1] == 2 and un.inputs[3] in inv) or
+                    (nd == 1 and un.op == "Gemv" and uses[0][1] == 3 and un.inputs[2] in inv)):
+                continue
+            found = (j, X, view, parts, un, nd)
             break
         if found is None:
             out_nodes.append(node)
             continue
         changed = True
-        j, X, parts, gm = found
+        j, X, view, parts, un, nd = found
         work = Plan(inner.name + "_blocks", dict(inner.vars), list(inner.inputs), list(inner.outputs), [])
-        z, al, _x, W, be = gm.inputs
+        if nd == 2:
+            z, al, _x, W, be = un.inputs
+        else:
+            z, al, W, _x, be = un.inputs
         one = work.add_const(1.0, inner.vars[al].dtype)
         nodes = []
         for n_ in inner.nodes:
-            if n_ is not gm:
+            if n_ is not un:
                 nodes.append(n_)
                 continue
             acc = z
             for k, (a, b, pk) in enumerate(parts):
-                wk = work.new_var(inner.vars[W].dtype, [None, inner.vars[W].shape[1]])
-                nodes.append(Node("Subtensor", [W], [wk], {"idx_list": [{"slice": [a, b, None]}]}))
-                out = gm.outputs[0] if k == len(parts) - 1 else \
-                    work.new_var(inner.vars[gm.outputs[0]].dtype, list(inner.vars[gm.outputs[0]].shape))
-                nodes.append(Node("Gemm", [acc, al, pk, wk, be if k == 0 else one], [out], dict(gm.params)))
+                wv = inner.vars[W]
+                if nd == 2:      # rows a:b of W
+                    wk = work.new_var(wv.dtype, [None, wv.shape[1]])
+                    nodes.append(Node("Subtensor", [W], [wk], {"idx_list": [{"slice": [a, b, None]}]}))
+                else:            # columns a:b of A
+                    wk = work.new_var(wv.dtype, [wv.shape[0], None])
+                    nodes.append(Node("Subtensor", [W], [wk], {"idx_list": [{"slice": [None, None, None]},
+                                                                            {"slice": [a, b, None]}]}))
+                out = un.outputs[0] if k == len(parts) - 1 else \
+                    work.new_var(inner.vars[un.outputs[0]].dtype, list(inner.vars[un.outputs[0]].shape))
+                ins_ = [acc, al, pk, wk, be if k == 0 else one] if nd == 2 else \
+                    [acc, al, wk, pk, be if k == 0 else one]
+                nodes.append(Node(un.op, ins_, [out], dict(un.params)))
                 acc = out
         work.outputs = inner.outputs[:nit0 + j] + [pk for _a, _b, pk in parts] + inner.outputs[nit0 + j + 1:]
         work.nodes = _prune_dead(work, nodes)
@@ -677,12 +705,21 @@ def split_assembled_columns(plan: Plan) -> Plan:
         o0 = n_mm + n_ms + n_ss
         old = node.outputs[o0 + j]
         ov = plan.vars[old]
-        pouts = [plan.new_var(ov.dtype, list(ov.shape[:-1]) + [None]) for _ in parts]
+        xv = inner.vars[X]
+        pshape = [None] + list(xv.shape[:-1]) + [None]               # [T, (B,) width]
+        pouts = [plan.new_var(ov.dtype, pshape) for _ in parts]
         new_outputs = list(node.outputs[:o0 + j]) + pouts + list(node.outputs[o0 + j + 1:])
         out_nodes.append(Node("Scan", new_inputs, new_outputs, p))
-        ax = plan.add_const(ov.ndim - 1, "int8")
-        whole = plan.new_var(ov.dtype, list(ov.shape))
-        out_nodes.append(Node("Join", [ax] + pouts, [whole], {}))
+        ax = plan.add_const(nd, "int8")
+        if view is None:
+            whole = plan.new_var(ov.dtype, list(ov.shape))
+            out_nodes.append(Node("Join", [ax] + pouts, [whole], {}))
+        else:
+            wide = plan.new_var(ov.dtype, pshape)
+            out_nodes.append(Node("Join", [ax] + pouts, [wide], {}))
+            whole = plan.new_var(ov.dtype, list(ov.shape))
+            order = [0] + [d if d == "x" else d + 1 for d in view.params["new_order"]]
+            out_nodes.append(Node("DimShuffle", [wide], [whole], {"new_order": order}))
         replaced[old] = whole
     if not changed:
         return orig

@@ -332,7 +332,8 @@ def test_varying_chunk_lengths_share_one_exchange_workspace(batch):
     assert set(ex.scan_modes.values()) == {"persistent"}, ex.scan_modes
 
 
-@pytest.mark.parametrize("name", ["gru_bptt_b1_f32", "lstm_bptt_vec_f32", "scan_grad_last_state_f32"])
+@pytest.mark.parametrize("name", ["gru_bptt_b1_f32", "lstm_bptt_vec_f32", "scan_grad_last_state_f32",
+                                  "lstm_fused_vec_bptt_f32", "lstm_fused_bptt_h64_f32", "rnn_bias_bptt_b4_f32"])
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_gradient_scans_run_persistent_and_match(name, use_graph):
     """aesara.grad through a recurrence: the forward Scan and the gradient Scan (mit-mot groups

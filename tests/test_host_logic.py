@@ -361,7 +361,8 @@ def test_accumulator_push_out_preserves_every_golden_scan_plan():
     assert {"rnn_bias_bptt_b4_f32", "lstm_fused_bptt_h64_f32"} <= set(changed), changed
 
 
-@pytest.mark.parametrize("name", ["lstm_fused_bptt_h64_f32", "lstm_bptt_float32", "lstm_bptt_float64"])
+@pytest.mark.parametrize("name", ["lstm_fused_bptt_h64_f32", "lstm_bptt_float32", "lstm_bptt_float64",
+                                  "lstm_fused_vec_bptt_f32"])
 def test_assembled_gate_gradients_leave_the_step(name):
     """fusion.split_assembled_columns (after push_out_accumulators) on fused-gate LSTM gradient
     Scans: the 4H-wide assembled gate gradient becomes per-gate nit-sot outputs + one Join after the
