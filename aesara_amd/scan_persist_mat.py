@@ -22,6 +22,13 @@ instead of 2 launches per step that re-stream 12 MiB of weights from the memory-
 Batch blocks are independent recurrences: block -> workgroup mapping ``bi = blockIdx % NB`` puts
 the workgroups of one block on one or two XCDs (``blockIdx % 8``), so a block's granules are
 polled through two L2s only.
+
+The same kernel runs gradient Scans (mit-mot groups [0, 1] -> [1]: a state plus a sequence that
+lives in the output buffer, ``scan_persist.analyze``), phases without a product (Elemwise only:
+no barrier, publishes deferred to the next hand-off), plain ``Dot22`` / ``Gemm`` nodes as product
+phases, several operands published together (one polling pass, loads in flight together),
+operand blocks that lend each other their LDS slot, and state widths that are not a multiple of
+64 (``SpecMat.Nt``: the executor zero-pads the weights, unowned columns are never published).
 """
 from __future__ import annotations
 
