@@ -64,6 +64,15 @@ def _prebuild_full_shapes(cases):
                            np.float32(0.1), fake((1 << 16,), "float32")]),
         ("softmax_rows_f32", [fake((4096, 1024), "float32")]),
     ]
+    # BASELINE config 4 and its training step at the bench shape: the persistent Scan kernels are
+    # specialised on the state length / batch (T is a run-time argument)
+    T, H = 512, 1024
+    Ws = [fake((H, H), "float32") for _ in range(6)]
+    for name, B in (("cfg4_gru_b1_f32", 1), ("cfg4_gru_b8_f32", 64), ("gru_bptt_b1_f32", 1),
+                    ("gru_bptt_b4_f32", 64)):
+        x = fake((T, H) if B == 1 else (T, B, H), "float32")
+        h0 = fake((H,) if B == 1 else (B, H), "float32")
+        work.append((name, [x, h0] + Ws))
     done = 0
     for name, args in work:
         c = cases.get(name)
