@@ -16,6 +16,11 @@ Two graph-level transformations, both decided on the *plan* (never on run-time v
    * ``extent``   — ``Shape_i`` of a split value along its split axis (local length; the global
      length is the sum).
 
+   Basic indexing that leaves the split axis whole keeps the split (``Subtensor`` /
+   ``IncSubtensor``); a ``Scan`` whose sequences and initial states are split along their batch
+   axis and whose step is row-local (same analysis on the inner plan) runs on every rank's rows
+   with no exchange (:func:`_shard_scan`).
+
    A ``partial`` (or an ``extent`` read by anything but an allocation) has to be combined before
    it is read: the plan is cut into *rounds*; round k runs locally, then ONE packed
    ``all_reduce`` per (reduction op, exchange dtype) sums / maxes all of round k's partials, and
@@ -61,8 +66,8 @@ def shard_rows(n_rows: int, world: int, rank: int) -> Tuple[int, int]:
 # ---------------------------------------------------------------------------------------------
 REP = ("rep",)
 _RED_OPS = {"add": "add", "maximum": "maximum", "minimum": "minimum"}
-_VIEW_REP_ONLY = {"Subtensor", "IncSubtensor", "AdvancedSubtensor1", "AdvancedIncSubtensor1",
-                  "AdvancedSubtensor", "AdvancedIncSubtensor", "Reshape", "Join", "Split", "Scan",
+_VIEW_REP_ONLY = {"AdvancedSubtensor1", "AdvancedIncSubtensor1",
+                  "AdvancedSubtensor", "AdvancedIncSubtensor", "Reshape", "Join", "Split",
                   "CumOp", "Argmax", "MaxAndArgmax", "Sort", "ArgSort", "IfElse", "BatchedDot",
                   "MatMul", "Ger"}
 
@@ -288,6 +293,33 @@ def shard_plan(plan: Plan, split_inputs: Dict[int, int]) -> ShardedPlanSpec:
                 raise ShardingError(f"{op} with operand states A={sA} B={sB} C={sC} beta={beta}")
         elif op in ("ScalarFromTensor", "TensorFromScalar"):
             state[n.outputs[0]] = ins[0]
+        elif op in ("Subtensor", "IncSubtensor"):
+            # basic indexing that leaves the split axis whole is row-local
+            idx = n.params["idx_list"]
+            n_idx_in = 2 if op == "IncSubtensor" else 1
+            sx = ins[0]
+            if any(s != REP for s in ins[n_idx_in:]):
+                raise ShardingError(f"{op}: index operands must be replicated")
+            if sx[0] != "split":
+                raise ShardingError(f"{op}: a split value written into / read through a replicated one")
+            a = sx[1]
+            if a < len(idx) and idx[a].get("slice") != [None, None, None]:
+                raise ShardingError(f"{op}: the index touches the split axis {a}")
+            sub_axis = a - sum(1 for e in idx[:a] if "index" in e)
+            if op == "Subtensor":
+                state[n.outputs[0]] = ("split", sub_axis)
+            else:
+                sy, yv = ins[1], plan.vars[n.inputs[1]]
+                sub_nd = plan.vars[n.inputs[0]].ndim - sum(1 for e in idx if "index" in e)
+                ya = sub_axis - (sub_nd - yv.ndim)          # right-aligned broadcasting of y
+                if sy == REP:
+                    if ya >= 0 and yv.shape[ya] != 1:
+                        raise ShardingError("IncSubtensor: the replicated value spans the split axis")
+                elif sy != ("split", ya):
+                    raise ShardingError(f"IncSubtensor: value split on {sy}, target rows on axis {ya}")
+                state[n.outputs[0]] = sx
+        elif op == "Scan":
+            _shard_scan(plan, n, ins, state)
         else:
             raise ShardingError(f"{op}: not provably row-local for a split operand "
                                 f"(operand states {ins})")
@@ -359,6 +391,55 @@ def shard_plan(plan: Plan, split_inputs: Dict[int, int]) -> ShardedPlanSpec:
         fin = rnd[o] + (1 if state[o][0] == "partial" else 0)
         out_src.append((fin, rounds[fin][0].outputs.index(o)))
     return ShardedPlanSpec(rounds, carried, out_src, out_state, state)
+
+
+def _shard_scan(plan: Plan, n: Node, ins, state):
+    """A Scan whose sequences / initial states are split along their BATCH axis (axis 1 of the
+    ``[T, B, ...]`` arrays): the recurrences of different batch rows are independent when the step
+    itself is row-local — checked by running the same analysis on the inner plan with the per-step
+    values split on axis 0 — so every rank runs the loop on its rows, no exchange.  Outputs keep the
+    batch split (``[T, B, ...]`` on axis 1)."""
+    p = n.params
+    if p.get("as_while") or p.get("n_shared_outs", 0) or p.get("mit_mot_in_slices"):
+        raise ShardingError("Scan: do-while / shared outputs / mit-mot taps are not sharded")
+    n_seqs, n_nit = p["n_seqs"], p["n_nit_sot"]
+    taps = [list(t) for t in p["mit_sot_in_slices"]] + [list(t) for t in p["sit_sot_in_slices"]]
+    n_rec = len(taps)
+    if ins[0] != REP or any(s != REP for s in ins[1 + n_seqs + n_rec:]):
+        raise ShardingError("Scan: the step count and the non-sequences must be replicated")
+    inner = p["inner"]
+    split_in, k = {}, 0
+    for j in range(n_seqs):
+        s = ins[1 + j]
+        if s != REP:
+            if s != ("split", 1):
+                raise ShardingError(f"Scan: sequence {j} is split on {s}, not on its batch axis 1")
+            split_in[k] = 0
+        k += 1
+    for r in range(n_rec):
+        s = ins[1 + n_seqs + r]
+        if s != REP and s != ("split", 1):
+            raise ShardingError(f"Scan: initial state {r} is split on {s}, not on its batch axis 1")
+        for _t in taps[r]:
+            if s != REP:
+                split_in[k] = 0
+            k += 1
+    spec = shard_plan(inner, split_in)            # raises when the step is not row-local
+    if spec.n_exchange_rounds:
+        raise ShardingError("Scan: the step combines values across the batch rows")
+    for r in range(n_rec):
+        s_in, s_out = ins[1 + n_seqs + r], spec.out_state[r]
+        if (s_in == REP) != (s_out == REP) or (s_out != REP and s_out != ("split", 0)):
+            raise ShardingError(f"Scan: state {r} enters as {s_in} and leaves the step as {s_out}")
+        state[n.outputs[r]] = s_in
+    for j in range(n_nit):
+        s_out = spec.out_state[n_rec + j]
+        if s_out == REP:
+            state[n.outputs[n_rec + j]] = REP
+        elif s_out[0] == "split":
+            state[n.outputs[n_rec + j]] = ("split", s_out[1] + 1)
+        else:
+            raise ShardingError(f"Scan: per-step output {j} leaves the step as {s_out}")
 
 
 def plan_split_outputs(plan: Plan, split_input: int, axis: int = 0) -> List[str]:

@@ -44,9 +44,12 @@ def _worker(rank, world, port, case_name, q):
             c = next(c for c in CASES if c["name"] == case_name)
             plan, ins = case_plan(c), case_inputs(c)
             split = {0: 0, 3: 0} if case_name == "cfg5_logistic" else {0: 0}
-        n = ins[0].shape[0]
+        if case_name == "cfg4_gru_b8_f32":
+            split = {0: 1, 1: 0}           # x [T, B, D] and h0 [B, H]: the batch axis
+        n = ins[0].shape[split[0]]
         lo, hi = shard_rows(n, world, rank)
-        local = [x[lo:hi] if k in split else x for k, x in enumerate(ins)]
+        local = [np.take(x, np.arange(lo, hi), axis=split[k]) if k in split else x
+                 for k, x in enumerate(ins)]
         sp = ShardedPlan(plan, split, executor_factory=oracle_factory)
         outs = sp(*local)
         outs2 = sp(*local)             # second call: packed buffers are reused
@@ -245,3 +248,52 @@ def test_random_plans_shard_soundly():
                         w = w[tuple(sl)]
                     assert o.shape == w.shape and np.array_equal(o, w), (seed, trial, r, st, plan.pretty())
     assert accepted >= 40 and refused >= 20, (accepted, refused)
+
+
+def test_scan_is_sharded_along_the_batch_axis():
+    """BASELINE config 4 with a matrix state: sequences ``[T, B, D]`` and the initial state
+    ``[B, H]`` split along the batch axis — the step is row-local (checked by the same analysis on
+    the inner plan), so every shard runs the loop on its rows with NO exchange and the outputs stay
+    split on the batch axis; bit-equal to the unsharded blocks.  Gradient Scans (mit-mot) and a
+    split along time are refused."""
+    import interp
+    from golden_util import CASES, case_inputs, case_plan
+    from aesara_amd.dist import ShardingError, run_local_shards, shard_plan, shard_rows
+    c = next(c for c in CASES if c["name"] == "cfg4_gru_b8_f32")
+    plan, ins = case_plan(c), case_inputs(c)
+    want = interp.run_plan(plan, ins)
+    B = ins[0].shape[1]
+    for k in (2, 3):
+        shards = []
+        for r in range(k):
+            lo, hi = shard_rows(B, k, r)
+            shards.append([ins[0][:, lo:hi], ins[1][lo:hi]] + list(ins[2:]))
+        outs, spec = run_local_shards(plan, {0: 1, 1: 0}, shards, executor_factory=oracle_factory)
+        assert spec.n_exchange_rounds == 0 and len(spec.rounds) == 1
+        assert spec.out_state == [("split", 1), ("split", 0)]
+        for r in range(k):
+            lo, hi = shard_rows(B, k, r)
+            assert np.array_equal(np.asarray(outs[r][0]), want[0][:, lo:hi])
+            assert np.array_equal(np.asarray(outs[r][1]), want[1][lo:hi])
+    with pytest.raises(ShardingError):          # the time axis cannot be split
+        shard_plan(plan, {0: 0})
+    with pytest.raises(ShardingError):          # h0 replicated next to a split x: states disagree
+        shard_plan(plan, {0: 1})
+    bptt = case_plan(next(c for c in CASES if c["name"] == "gru_bptt_b4_f32"))
+    with pytest.raises(ShardingError):          # gradient Scan / Reshape of the split arrays
+        shard_plan(bptt, {0: 1, 1: 0})
+
+
+def test_batch_sharded_scan_over_two_gloo_ranks():
+    """``ShardedPlan`` over a world-size-2 gloo group on BASELINE config 4 (matrix state) split
+    along the batch: no exchange round, every rank returns its rows of all hidden states."""
+    from golden_util import CASES, case_expected
+    got = _run2("cfg4_gru_b8_f32")
+    c = next(c for c in CASES if c["name"] == "cfg4_gru_b8_f32")
+    hs, hT = case_expected(c)
+    B = hs.shape[1]
+    for rank, n_rounds, states, outs in got:
+        assert n_rounds == 0 and states == ["split", "split"]
+        lo, hi = (0, B // 2) if rank == 0 else (B // 2, B)
+        np.testing.assert_allclose(outs[0], hs[:, lo:hi], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(outs[1], hT[lo:hi], rtol=1e-5, atol=1e-6)
