@@ -236,6 +236,17 @@ def main():
         for name, fn in SECONDARY:
             if only and name not in only:
                 continue
+            if world > 1 and name == "cfg4":
+                # config 4 with a matrix state shards along the batch: strong scaling,
+                # no collective on the data path.  Guarded: an extra row must never cost the line.
+                try:
+                    r = sec_cfg4_sharded(ctx)
+                except Exception as e:              # noqa: BLE001
+                    r = {"config": "cfg4 Scan GRU B=64 batch-sharded", "error": "%s: %s" % (type(e).__name__, e)}
+                if rank == 0:
+                    secondary.append(r)
+                torch.cuda.empty_cache()
+                continue
             if world > 1 and name != "cfg5":
                 continue              # replicas only: measured at N=1
             r = fn(ctx)
@@ -421,6 +432,38 @@ def sec_cfg4(c):
                                "gradients": "tests/test_gpu_fullsize.py::test_gru_bptt_against_torch_autograd"}})
         del ex
     return rows
+
+
+def sec_cfg4_sharded(c):
+    """Config 4, B = 64, split along the batch over the ranks (aesara_amd/dist.py: the step is
+    row-local, every rank runs the persistent loop on its B / N rows; no exchange).  Strong
+    scaling: `evals_per_s` is whole-job (one eval = all 64 sequences)."""
+    torch, np, dist = c["torch"], c["np"], c["dist"]
+    from aesara_amd.dist import ShardedPlan, shard_rows
+    f32 = torch.float32
+    T, H, B = 512, 1024, 64
+    world, rank = c["world"], c["rank"]
+    lo, hi = shard_rows(B, world, rank)
+    Ws = [c["randn"]((H, H), f32, 5 + k) / np.sqrt(H) for k in range(6)]
+    x = c["randn"]((T, B, H), f32, 4)[:, lo:hi].contiguous() * 0.1
+    h0 = torch.zeros((hi - lo, H), dtype=f32, device="cuda")
+    sp = ShardedPlan(c["plan_of"]("cfg4_gru_b8_f32"), split_inputs={0: 1, 1: 0}, use_graph=c["G"], borrow=True,
+                     group=dist.group.WORLD)
+    outs = sp(x, h0, *Ws)
+    ref = _gru_ref(torch, x, h0, Ws)
+    err = ((outs[-1].double() - ref).abs().max() / ref.abs().max()).item()
+    assert err <= 1e-5, f"cfg4 sharded: h_T rel err {err}"
+    dist.barrier()
+    d, w = c["timer"].time(lambda: sp(x, h0, *Ws), 5, warmup=1)
+    t = torch.tensor([d, w], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    d, w = t.tolist()
+    return {"config": "cfg4 Scan GRU T=512 H=1024 fp32 B=64 batch-sharded, %d rank(s) x %d rows, strong scaling"
+                      % (world, hi - lo), "dtype": "f32", "n_gpus": world, "scaling": "strong",
+            "evals_per_s": 1e3 / max(d, w), "ms_per_eval": d, "collective": "none on the data path",
+            "roofline": roof("mfma", T * 6 * 2 * (hi - lo) * H * H, d, MFMA_F32_PEAK, us_per_step=d * 1e3 / T,
+                             note="per-rank flops; kernel_ms is the max over the ranks"),
+            "check": {"hT_max_rel_err_vs_fp64_local_rows": err, "bar": 1e-5}}
 
 
 def sec_cfg5(c):
