@@ -398,13 +398,16 @@ def _shard_scan(plan: Plan, n: Node, ins, state):
     ``[T, B, ...]`` arrays): the recurrences of different batch rows are independent when the step
     itself is row-local — checked by running the same analysis on the inner plan with the per-step
     values split on axis 0 — so every rank runs the loop on its rows, no exchange.  Outputs keep the
-    batch split (``[T, B, ...]`` on axis 1)."""
+    batch split (``[T, B, ...]`` on axis 1).  Covers forward Scans and the gradient Scans of
+    ``aesara.grad`` (mit-mot groups: every tap of a split buffer is a split per-step value)."""
     p = n.params
-    if p.get("as_while") or p.get("n_shared_outs", 0) or p.get("mit_mot_in_slices"):
-        raise ShardingError("Scan: do-while / shared outputs / mit-mot taps are not sharded")
+    if p.get("as_while") or p.get("n_shared_outs", 0):
+        raise ShardingError("Scan: do-while / shared outputs are not sharded")
     n_seqs, n_nit = p["n_seqs"], p["n_nit_sot"]
-    taps = [list(t) for t in p["mit_sot_in_slices"]] + [list(t) for t in p["sit_sot_in_slices"]]
-    n_rec = len(taps)
+    mm_in = [list(t) for t in p.get("mit_mot_in_slices", [])]
+    mm_out = [list(t) for t in p.get("mit_mot_out_slices", [])]
+    taps = mm_in + [list(t) for t in p["mit_sot_in_slices"]] + [list(t) for t in p["sit_sot_in_slices"]]
+    n_mm, n_rec = len(mm_in), len(taps)
     if ins[0] != REP or any(s != REP for s in ins[1 + n_seqs + n_rec:]):
         raise ShardingError("Scan: the step count and the non-sequences must be replicated")
     inner = p["inner"]
@@ -412,28 +415,32 @@ def _shard_scan(plan: Plan, n: Node, ins, state):
     for j in range(n_seqs):
         s = ins[1 + j]
         if s != REP:
-            if s != ("split", 1):
-                raise ShardingError(f"Scan: sequence {j} is split on {s}, not on its batch axis 1")
-            split_in[k] = 0
+            if s[0] != "split" or s[1] < 1:
+                raise ShardingError(f"Scan: sequence {j} is split on {s} (the time axis cannot be split)")
+            split_in[k] = s[1] - 1
         k += 1
     for r in range(n_rec):
         s = ins[1 + n_seqs + r]
-        if s != REP and s != ("split", 1):
-            raise ShardingError(f"Scan: initial state {r} is split on {s}, not on its batch axis 1")
+        if s != REP and (s[0] != "split" or s[1] < 1):
+            raise ShardingError(f"Scan: initial state {r} is split on {s} (the time axis cannot be split)")
         for _t in taps[r]:
             if s != REP:
-                split_in[k] = 0
+                split_in[k] = s[1] - 1
             k += 1
     spec = shard_plan(inner, split_in)            # raises when the step is not row-local
     if spec.n_exchange_rounds:
         raise ShardingError("Scan: the step combines values across the batch rows")
+    o = 0
     for r in range(n_rec):
-        s_in, s_out = ins[1 + n_seqs + r], spec.out_state[r]
-        if (s_in == REP) != (s_out == REP) or (s_out != REP and s_out != ("split", 0)):
-            raise ShardingError(f"Scan: state {r} enters as {s_in} and leaves the step as {s_out}")
+        s_in = ins[1 + n_seqs + r]
+        for _ in range(len(mm_out[r]) if r < n_mm else 1):
+            s_out = spec.out_state[o]
+            o += 1
+            if (s_in == REP) != (s_out == REP) or (s_out != REP and s_out != ("split", s_in[1] - 1)):
+                raise ShardingError(f"Scan: state {r} enters as {s_in} and leaves the step as {s_out}")
         state[n.outputs[r]] = s_in
     for j in range(n_nit):
-        s_out = spec.out_state[n_rec + j]
+        s_out = spec.out_state[o + j]
         if s_out == REP:
             state[n.outputs[n_rec + j]] = REP
         elif s_out[0] == "split":
