@@ -197,3 +197,33 @@ def test_random_plans_shard_soundly_on_the_hip_executor(use_graph):
                         w = w[tuple(sl)]
                     assert o.shape == w.shape and np.array_equal(o, w), (trial, call, r, st, plan.pretty())
     assert accepted >= 15, accepted
+
+
+@pytest.mark.parametrize("k", [2, 3])
+def test_batch_sharded_scan_on_the_hip_executor(k):
+    """BASELINE config 4 (matrix state) split along the batch into k logical shards, each running
+    the persistent kernel on its rows (no exchange round): every shard's hidden states equal the
+    unsharded run's rows (same kernel arithmetic per row block up to the GEMM tiling of the hoisted
+    products)."""
+    import torch
+    from golden_util import CASES, case_plan
+    from aesara_amd.dist import run_local_shards, shard_rows
+    from aesara_amd.executor import PlanExecutor
+    plan = case_plan(next(c for c in CASES if c["name"] == "cfg4_gru_b8_f32"))
+    T, B, H = 24, 40, 128
+    g = torch.Generator(device="cuda")
+    g.manual_seed(31)
+    x = torch.randn(T, B, H, device="cuda", generator=g) * 0.1
+    h0 = torch.randn(B, H, device="cuda", generator=g) * 0.5
+    Ws = [torch.randn(H, H, device="cuda", generator=g) / np.sqrt(H) for _ in range(6)]
+    whole = PlanExecutor(plan)(x, h0, *Ws)
+    shards = []
+    for r in range(k):
+        lo, hi = shard_rows(B, k, r)
+        shards.append([x[:, lo:hi].contiguous(), h0[lo:hi].contiguous()] + Ws)
+    outs, spec = run_local_shards(plan, {0: 1, 1: 0}, shards)
+    assert spec.n_exchange_rounds == 0 and spec.out_state == [("split", 1), ("split", 0)]
+    for r in range(k):
+        lo, hi = shard_rows(B, k, r)
+        assert torch.allclose(outs[r][0], whole[0][:, lo:hi], rtol=1e-4, atol=2e-6)
+        assert torch.allclose(outs[r][1], whole[1][lo:hi], rtol=1e-4, atol=2e-6)
