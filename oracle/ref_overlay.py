@@ -1,16 +1,28 @@
-"""Import the *reference* Aesara (overlay of /root/reference) in the authoring container.
+"""Import the *reference* Aesara (an overlay of /root/reference) as the checker / CPU baseline.
 
-TEST INFRASTRUCTURE ONLY.  Only tests/, oracle/ scripts and bench.py's cpu_baseline leg may
-import this; the product package `aesara_amd` never does.  On the GPU box `/root/reference`
-does not exist and `available()` returns False.
+TEST INFRASTRUCTURE ONLY.  Only tests/, oracle/ scripts and bench.py's ``cpu_baseline`` and
+``through_function`` legs may import this; the product package `aesara_amd` never does.
+
+Where the reference front end comes from, in this order:
+
+1. an overlay that is already built (``$AESARA_REF_OVERLAY/.built``);
+2. ``/root/reference`` (authoring container): ``build_ref_overlay.sh`` builds the overlay;
+3. ``oracle/_ref/aesara_ref_overlay.tar.gz`` — the packed overlay ``pack_ref_overlay.sh`` writes
+   (git-ignored build artefact, never committed; it travels to the GPU box with the snapshot the
+   same way the built ``.so`` files do) — unpacked under ``/tmp``.
+
+With none of them ``available()`` is False and everything that needs the front end skips.
 """
 import os
 import subprocess
 import sys
+import tarfile
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 OVERLAY = os.environ.get("AESARA_REF_OVERLAY", "/tmp/aesara_ref_overlay")
 REFERENCE = os.environ.get("AESARA_REFERENCE", "/root/reference")
+ARCHIVE = os.path.join(_HERE, "_ref", "aesara_ref_overlay.tar.gz")
+COMPILEDIR = "/tmp/aesara_ref_compiledir" + os.environ.get("AESARA_REF_COMPILEDIR_SUFFIX", "")
 
 _CXXFLAGS = (
     "-DNPY_PY3K=1 -DPyInt_AsLong=PyLong_AsLong -DPyInt_FromLong=PyLong_FromLong "
@@ -20,24 +32,54 @@ _CXXFLAGS = (
 )
 
 
+def _built():
+    return os.path.isfile(os.path.join(OVERLAY, ".built"))
+
+
+def source():
+    """Which of the three sources would be used: 'overlay', 'reference', 'archive' or None."""
+    if _built():
+        return "overlay"
+    if os.path.isdir(os.path.join(REFERENCE, "aesara")):
+        return "reference"
+    if os.path.isfile(ARCHIVE):
+        return "archive"
+    return None
+
+
 def available():
-    return os.path.isdir(os.path.join(REFERENCE, "aesara"))
+    return source() is not None
+
+
+def _unpack():
+    parent = os.path.dirname(OVERLAY.rstrip("/")) or "/"
+    os.makedirs(parent, exist_ok=True)
+    with tarfile.open(ARCHIVE) as tf:
+        top = tf.getnames()[0].split("/")[0]
+        tf.extractall(parent)
+    got = os.path.join(parent, top)
+    if os.path.abspath(got) != os.path.abspath(OVERLAY):
+        os.replace(got, OVERLAY)
 
 
 def import_reference():
-    """Build the overlay if needed and return the imported reference `aesara` module."""
+    """Make the overlay importable and return the imported reference `aesara` module."""
     if "aesara" in sys.modules:
         return sys.modules["aesara"]
-    if not available():
-        raise ImportError("reference Aesara not present (expected on the GPU box)")
-    subprocess.run([os.path.join(_HERE, "build_ref_overlay.sh")], check=True,
-                   stdout=subprocess.DEVNULL)
+    src = source()
+    if src is None:
+        raise ImportError("reference Aesara not present (no /root/reference, no packed overlay)")
+    if src == "reference":
+        subprocess.run([os.path.join(_HERE, "build_ref_overlay.sh")], check=True,
+                       stdout=subprocess.DEVNULL)
+    elif src == "archive":
+        _unpack()
     stubs = os.path.join(_HERE, "stubs")
     for p in (stubs, OVERLAY):
         if p not in sys.path:
             sys.path.insert(0, p)
     flags = os.environ.get("AESARA_FLAGS", "")
-    extra = f"base_compiledir=/tmp/aesara_ref_compiledir,gcc__cxxflags={_CXXFLAGS}"
+    extra = f"base_compiledir={COMPILEDIR},gcc__cxxflags={_CXXFLAGS}"
     os.environ["AESARA_FLAGS"] = (flags + "," if flags else "") + extra
     import warnings
 
