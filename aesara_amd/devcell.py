@@ -56,8 +56,9 @@ class DeviceCellMixin:
             return
         self._host_set(value)
         if self.device is not None and isinstance(self.storage[0], np.ndarray):
+            # (np.ascontiguousarray would turn a 0-d value — a scalar parameter — into shape (1,))
             self.storage[0] = torch.from_numpy(
-                np.ascontiguousarray(self.storage[0])).to(self.device)
+                np.array(self.storage[0], order="C", copy=True)).to(self.device)
 
 
 class PlainType:

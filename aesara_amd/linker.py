@@ -63,13 +63,32 @@ class HipLinker(JITLinker):
         # test hook: lets CPU-only tests substitute a checker for the device executor.
         self.executor_factory = executor_factory
         self.plan = None
+        self.profile = None
+
+    def accept(self, fgraph, no_recycling=None, profile=None):
+        """``PerformLinker.accept`` (link/basic.py:300) drops ``profile`` and, when the instance
+        is already bound to another graph, re-creates the linker from ``allow_gc`` alone; this
+        one keeps its options (``return_numpy``, ``use_graph`` ...) and remembers the
+        ``ProfileStats`` so the executor can time its steps (``VMLinker.accept`` link/vm.py:868)."""
+        if self.fgraph is not None and self.fgraph is not fgraph:
+            from copy import copy
+
+            new = copy(self)
+            new.fgraph = None
+            for k in ("executor", "_update_outputs"):
+                new.__dict__.pop(k, None)
+            new.plan = None
+            return new.accept(fgraph, no_recycling, profile)
+        super().accept(fgraph, no_recycling=no_recycling, profile=profile)
+        self.profile = profile
+        return self
 
     def __getstate__(self):
         # a pickled / deep-copied Function is re-linked when it is loaded (the reference pickles the
         # FunctionMaker, compile/function/types.py:1125 _pickle_Function): device executors,
         # module handles and the lowered plan are rebuilt then, never serialised
         state = dict(self.__dict__)
-        for k in ("executor", "plan", "_update_outputs"):
+        for k in ("executor", "plan", "_update_outputs", "_order"):
             state.pop(k, None)
         state["plan"] = None
         return state
@@ -77,6 +96,7 @@ class HipLinker(JITLinker):
     # -- JITLinker API ---------------------------------------------------------------
     def fgraph_convert(self, fgraph, order=None, input_storage=None, output_storage=None,
                        storage_map=None, **kwargs):
+        self._order = list(order) if order is not None else list(fgraph.toposort())
         self.plan = lower_fgraph(fgraph, order=order, name=getattr(fgraph, "name", None)
                                  or "fgraph", inner_rewriter=hip_mode.optimizer)
         # outputs that are ``updates=`` expressions go back into shared-variable cells
@@ -91,6 +111,8 @@ class HipLinker(JITLinker):
         from .executor import PlanExecutor  # imports the C-ABI; fails loudly if missing
 
         ex = PlanExecutor(plan, use_graph=self.use_graph)
+        if self.profile:
+            ex.enable_profile()
         self.executor = ex
         return ex
 
@@ -135,24 +157,97 @@ class HipLinker(JITLinker):
         else:
             call = lambda: jit(*[c[0] for c in in_cells])              # noqa: E731
 
+        # cells the reference's ``streamline`` clears before every run (link/utils.py:196-197):
+        # outputs that are not borrowed must never be recycled — the executor hands out fresh
+        # tensors for them anyway; the cells are dropped so no stale reference outlives a failure
+        clear = [c for c in self._no_recycling_cells(slow_fn) if c in out_cells]
+
         if plain and len(out_cells) == 1:
             oc = out_cells[0]
 
-            def vm():
+            def run():
                 oc[0] = call()[0]
         elif plain:
-            def vm():
+            def run():
                 for cell, val in zip(out_cells, call()):
                     cell[0] = val
         else:
-            def vm():
+            def run():
                 for var, cell, val in zip(out_vars, out_cells, call()):
                     cell[0] = ofilter(var, val)
+
+        def vm():
+            try:
+                run()
+            except Exception as e:
+                # ``Function.__call__`` (types.py:974-991) re-raises through ``raise_with_op`` with
+                # ``vm.nodes[vm.position_of_error]`` when the VM names a position
+                for c in clear:
+                    c[0] = None
+                pos = vm.position_of_error = self._locate_error(e)
+                n = order[pos]
+                vm.thunks[pos] = _NodeCells([[_describe(smap[i][0])] for i in n.inputs],
+                                            [smap[o] for o in n.outputs])
+                raise
+
         for attr in ("jit_fn", "allow_gc", "storage_map"):
             setattr(vm, attr, getattr(slow_fn, attr))
-        vm.thunks, vm.nodes = [thunk], getattr(slow_fn, "nodes", None)
+        # one entry per Apply node of the schedule (what ``position_of_error`` indexes); the
+        # "thunk" of a node only lends ``raise_with_op`` its input cells (shapes / strides)
+        order = list(self._order)
+        smap = slow_fn.storage_map
+        vm.nodes = order
+        vm.thunks = [_NodeCells([smap[i] for i in n.inputs], [smap[o] for o in n.outputs])
+                     for n in order]
+        vm.jit_thunk = thunk
         vm.slow_vm = slow_fn
+        vm.update_profile = self._update_profile
         return vm
+
+    def _no_recycling_cells(self, slow_fn):
+        nr = self.no_recycling
+        smap = slow_fn.storage_map
+        if nr is True:
+            return list(smap.values())
+        return [smap[r] for r in (nr or ()) if r not in self.fgraph.inputs]
+
+    def _apply_position(self, ex, si):
+        """Executor step -> position of its Apply node in the schedule (None if unknown)."""
+        origin = getattr(self.plan, "var_origin", None) or {}
+        st = ex.steps[si]
+        outs = list(st.outputs) + ([st.reduce["out"]] if st.reduce is not None else [])
+        for o in outs:
+            if o in origin:
+                return origin[o]
+        return None
+
+    def _locate_error(self, e):
+        hs = getattr(e, "hip_step", None)
+        pos = None
+        if hs is not None and hs[0] is getattr(self, "executor", None):
+            pos = self._apply_position(*hs)
+        if pos is None:                      # unknown: the node of the first computed output
+            owners = [o.owner for o in self.fgraph.outputs if o.owner is not None]
+            pos = self._order.index(owners[0]) if owners and owners[0] in self._order else 0
+        return pos
+
+    def _update_profile(self, profile):
+        """``VM.update_profile`` (link/vm.py:251): per-Apply device time (HIP events around the
+        executor's steps; a fused step is booked on the node that produces its result) and call
+        counts.  Nodes that became views / host shape arithmetic cost no device time."""
+        ex = getattr(self, "executor", None)
+        if ex is None or not getattr(ex, "profiling", False):
+            return
+        fg = self.fgraph
+        for si, (t, c) in enumerate(zip(ex.step_time, ex.step_count)):
+            pos = self._apply_position(ex, si)
+            if pos is None or not c:
+                continue
+            node = self._order[pos]
+            profile.apply_time[(fg, node)] = profile.apply_time.get((fg, node), 0.0) + t
+            profile.apply_callcount[(fg, node)] = profile.apply_callcount.get((fg, node), 0) + c
+            profile.apply_cimpl[node] = False
+            ex.step_time[si], ex.step_count[si] = 0.0, 0
 
     def create_thunk_inputs(self, storage_map):
         return [storage_map[n] for n in self.fgraph.inputs]
@@ -162,6 +257,33 @@ class HipLinker(JITLinker):
                 and var not in getattr(self, "_update_outputs", ()):
             return out.detach().cpu().numpy()
         return out
+
+
+class _ValueView:
+    """What ``raise_with_op`` prints about a value (shape, strides, size) for a device tensor —
+    ``torch.Tensor.size`` is a method, ``raise_with_op`` compares it with an int."""
+
+    def __init__(self, t):
+        self.shape = tuple(t.shape)
+        self.strides = tuple(s * t.element_size() for s in t.stride())
+        self.size = t.numel()
+        self.dtype = str(t.dtype).replace("torch.", "")
+        self.device = str(t.device)
+
+    def __repr__(self):
+        return f"<{self.dtype}{list(self.shape)} on {self.device}>"
+
+
+def _describe(v):
+    return _ValueView(v) if hasattr(v, "element_size") and callable(getattr(v, "size", None)) else v
+
+
+class _NodeCells:
+    """The storage cells of one Apply node, in the shape ``raise_with_op`` reads from a thunk."""
+    __slots__ = ("inputs", "outputs")
+
+    def __init__(self, inputs, outputs):
+        self.inputs, self.outputs = inputs, outputs
 
 
 hip_linker = HipLinker()

@@ -197,9 +197,21 @@ def lower_fgraph(fgraph, order=None, name="fgraph", inner_rewriter=None) -> Plan
     ctx = _Ctx(plan, inner_rewriter)
     for v in fgraph.inputs:
         plan.inputs.append(ctx.new(v))
-    for node in (order if order is not None else fgraph.toposort()):
+    # plan variable -> position (in ``order``) of the Apply node it was lowered from: how the
+    # linker maps a failing / timed executor step back to the graph (raise_with_op, fn.profile).
+    # A plain attribute, not part of the serialised plan.
+    origin = {}
+    for k, node in enumerate(order if order is not None else fgraph.toposort()):
+        n0 = len(plan.nodes)
         hip_lower(node.op, node, ctx)
+        for pn in plan.nodes[n0:]:
+            for o in pn.outputs:
+                origin[o] = k
+        for o in node.outputs:
+            if o in ctx.vmap:
+                origin.setdefault(ctx.vmap[o], k)
     plan.outputs = [ctx.vid(o) for o in fgraph.outputs]
+    plan.var_origin = origin
     return plan
 
 

@@ -166,6 +166,81 @@ def test_mlp_training_step_through_the_linker_matches_c_linker(ae):
         np.testing.assert_allclose(ph.get_value(), pr.get_value(), rtol=1e-9, atol=1e-12)
 
 
+def _dry_linker(**kw):
+    """HipLinker over the REAL PlanExecutor in dry-run mode (host logic, no device): the error
+    and profile plumbing between executor steps and Apply nodes runs exactly as on the GPU."""
+    from aesara_amd.executor import PlanExecutor
+    from aesara_amd.linker import HipLinker
+
+    class DryHipLinker(HipLinker):
+        def jit_compile(self, plan):
+            ex = PlanExecutor(plan, dry_run=True)
+            if self.profile:
+                ex.enable_profile()
+            self.executor = ex
+            return ex
+    return DryHipLinker(**kw)
+
+
+def test_errors_are_annotated_with_the_apply_node(ae):
+    """``Function.__call__`` re-raises through ``raise_with_op`` (link/utils.py:270) with the
+    Apply node named by ``vm.position_of_error`` (types.py:974-991); the exception keeps its
+    type (tests/tensor/test_elemwise.py:769-792 match on ValueError)."""
+    import aesara.tensor as at
+    from aesara.compile.mode import Mode
+    from aesara_amd.linker import HIP_QUERY
+    a, b, v = at.dmatrix("a"), at.dmatrix("b"), at.dvector("v")
+    f = ae.function([a, b, v], [at.dot(a, v).sum(), at.exp(a) + b * 2.0],
+                    mode=Mode(_dry_linker(), HIP_QUERY))
+    with pytest.raises(ValueError) as ei:
+        f(np.zeros((3, 4)), np.zeros((5, 4)), np.zeros(4))
+    msg = str(ei.value)
+    assert "Shapes on dimension 0 do not match" in msg
+    assert "Apply node that caused the error: Elemwise{Composite" in msg
+    assert "Inputs shapes: [(3, 4), (1, 1), (5, 4)]" in msg and "[HIP step" in msg
+    with pytest.raises(ValueError) as ei:          # the OTHER node of the same function
+        f(np.zeros((3, 4)), np.zeros((3, 4)), np.zeros(7))
+    line = next(ln for ln in str(ei.value).splitlines() if ln.startswith("Apply node that caused"))
+    assert "Gemv" in line or "dot" in line.lower(), line
+    # a later valid call is unaffected and the cells of non-borrowed outputs were dropped
+    assert len(f(np.zeros((3, 4)), np.zeros((3, 4)), np.zeros(4))) == 2
+
+
+def test_profile_stats_are_filled_per_apply_node(ae):
+    """``aesara.function(profile=True)``: the linker keeps the ProfileStats it ``accept``s
+    (link/vm.py:868) and ``vm.update_profile`` (link/vm.py:251) books step times on Apply nodes."""
+    import aesara.tensor as at
+    from aesara.compile.mode import Mode
+    from aesara_amd.linker import HIP_QUERY
+    x, v = at.dmatrix("x"), at.dvector("v")
+    f = ae.function([x, v], [at.dot(x, v).sum(), at.exp(x).sum(axis=0)],
+                    mode=Mode(_dry_linker(), HIP_QUERY), profile=True)
+    assert f.maker.linker.profile is f.profile and f.maker.linker.executor.profiling
+    for _ in range(4):
+        f(np.ones((40, 30)), np.arange(30.0))
+    prof = f.profile
+    assert prof.fct_callcount >= 3 and prof.vm_call_time > 0
+    assert prof.apply_time and sum(prof.apply_time.values()) > 0
+    assert all(c >= 3 for c in prof.apply_callcount.values())
+    # fused steps are booked on the node that produces their result: here the two Sums
+    topo = f.maker.fgraph.toposort()
+    assert len(prof.apply_time) >= 2 and all(n in topo for (_fg, n) in prof.apply_time)
+    assert all(fg is f.maker.fgraph for (fg, _n) in prof.apply_time)
+
+
+def test_accept_keeps_linker_options(ae):
+    """A bound linker asked to accept another graph (PerformLinker.accept re-creates itself from
+    allow_gc alone, link/basic.py:319-322) keeps return_numpy / use_graph / fast_call."""
+    import aesara.tensor as at
+    from aesara.graph.fg import FunctionGraph
+    from aesara_amd.linker import HipLinker
+    x = at.dvector("x")
+    l1 = HipLinker(return_numpy=True, use_graph=False).accept(FunctionGraph([x], [x + 1.0]))
+    y = at.dvector("y")
+    l2 = l1.accept(FunctionGraph([y], [y * 2.0]))
+    assert l2 is not l1 and l2.return_numpy and not l2.use_graph and l2.fgraph is not l1.fgraph
+
+
 def test_linker_clone_and_scan_inner_mode(ae):
     """Linker.clone(allow_gc=…) is used by Scan/Mode.clone (link/basic.py:190)."""
     from aesara_amd.linker import HipLinker
