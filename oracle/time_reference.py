@@ -1,79 +1,146 @@
-"""CPU baseline of the REFERENCE itself (authoring container only): BASELINE
-configs 1b / 2 / 3b compiled with the reference's own ``Mode("cvm", "fast_run")`` C linker,
-``trust_input``, 2 warm-ups + median of 5 evals; run once with the default flags (Elemwise loops
-single-threaded: ``openmp=False``, configdefaults.py:1037) and once with
-``AESARA_FLAGS=openmp=True OMP_NUM_THREADS=<nproc>``.  TEST / BASELINE INFRASTRUCTURE.
+"""CPU baseline = the REFERENCE itself: the BASELINE configs compiled with the reference's own
+``Mode("cvm", "fast_run")`` C linker (compile/mode.py:443-446) and timed on this host's cores.
+TEST / BASELINE INFRASTRUCTURE — used by ``bench.py``'s ``cpu_baseline`` leg (never by the product).
 
-usage: python oracle/time_reference.py            -> profiles/r02_reference_cpu_timings.json
+The reference front end comes from ``ref_overlay`` (``/root/reference`` in the authoring container,
+the packed overlay ``oracle/_ref/`` on the GPU box).  Thread settings are the reference's defaults:
+Elemwise / CAReduce loops single-threaded (``openmp=False``, configdefaults.py:1037), BLAS = the
+OpenBLAS bundled with NumPy / SciPy at its default thread count (``blas__ldflags`` is empty here, so
+Gemm/Dot22 go through the NumPy C-API alt-BLAS, blas_headers.py:744-777, and Gemv through SciPy
+fblas, blas.py:279-310).  ``--openmp`` runs the ``AESARA_FLAGS=openmp=True`` form instead.
+
+usage:
+  python oracle/time_reference.py --warm [--configs a,b]     compile everything into the cache, exit
+  python oracle/time_reference.py --configs cfg2,cfg3b --budget 6
+        -> one JSON line {"host": .., "rows": {cfg: {"ms_per_eval": .., "evals": .., "cores": ..}}}
 """
+import argparse
 import json
 import os
-import subprocess
 import sys
 import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-ROOT = os.path.dirname(HERE)
+ALL = ["cfg2", "cfg1b", "cfg3a", "cfg3b", "cfg4_b1", "cfg4_b64", "cfg5"]
 
 
-def child():
-    sys.path.insert(0, HERE)
-    import numpy as np
-    import ref_overlay
-    ae = ref_overlay.import_reference()
+def build(ae, name, np, tiny=False):
+    """-> (function, args, sample description, cores used).  ``tiny``: small shapes (same graph
+    and dtypes — the compiled modules are shape-independent), used by --warm."""
     import aesara.tensor as at
     from aesara.compile.mode import Mode
     mode = Mode("cvm", "fast_run")
-    res = {}
+    nthreads = os.cpu_count()
+    n = 64 if tiny else 4096
+    if name == "cfg2":
+        x, mu, sg = at.dmatrix("x"), at.dscalar("mu"), at.dscalar("sigma")
+        f = ae.function([x, mu, sg], at.exp(-((x - mu) ** 2) / (2 * sg ** 2)).sum(), mode=mode)
+        xv = np.random.default_rng(1).standard_normal((n, n))
+        return f, (xv, np.asarray(0.1), np.asarray(1.3)), "fp64 %dx%d exp-sum graph" % (n, n), \
+            (nthreads if ae.config.openmp else 1)
+    if name == "cfg1b":
+        x, y = at.dmatrix("x"), at.dmatrix("y")
+        f = ae.function([x, y], x + y, mode=mode)
+        return f, (np.random.default_rng(0).random((n, n)), np.random.default_rng(1).random((n, n))), \
+            "fp64 %dx%d add" % (n, n), (nthreads if ae.config.openmp else 1)
+    if name == "cfg3a":
+        M, v, a = at.dmatrix("M"), at.dvector("v"), at.dscalar("a")
+        f = ae.function([M, v, a], at.dot(M, v) + a, mode=mode)
+        return f, (np.random.default_rng(2).standard_normal((n, n)),
+                   np.random.default_rng(3).standard_normal(n), np.asarray(2.0)), \
+            "fp64 %dx%d M.dot(v)+a (Gemv through SciPy fblas)" % (n, n), nthreads
+    if name == "cfg3b":
+        A = ae.shared(np.random.default_rng(3).standard_normal((n, n)).astype("float32"), "A")
+        B = ae.shared(np.random.default_rng(4).standard_normal((n, n)).astype("float32"), "B")
+        Cs = ae.shared(np.zeros((n, n), "float32"), "C")
+        f = ae.function([], [], updates=[(Cs, np.float32(0.4) * Cs + np.float32(0.8) * at.dot(A, B))],
+                        mode=mode)
+        return f, (), "fp32 %d^3 Gemm update (alt-BLAS -> NumPy's OpenBLAS)" % n, nthreads
+    if name in ("cfg4_b1", "cfg4_b64"):
+        B_ = 1 if name == "cfg4_b1" else 64
+        T_, H = (8, 32) if tiny else (128, 1024)      # 1/4 of the config's 512 steps (bounded sample)
+        if tiny and B_ > 1:
+            B_ = 4
+        x = at.fmatrix("x") if B_ == 1 else at.ftensor3("x")
+        h0 = at.fvector("h0") if B_ == 1 else at.fmatrix("h0")
+        Ws = [ae.shared((np.random.default_rng(5 + k).standard_normal((H, H)) / np.sqrt(H)).astype("float32"),
+                        nm) for k, nm in enumerate(("Wz", "Uz", "Wr", "Ur", "Wh", "Uh"))]
 
-    def timed(f, args, n=5):
-        f.trust_input = True
-        for _ in range(2):
-            f(*args)
-        ts = []
-        for _ in range(n):
-            t = time.perf_counter()
-            f(*args)
-            ts.append(time.perf_counter() - t)
-        return sorted(ts)[len(ts) // 2] * 1e3
-
-    x, y = at.dmatrix("x"), at.dmatrix("y")
-    xv = np.random.default_rng(0).random((4096, 4096))
-    yv = np.random.default_rng(1).random((4096, 4096))
-    res["cfg1b add f64 4096^2 ms"] = timed(ae.function([x, y], x + y, mode=mode), (xv, yv))
-    mu, sg = at.dscalar("mu"), at.dscalar("sigma")
-    f2 = ae.function([x, mu, sg], at.exp(-((x - mu) ** 2) / (2 * sg ** 2)).sum(), mode=mode)
-    xn = np.random.default_rng(1).standard_normal((4096, 4096))
-    res["cfg2 exp-sum f64 4096^2 ms"] = timed(f2, (xn, np.asarray(0.1), np.asarray(1.3)))
-    A = ae.shared(np.random.default_rng(3).standard_normal((4096, 4096)).astype("float32"), "A")
-    B = ae.shared(np.random.default_rng(4).standard_normal((4096, 4096)).astype("float32"), "B")
-    Cs = ae.shared(np.zeros((4096, 4096), "float32"), "C")
-    f3 = ae.function([], [], updates=[(Cs, 0.4 * Cs + 0.8 * at.dot(A, B))], mode=mode)
-    res["cfg3b gemm f32 4096^3 ms"] = timed(f3, (), n=3)
-    res["openmp"] = bool(ae.config.openmp)
-    res["nodes cfg2"] = [str(n.op) for n in f2.maker.fgraph.toposort()]
-    print("RESULT " + json.dumps(res))
+        def step(x_t, h, Wz, Uz, Wr, Ur, Wh, Uh):
+            z = at.sigmoid(at.dot(x_t, Wz) + at.dot(h, Uz))
+            r = at.sigmoid(at.dot(x_t, Wr) + at.dot(h, Ur))
+            hh = at.tanh(at.dot(x_t, Wh) + at.dot(r * h, Uh))
+            return (1 - z) * h + z * hh
+        hs, _ = ae.scan(step, sequences=[x], outputs_info=[h0], non_sequences=Ws)
+        f = ae.function([x, h0], hs[-1], mode=mode)
+        xs = (T_, H) if B_ == 1 else (T_, B_, H)
+        xv = (np.random.default_rng(4).standard_normal(xs) * 0.1).astype("float32")
+        return f, (xv, np.zeros(xs[1:], "float32")), \
+            "fp32 Scan GRU T=%d of 512 steps (x4 for the config), H=%d B=%d (scan_perform.pyx loop, inner cvm " \
+            "function)" % (T_, H, B_), nthreads
+    if name == "cfg5":
+        N, D = (256, 16) if tiny else (1 << 20, 256)
+        X, w, b, y = at.fmatrix("X"), at.fvector("w"), at.fscalar("b"), at.fvector("y")
+        p = at.sigmoid(at.dot(X, w) + b)
+        logp = (y * at.log(p) + (1 - y) * at.log(1 - p)).sum()
+        gw, gb = ae.grad(logp, [w, b])
+        f = ae.function([X, w, b, y], [logp, gw, gb], mode=mode)
+        rng = np.random.default_rng(6)
+        return f, (rng.standard_normal((N, D), dtype="float32"),
+                   (np.random.default_rng(7).standard_normal(D) / 16).astype("float32"),
+                   np.asarray(0.1, "float32"), (np.random.default_rng(8).random(N) < 0.5).astype("float32")), \
+            "fp32 logistic logp+grad N=2^%d D=%d (1/16 of the config's rows: x16 for the full batch)" % (
+                N.bit_length() - 1, D), nthreads
+    raise ValueError(name)
 
 
 def main():
-    if os.environ.get("_TIME_REF_CHILD"):
-        return child()
-    nproc = os.cpu_count()
-    out = {"host": {"nproc": nproc}, "mode": "Mode('cvm','fast_run'), trust_input, median of 5",
-           "blas": "NumPy C-API alt-BLAS -> bundled OpenBLAS (blas__ldflags empty), threads = OpenBLAS default"}
-    for label, flags in (("default (openmp=False)", ""), ("openmp=True", "openmp=True")):
-        env = dict(os.environ, _TIME_REF_CHILD="1", OMP_NUM_THREADS=str(nproc))
-        env["AESARA_FLAGS"] = flags
-        if flags:
-            env["AESARA_REF_COMPILEDIR_SUFFIX"] = "_omp"
-        p = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True,
-                           text=True)
-        line = next((l for l in p.stdout.splitlines() if l.startswith("RESULT ")), None)
-        out[label] = json.loads(line[7:]) if line else {"error": (p.stderr or p.stdout)[-800:]}
-    path = os.path.join(ROOT, "profiles", "r02_reference_cpu_timings.json")
-    with open(path, "w") as f:
-        json.dump(out, f, indent=1)
-    print(json.dumps(out, indent=1))
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", default=",".join(ALL))
+    ap.add_argument("--budget", type=float, default=5.0, help="seconds of timed evals per config")
+    ap.add_argument("--warm", action="store_true")
+    ap.add_argument("--openmp", action="store_true")
+    args = ap.parse_args()
+    if args.openmp:
+        os.environ["AESARA_FLAGS"] = "openmp=True"
+        os.environ.setdefault("OMP_NUM_THREADS", str(os.cpu_count()))
+        os.environ["AESARA_REF_COMPILEDIR_SUFFIX"] = "_omp"
+    sys.path.insert(0, HERE)
+    import numpy as np
+    import ref_overlay
+    t_imp = time.perf_counter()
+    ae = ref_overlay.import_reference()
+    t_imp = time.perf_counter() - t_imp
+    rows = {}
+    for name in [c for c in args.configs.split(",") if c]:
+        t0 = time.perf_counter()
+        try:
+            f, fargs, sample, cores = build(ae, name, np, tiny=args.warm)
+            f.trust_input = True
+            row = {"cores": cores, "sample": sample}
+            t = time.perf_counter()
+            f(*fargs)                                   # first eval (page faults, lazy imports)
+            first = time.perf_counter() - t
+            row["build_s"] = time.perf_counter() - t0 - first
+            if not args.warm:
+                ts = []
+                t_end = time.perf_counter() + args.budget
+                if first > args.budget / 2:             # slow config: the first eval IS the sample
+                    ts = [first]
+                while not ts or (time.perf_counter() < t_end and len(ts) < 50):
+                    t = time.perf_counter()
+                    f(*fargs)
+                    ts.append(time.perf_counter() - t)
+                ts.sort()
+                row.update(ms_per_eval=ts[len(ts) // 2] * 1e3, evals=len(ts),
+                           nodes=[str(n.op) for n in f.maker.fgraph.toposort()][:24])
+        except Exception as e:                          # noqa: BLE001  (a baseline row must not kill the rest)
+            row = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        rows[name] = row
+    print("RESULT " + json.dumps({
+        "host": {"nproc": os.cpu_count()}, "import_s": t_imp, "source": ref_overlay.source(),
+        "mode": "Mode('cvm','fast_run'), trust_input, median", "openmp": bool(ae.config.openmp),
+        "blas": "NumPy C-API alt-BLAS / SciPy fblas -> bundled OpenBLAS, default threads", "rows": rows}))
 
 
 if __name__ == "__main__":

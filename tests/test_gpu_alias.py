@@ -93,3 +93,34 @@ def test_replayed_call_with_bad_index_raises():
         for _ in range(3):
             ex(*dev)
             torch.cuda.synchronize()
+
+
+def test_rebound_replay_does_not_pin_generations_of_inputs():
+    """fresh outputs make every step's updated state a NEW tensor; the replay cache
+    must not keep those generations (or the batches) alive.  200 update steps of the
+    check_blas pattern: device memory stays flat."""
+    import torch
+    from golden_util import CASES, case_plan
+    from aesara_amd.executor import PlanExecutor
+    plan = case_plan(next(c for c in CASES if c["name"] == "cfg3b_gemm_update"))   # (C, A, B) -> C'
+    ex = PlanExecutor(plan, use_graph=True)
+    n = 512                                                     # 1 MiB per matrix
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0)
+    C = torch.randn(n, n, device="cuda", generator=g)
+    A = torch.randn(n, n, device="cuda", generator=g) * 0.03
+    B = torch.randn(n, n, device="cuda", generator=g) * 0.03
+    want = C.double()
+    ab = A.double() @ B.double()
+    base = None
+    for step in range(200):
+        (C,) = ex(C, A.clone(), B)                              # new state AND a new "batch" tensor
+        want = 0.4 * want + 0.8 * ab
+        if step == 20:
+            torch.cuda.synchronize()
+            base = torch.cuda.memory_allocated()
+    torch.cuda.synchronize()
+    grown = torch.cuda.memory_allocated() - base
+    assert grown < 8 << 20, f"replay cache pinned {grown / 2**20:.1f} MiB of dead inputs"
+    assert torch.allclose(C.double(), want, rtol=2e-5, atol=1e-5)
+    assert len(ex._reloc) >= 1, "the loop was meant to take the rebinding path"
