@@ -374,7 +374,8 @@ def split_column_slices(plan: Plan, invariant: set) -> Plan:
                 y = n.inputs[0]
                 if not (y in producer and producer[y][1].op == "AllocEmpty"):
                     todo.append(y)                 # beta != 0: accumulates onto a chain value
-            elif n.op == "Elemwise" and len(n.outputs) == 1 and V[n.outputs[0]].ndim == nd:
+            elif n.op == "Elemwise" and len(n.outputs) == 1 and V[n.outputs[0]].ndim == nd \
+                    and V[n.outputs[0]].shape[-1] != 1:
                 chain.add(ni)
                 for i in n.inputs:
                     if (i in inv or V[i].const is not None) and V[i].ndim == nd and \
@@ -435,8 +436,11 @@ def split_column_slices(plan: Plan, invariant: set) -> Plan:
                     nn = Node("Gemv", [m[y] if y in m else part(y, 0), n.inputs[1], part(n.inputs[2], 0),
                                        n.inputs[3], n.inputs[4]], [out], dict(n.params))
                 else:
-                    nn = Node("Elemwise", [m[i] if i in m else part(i, -1) for i in n.inputs], [out],
-                              copy.deepcopy(n.params))
+                    # an operand that is broadcast along the sliced axis (static extent 1: a
+                    # scalar handed in as [1, 1], a length-1 vector) has no columns a:b to cut —
+                    # it stays whole and keeps broadcasting
+                    nn = Node("Elemwise", [m[i] if i in m else (i if V[i].shape[-1] == 1 else part(i, -1))
+                                           for i in n.inputs], [out], copy.deepcopy(n.params))
                 m[n.outputs[0]] = out
                 sink.append(nn)
             replaced[plan.nodes[cni].outputs[0]] = m[root]
@@ -466,9 +470,11 @@ def push_out_accumulators(plan: Plan) -> Plan:
     ``g_t = sum(delta_t, axis=0)`` for a batch (Scan.L_op, scan/op.py:2379) — although ``delta_t`` is
     a nit-sot output of the same Scan anyway (the weight gradients are GEMMs over it after the loop).
     Such an accumulator is taken out of the loop: its whole buffer is rebuilt after the Scan as
-    ``init + cumsum_t(reduce(delta))`` (the same additions in the same order, one CAReduce + one
-    CumOp over [T, H]), cut to the buffer length the caller allocated, so every use of the old output
-    — whatever row it reads — sees the same values.  The step loses its batch reduction, which is
+    ``cumsum([init; reduce(delta_1); ...; reduce(delta_T)])`` (the loop's additions, associated as
+    the CumOp kernel associates long columns — equal up to float reordering; one CAReduce + one CumOp
+    over [T + 1, H]), cut — or, for a buffer longer than T + 1, zero-padded like the reference's
+    scan/op.py:2139 — to the buffer length the caller allocated, so every use of the old output —
+    whatever row it reads — sees the same values.  The step loses its batch reduction, which is
     what kept batched recurrences with biases off the persistent gradient kernel."""
     def is_add(sc):
         return (sc.get("n_in") == 2 and len(sc["nodes"]) == 1 and sc["nodes"][0]["op"] == "add"
@@ -555,24 +561,41 @@ def push_out_accumulators(plan: Plan) -> Plan:
             if red is not None:
                 r = plan.new_var(dt, [None] + list(width))
                 out_nodes.append(Node("CAReduce", [vall], [r], dict(red, axis=[1])))
-            cs = plan.new_var(dt, [None] + list(width))
-            out_nodes.append(Node("CumOp", [r], [cs], {"axis": 0, "mode": "add"}))
+            # rows 0..T of the old buffer: init, init + g_1, (init + g_1) + g_2, ... — ONE cumulative
+            # sum over [init; g_1; ...; g_T] (the loop's additions up to the association the CumOp
+            # kernel uses for long columns: tolerance-level, like any reordered float sum)
             row = plan.new_var(dt, [1] + list(width))
             out_nodes.append(Node("Subtensor", [init_buf], [row], {"idx_list": [{"slice": [0, 1, None]}]}))
-            add2 = {"n_in": 2, "nodes": [{"op": "add", "in": [["i", 0], ["i", 1]], "dtype": dt}], "out": [["t", 0]]}
-            rows = plan.new_var(dt, [None] + list(width))
-            out_nodes.append(Node("Elemwise", [cs, row], [rows], {"scalar": add2}))
             ax = plan.add_const(0, "int8")
-            full = plan.new_var(dt, [None] + list(width))
-            out_nodes.append(Node("Join", [ax, row, rows], [full], {}))
-            # keep the last `store` rows (the caller's buffer may be shorter than T + 1)
-            nfull = plan.new_var("int64", [])
-            out_nodes.append(Node("Shape_i", [full], [nfull], {"i": 0}))
+            cat = plan.new_var(dt, [None] + list(width))
+            out_nodes.append(Node("Join", [ax, row, r], [cat], {}))
+            full0 = plan.new_var(dt, [None] + list(width))
+            out_nodes.append(Node("CumOp", [cat], [full0], {"axis": 0, "mode": "add"}))
+            # the caller's buffer holds `store` rows.  store <= T + 1 (the usual case, and what
+            # Scan's memory-saving rewrites produce): the LAST `store` rows.  store > T + 1
+            # (truncated BPTT): rows beyond T stay zero, scan/op.py:2139-2144.
+            n1 = plan.new_var("int64", [])
+            out_nodes.append(Node("Shape_i", [full0], [n1], {"i": 0}))
             store = plan.new_var("int64", [])
             out_nodes.append(Node("Shape_i", [init_buf], [store], {"i": 0}))
-            start = plan.new_var("int64", [])
-            sub2 = {"n_in": 2, "nodes": [{"op": "sub", "in": [["i", 0], ["i", 1]], "dtype": "int64"}], "out": [["t", 0]]}
-            out_nodes.append(Node("Elemwise", [nfull, store], [start], {"scalar": sub2}))
+
+            def clamp_diff(a_, b_):       # max(a - b, 0) on host integers
+                d_ = plan.new_var("int64", [])
+                sc = {"n_in": 2, "nodes": [{"op": "sub", "in": [["i", 0], ["i", 1]], "dtype": "int64"},
+                                           {"op": "maximum", "in": [["t", 0], ["c", 0, "int64"]], "dtype": "int64"}],
+                      "out": [["t", 1]]}
+                out_nodes.append(Node("Elemwise", [a_, b_], [d_], {"scalar": sc}))
+                return d_
+            start, npad = clamp_diff(n1, store), clamp_diff(store, n1)
+            wdims = []
+            for d_ in range(1, len(width) + 1):
+                wv = plan.new_var("int64", [])
+                out_nodes.append(Node("Shape_i", [init_buf], [wv], {"i": d_}))
+                wdims.append(wv)
+            tail = plan.new_var(dt, [None] + list(width))
+            out_nodes.append(Node("Alloc", [plan.add_const(0, dt), npad] + wdims, [tail], {}))
+            full = plan.new_var(dt, [None] + list(width))
+            out_nodes.append(Node("Join", [ax, full0, tail], [full], {}))
             new = plan.new_var(dt, list(V[old].shape))
             out_nodes.append(Node("Subtensor", [full, start], [new], {"idx_list": [{"slice": ["in", None, None]}]}))
             replaced[old] = new

@@ -44,6 +44,7 @@ SM_MAXMAT = 8
 SM_MAXSEQ = 28
 SM_MAXNSQ = 8
 SM_MAXOUT = 16
+TRACE_T0, TRACE_NT, TRACE_MARKS = 200, 32, 24      # steps traced, stamps per step (u64 each)
 
 
 class SmArgs(C.Structure):
@@ -96,10 +97,13 @@ class SpecMat:
         # exchange form: "flag" = untagged 8-byte float pairs + ONE tag word per producing
         # workgroup (half the bytes, one polling pass); "granule" = {tag, value} per element
         self.xmode = os.environ.get("AESARA_HIP_SM_XMODE", "flag")
+        # per-phase timeline (tools/sm_trace.py): thread 0 of workgroups 0 and NB*NJ/2 stamps
+        # s_memtime at every mark of steps TRACE_T0 .. TRACE_T0+TRACE_NT-1 into ctl[16..]
+        self.trace = bool(int(os.environ.get("AESARA_HIP_SM_TRACE", "0")))
 
     def key(self):
         pr = self.prog
-        blob = json.dumps(["sm6", self.chunk, self.xmode, self.B, self.N, self.Nt, sorted(self.Ks.items()), sorted(pr.seq.items()),
+        blob = json.dumps(["sm6" + ("t" if self.trace else ""), self.chunk, self.xmode, self.B, self.N, self.Nt, sorted(self.Ks.items()), sorted(pr.seq.items()),
                            sorted(pr.state.items()), sorted(pr.nsq.items()), sorted(pr.mats.items()),
                            [[ph["dots"], ph["ins"], ph["outs"], ph["scalar"], ph["out_refs"]]
                             for ph in pr.phases], pr.outs, pr.exchanged, sorted(pr.tap_seq.items())],
@@ -179,6 +183,12 @@ def generate(spec: SpecMat):
     L.append("  const int vrows = (%d - bi * 16) < 16 ? (%d - bi * 16) : 16;   // valid rows of this batch block" % (B, B))
     L.append("  const unsigned base = __hip_atomic_load(a.ctl, %s);" % AG)
     L.append("  unsigned* errp = a.ctl + 1;")
+    if spec.trace:
+        L.append("  const bool tr_on = tid == 0 && (blockIdx.x == 0 || blockIdx.x == %d);" % (NB * NJ // 2))
+        L.append("  unsigned long long* tr = (unsigned long long*)(a.ctl + 16) + (blockIdx.x == 0 ? 0 : %d);"
+                 % (TRACE_NT * TRACE_MARKS + 4))
+        L.append("  if (tr_on) { tr[%d] = __builtin_amdgcn_s_memtime(); tr[%d] = __builtin_amdgcn_s_memrealtime(); }"
+                 % (TRACE_NT * TRACE_MARKS, TRACE_NT * TRACE_MARKS + 1))
     # ---- weights -> registers, MFMA B layout: lane (r16, grp) of wave w holds
     #      W[w*K/4 + grp*K/16 + s][nj*16 + r16], s = 0 .. K/16 - 1
     for av, slot in sorted(pr.mats.items(), key=lambda t: t[1]):
@@ -236,9 +246,22 @@ def generate(spec: SpecMat):
         L.append("      for (int i = 0; i < 4; ++i) part[%d][wave][(4 * grp + i) * 16 + r16] = acc[i];" % d)
         L.append("    }")
 
+    marks = []
+
+    def stamp(label):
+        """record s_memtime under `label` (trace builds only; marks are numbered in code order)"""
+        if not spec.trace:
+            return
+        k = len(marks)
+        marks.append(label)
+        assert k < TRACE_MARKS
+        L.append("    if (tr_on && t >= %d && t < %d) tr[(t - %d) * %d + %d] = __builtin_amdgcn_s_memtime();"
+                 % (TRACE_T0, TRACE_T0 + TRACE_NT, TRACE_T0, TRACE_MARKS, k))
+
     pending_pub = []
     for pi, ph in enumerate(pr.phases):
         L.append("    // ---- phase %d" % pi)
+        stamp("p%d start" % pi)
         early, late = [], []
         for d, (a_, x) in enumerate(ph["dots"]):
             kind = "prev" if x in pr.state else "cur"
@@ -356,6 +379,7 @@ def generate(spec: SpecMat):
                 L.append(ind + "  }")
                 L.append(ind + "}")
                 L.append(ind + "__syncthreads();")
+                stamp("p%d flags seen" % pi)
                 L.append(ind + "const u64* src = a.xch + %d + (%s & 3) * %d + (i64)bi * %d;" % (po_, step_expr, lpp, 16 * K // 2))
                 L.append(ind + "u64 g[%d];" % PT)
                 for u in range(PT):
@@ -394,9 +418,11 @@ def generate(spec: SpecMat):
         if D:
             if newly or not early:
                 L.append("    __syncthreads();")
+            stamp("p%d operand in LDS" % pi)
             for d, a_, x in late:
                 emit_mfma(pi, d, a_, x)
             L.append("    __syncthreads();")
+            stamp("p%d products done" % pi)
         for d in range(D):
             L.append("    const float dot_%d_%d = part[%d][0][tid] + part[%d][1][tid] + part[%d][2][tid] + part[%d][3][tid];"
                      % (pi, d, d, d, d, d))
@@ -434,16 +460,24 @@ def generate(spec: SpecMat):
                          % (po_, lpp, 16 * N // 2, N // 2, AG))
                 L.append("      } }")
             if pub:
+                stamp("p%d epilogue + payload stores issued" % pi)
                 # payload complete (write-through stores acknowledged) before the tag is raised
                 L.append('    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");')
+                stamp("p%d own stores acknowledged" % pi)
                 L.append("    __syncthreads();")
+                stamp("p%d all stores acknowledged" % pi)
                 for o in pub:
                     po_, lpp, fo_, lpf = xoff[o]
                     L.append("    if (tid == 0) __hip_atomic_store(a.xch + %d + (t & 3) * %d + (i64)bi * %d + nj, "
                              "(unsigned long long)(base + (unsigned)t + 1u), %s);" % (fo_, lpf, NJ, AG))
+    stamp("step end (tag raised)")
     for v, nv in pr.new_of_state.items():
         L.append("    own_%d = own_%d;" % (v, nv))
     L.append("  }")
+    if spec.trace:
+        L.append("  if (tr_on) { tr[%d] = __builtin_amdgcn_s_memtime(); tr[%d] = __builtin_amdgcn_s_memrealtime(); }"
+                 % (TRACE_NT * TRACE_MARKS + 2, TRACE_NT * TRACE_MARKS + 3))
+        spec.marks = list(marks)
     L.append("  if (blockIdx.x == 0 && tid == 0) __hip_atomic_store(a.ctl, base + (unsigned)a.T, %s);" % AG)
     L.append("}")
     return "\n".join(L) + "\n", (name,)

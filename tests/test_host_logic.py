@@ -381,3 +381,96 @@ def test_assembled_gate_gradients_leave_the_step(name):
     tol = 1e-6 if "32" in name else 1e-13
     for g, w in zip(interp.run_plan(p2, ins), interp.run_plan(plan, ins)):
         np.testing.assert_allclose(np.asarray(g, "float64"), np.asarray(w, "float64"), rtol=tol, atol=tol)
+
+
+def test_column_slice_splitting_keeps_broadcast_operands_whole():
+    """an invariant scalar handed in as [1, 1] (``DimShuffle('x','x')`` of a shared
+    scalar) multiplies the fused product before it is sliced per gate.  The rewritten step must
+    leave that operand unsliced (it has no columns a:b) — it used to be cut to an empty [1, 0]
+    array for every gate with a >= 1."""
+    import interp
+    from aesara_amd.fusion import split_column_slices
+    from aesara_amd.plan import Node, Plan
+    p = Plan("bcast_gate", {}, [], [], [])
+    h = p.new_var("float64", [None, None], "h")          # [B, H]
+    W = p.new_var("float64", [None, None], "W")          # [H, 2H] invariant
+    s = p.new_var("float64", [1, 1], "s")                # invariant scalar as [1, 1]
+    b = p.new_var("float64", [1, None], "b")             # invariant row [1, 2H]
+    p.inputs = [h, W, s, b]
+    prod = p.new_var("float64", [None, None])
+    p.nodes.append(Node("Dot22", [h, W], [prod], {}))
+    mul = {"n_in": 3, "nodes": [{"op": "mul", "in": [["i", 0], ["i", 1]], "dtype": "float64"},
+                                {"op": "add", "in": [["t", 0], ["i", 2]], "dtype": "float64"}],
+           "out": [["t", 1]]}
+    pre = p.new_var("float64", [None, None])
+    p.nodes.append(Node("Elemwise", [prod, s, b], [pre], {"scalar": mul}))
+    H = 5
+    outs = []
+    for k in range(2):
+        o = p.new_var("float64", [None, None])
+        p.nodes.append(Node("Subtensor", [pre], [o],
+                            {"idx_list": [{"slice": [None, None, None]}, {"slice": [k * H, (k + 1) * H, None]}]}))
+        t = p.new_var("float64", [None, None])
+        p.nodes.append(Node("Elemwise", [o], [t], {"scalar": {
+            "n_in": 1, "nodes": [{"op": "tanh", "in": [["i", 0]], "dtype": "float64"}], "out": [["t", 0]]}}))
+        outs.append(t)
+    p.outputs = outs
+    rng = np.random.default_rng(0)
+    ins = [rng.standard_normal((3, H)), rng.standard_normal((H, 2 * H)), np.array([[0.7]]),
+           rng.standard_normal((1, 2 * H))]
+    want = interp.run_plan(p, ins)
+    q = split_column_slices(p, {W, s, b})
+    assert q is not p and sum(n.op == "Dot22" for n in q.nodes) == 2     # one product per gate
+    got = interp.run_plan(q, ins)
+    for g, w in zip(got, want):
+        np.testing.assert_allclose(g, w, rtol=1e-13)
+    # a chain VALUE that is broadcast along the sliced axis is outside the pattern: left alone
+    p2 = Plan("bcast_chain", dict(p.vars), list(p.inputs), list(p.outputs), list(p.nodes))
+    p2.vars = {k: type(v)(v.id, v.dtype, list(v.shape), v.name, v.const) for k, v in p.vars.items()}
+    p2.vars[pre].shape = [None, 1]
+    assert split_column_slices(p2, {W, s, b}) is p2
+
+
+def test_accumulator_push_out_with_a_buffer_longer_than_the_loop():
+    """when the caller's accumulator buffer holds MORE than T + 1 rows (truncated
+    BPTT) the reference leaves the rows beyond T zero (scan/op.py:2139-2144); the rebuilt buffer
+    must do the same instead of slicing from a negative start."""
+    import copy
+    import interp
+    from golden_util import CASES, case_inputs, case_plan
+    from aesara_amd.fusion import push_out_accumulators
+    from aesara_amd.plan import Node
+    c = next(c for c in CASES if c["name"] == "rnn_bias_bptt_b4_f32")
+    plan = copy.deepcopy(case_plan(c))
+    ref = push_out_accumulators(case_plan(c))
+    # which Scan input is the accumulator that leaves the loop: the one the rewrite reads rows of
+    scan_i = next(i for i, n in enumerate(plan.nodes) if n.op == "Scan" and n.params.get("mit_mot_in_slices"))
+    scan = plan.nodes[scan_i]
+    p = scan.params
+    n_mm, n_ms = len(p["mit_mot_in_slices"]), len(p["mit_sot_in_slices"])
+    base_in = 1 + p["n_seqs"] + n_mm + n_ms
+    new_scan = next(n for n in ref.nodes if n.op == "Scan" and n.params.get("mit_mot_in_slices"))
+    q = next(k for k in range(len(p["sit_sot_in_slices"]))
+             if scan.inputs[base_in + k] not in new_scan.inputs)
+    init_buf = scan.inputs[base_in + q]
+    acc_out = scan.outputs[n_mm + n_ms + q]
+    v = plan.vars[init_buf]
+    # init' = [init; 20 rows of garbage] (more than T + 1 rows): the Scan zeroes rows T+1.. itself
+    w = plan.new_var("int64", [])
+    padb = plan.new_var(v.dtype, [None] + list(v.shape[1:]))
+    three = plan.add_const(20, "int64")
+    init2 = plan.new_var(v.dtype, [None] + list(v.shape[1:]))
+    pre = [Node("Shape_i", [init_buf], [w], {"i": 1}),
+           Node("Alloc", [plan.add_const(7.0, v.dtype), three, w], [padb], {}),
+           Node("Join", [plan.add_const(0, "int8"), init_buf, padb], [init2], {})]
+    scan.inputs[base_in + q] = init2
+    plan.nodes[scan_i:scan_i] = pre
+    plan.outputs = list(plan.outputs) + [acc_out]           # the whole buffer, tail included
+    ins = case_inputs(c)
+    want = interp.run_plan(plan, ins)
+    new = push_out_accumulators(plan)
+    assert new is not plan
+    got = interp.run_plan(new, ins)
+    assert want[-1].shape == got[-1].shape and np.all(want[-1][-3:] == 0) and np.any(want[-1][:-12] != 0)
+    for g, w_ in zip(got, want):
+        np.testing.assert_allclose(np.asarray(g, "float64"), np.asarray(w_, "float64"), rtol=1e-6, atol=1e-7)
