@@ -625,6 +625,9 @@ def _kernel_prologue(spec, name, L):
     return hoisted, inv_in
 
 
+REDUCE_ERR_OFF = 128     # error word of the in-kernel finalize: bytes past the shard sums (epoch at +64)
+
+
 def _reduce_all_finalize(spec, red, L):
     """Deterministic in-kernel finalize of a full reduction (appended after the streaming loop:
     `acc` holds the thread's partial)."""
@@ -655,6 +658,7 @@ def _reduce_all_finalize(spec, red, L):
     L.append("  unsigned long long* wsp = (unsigned long long*)a.ws;")
     L.append("  unsigned long long* shard_sum = (unsigned long long*)((char*)a.ws + a.aux1);")
     L.append("  unsigned* epochp = (unsigned*)((char*)a.ws + a.aux1 + 2048 + 64);")
+    L.append("  unsigned* errp = (unsigned*)((char*)a.ws + a.aux1 + 2048 + %d);" % REDUCE_ERR_OFF)
     L.append("  const unsigned ep = ep0 + 1u;")
     L.append("  auto publish = [&](unsigned long long* slot, %s v) {" % acc_t)
     L.append("    union { unsigned long long u; %s v; } cv; cv.u = 0; cv.v = v;" % acc_t)
@@ -663,11 +667,16 @@ def _reduce_all_finalize(spec, red, L):
     L.append("  };")
     L.append("  auto collect = [&](unsigned long long* slot) -> %s {" % acc_t)
     L.append("    unsigned long long g0 = 0, g1 = 0;")
+    L.append("    bool seen = false;")
     L.append("    for (int spin = 0; spin < (1 << 24); ++spin) {")
     L.append("      g0 = __hip_atomic_load(slot, %s);" % AG)
     L.append("      g1 = __hip_atomic_load(slot + 1, %s);" % AG)
-    L.append("      if ((unsigned)g0 == ep && (unsigned)g1 == ep) break;")
+    L.append("      if ((unsigned)g0 == ep && (unsigned)g1 == ep) { seen = true; break; }")
     L.append("    }")
+    # a partial that never arrived (the producing workgroup starved for ~2^24 polls: a device
+    # shared with something that never yields) must not become a silently wrong sum: the error
+    # word is what the host reports (executor.check / deferred check), a float result is NaN
+    L.append("    if (!seen) __hip_atomic_store(errp, 1u, %s);" % AG)
     L.append("    union { unsigned long long u; %s v; } cv; cv.u = ((g0 >> 32) << 32) | (g1 >> 32);" % acc_t)
     L.append("    return cv.v;")
     L.append("  };")
@@ -702,8 +711,10 @@ def _reduce_all_finalize(spec, red, L):
     L.append("    acc = threadIdx.x < nsh ? collect(shard_sum + 2 * (size_t)threadIdx.x) : %s;" % ident)
     L.append("  }")
     L.append("  {")
-    L.append("    const %s r = block_fold();" % acc_t)
+    L.append("    %s r = block_fold();" % acc_t)
     L.append("    if (threadIdx.x == 0) {")
+    if _is_float(red["acc"]):
+        L.append("      if (__hip_atomic_load(errp, %s) != 0u) r = (%s)__builtin_nan(\"\");" % (AG, acc_t))
     L.append("      *(%s*)a.out = %s;" % (CTYPE[red["out"]], _store_val("r", red["acc"], red["out"])))
     L.append("      __hip_atomic_store(epochp, ep, %s);" % AG)
     L.append("    }")

@@ -96,14 +96,24 @@ class SpecMat:
         self.chunk = int(os.environ.get("AESARA_HIP_SM_CHUNK", "32"))
         # exchange form: "flag" = untagged 8-byte float pairs + ONE tag word per producing
         # workgroup (half the bytes, one polling pass); "granule" = {tag, value} per element
-        self.xmode = os.environ.get("AESARA_HIP_SM_XMODE", "flag")
+        #   "frag" (default when the registers allow it) = the flag form with the payload laid out
+        #   in MFMA A-FRAGMENT order: a consumer wavefront polls only the tags of the producers of
+        #   ITS K quarter and pulls that quarter with coalesced 16-byte sc1 loads straight into the
+        #   registers the MFMAs read — no LDS image, no staging pass, no barrier between hand-off
+        #   and product (round 3: the r03 timeline showed 2.5 of 8.6 us per step in the LDS staging
+        #   of the payload and 3.6 us in LDS-latency-serialised dependent MFMA chains)
+        nstaged = len({(x, "prev" if x in prog.state else "cur") for ph in prog.phases for _a, x in ph["dots"]})
+        K0 = max(Ks.values()) if Ks else 64
+        regs = sum(K // 16 for K in Ks.values()) + 4 * (K0 // 64) * nstaged
+        self.xmode = os.environ.get("AESARA_HIP_SM_XMODE", "frag" if regs <= 384 else "flag")
+        self.early_first = os.environ.get("AESARA_HIP_SM_EARLY", "after") == "first"
         # per-phase timeline (tools/sm_trace.py): thread 0 of workgroups 0 and NB*NJ/2 stamps
         # s_memtime at every mark of steps TRACE_T0 .. TRACE_T0+TRACE_NT-1 into ctl[16..]
         self.trace = bool(int(os.environ.get("AESARA_HIP_SM_TRACE", "0")))
 
     def key(self):
         pr = self.prog
-        blob = json.dumps(["sm6" + ("t" if self.trace else ""), self.chunk, self.xmode, self.B, self.N, self.Nt, sorted(self.Ks.items()), sorted(pr.seq.items()),
+        blob = json.dumps(["sm7" + ("t" if self.trace else ""), self.chunk, self.xmode, self.early_first, self.B, self.N, self.Nt, sorted(self.Ks.items()), sorted(pr.seq.items()),
                            sorted(pr.state.items()), sorted(pr.nsq.items()), sorted(pr.mats.items()),
                            [[ph["dots"], ph["ins"], ph["outs"], ph["scalar"], ph["out_refs"]]
                             for ph in pr.phases], pr.outs, pr.exchanged, sorted(pr.tap_seq.items())],
@@ -123,6 +133,7 @@ def xch_layout(prog, NB, N, xmode="flag"):
             off[v] = (total, lp)
             total += 4 * lp
         return off, total
+    # ("flag" and "frag" share this layout; "frag" orders the payload of a block by MFMA fragment)
     lpp, lpf = NB * 16 * N // 2, NB * (N // 16)
     for v in prog.exchanged:
         off[v] = (total, lpp, total + 4 * lpp, lpf)
@@ -166,7 +177,10 @@ def generate(spec: SpecMat):
     AG = "__ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT"
     L = [cg.PRELUDE, SM_STRUCT]
     xoff, _tot = xch_layout(pr, NB, N, spec.xmode)
-    FLAG = spec.xmode == "flag"
+    FRAG = spec.xmode == "frag"
+    FLAG = spec.xmode in ("flag", "frag")
+    if FRAG:
+        return _generate_frag(spec, name, xoff, _tot)
 
     # staged operand blocks (LDS images, pitch K + 4 floats)
     stage, stot = stage_slots(pr, spec.Ks)
@@ -471,6 +485,257 @@ def generate(spec: SpecMat):
                     L.append("    if (tid == 0) __hip_atomic_store(a.xch + %d + (t & 3) * %d + (i64)bi * %d + nj, "
                              "(unsigned long long)(base + (unsigned)t + 1u), %s);" % (fo_, lpf, NJ, AG))
     stamp("step end (tag raised)")
+    for v, nv in pr.new_of_state.items():
+        L.append("    own_%d = own_%d;" % (v, nv))
+    L.append("  }")
+    if spec.trace:
+        L.append("  if (tr_on) { tr[%d] = __builtin_amdgcn_s_memtime(); tr[%d] = __builtin_amdgcn_s_memrealtime(); }"
+                 % (TRACE_NT * TRACE_MARKS + 2, TRACE_NT * TRACE_MARKS + 3))
+        spec.marks = list(marks)
+    L.append("  if (blockIdx.x == 0 && tid == 0) __hip_atomic_store(a.ctl, base + (unsigned)a.T, %s);" % AG)
+    L.append("}")
+    return "\n".join(L) + "\n", (name,)
+
+
+def _generate_frag(spec: SpecMat, name, xoff, xtot):
+    """The "frag" exchange form (see ``SpecMat``).  Exchange buffer of one operand block (16 rows
+    x K floats, K = N): float4 number ``(w * K/64 + q) * 64 + lane`` holds, for lane
+    (r16 = lane & 15, grp = lane >> 4) of consumer wavefront w, the A-operand values
+    ``h[r16][w*K/4 + grp*K/16 + 4q .. +3]`` — exactly MFMA k-steps 4q .. 4q+3 of that lane, so the
+    q-th load of a wavefront is one coalesced 1 KiB line set.  A producer (column slice nj) owns
+    16 consecutive k: four float4 per row, written with 16-byte sc1 (write-through) stores."""
+    pr, B, N, NB, NJ = spec.prog, spec.B, spec.N, spec.NB, spec.NJ
+    AG = "__ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT"
+    L = [cg.PRELUDE, SM_STRUCT, "typedef unsigned u4v __attribute__((ext_vector_type(4)));"]
+    keys = []
+    for ph in pr.phases:
+        for a_, x in ph["dots"]:
+            key = (x, "prev" if x in pr.state else "cur")
+            if key not in keys:
+                keys.append(key)
+    K = N
+    Q = K // 64                       # float4 fragments per lane per operand block
+    PW = NJ // 4                      # producers (column slices) feeding one wavefront's K quarter
+    ndots_max = max(len(ph["dots"]) for ph in pr.phases)
+    L.append('extern "C" __global__ __launch_bounds__(256) void %s(SmArgs a) {' % name)
+    L.append("  __shared__ float part[2][%d][4][256];" % max(ndots_max, 1))
+    L.append("  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;")
+    L.append("  const int r16 = lane & 15, grp = lane >> 4;")
+    L.append("  const int bi = blockIdx.x %% %d, nj = blockIdx.x / %d;" % (NB, NB))
+    L.append("  const int erow = tid >> 4, ecol = tid & 15;        // tile element owned by this thread")
+    L.append("  const i64 eb = (i64)bi * 16 + erow, en = (i64)nj * 16 + ecol;")
+    L.append("  const bool owner = eb < %d && en < %d;" % (B, spec.Nt))
+    L.append("  const int vrows = (%d - bi * 16) < 16 ? (%d - bi * 16) : 16;   // valid rows of this batch block" % (B, B))
+    L.append("  const unsigned base = __hip_atomic_load(a.ctl, %s);" % AG)
+    L.append("  unsigned* errp = a.ctl + 1;")
+    L.append("  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.xch, 0, %du, 0x00020000);"
+             % (xtot * 8))
+    # where this workgroup's 16 columns live in a consumer's fragment order
+    L.append("  const int pk = nj * 16 + (ecol & ~3);                       // first of 4 consecutive k")
+    L.append("  const int pw = pk / %d, pkk = pk %% %d;" % (K // 4, K // 4))
+    L.append("  const unsigned pub_off = (unsigned)((((pw * %d + (pkk %% %d) / 4) * 64) + (pkk / %d) * 16 + erow) * 16);"
+             % (Q, K // 16, K // 16))
+    L.append("  const unsigned ld_off = (unsigned)(((wave * %d) * 64 + lane) * 16);" % Q)
+    marks = []
+
+    def stamp(label):
+        if not spec.trace:
+            return
+        k = len(marks)
+        marks.append(label)
+        assert k < TRACE_MARKS
+        L.append("    if (tr_on && t >= %d && t < %d) tr[(t - %d) * %d + %d] = __builtin_amdgcn_s_memtime();"
+                 % (TRACE_T0, TRACE_T0 + TRACE_NT, TRACE_T0, TRACE_MARKS, k))
+    if spec.trace:
+        L.append("  const bool tr_on = tid == 0 && (blockIdx.x == 0 || blockIdx.x == %d);" % (NB * NJ // 2))
+        L.append("  unsigned long long* tr = (unsigned long long*)(a.ctl + 16) + (blockIdx.x == 0 ? 0 : %d);"
+                 % (TRACE_NT * TRACE_MARKS + 4))
+        L.append("  if (tr_on) { tr[%d] = __builtin_amdgcn_s_memtime(); tr[%d] = __builtin_amdgcn_s_memrealtime(); }"
+                 % (TRACE_NT * TRACE_MARKS, TRACE_NT * TRACE_MARKS + 1))
+    # ---- weights -> registers, MFMA B layout (as in the LDS form)
+    for av, slot in sorted(pr.mats.items(), key=lambda t: t[1]):
+        Km = spec.Ks[av]
+        assert Km == K
+        L.append("  const i64 wk%d = (i64)wave * %d + grp * %d;" % (slot, Km // 4, Km // 16))
+        for s_ in range(Km // 16):
+            L.append("  const float w%d_%d = ((const float*)a.mat[%d])[(wk%d + %d) * a.mat_rs[%d] + nj * 16 + r16];"
+                     % (slot, s_, slot, slot, s_, slot))
+    out_of = {}
+    for o, kind, j in pr.outs:
+        out_of.setdefault(o, []).append((kind, j))
+    for v, k in pr.state.items():
+        L.append("  float own_%d = 0.f;" % v)
+        L.append("  if (owner) own_%d = ((const float*)a.out[%d])[((a.out_pos0[%d] + a.out_store[%d] - 1) %% "
+                 "a.out_store[%d]) * a.out_ts[%d] + eb * a.out_rs[%d] + en];" % (v, k, k, k, k, k, k))
+    pw_nsq = sorted({v for ph in pr.phases for v in ph["ins"] if v in pr.nsq})
+    for v in pw_nsq:
+        s_ = pr.nsq[v]
+        L.append("  float own_%d = 0.f;" % v)
+        L.append("  if (owner) own_%d = ((const float*)a.nsq[%d])[eb * a.nsq_rs[%d] + en * a.nsq_cs[%d]];"
+                 % (v, s_, s_, s_))
+    pw_seq = sorted({v for ph in pr.phases for v in ph["ins"] if v in pr.seq})
+    for v in pw_seq:
+        s_ = pr.seq[v]
+        L.append("  float nxt_%d = 0.f, own_%d = 0.f;" % (v, v))
+        L.append("  if (owner && a.T > 0) nxt_%d = ((const float*)a.seq[%d])[eb * a.seq_rs[%d] + en * a.seq_cs[%d]];"
+                 % (v, s_, s_, s_))
+    for ph in pr.phases:
+        for o in ph["outs"]:
+            L.append("  float own_%d = 0.f;" % o)
+    for ki in range(len(keys)):
+        L.append("  f4 fr%d[%d];" % (ki, Q))
+    L.append("  for (i64 t = 0; t < a.T; ++t) {")
+    for v in pw_seq:
+        s_ = pr.seq[v]
+        L.append("    own_%d = nxt_%d;" % (v, v))
+        L.append("    if (owner && t + 1 < a.T) nxt_%d = ((const float*)a.seq[%d])[(t + 1) * a.seq_ts[%d] + "
+                 "eb * a.seq_rs[%d] + en * a.seq_cs[%d]];" % (v, s_, s_, s_, s_))
+    staged_this_step = set()
+
+    def emit_mfma(pi, d, a_, x):
+        """one product on this wavefront's K quarter: two independent accumulator chains (a chain
+        of dependent 16x16x4 MFMAs issues every 40 cycles, two interleaved ones every 32)"""
+        slot = pr.mats[a_]
+        ki = keys.index((x, "prev" if x in pr.state else "cur"))
+        L.append("    {")
+        L.append("      f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};")
+        for q in range(Q):
+            for e, c in enumerate("xyzw"):
+                acc = "acc%d" % ((4 * q + e) & 1)
+                L.append("      %s = __builtin_amdgcn_mfma_f32_16x16x4f32(fr%d[%d].%s, w%d_%d, %s, 0, 0, 0);"
+                         % (acc, ki, q, c, slot, 4 * q + e, acc))
+        L.append("      for (int i = 0; i < 4; ++i) part[pp%d][%d][wave][(4 * grp + i) * 16 + r16] = acc0[i] + acc1[i];"
+                 % (pi, d))
+        L.append("    }")
+
+    def emit_fetch(pi, x, kind):
+        """wait for the tags of this wavefront's producers, then pull its K quarter into fr"""
+        ki = keys.index((x, kind))
+        src = pr.new_of_state.get(x, x)
+        po_, lpp, fo_, lpf = xoff[src]
+        if kind == "prev":
+            k_out = pr.state[x]
+            L.append("    if (t == 0) {")
+            L.append("      const float* ini = (const float*)a.out[%d] + ((a.out_pos0[%d] + a.out_store[%d] - 1) %% "
+                     "a.out_store[%d]) * a.out_ts[%d] + ((i64)bi * 16 + r16) * a.out_rs[%d] + wave * %d + grp * %d;"
+                     % (k_out, k_out, k_out, k_out, k_out, k_out, K // 4, K // 16))
+            L.append("      const int c0 = wave * %d + grp * %d;" % (K // 4, K // 16))
+            for q in range(Q):
+                L.append("      { f4 v = {0.f, 0.f, 0.f, 0.f};")
+                L.append("        if (r16 < vrows) { for (int e = 0; e < 4; ++e) if (c0 + %d + e < %d) v[e] = ini[%d + e]; }"
+                         % (4 * q, spec.Nt, 4 * q))
+                L.append("        fr%d[%d] = v; }" % (ki, q))
+            L.append("    } else {")
+            step_expr = "(t - 1)"
+        else:
+            L.append("    {")
+            step_expr = "t"
+        ind = "      "
+        L.append(ind + "const unsigned long long want64 = (unsigned long long)(base + (unsigned)%s + 1u);" % step_expr)
+        L.append(ind + "const u64* fl = a.xch + %d + (%s & 3) * %d + (i64)bi * %d + wave * %d;"
+                 % (fo_, step_expr, lpf, NJ, PW))
+        L.append(ind + "for (int spin = 0;; ++spin) {")
+        L.append(ind + "  bool ok = true;")
+        L.append(ind + "  for (int j = lane; j < %d; j += 64) ok = ok && (__hip_atomic_load(fl + j, %s) == want64);" % (PW, AG))
+        L.append(ind + "  if (__all(ok)) break;")
+        L.append(ind + "  if (spin > %d || ((spin & 255) == 255 && __hip_atomic_load(errp, %s) != 0u)) "
+                 "{ __hip_atomic_store(errp, 1u, %s); break; }" % (SPIN_LIMIT, AG, AG))
+        L.append(ind + "  __builtin_amdgcn_s_sleep(1);")
+        L.append(ind + "}")
+        L.append(ind + "const unsigned so_ = (unsigned)((%d + (%s & 3) * %d + (i64)bi * %d) * 8);"
+                 % (po_, step_expr, lpp, 16 * K // 2))
+        for q in range(Q):
+            L.append(ind + "{ const u4v g = __builtin_amdgcn_raw_buffer_load_b128(xr, ld_off + %du, so_, 16);"
+                     " fr%d[%d] = __builtin_bit_cast(f4, g); }" % (q * 64 * 16, ki, q))
+        L.append("    }")
+
+    pending_pub = []
+    # `part` is double-buffered by the running count of product phases (across steps): a phase's
+    # epilogue reads never meet the next product phase's writes, and the barrier of the phase in
+    # between orders everything two phases apart — no barrier between hand-off and products
+    dot_phases = [pi for pi, ph in enumerate(pr.phases) if ph["dots"]]
+    for pi, ph in enumerate(pr.phases):
+        L.append("    // ---- phase %d" % pi)
+        if ph["dots"]:
+            L.append("    const int pp%d = (int)((t * %d + %d) & 1);" % (pi, len(dot_phases), dot_phases.index(pi)))
+        stamp("p%d start" % pi)
+        early, late, fresh = [], [], []
+        for d, (a_, x) in enumerate(ph["dots"]):
+            kind = "prev" if x in pr.state else "cur"
+            if (x, kind) in staged_this_step:
+                early.append((d, a_, x))
+            else:
+                late.append((d, a_, x))
+                if (x, kind) not in fresh:
+                    fresh.append((x, kind))
+        if spec.early_first:
+            for d, a_, x in early:
+                emit_mfma(pi, d, a_, x)
+        for x, kind in fresh:
+            emit_fetch(pi, x, kind)
+            staged_this_step.add((x, kind))
+        if fresh:
+            stamp("p%d tags seen, loads issued" % pi)
+        if not spec.early_first:
+            # the products on operands already in registers run while the new operand is in flight
+            for d, a_, x in early:
+                emit_mfma(pi, d, a_, x)
+        if early:
+            stamp("p%d early products done" % pi)
+        for d, a_, x in late:
+            emit_mfma(pi, d, a_, x)
+        D = len(ph["dots"])
+        if D:
+            L.append("    __syncthreads();")
+            stamp("p%d products done" % pi)
+        for d in range(D):
+            L.append("    const float dot_%d_%d = part[pp%d][%d][0][tid] + part[pp%d][%d][1][tid] + part[pp%d][%d][2][tid] + part[pp%d][%d][3][tid];"
+                     % (pi, d, pi, d, pi, d, pi, d, pi, d))
+        L.append("    if (owner) {")
+        ins = ["dot_%d_%d" % (pi, d) for d in range(D)] + ["own_%d" % v for v in ph["ins"]]
+        lines, outs, odts = cg.emit_scalar_body(ph["scalar"], ins, ["float32"] * len(ins),
+                                                indent="      ", suffix="_p%d" % pi)
+        L.extend(lines)
+        for o, ri in zip(ph["outs"], ph["out_refs"]):
+            L.append("      own_%d = %s;" % (o, cg._cast(outs[ri], odts[ri], "float32")))
+        L.append("    }")
+        # publish first (the hand-off is the critical path), the stores into the output buffers after
+        pending_pub.extend(o for o in ph["outs"] if o in xoff)
+        nxt_has_dots = pi + 1 < len(pr.phases) and bool(pr.phases[pi + 1]["dots"])
+        pub = pending_pub if (nxt_has_dots or pi + 1 == len(pr.phases)) else []
+        if pub:
+            pending_pub = []
+        for o in pub:
+            po_, lpp, fo_, lpf = xoff[o]
+            L.append("    { const float v0_ = owner ? own_%d : 0.f;" % o)
+            L.append("      const float v1_ = __shfl_down(v0_, 1, 64), v2_ = __shfl_down(v0_, 2, 64), v3_ = __shfl_down(v0_, 3, 64);")
+            L.append("      if ((ecol & 3) == 0 && eb < %d) {" % B)
+            L.append("        const f4 pv = {v0_, v1_, v2_, v3_};")
+            L.append("        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, pv), xr, pub_off, "
+                     "(unsigned)((%d + (t & 3) * %d + (i64)bi * %d) * 8), 16);" % (po_, lpp, 16 * K // 2))
+            L.append("      } }")
+        if pub:
+            stamp("p%d epilogue + payload stores issued" % pi)
+        L.append("    if (owner) {")
+        for o in ph["outs"]:
+            for _kind, j in out_of.get(o, []):
+                L.append("      ((float*)a.out[%d])[((a.out_pos0[%d] + t) %% a.out_store[%d]) * a.out_ts[%d] + "
+                         "eb * a.out_rs[%d] + en] = own_%d;" % (j, j, j, j, j, o))
+        L.append("    }")
+        if pub:
+            L.append('    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");')
+            stamp("p%d own stores acknowledged" % pi)
+            L.append("    __syncthreads();")
+            for o in pub:
+                po_, lpp, fo_, lpf = xoff[o]
+                L.append("    if (tid == 0) __hip_atomic_store(a.xch + %d + (t & 3) * %d + (i64)bi * %d + nj, "
+                         "(unsigned long long)(base + (unsigned)t + 1u), %s);" % (fo_, lpf, NJ, AG))
+            stamp("p%d tag raised" % pi)
+        elif D:
+            # no publish between this phase's `part` reads and the next writes of the same parity
+            # two phases on: the products-done barrier of the next phase orders them
+            pass
+    stamp("step end")
     for v, nv in pr.new_of_state.items():
         L.append("    own_%d = own_%d;" % (v, nv))
     L.append("  }")

@@ -49,7 +49,7 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (guide: 8.0 TB/s; ~6.3 TB/s achievable)
 MFMA_F32_PEAK = 157.3          # TFLOP/s, v_mfma_f32_16x16x4_f32 dense (guide)
-ROWS, COLS = 4096, 4096
+ROWS, COLS = int(os.environ.get("AESARA_BENCH_ROWS", "4096")), 4096   # (rows: size sweeps of tools/ only)
 ALGO_BYTES = ROWS * COLS * 8   # x read once (134 217 728 B per eval)
 
 
