@@ -106,7 +106,10 @@ class SpecMat:
         K0 = max(Ks.values()) if Ks else 64
         regs = sum(K // 16 for K in Ks.values()) + 4 * (K0 // 64) * nstaged
         self.xmode = os.environ.get("AESARA_HIP_SM_XMODE", "frag" if regs <= 384 else "flag")
-        self.early_first = os.environ.get("AESARA_HIP_SM_EARLY", "after") == "first"
+        # products on operands that are already in registers run BEFORE the wait for the new
+        # operand's tags (r03 timeline, config 4 B = 64: 6.7 us per step; issuing them after the
+        # loads — to cover the load latency instead of the tag latency — measured 8.5)
+        self.early_first = os.environ.get("AESARA_HIP_SM_EARLY", "first") == "first"
         # per-phase timeline (tools/sm_trace.py): thread 0 of workgroups 0 and NB*NJ/2 stamps
         # s_memtime at every mark of steps TRACE_T0 .. TRACE_T0+TRACE_NT-1 into ctl[16..]
         self.trace = bool(int(os.environ.get("AESARA_HIP_SM_TRACE", "0")))
