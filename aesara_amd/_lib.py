@@ -121,6 +121,9 @@ SIGNATURES = {
     "ahip_module_get_function": (i32, [vp, C.c_char_p, p_vp]),
     "ahip_module_unload": (i32, [vp]),
     "ahip_launch": (i32, [vp, u32, u32, u32, u32, u32, u32, u32, vp, sz, vp]),
+    "ahip_launch_p": (i32, [vp, u32, u32, u32, u32, u32, u32, u32, vp, sz, C.POINTER(C.c_uint16), i32,
+                            i32, vp]),
+    "ahip_occupancy": (i32, [vp, i32, sz, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ahip_elemwise": (i32, [vp, i32, p_i64, i32, p_vp, p_i64, i32, i32, vp]),
     "ahip_elemwise_tiled": (i32, [vp, i32, p_i64, i32, p_vp, p_i64, i32, i32, vp, vp, sz, vp]),
     "ahip_reduce_ws_bytes": (sz, []),
@@ -174,6 +177,13 @@ SIGNATURES = {
     "ahip_graph_end": (i32, [vp, p_vp]),
     "ahip_graph_launch": (i32, [vp, vp]),
     "ahip_graph_destroy": (i32, [vp]),
+    "ahip_comm_set_library": (i32, [C.c_char_p]),
+    "ahip_comm_unique_id": (i32, [vp, sz]),
+    "ahip_comm_init_rank": (i32, [vp, i32, i32, p_vp]),
+    "ahip_comm_size": (i32, [vp]),
+    "ahip_comm_rank": (i32, [vp]),
+    "ahip_allreduce": (i32, [vp, i32, i32, vp, vp, i64, vp]),
+    "ahip_comm_destroy": (i32, [vp]),
     "ahip_event_create": (i32, [p_vp]),
     "ahip_event_record": (i32, [vp, vp]),
     "ahip_event_elapsed_ms": (i32, [vp, vp, C.POINTER(C.c_float)]),
@@ -203,6 +213,35 @@ def _load():
 
 
 lib = _load()
+
+
+_PTR_OFFS = {}
+
+
+def ptr_offsets(struct_cls):
+    """(ctypes uint16 array, n): byte offsets of the device pointers (``c_void_p`` fields and
+    arrays of them) of a kernel-argument Structure — the pointer map ``ahip_launch_p`` takes, so
+    a recorded launch is only ever re-pointed at words that ARE pointers."""
+    ent = _PTR_OFFS.get(struct_cls)
+    if ent is None:
+        offs = []
+        for name, typ in struct_cls._fields_:
+            base = getattr(struct_cls, name).offset
+            if typ is C.c_void_p:
+                offs.append(base)
+            elif isinstance(typ, type) and issubclass(typ, C.Array):
+                t, n = typ, 1
+                while isinstance(t, type) and issubclass(t, C.Array):
+                    n *= t._length_
+                    t = t._type_
+                if t is C.c_void_p:
+                    offs.extend(base + 8 * i for i in range(n))
+        ent = _PTR_OFFS[struct_cls] = ((C.c_uint16 * max(len(offs), 1))(*offs), len(offs))
+    return ent
+
+
+COMM_ID_BYTES = 128
+RED_OPS = {"add": 0, "mul": 1, "maximum": 2, "minimum": 3}
 
 
 def check(rc):

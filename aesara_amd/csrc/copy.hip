@@ -17,6 +17,7 @@ struct CopyArgs {
   const void* src;
   void* dst;
 };
+AHIP_PTRS_BEGIN(CopyArgs) AHIP_PTR1(src) AHIP_PTR1(dst) AHIP_PTRS_END
 
 template <typename T, int VEC> struct alignas(sizeof(T) * VEC) Pack { T v[VEC]; };
 
@@ -58,6 +59,7 @@ __global__ __launch_bounds__(256) void copy_kernel(CopyArgs a) {
 }
 
 struct FillArgs { void* dst; int64_t n; uint64_t bits; };
+AHIP_PTRS_BEGIN(FillArgs) AHIP_PTR1(dst) AHIP_PTRS_END
 
 template <typename T>
 __global__ __launch_bounds__(256) void fill_kernel(FillArgs f) {
@@ -95,6 +97,7 @@ int copy_typed(CopyArgs& a, int vec, int accumulate, hipStream_t s) {
 // ---- ARange: out[i] = first + i * delta in the output dtype (np.arange's fill rule; the caller
 // passes first = dtype(start) and delta = dtype(start + step) - first) ----
 struct ArangeArgs { void* dst; int64_t n; double fstart, fdelta; int64_t istart, istep; };
+AHIP_PTRS_BEGIN(ArangeArgs) AHIP_PTR1(dst) AHIP_PTRS_END
 
 template <typename T, bool FLT>
 __global__ __launch_bounds__(256) void arange_kernel(ArangeArgs a) {

@@ -27,6 +27,7 @@ struct CumArgs {
   int64_t chunk, nchunks;
   const void* carry; void* totals;
 };
+AHIP_PTRS_BEGIN(CumArgs) AHIP_PTR1(x) AHIP_PTR1(out) AHIP_PTR1(carry) AHIP_PTR1(totals) AHIP_PTRS_END
 
 template <typename T> __device__ __forceinline__ T comb(T a, T b, int mul) { return mul ? a * b : a + b; }
 

@@ -31,8 +31,10 @@ static int pack_args(ahip_ew_args* a, int nd, const int64_t* shape, int nops, vo
 
 static int launch(ahip_fn_t k, uint32_t gx, uint32_t gy, uint32_t block, const ahip_ew_args* a,
                   void* stream) {
+  uint16_t po[AHIP_MAX_PTRS];
+  const int np = ahip_ptrs(a, po);
   return ahip_launch_module(k->fn, dim3(gx, gy, 1), dim3(block, 1, 1), 0, as_stream(stream), a,
-                            sizeof(*a));
+                            sizeof(*a), po, np);
 }
 
 // Memory-bound streaming kernels: enough workgroups to fill 256 CUs x 8 resident blocks,
@@ -188,8 +190,10 @@ int ahip_gemv_epilogue(ahip_fn_t k, const ahip_gv_args* args, int block, void* s
   int64_t want = (args->M + waves - 1) / waves;
   int64_t cap = (int64_t)ahip_cu_count() * 8;
   if (want > cap) want = cap;
+  uint16_t po[AHIP_MAX_PTRS];
+  const int np = ahip_ptrs(args, po);
   return ahip_launch_module(k->fn, dim3((unsigned)want, 1, 1), dim3(block, 1, 1), 0,
-                            as_stream(stream), args, sizeof(*args));
+                            as_stream(stream), args, sizeof(*args), po, np);
 }
 
 int ahip_rowpass_grid(int64_t N, int block, int rows_per_wave) {
@@ -208,8 +212,10 @@ int ahip_rowpass(ahip_fn_t k, const ahip_rp_args* args, int block, int rows_per_
   AHIP_REQUIRE(args->nops >= 0 && args->nops <= AHIP_RP_MAXOPS, "bad nops");
   int grid = ahip_rowpass_grid(args->N, block, rows_per_wave);
   if (grid <= 0) return AHIP_OK;
+  uint16_t po[AHIP_MAX_PTRS];
+  const int np = ahip_ptrs(args, po);
   return ahip_launch_module(k->fn, dim3((unsigned)grid, 1, 1), dim3(block, 1, 1), shmem_bytes,
-                            as_stream(stream), args, sizeof(*args));
+                            as_stream(stream), args, sizeof(*args), po, np);
 }
 
 int ahip_rowchain(ahip_fn_t k, const ahip_rc_args* args, int block, int rows_per_wave,
@@ -225,8 +231,10 @@ int ahip_rowchain(ahip_fn_t k, const ahip_rc_args* args, int block, int rows_per
   } else {
     grid = ahip_rowpass_grid(args->N, block, rows_per_wave);
   }
+  uint16_t po[AHIP_MAX_PTRS];
+  const int np = ahip_ptrs(args, po);
   return ahip_launch_module(k->fn, dim3((unsigned)grid, 1, 1), dim3(block, 1, 1), 0,
-                            as_stream(stream), args, sizeof(*args));
+                            as_stream(stream), args, sizeof(*args), po, np);
 }
 
 int ahip_gemm_epilogue(ahip_fn_t k, const ahip_ge_args* args, int nf, int waves, void* stream) {
@@ -236,8 +244,10 @@ int ahip_gemm_epilogue(ahip_fn_t k, const ahip_ge_args* args, int nf, int waves,
   if (args->M <= 0 || args->N <= 0) return AHIP_OK;
   const int64_t gx = (args->N + 16 * nf - 1) / (16 * nf), gy = (args->M + 15) / 16;
   AHIP_REQUIRE(gy < 65536, "M too large for the small-M kernel");
+  uint16_t po[AHIP_MAX_PTRS];
+  const int np = ahip_ptrs(args, po);
   return ahip_launch_module(k->fn, dim3((unsigned)gx, (unsigned)gy, 1), dim3(64 * waves, 1, 1), 0,
-                            as_stream(stream), args, sizeof(*args));
+                            as_stream(stream), args, sizeof(*args), po, np);
 }
 
 }  // extern "C"

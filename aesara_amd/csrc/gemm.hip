@@ -79,6 +79,7 @@ struct GemmArgs {
   int group;             // tile-rows per group of the workgroup walk (L2 reuse of the B panels)
   int64_t a_lim, b_lim;  // bytes from A / B (per batch item) to the end of their valid extent
 };
+AHIP_PTRS_BEGIN(GemmArgs) AHIP_PTR1(A) AHIP_PTR1(B) AHIP_PTR1(Cin) AHIP_PTR1(C) AHIP_PTRS_END
 
 void set_limits(GemmArgs& g, int64_t isz);
 
@@ -977,6 +978,7 @@ int gemm_dispatch(GemmArgs& g, int64_t batch, hipStream_t s) {
 // the alpha / beta epilogue (deterministic; no float atomics).
 struct SplitArgs { const void* ws; const void* Cin; void* C; int64_t M, N, S, ci_rs, ci_cs, c_rs, c_cs;
                    double alpha, beta; };
+AHIP_PTRS_BEGIN(SplitArgs) AHIP_PTR1(ws) AHIP_PTR1(Cin) AHIP_PTR1(C) AHIP_PTRS_END
 
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(SplitArgs a) {

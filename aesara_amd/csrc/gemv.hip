@@ -40,6 +40,7 @@ struct GemvArgs {
   double alpha, beta;
   int nslice; int tm; int64_t rows_per_slice;
 };
+AHIP_PTRS_BEGIN(GemvArgs) AHIP_PTR1(A) AHIP_PTR1(x) AHIP_PTR1(y_in) AHIP_PTR1(y_out) AHIP_PTR1(ws) AHIP_PTRS_END
 
 // ---- ROW layout ----------------------------------------------------------------------------
 template <typename T, bool VECLOAD>
@@ -265,6 +266,7 @@ struct GerArgs {
   void* A_out; int64_t ao_rs, ao_cs;
   double alpha;
 };
+AHIP_PTRS_BEGIN(GerArgs) AHIP_PTR1(x) AHIP_PTR1(y) AHIP_PTR1(A_in) AHIP_PTR1(A_out) AHIP_PTRS_END
 
 template <typename T>
 __global__ void ger_kernel(GerArgs g) {

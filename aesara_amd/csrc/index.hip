@@ -42,6 +42,7 @@ struct IdxArgs {
   const int* hot_off;   // scatter-add only: when set, rows with <= ORDERED_MAX entries are skipped
   const int* nhot;      // with hot_off: number of such rows left (0: the kernel returns at once)
 };
+AHIP_PTRS_BEGIN(IdxArgs) AHIP_PTR1(src) AHIP_PTR1(dst) AHIP_PTR1(idx) AHIP_PTR1(bad) AHIP_PTR1(hot_off) AHIP_PTR1(nhot) AHIP_PTRS_END
 
 constexpr int ORDERED_MAX = 64;   // entries per destination row the ordered form sums in index order
 __device__ __forceinline__ bool cold_row(const int* off, int64_t r) {
@@ -129,6 +130,7 @@ __global__ __launch_bounds__(256) void scatter_set_kernel(IdxArgs a) {
 // above does one per element; measured r01: gather of 65536 16-KiB rows 3.0 TB/s).
 struct VecGeom { int64_t row_v, src_rs_v, dst_rs_v; int lg; };   // lg = log2(lanes per row)
 struct IdxVecArgs { IdxArgs a; VecGeom g; };
+AHIP_PTRS_BEGIN(IdxVecArgs) AHIP_PTR1(a.src) AHIP_PTR1(a.dst) AHIP_PTR1(a.idx) AHIP_PTR1(a.bad) AHIP_PTR1(a.hot_off) AHIP_PTR1(a.nhot) AHIP_PTRS_END
 
 template <typename I>
 __global__ __launch_bounds__(256) void take_rows_vec_kernel(IdxVecArgs w) {
@@ -210,6 +212,7 @@ struct OrdArgs {
   int* bucket;   // [nidx] list positions grouped by destination row
   int* nhot;     // [1] number of rows left to the atomic form (zeroed with cnt)
 };
+AHIP_PTRS_BEGIN(OrdArgs) AHIP_PTR1(a.src) AHIP_PTR1(a.dst) AHIP_PTR1(a.idx) AHIP_PTR1(a.bad) AHIP_PTR1(a.hot_off) AHIP_PTR1(a.nhot) AHIP_PTR1(cnt) AHIP_PTR1(off) AHIP_PTR1(cursor) AHIP_PTR1(bucket) AHIP_PTR1(nhot) AHIP_PTRS_END
 
 __global__ __launch_bounds__(256) void ord_zero_kernel(OrdArgs o) {   // cnt and cursor
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i <= o.a.nrows;
@@ -543,6 +546,7 @@ struct ArgmaxArgs {
   const void* x; int64_t* out; int64_t nrows, k, x_rs, x_cs;
   void* pval; int64_t* pidx; int64_t nslices;   // column form: per-slice partial (value, index)
 };
+AHIP_PTRS_BEGIN(ArgmaxArgs) AHIP_PTR1(x) AHIP_PTR1(out) AHIP_PTR1(pval) AHIP_PTR1(pidx) AHIP_PTRS_END
 
 template <typename T>
 __global__ __launch_bounds__(256) void argmax_rows_kernel(ArgmaxArgs a) {
@@ -718,6 +722,7 @@ struct LinArgs {
   int64_t dim[LIN_MAX]; int64_t mult[LIN_MAX];
   int64_t n; int64_t* out; int64_t* bad; int nidx;
 };
+AHIP_PTRS_BEGIN(LinArgs) AHIP_PTRA(idx, LIN_MAX) AHIP_PTR1(out) AHIP_PTR1(bad) AHIP_PTRS_END
 
 __device__ __forceinline__ int64_t load_index(const void* p, int dtype, int64_t i) {
   switch (dtype) {
@@ -755,6 +760,7 @@ __global__ __launch_bounds__(256) void linearize_kernel(LinArgs a) {
 // ---- Nonzero: coordinates of the set entries of a flat inclusive count (compaction) ----
 constexpr int NZ_MAXD = 8;
 struct NzArgs { const int64_t* cnt; int64_t n; int nd; int64_t shape[NZ_MAXD]; int64_t* out[NZ_MAXD]; };
+AHIP_PTRS_BEGIN(NzArgs) AHIP_PTR1(cnt) AHIP_PTRA(out, NZ_MAXD) AHIP_PTRS_END
 
 __global__ __launch_bounds__(256) void nonzero_write_kernel(NzArgs a) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.n;

@@ -33,12 +33,19 @@ int ahip_cu_count() {
 struct ahip_graph_s { hipGraph_t graph; hipGraphExec_t exec; };
 
 // ---- launch lists --------------------------------------------------------------------------
+struct ahip_comm_s;
+enum RecKind : uint8_t { REC_STATIC = 0, REC_MODULE = 1, REC_MODULE_COOP = 2, REC_ALLREDUCE = 3 };
 struct LaunchRec {
   const void* func;      // static kernel (hipLaunchKernel) or nullptr
   hipFunction_t mfunc;   // module kernel (hipModuleLaunchKernel) or nullptr
   dim3 grid, block;
   unsigned shmem;
-  std::vector<char> arg; // by-value argument block
+  std::vector<char> arg; // by-value argument block (REC_ALLREDUCE: {send pointer, recv pointer})
+  RecKind kind;
+  bool has_ptrs;                 // the launch site declared where the device pointers are
+  std::vector<uint16_t> ptrs;    // their byte offsets inside `arg`
+  // REC_ALLREDUCE
+  ahip_comm_s* comm; int dtype, op; int64_t count;
 };
 // relocation: 8-byte word `off` of launch `rec`'s argument block points into rebinding range `base`
 struct Reloc { uint32_t rec, off, base; };
@@ -49,10 +56,23 @@ struct ahip_list_s {
 };
 static thread_local ahip_list_s* g_recording = nullptr;
 
+int ahip_comm_issue(ahip_comm_s* c, int dtype, int op, const void* send, void* recv, int64_t count,
+                    hipStream_t s);   // comm.hip
+
 static int issue(const LaunchRec& r, hipStream_t s) {
+  if (r.kind == REC_ALLREDUCE) {
+    const void* send; void* recv;
+    memcpy(&send, r.arg.data(), 8);
+    memcpy(&recv, r.arg.data() + 8, 8);
+    return ahip_comm_issue(r.comm, r.dtype, r.op, send, recv, r.count, s);
+  }
   if (r.func) {
     void* args[] = {const_cast<char*>(r.arg.data())};
     AHIP_CHECK_HIP(hipLaunchKernel(r.func, r.grid, r.block, args, r.shmem, s));
+  } else if (r.kind == REC_MODULE_COOP) {
+    void* params[] = {const_cast<char*>(r.arg.data())};
+    AHIP_CHECK_HIP(hipModuleLaunchCooperativeKernel(r.mfunc, r.grid.x, r.grid.y, r.grid.z, r.block.x,
+                                                    r.block.y, r.block.z, r.shmem, s, params));
   } else {
     size_t sz = r.arg.size();
     void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, const_cast<char*>(r.arg.data()),
@@ -64,20 +84,35 @@ static int issue(const LaunchRec& r, hipStream_t s) {
 }
 
 static int launch_or_record(const void* func, hipFunction_t mfunc, dim3 grid, dim3 block,
-                            size_t shmem, hipStream_t s, const void* arg, size_t arg_size) {
+                            size_t shmem, hipStream_t s, const void* arg, size_t arg_size,
+                            const uint16_t* ptr_off, int n_ptr, int coop) {
   if (grid.x == 0 || grid.y == 0 || grid.z == 0) {
     ahip_set_error("empty launch grid");
     return AHIP_EINVAL;
   }
+  for (int k = 0; k < n_ptr; ++k)
+    if ((size_t)ptr_off[k] + 8 > arg_size || (ptr_off[k] & 7)) {
+      ahip_set_error("pointer offset %d outside / misaligned in a %zu-byte argument block",
+                     (int)ptr_off[k], arg_size);
+      return AHIP_EINVAL;
+    }
   if (g_recording) {
-    LaunchRec r{func, mfunc, grid, block, (unsigned)shmem, {}};
+    LaunchRec r{};
+    r.func = func; r.mfunc = mfunc; r.grid = grid; r.block = block; r.shmem = (unsigned)shmem;
+    r.kind = func ? REC_STATIC : (coop ? REC_MODULE_COOP : REC_MODULE);
     r.arg.assign(static_cast<const char*>(arg), static_cast<const char*>(arg) + arg_size);
+    r.has_ptrs = n_ptr >= 0;
+    if (n_ptr > 0) r.ptrs.assign(ptr_off, ptr_off + n_ptr);
     g_recording->recs.push_back(std::move(r));
     return AHIP_OK;
   }
   if (func) {
     void* args[] = {const_cast<void*>(arg)};
     AHIP_CHECK_HIP(hipLaunchKernel(func, grid, block, args, shmem, s));
+  } else if (coop) {
+    void* params[] = {const_cast<void*>(arg)};
+    AHIP_CHECK_HIP(hipModuleLaunchCooperativeKernel(mfunc, grid.x, grid.y, grid.z, block.x, block.y,
+                                                    block.z, (unsigned)shmem, s, params));
   } else {
     size_t sz = arg_size;
     void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, const_cast<void*>(arg),
@@ -89,12 +124,29 @@ static int launch_or_record(const void* func, hipFunction_t mfunc, dim3 grid, di
 }
 
 int ahip_launch_static(const void* func, dim3 grid, dim3 block, size_t shmem, hipStream_t s,
-                       const void* arg, size_t arg_size) {
-  return launch_or_record(func, nullptr, grid, block, shmem, s, arg, arg_size);
+                       const void* arg, size_t arg_size, const uint16_t* ptr_off, int n_ptr) {
+  return launch_or_record(func, nullptr, grid, block, shmem, s, arg, arg_size, ptr_off, n_ptr, 0);
 }
 int ahip_launch_module(hipFunction_t f, dim3 grid, dim3 block, size_t shmem, hipStream_t s,
-                       const void* arg, size_t arg_size) {
-  return launch_or_record(nullptr, f, grid, block, shmem, s, arg, arg_size);
+                       const void* arg, size_t arg_size, const uint16_t* ptr_off, int n_ptr,
+                       int cooperative) {
+  return launch_or_record(nullptr, f, grid, block, shmem, s, arg, arg_size, ptr_off, n_ptr,
+                          cooperative);
+}
+// a collective as a launch-list entry (comm.hip calls this while a list is being recorded)
+bool ahip_list_recording() { return g_recording != nullptr; }
+int ahip_list_record_allreduce(ahip_comm_s* c, int dtype, int op, const void* send, void* recv,
+                               int64_t count) {
+  LaunchRec r{};
+  r.kind = REC_ALLREDUCE; r.comm = c; r.dtype = dtype; r.op = op; r.count = count;
+  r.grid = dim3(1); r.block = dim3(1);
+  r.arg.resize(16);
+  memcpy(r.arg.data(), &send, 8);
+  memcpy(r.arg.data() + 8, &recv, 8);
+  r.has_ptrs = true;
+  r.ptrs = {0, 8};
+  g_recording->recs.push_back(std::move(r));
+  return AHIP_OK;
 }
 struct ahip_event_s { hipEvent_t ev; };
 
@@ -218,7 +270,30 @@ int ahip_launch(ahip_fn_t f, uint32_t gx, uint32_t gy, uint32_t gz, uint32_t bx,
   AHIP_REQUIRE(f != nullptr, "null kernel");
   AHIP_REQUIRE(gx > 0 && gy > 0 && gz > 0 && bx > 0, "empty launch");
   return ahip_launch_module(f->fn, dim3(gx, gy, gz), dim3(bx, by, bz), shmem_bytes,
-                            as_stream(stream), kernarg, kernarg_size);
+                            as_stream(stream), kernarg, kernarg_size, nullptr, -1);
+}
+
+int ahip_launch_p(ahip_fn_t f, uint32_t gx, uint32_t gy, uint32_t gz, uint32_t bx, uint32_t by,
+                  uint32_t bz, uint32_t shmem_bytes, const void* kernarg, size_t kernarg_size,
+                  const uint16_t* ptr_offsets, int n_ptrs, int cooperative, void* stream) {
+  AHIP_REQUIRE(f != nullptr, "null kernel");
+  AHIP_REQUIRE(gx > 0 && gy > 0 && gz > 0 && bx > 0, "empty launch");
+  AHIP_REQUIRE(n_ptrs >= 0 && (n_ptrs == 0 || ptr_offsets), "bad pointer map");
+  return ahip_launch_module(f->fn, dim3(gx, gy, gz), dim3(bx, by, bz), shmem_bytes,
+                            as_stream(stream), kernarg, kernarg_size, ptr_offsets, n_ptrs,
+                            cooperative);
+}
+
+// co-residency of a persistent (spinning) grid: how many workgroups of `f` fit on the device
+int ahip_occupancy(ahip_fn_t f, int block_threads, size_t dyn_lds_bytes, int* blocks_per_cu,
+                   int* cu_count) {
+  AHIP_REQUIRE(f && blocks_per_cu && cu_count, "null argument");
+  int nb = 0;
+  AHIP_CHECK_HIP(hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, f->fn, block_threads,
+                                                                    dyn_lds_bytes));
+  *blocks_per_cu = nb;
+  *cu_count = ahip_cu_count();
+  return AHIP_OK;
 }
 
 // ---- hipGraph capture / replay -----------------------------------------------------------
@@ -290,8 +365,8 @@ int ahip_list_run(ahip_list_t l, void* stream) {
 
 // Zero-copy replay for fresh buffers (a training loop hands over a NEW batch tensor on every
 // call): after recording, the caller names the address ranges of its rebindable buffers (plan
-// inputs, `out=` targets); every 8-byte word of every recorded argument block that points into
-// one of them becomes a relocation.  ahip_list_run_rebased patches those words by the distance
+// inputs, `out=` targets); every DECLARED pointer word (the pointer map each launch site passes
+// with its argument block) that points into one of them becomes a relocation.  ahip_list_run_rebased patches those words by the distance
 // the buffers moved and re-issues the launches — one host call, no staging copy.
 int ahip_list_bind_bases(ahip_list_t l, const uint64_t* lo, const uint64_t* hi, int n) {
   AHIP_REQUIRE(l != nullptr && (n == 0 || (lo && hi)), "null argument");
@@ -301,11 +376,17 @@ int ahip_list_bind_bases(ahip_list_t l, const uint64_t* lo, const uint64_t* hi, 
     for (int b = 0; b < a; ++b)
       AHIP_REQUIRE(hi[a] <= lo[b] || hi[b] <= lo[a] || lo[a] == hi[a] || lo[b] == hi[b],
                    "rebinding ranges %d and %d overlap", a, b);
+  // only words a launch site DECLARED as device pointers are candidates: a scalar whose bit
+  // pattern happens to fall into a range is never touched, a pointer is never missed
   for (size_t r = 0; r < l->recs.size(); ++r) {
-    std::vector<char>& arg = l->recs[r].arg;
-    for (size_t off = 0; off + 8 <= arg.size(); off += 8) {
+    const LaunchRec& rec = l->recs[r];
+    if (!rec.has_ptrs) {
+      ahip_set_error("launch %zu of the list was recorded without a pointer map", r);
+      return -2;
+    }
+    for (uint16_t off : rec.ptrs) {
       uint64_t v;
-      memcpy(&v, arg.data() + off, 8);
+      memcpy(&v, rec.arg.data() + off, 8);
       for (int k = 0; k < n; ++k)
         if (v >= lo[k] && v < hi[k]) {
           l->relocs.push_back(Reloc{(uint32_t)r, (uint32_t)off, (uint32_t)k});

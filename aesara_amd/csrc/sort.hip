@@ -28,6 +28,7 @@ struct SortArgs {
   int64_t rows, n, x_rs, x_cs;     // element strides of the [rows, n] view; outputs are contiguous
   int n2;                          // n padded to a power of two
 };
+AHIP_PTRS_BEGIN(SortArgs) AHIP_PTR1(x) AHIP_PTR1(keys_out) AHIP_PTR1(idx_out) AHIP_PTRS_END
 
 template <typename T>
 __global__ __launch_bounds__(256) void sort_rows_kernel(SortArgs a) {

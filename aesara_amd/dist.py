@@ -500,7 +500,74 @@ class LocalGroup:
             b.copy_(acc)
 
 
+class _Done:
+    """Handle of a collective that is ordered by the launch stream (nothing to wait for)."""
+
+    def wait(self):
+        return True
+
+
+class HipComm:
+    """RCCL communicator owned by the C-ABI (``ahip_comm_*``, include/aesara_hip.h): the
+    all-reduce of an exchange round is enqueued by the shim on the LAUNCH stream — between the
+    kernels of the rounds around it, no second stream, no event hand-shake, and (while a launch
+    list is being recorded) as a list entry that ``ahip_list_run`` replays.  One process per GPU.
+
+    Bootstrap: rank 0 draws the 128-byte id and every other rank receives it through
+    ``torch.distributed`` (any initialised backend; gloo is enough) — or pass ``unique_id``
+    yourself.  ``world == 1`` needs no bootstrap (and still runs RCCL: the single-GPU test of the
+    path)."""
+
+    def __init__(self, world=None, rank=None, unique_id=None, bootstrap_group=None):
+        import ctypes as C
+        import os
+        import torch
+        import torch.distributed as dist
+        from ._lib import COMM_ID_BYTES, check, lib
+        if world is None:
+            world = dist.get_world_size(bootstrap_group) if dist.is_initialized() else 1
+            rank = dist.get_rank(bootstrap_group) if dist.is_initialized() else 0
+        self.world, self.rank = int(world), int(rank or 0)
+        bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if os.path.exists(bundled) and not os.environ.get("AESARA_HIP_RCCL"):
+            check(lib.ahip_comm_set_library(bundled.encode()))     # the copy torch itself uses
+        if unique_id is None:
+            buf = C.create_string_buffer(COMM_ID_BYTES)
+            if self.rank == 0:
+                check(lib.ahip_comm_unique_id(buf, COMM_ID_BYTES))
+            if self.world > 1:
+                box = [buf.raw if self.rank == 0 else None]
+                dist.broadcast_object_list(box, src=0, group=bootstrap_group)
+                buf = C.create_string_buffer(box[0], COMM_ID_BYTES)
+            unique_id = buf.raw
+        self._h = C.c_void_p()
+        check(lib.ahip_comm_init_rank(C.create_string_buffer(unique_id, COMM_ID_BYTES), self.world,
+                                      self.rank, C.byref(self._h)))
+
+    def all_reduce(self, buf, op="add"):
+        """In-place all-reduce of a contiguous device tensor on the current (launch) stream."""
+        import ctypes as C
+        import torch
+        from ._lib import RED_OPS, check, lib
+        from .device import dtype_code
+        if not buf.is_contiguous():
+            raise ValueError("HipComm.all_reduce needs a contiguous buffer")
+        name = str(buf.dtype).replace("torch.", "")
+        ptr = C.c_void_p(buf.data_ptr())
+        check(lib.ahip_allreduce(self._h, dtype_code(name), RED_OPS[op], ptr, ptr, buf.numel(),
+                                 C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return _Done()
+
+    def close(self):
+        from ._lib import lib
+        if self._h:
+            lib.ahip_comm_destroy(self._h)
+            self._h = None
+
+
 def _dist_reduce(buf, op, group, async_op=False):
+    if isinstance(group, HipComm):
+        return group.all_reduce(buf, op)        # stream-ordered: sync and async are the same
     import torch.distributed as dist
     rop = {"add": dist.ReduceOp.SUM, "maximum": dist.ReduceOp.MAX, "minimum": dist.ReduceOp.MIN}[op]
     return dist.all_reduce(buf, op=rop, group=group, async_op=async_op)
@@ -526,7 +593,11 @@ class ShardedPlan:
     the next round's replay reading views of that buffer."""
 
     def __init__(self, plan: Plan, split_inputs: Dict[int, int], group=None, use_graph=False,
-                 executor_factory: Optional[Callable] = None, device=None, borrow=False):
+                 executor_factory: Optional[Callable] = None, device=None, borrow=False,
+                 force_collectives=False):
+        # force_collectives: issue the all-reduces also in a world of ONE rank (an identity that
+        # still goes through RCCL: how a single-GPU box exercises the collective path)
+        self.force_collectives = force_collectives
         self.spec = shard_plan(plan, split_inputs)
         self.borrow = borrow or not use_graph
         self.group = group
@@ -543,7 +614,7 @@ class ShardedPlan:
 
     # -- world size of the group this instance communicates over --------------------------------
     def _world(self):
-        if isinstance(self.group, LocalGroup):
+        if isinstance(self.group, (LocalGroup, HipComm)):
             return self.group.world
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized():
@@ -616,7 +687,7 @@ class ShardedPlan:
                     if o.data_ptr() != views[pos].data_ptr():
                         views[pos].copy_(o.reshape(views[pos].shape))
                     outs[pos] = views[pos]
-                if world > 1:
+                if world > 1 or self.force_collectives:
                     last = k + 1 == len(spec.rounds) or not any(
                         q.nodes for q, _ in spec.rounds[k + 1:])
                     for (rop, _xdt), buf in bufs.items():
@@ -789,6 +860,11 @@ class ShardedFunction:
 
         outs = list(self.executor(*local_inputs))
         handles = []
+        if isinstance(self.group, HipComm):
+            for o, k in zip(outs, self.kinds):
+                if k == "allreduce":
+                    handles.append(self.group.all_reduce(o, "add"))
+            return (outs, handles if async_op else []) if async_op else outs
         if dist.is_initialized() and dist.get_world_size(self.group) > 1:
             for o, k in zip(outs, self.kinds):
                 if k == "allreduce":

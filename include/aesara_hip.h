@@ -51,7 +51,10 @@ typedef struct ahip_func_s* ahip_fn_t;
 typedef struct ahip_graph_s* ahip_graph_t;
 typedef struct ahip_event_s* ahip_event_t;
 typedef struct ahip_list_s* ahip_list_t;
-typedef struct ahip_list_s* ahip_list_t;
+typedef struct ahip_comm_s* ahip_comm_t;
+
+#define AHIP_COMM_ID_BYTES 128
+enum ahip_red_op { AHIP_RED_SUM = 0, AHIP_RED_PROD = 1, AHIP_RED_MAX = 2, AHIP_RED_MIN = 3 };
 
 /* Kernel-argument block of every GENERATED fused Elemwise(+CAReduce) kernel
  *   extern "C" __global__ void k(ahip_ew_args a);
@@ -169,10 +172,24 @@ int ahip_free_code(void* code);
 int ahip_module_load(const void* code, size_t size, ahip_module_t* out);
 int ahip_module_get_function(ahip_module_t m, const char* kernel_name, ahip_fn_t* out);
 int ahip_module_unload(ahip_module_t m);
-/* raw launch of a loaded kernel with an opaque kernarg block */
+/* raw launch of a loaded kernel with an opaque kernarg block (a list that records such a launch
+ * cannot be rebound: nothing says where its pointers are) */
 int ahip_launch(ahip_fn_t f, uint32_t gx, uint32_t gy, uint32_t gz, uint32_t bx, uint32_t by,
                 uint32_t bz, uint32_t shmem_bytes, const void* kernarg, size_t kernarg_size,
                 void* stream);
+/* the same with the POINTER MAP of the kernarg block — byte offsets (multiples of 8) of its device
+ * pointers, the only words ahip_list_bind_bases may ever re-point — and an optional cooperative
+ * launch (hipModuleLaunchCooperativeKernel: the runtime refuses a grid that cannot be co-resident).
+ * Used for the persistent one-kernel Scan loops (replaces scan/scan_perform.pyx:309-541).       */
+int ahip_launch_p(ahip_fn_t f, uint32_t gx, uint32_t gy, uint32_t gz, uint32_t bx, uint32_t by,
+                  uint32_t bz, uint32_t shmem_bytes, const void* kernarg, size_t kernarg_size,
+                  const uint16_t* ptr_offsets, int n_ptrs, int cooperative, void* stream);
+/* workgroups of `f` (block_threads threads, dyn_lds_bytes of dynamic LDS) that fit on one CU, and
+ * the CU count: a persistent kernel whose workgroups wait for each other is only launched when
+ * grid <= blocks_per_cu * cu_count (the reference loop has no such hazard: scan_perform.pyx is
+ * sequential; here co-residency is what makes the in-kernel exchange terminate)                 */
+int ahip_occupancy(ahip_fn_t f, int block_threads, size_t dyn_lds_bytes, int* blocks_per_cu,
+                   int* cu_count);
 
 /* ---- K1/K3: fused broadcast Elemwise ----------------------------------------------------
  * replaces: tensor/elemwise.py:725 Elemwise.perform / :835 _c_all (C loop nest generated by
@@ -390,8 +407,9 @@ int ahip_list_run(ahip_list_t l, void* stream);
 /* Zero-copy replay with rebound buffers (Function.__call__ binds NEW input arrays on every call,
  * compile/function/types.py:835-843; the reference's thunks read them through storage cells).
  * ahip_list_bind_bases: declare n address ranges [lo[k], hi[k]) (the plan inputs / output targets
- * of the recorded call; must not overlap); every 8-byte word of a recorded argument block that
- * points into a range becomes a relocation; returns their number (< 0: error).
+ * of the recorded call; must not overlap); every word a launch site DECLARED as a device pointer
+ * (the pointer map passed next to each argument block) that points into a range becomes a
+ * relocation; returns their number (< 0: error; -2: a launch was recorded without a map).
  * ahip_list_run_rebased: patch the relocations for the new base addresses and re-issue. */
 int ahip_list_bind_bases(ahip_list_t l, const uint64_t* lo, const uint64_t* hi, int n);
 int ahip_list_run_rebased(ahip_list_t l, const uint64_t* bases, int n, void* stream);
@@ -400,6 +418,24 @@ int ahip_graph_begin(void* stream);
 int ahip_graph_end(void* stream, ahip_graph_t* out);
 int ahip_graph_launch(ahip_graph_t g, void* stream);
 int ahip_graph_destroy(ahip_graph_t g);
+
+/* ---- the one collective of the path: RCCL all-reduce on the LAUNCH stream ----
+ * replaces: nothing in the reference's data path (tensor/io.py:108-262 MPI send/recv is its only
+ * communication code); it is what a CAReduce / contraction over a batch axis that has been split
+ * over the GPUs of a node needs: local partials -> ONE all-reduce -> continue.  One process per
+ * GPU.  Rank 0 creates the 128-byte id (ahip_comm_unique_id) and hands it to the other ranks out
+ * of band (aesara_amd/dist.py: torch.distributed broadcast); every rank then calls
+ * ahip_comm_init_rank.  ahip_allreduce enqueues on `stream`; while a launch list is being
+ * recorded it becomes a list entry (replayed by ahip_list_run between the kernels around it).
+ * RCCL itself is dlopen'ed at first use (ahip_comm_set_library / $AESARA_HIP_RCCL name a path). */
+int ahip_comm_set_library(const char* path);
+int ahip_comm_unique_id(void* id_out, size_t id_bytes /* >= AHIP_COMM_ID_BYTES */);
+int ahip_comm_init_rank(const void* id, int nranks, int rank, ahip_comm_t* out);
+int ahip_comm_size(ahip_comm_t c);
+int ahip_comm_rank(ahip_comm_t c);
+int ahip_allreduce(ahip_comm_t c, int dtype, int op /* ahip_red_op */, const void* sendbuf,
+                   void* recvbuf, int64_t count, void* stream);
+int ahip_comm_destroy(ahip_comm_t c);
 
 /* ---- timing on the launch stream (bench.py roofline leg) ----------------------------------- */
 int ahip_event_create(ahip_event_t* out);

@@ -80,3 +80,32 @@ def test_compile_error_is_reported():
     with pytest.raises(_lib.HipError) as ei:
         _lib.compile_source("this is not HIP")
     assert "error" in str(ei.value)
+
+
+def test_pointer_maps_of_the_kernel_argument_structs():
+    """``ptr_offsets``: what ``ahip_launch_p`` is told about a kernarg block — every ``c_void_p``
+    field / array element, nothing else (scalars are never candidates for rebinding)."""
+    from aesara_amd import _lib
+    from aesara_amd.scan_persist import SpArgs, SP_MAXMAT, SP_MAXSEQ, SP_MAXNSQ, SP_MAXOUT
+    from aesara_amd.scan_persist_mat import SmArgs
+    offs, n = _lib.ptr_offsets(SpArgs)
+    assert n == SP_MAXMAT + SP_MAXSEQ + SP_MAXNSQ + SP_MAXOUT + 2
+    got = list(offs)[:n]
+    assert got == sorted(got) and all(o % 8 == 0 and o + 8 <= C.sizeof(SpArgs) for o in got)
+    assert SpArgs.T.offset not in got and SpArgs.xch.offset in got and SpArgs.ctl.offset in got
+    assert SpArgs.mat.offset in got and SpArgs.mat_rs.offset not in got
+    offs2, n2 = _lib.ptr_offsets(SmArgs)
+    assert n2 > 0 and SmArgs.out.offset in list(offs2)[:n2] and SmArgs.out_ts.offset not in list(offs2)[:n2]
+
+
+def test_collective_entry_points_validate_arguments_without_a_gpu():
+    """No RCCL call is made: only the argument checks of the shim (no GPU in this tier)."""
+    from aesara_amd import _lib
+    lib = _lib.lib
+    assert lib.ahip_comm_size(None) == -1 and lib.ahip_comm_rank(None) == -1
+    assert lib.ahip_allreduce(None, 10, 0, None, None, 4, None) == _lib.AHIP_EINVAL
+    assert b"null communicator" in lib.ahip_last_error()
+    buf = C.create_string_buffer(16)
+    assert lib.ahip_comm_unique_id(buf, 16) == _lib.AHIP_EINVAL          # id buffer too small
+    assert lib.ahip_comm_init_rank(buf, 2, 5, C.byref(C.c_void_p())) == _lib.AHIP_EINVAL
+    assert lib.ahip_comm_destroy(None) == 0

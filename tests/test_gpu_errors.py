@@ -154,3 +154,43 @@ def test_uint64_index_beyond_int64_is_out_of_bounds():
     bad = torch.from_numpy(np.array([0, 2 ** 64 - 1, 1], dtype=np.uint64).view(np.int64)).cuda().view(torch.uint64)
     with pytest.raises(IndexError):
         ex(x, bad)
+
+
+def test_rebinding_only_touches_declared_pointer_words():
+    """a scalar of a recorded argument block whose BIT PATTERN equals an
+    address inside a rebindable range (here: the fill value of an int64 fill is the address of
+    its own destination) must never be patched — only the words the launch site declared as
+    device pointers are."""
+    import ctypes as C
+    import torch
+    from aesara_amd._lib import check, lib
+    a = torch.zeros(1024, dtype=torch.int64, device="cuda")
+    b = torch.zeros(1024, dtype=torch.int64, device="cuda")
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    addr = a.data_ptr() + 64                       # a value INSIDE the rebindable range of `a`
+    val = C.c_int64(addr)
+    lst = C.c_void_p()
+    check(lib.ahip_list_begin())
+    try:
+        check(lib.ahip_fill(4, C.byref(val), C.c_void_p(a.data_ptr()), 1024, stream))
+    finally:
+        check(lib.ahip_list_end(C.byref(lst)))
+    lo = (C.c_uint64 * 1)(a.data_ptr())
+    hi = (C.c_uint64 * 1)(a.data_ptr() + 8192)
+    assert lib.ahip_list_bind_bases(lst, lo, hi, 1) == 1            # the pointer, not the value
+    bases = (C.c_uint64 * 1)(b.data_ptr())
+    check(lib.ahip_list_run_rebased(lst, bases, 1, stream))
+    torch.cuda.synchronize()
+    assert int(a.abs().max()) == 0 and bool((b == addr).all())      # new buffer, ORIGINAL value
+    lib.ahip_list_destroy(lst)
+    # a launch recorded without a pointer map makes the list non-rebindable (never scanned)
+    from aesara_amd.device import load_kernels
+    (k,) = load_kernels('extern "C" __global__ void kk(long* p){ if (threadIdx.x == 0) p[0] = 7; }', ("kk",))
+    arg = (C.c_void_p * 1)(a.data_ptr())
+    check(lib.ahip_list_begin())
+    try:
+        check(lib.ahip_launch(k, 1, 1, 1, 64, 1, 1, 0, arg, 8, stream))
+    finally:
+        check(lib.ahip_list_end(C.byref(lst)))
+    assert lib.ahip_list_bind_bases(lst, lo, hi, 1) == -2
+    lib.ahip_list_destroy(lst)

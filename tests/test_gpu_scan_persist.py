@@ -460,3 +460,56 @@ def test_fused_gate_lstm_vector_state_runs_persistent(T, D):
         for gv, wv in ((got_hs, want_hs), (got_c, want_c)):
             err = ((gv.double() - wv).abs().max() / wv.abs().max()).item()
             assert gv.shape == wv.shape and err <= 2e-5, (use_graph, err)
+
+
+def test_persistent_scan_next_to_a_saturating_stream_and_occupancy_refusal():
+    """VERDICT r2 #6c.  (1) A second stream keeps every CU busy with long kernels while the
+    persistent Scan kernel (whose workgroups wait for each other) runs: the answer is right — or
+    the call raises promptly (bounded spins -> error word -> RuntimeError in THIS call).
+    (2) A grid that cannot be co-resident is refused BEFORE launch (occupancy query) and the
+    launch-list path runs instead."""
+    import torch
+    from golden_util import CASES, case_expected, case_inputs, case_plan
+    from aesara_amd.executor import PlanExecutor, _Kernels
+    c = next(c for c in CASES if c["name"] == "sp_gru_last_f32")
+    plan = case_plan(c)
+    ins = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in case_inputs(c)]
+    want = case_expected(c)
+    ex = PlanExecutor(plan, use_graph=False)
+    ex(*ins)
+    assert list(ex.scan_modes.values()) == ["persistent"]
+    side = torch.cuda.Stream()
+    big = torch.randn(8192, 8192, device="cuda")
+    ok = err = 0
+    for rep in range(6):
+        with torch.cuda.stream(side):
+            for _ in range(4):
+                big = torch.tanh(big @ big * 1e-4)            # ~1.1 TFLOP each: the device is full
+        try:
+            outs = ex(*ins)
+            for o, w in zip(outs, want):
+                np.testing.assert_allclose(o.cpu().numpy(), w, rtol=c["rtol"], atol=c["atol"])
+            ok += 1
+        except RuntimeError as e:
+            assert "persistent Scan kernel" in str(e)
+            err += 1
+        side.synchronize()
+    assert ok + err == 6 and ok >= 1
+    outs = ex(*ins)                                            # and afterwards all is well
+    for o, w in zip(outs, want):
+        np.testing.assert_allclose(o.cpu().numpy(), w, rtol=c["rtol"], atol=c["atol"])
+    # (2) pretend the device holds fewer workgroups than the grid needs
+    ex2 = PlanExecutor(plan, use_graph=False)
+    saved = dict(_Kernels.cache)
+    try:
+        for k in list(_Kernels.cache):
+            if isinstance(k, tuple) and k and k[0] == "occ":
+                _Kernels.cache[k] = 1
+        outs = ex2(*ins)
+        (mode,) = ex2.scan_modes.values()
+        assert mode.startswith("launch-list: grid of") and "co-resident" in mode
+        for o, w in zip(outs, want):
+            np.testing.assert_allclose(o.cpu().numpy(), w, rtol=c["rtol"], atol=c["atol"])
+    finally:
+        _Kernels.cache.clear()
+        _Kernels.cache.update(saved)
