@@ -780,7 +780,7 @@ def cpu_baseline(np, ref_warm=None, secondary=None):
         try:
             if ref_warm is not None:
                 ref_warm.wait(timeout=300)
-            r = reference_rows(6.0, ["cfg2", "cfg1b", "cfg3a", "cfg3b", "cfg4_b1", "cfg4_b64", "cfg5"])
+            r = reference_rows(4.0, ["cfg2", "cfg1b", "cfg3a", "cfg3b", "cfg4_b1", "cfg4_b64", "cfg5"])
             row = r["rows"]["cfg2"]
             res = {"value": 1e3 / row["ms_per_eval"], "unit": "evals/s", "cores": row["cores"],
                    "kind": "reference", "ms_per_eval": row["ms_per_eval"],
@@ -790,7 +790,7 @@ def cpu_baseline(np, ref_warm=None, secondary=None):
                    "threads": "Elemwise/CAReduce loops single-threaded (openmp=False, the reference default); "
                               "BLAS rows: bundled OpenBLAS at its default thread count",
                    "graph": row.get("nodes")}
-            scale = {"cfg4_b1": 4.0, "cfg4_b64": 4.0, "cfg5": 16.0}
+            scale = {"cfg4_b1": 8.0, "cfg4_b64": 8.0, "cfg5": 16.0}
             others = {}
             for k, v in r["rows"].items():
                 if k == "cfg2":

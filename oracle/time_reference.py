@@ -58,7 +58,7 @@ def build(ae, name, np, tiny=False):
         return f, (), "fp32 %d^3 Gemm update (alt-BLAS -> NumPy's OpenBLAS)" % n, nthreads
     if name in ("cfg4_b1", "cfg4_b64"):
         B_ = 1 if name == "cfg4_b1" else 64
-        T_, H = (8, 32) if tiny else (128, 1024)      # 1/4 of the config's 512 steps (bounded sample)
+        T_, H = (8, 32) if tiny else (64, 1024)       # 1/8 of the config's 512 steps (bounded sample)
         if tiny and B_ > 1:
             B_ = 4
         x = at.fmatrix("x") if B_ == 1 else at.ftensor3("x")
@@ -76,7 +76,7 @@ def build(ae, name, np, tiny=False):
         xs = (T_, H) if B_ == 1 else (T_, B_, H)
         xv = (np.random.default_rng(4).standard_normal(xs) * 0.1).astype("float32")
         return f, (xv, np.zeros(xs[1:], "float32")), \
-            "fp32 Scan GRU T=%d of 512 steps (x4 for the config), H=%d B=%d (scan_perform.pyx loop, inner cvm " \
+            "fp32 Scan GRU T=%d of 512 steps (x8 for the config), H=%d B=%d (scan_perform.pyx loop, inner cvm " \
             "function)" % (T_, H, B_), nthreads
     if name == "cfg5":
         N, D = (256, 16) if tiny else (1 << 20, 256)
