@@ -100,17 +100,20 @@ class Program:
         self.exchanged = []         # produced vars that some dot needs in full
         self.mode = "vec"
         self.dtype = "float32"
+        self.older = {}             # inner input var of a tap < -1 -> (recurrent output, depth)
+        self.depth = {}             # recurrent output -> deepest tap (1 = the usual sit-sot)
+        self.n_rec_inputs = 0       # inner inputs taken by the recurrent outputs' taps
 
 
 class _DotPhase:
     """Stand-in step for a plain ``Dot22(operand, invariant matrix)`` node of a matrix-state loop."""
     kind, reduce, post, fallback, extra = "gemm_epi", None, (), (), {}
 
-    def __init__(self, operand, weight, out, add=None):
+    def __init__(self, operand, weight, out, add=None, dtype="float32"):
         self.dots = [[operand, weight]]
         self.inputs, self.outputs = ([] if add is None else [add]), [out]
         self.scalar = {"n_in": 1, "nodes": [], "out": [["i", 0]]} if add is None else \
-            {"n_in": 2, "nodes": [{"op": "add", "in": [["i", 0], ["i", 1]], "dtype": "float32"}],
+            {"n_in": 2, "nodes": [{"op": "add", "in": [["i", 0], ["i", 1]], "dtype": dtype}],
              "out": [["t", 0]]}
         self.out_refs = [0]
         self.node = None
@@ -137,9 +140,13 @@ def analyze(inner, p, n_seqdots):
     if any(t != [0, 1] for t in mm_in) or any(t != [1] for t in mm_out):
         return None, "mit-mot taps other than [0, 1] -> [1]"
     n_mm = len(mm_in)
+    # sit-sot / mit-sot outputs: the tap -1 value is the recurrent state proper (may feed dots, is
+    # exchanged); older taps (-2, -3, ...: scan_perform.pyx:321-340 hands the step one row per
+    # tap) are values the ROW OWNER produced itself 2, 3, ... steps ago — they stay in its
+    # registers (a shift per step), so they may only be used element-wise
     taps = [list(t) for t in p["mit_sot_in_slices"]] + [list(t) for t in p["sit_sot_in_slices"]]
-    if any(t != [-1] for t in taps):
-        return None, "taps other than [-1]"
+    if any((-1 not in t) or any(x >= 0 for x in t) or len(set(t)) != len(t) or min(t) < -8 for t in taps):
+        return None, "taps without -1 / non-negative / deeper than 8"
     n_rec, n_nit = n_mm + len(taps), p["n_nit_sot"]
     if n_rec == 0:
         return None, "no recurrent state"
@@ -154,9 +161,15 @@ def analyze(inner, p, n_seqdots):
         pr.seq[ins[idx + 1]] = n_seqs + n_seqdots + g     # slot of the buffer-resident sequence
         pr.tap_seq[ins[idx + 1]] = g
         idx += 2
-    for k in range(len(taps)):
-        pr.state[ins[idx]] = n_mm + k
-        idx += 1
+    for k, tk in enumerate(taps):
+        for tap in tk:
+            if tap == -1:
+                pr.state[ins[idx]] = n_mm + k
+            else:
+                pr.older[ins[idx]] = (n_mm + k, -tap)
+            idx += 1
+        pr.depth[n_mm + k] = -min(tk)
+    pr.n_rec_inputs = idx - n_seqs
     inv = ins[idx:n_fixed]
     for j, v in enumerate(ins[n_fixed:]):
         pr.seq[v] = n_seqs + j
@@ -171,7 +184,7 @@ def analyze(inner, p, n_seqdots):
                                   and plan.vars[st.outputs[0]].ndim == 2) for st in inner.steps) else "vec"
     # one floating dtype throughout (the state's): float32 always, float64 for the vector class
     pr.dtype = plan.vars[plan.outputs[0]].dtype
-    if pr.dtype not in (("float32",) if pr.mode == "mat" else ("float32", "float64")):
+    if pr.dtype not in ("float32", "float64"):
         return None, "state dtype %s" % pr.dtype
     nd = 2 if pr.mode == "mat" else 1
     ok_kinds = ("gemm_epi", "elemwise") if pr.mode == "mat" else ("gemv_epi", "elemwise")
@@ -207,12 +220,12 @@ def analyze(inner, p, n_seqdots):
                 len(st.inputs) == 2 and st.inputs[1] in inv_set:
             # a product that feeds several Elemwise steps (no single epilogue to fuse with): a
             # phase whose "epilogue" hands the dot through
-            st = _DotPhase(st.inputs[0], st.inputs[1], st.outputs[0])
+            st = _DotPhase(st.inputs[0], st.inputs[1], st.outputs[0], dtype=pr.dtype)
         if st.kind == "node" and st.node.op == "Gemm" and pr.mode == "mat" and \
                 st.inputs[3] in inv_set and _const1(plan, st.inputs[1]) and _const1(plan, st.inputs[4]):
             # z + x @ W with nothing fused behind it (the state update of a plain RNN's gradient
             # step): a product phase whose epilogue adds z
-            st = _DotPhase(st.inputs[2], st.inputs[3], st.outputs[0], add=st.inputs[0])
+            st = _DotPhase(st.inputs[2], st.inputs[3], st.outputs[0], add=st.inputs[0], dtype=pr.dtype)
         if st.kind == "node" and st.node.op == "DimShuffle" and pr.mode == "vec" and \
                 [d for d in st.node.params["new_order"] if d != "x"] == [0] and \
                 plan.vars[st.inputs[0]].ndim == 1 and not readers.get(st.outputs[0]) and \
@@ -232,6 +245,8 @@ def analyze(inner, p, n_seqdots):
                 return None, "dot with a loop-varying matrix"
             if a not in pr.mats:
                 pr.mats[a] = len(pr.mats)
+            if x in pr.older:
+                return None, "dot with a tap older than -1"
             if not (x in pr.seq or x in pr.state or x in produced or x in inv_set):
                 return None, "dot vector of unknown origin"
             if x in pr.tap_seq:
@@ -245,7 +260,7 @@ def analyze(inner, p, n_seqdots):
                     return None, "matrix used element-wise"
                 if v not in pr.nsq:
                     pr.nsq[v] = len(pr.nsq)
-            elif not (v in pr.seq or v in pr.state or v in produced):
+            elif not (v in pr.seq or v in pr.state or v in produced or v in pr.older):
                 return None, "operand of unknown origin"
             if plan.vars[v].dtype != pr.dtype:
                 return None, "operand dtype differs from the state's"
@@ -257,6 +272,8 @@ def analyze(inner, p, n_seqdots):
                           "scalar": st.scalar, "out_refs": list(st.out_refs)})
     if len(pr.mats) > SP_MAXMAT or len(pr.nsq) > SP_MAXNSQ or not pr.mats:
         return None, "no / too many matrices"
+    if pr.older and pr.mode == "mat":
+        return None, "taps other than [-1] on a matrix state"
     if len(plan.outputs) != n_rec + n_nit or len(plan.outputs) > SP_MAXOUT:
         return None, "output count"
     for j, o in enumerate(plan.outputs):
@@ -302,7 +319,7 @@ class Spec:
 
     def key(self):
         pr = self.prog
-        blob = json.dumps(["sp7", self.dtype, sorted(self.var.items()), sorted(self.place.items()), self.M, sorted(self.Ks.items()), sorted(self.lens.items()),
+        blob = json.dumps(["sp8", sorted(self.prog.older.items()), self.dtype, sorted(self.var.items()), sorted(self.place.items()), self.M, sorted(self.Ks.items()), sorted(self.lens.items()),
                            self.R, self.nw, sorted(pr.seq.items()), sorted(pr.state.items()),
                            sorted(pr.nsq.items()), sorted(pr.mats.items()),
                            [[ph["dots"], ph["ins"], ph["outs"], ph["scalar"], ph["out_refs"]]
@@ -415,6 +432,17 @@ def generate(spec: Spec):
         L.append("  %s own_%d = 0;" % (T, v))
         L.append("  if (owner) own_%d = ((const %s*)a.out[%d])[((a.out_pos0[%d] + a.out_store[%d] - 1) %% "
                  "a.out_store[%d]) * a.out_rs[%d] + myrow];" % (v, T, k, k, k, k, k))
+    # older taps: the owner's own values of 2 .. depth steps ago (buffer row pos0 - d holds the
+    # initial one); a depth no tap names still needs its register (taps [-1, -3] pass through -2)
+    hist = {}
+    by_kd = {kd: v for v, kd in pr.older.items()}
+    for k, D in sorted(pr.depth.items()):
+        for d in range(2, D + 1):
+            nm = ("own_%d" % by_kd[(k, d)]) if (k, d) in by_kd else "hist_%d_%d" % (k, d)
+            hist[(k, d)] = nm
+            L.append("  %s %s = 0;" % (T, nm))
+            L.append("  if (owner) %s = ((const %s*)a.out[%d])[((a.out_pos0[%d] + a.out_store[%d] * 8 - %d) %% "
+                     "a.out_store[%d]) * a.out_rs[%d] + myrow];" % (nm, T, k, k, k, d, k, k))
     pw_nsq = sorted({v for ph in pr.phases for v in ph["ins"] if v in pr.nsq})
     for v in pw_nsq:
         es_one = spec.lens[v] == 1
@@ -592,6 +620,9 @@ def generate(spec: Spec):
                          % (T, j, j, j, j, o))
         L.append("    }")
     for v, nv in pr.new_of_state.items():
+        k = pr.state[v]
+        for d in range(pr.depth.get(k, 1), 1, -1):      # shift the owner's history, oldest first
+            L.append("    %s = %s;" % (hist[(k, d)], hist[(k, d - 1)] if d > 2 else "own_%d" % v))
         L.append("    own_%d = own_%d;" % (v, nv))
     L.append("  }")
     # every workgroup read `base` before workgroup 0 can get here (it gathered, in its last

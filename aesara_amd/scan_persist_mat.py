@@ -84,7 +84,8 @@ typedef unsigned long long u64;
 class SpecMat:
     """Shape-specialised kernel: B batch rows, N state columns, K per weight matrix."""
 
-    def __init__(self, prog, B, N, Ks, Nt=None):
+    def __init__(self, prog, B, N, Ks, Nt=None, dtype="float32"):
+        self.dtype = dtype
         # N: state width the tiles cover (a multiple of 64); Nt: the true width (<= N) when the
         # executor zero-padded the weights — columns Nt .. N-1 are never owned, never published
         # (they read as the zeros the exchange buffer starts with) and hit zero weight rows
@@ -104,8 +105,11 @@ class SpecMat:
         #   of the payload and 3.6 us in LDS-latency-serialised dependent MFMA chains)
         nstaged = len({(x, "prev" if x in prog.state else "cur") for ph in prog.phases for _a, x in ph["dots"]})
         K0 = max(Ks.values()) if Ks else 64
-        regs = sum(K // 16 for K in Ks.values()) + 4 * (K0 // 64) * nstaged
+        wpr = 2 if dtype == "float64" else 1          # 32-bit registers per value
+        regs = wpr * (sum(K // 16 for K in Ks.values()) + (K0 // 16) * nstaged)
         self.xmode = os.environ.get("AESARA_HIP_SM_XMODE", "frag" if regs <= 384 else "flag")
+        if dtype == "float64":
+            self.xmode = "frag" if regs <= 384 else "none"     # float64 exists in the fragment form only
         # products on operands that are already in registers run BEFORE the wait for the new
         # operand's tags (r03 timeline, config 4 B = 64: 6.7 us per step; issuing them after the
         # loads — to cover the load latency instead of the tag latency — measured 8.5)
@@ -116,7 +120,7 @@ class SpecMat:
 
     def key(self):
         pr = self.prog
-        blob = json.dumps(["sm7" + ("t" if self.trace else ""), self.chunk, self.xmode, self.early_first, self.B, self.N, self.Nt, sorted(self.Ks.items()), sorted(pr.seq.items()),
+        blob = json.dumps(["sm8" + ("t" if self.trace else ""), self.dtype, self.chunk, self.xmode, self.early_first, self.B, self.N, self.Nt, sorted(self.Ks.items()), sorted(pr.seq.items()),
                            sorted(pr.state.items()), sorted(pr.nsq.items()), sorted(pr.mats.items()),
                            [[ph["dots"], ph["ins"], ph["outs"], ph["scalar"], ph["out_refs"]]
                             for ph in pr.phases], pr.outs, pr.exchanged, sorted(pr.tap_seq.items())],
@@ -124,7 +128,7 @@ class SpecMat:
         return hashlib.sha256(blob.encode()).hexdigest()[:24]
 
 
-def xch_layout(prog, NB, N, xmode="flag"):
+def xch_layout(prog, NB, N, xmode="flag", itemsize=4):
     """u64 offsets of the exchange buffer.  granule form: per exchanged matrix 4 slots of NB
     blocks of 16 x N granules -> {var: (offset, slot length)}.  flag form: 4 slots of
     NB x 16 x N/2 float pairs followed by 4 slots of NB x NJ tag words ->
@@ -137,7 +141,7 @@ def xch_layout(prog, NB, N, xmode="flag"):
             total += 4 * lp
         return off, total
     # ("flag" and "frag" share this layout; "frag" orders the payload of a block by MFMA fragment)
-    lpp, lpf = NB * 16 * N // 2, NB * (N // 16)
+    lpp, lpf = NB * 16 * N * itemsize // 8, NB * (N // 16)
     for v in prog.exchanged:
         off[v] = (total, lpp, total + 4 * lpp, lpf)
         total += 4 * (lpp + lpf)
@@ -179,7 +183,7 @@ def generate(spec: SpecMat):
     name = "sm_" + spec.key()
     AG = "__ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT"
     L = [cg.PRELUDE, SM_STRUCT]
-    xoff, _tot = xch_layout(pr, NB, N, spec.xmode)
+    xoff, _tot = xch_layout(pr, NB, N, spec.xmode, 8 if spec.dtype == "float64" else 4)
     FRAG = spec.xmode == "frag"
     FLAG = spec.xmode in ("flag", "frag")
     if FRAG:
@@ -509,7 +513,20 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
     16 consecutive k: four float4 per row, written with 16-byte sc1 (write-through) stores."""
     pr, B, N, NB, NJ = spec.prog, spec.B, spec.N, spec.NB, spec.NJ
     AG = "__ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT"
-    L = [cg.PRELUDE, SM_STRUCT, "typedef unsigned u4v __attribute__((ext_vector_type(4)));"]
+    F64 = spec.dtype == "float64"
+    T = "double" if F64 else "float"          # element type
+    PV = 2 if F64 else 4                      # values per 16-byte vector
+    VT, AT = ("d2v", "d4v") if F64 else ("f4", "f4")       # fragment vector / MFMA accumulator
+    ISZ = 8 if F64 else 4
+    ZERO = "0.0" if F64 else "0.f"
+    MFMA = "__builtin_amdgcn_mfma_f64_16x16x4f64" if F64 else "__builtin_amdgcn_mfma_f32_16x16x4f32"
+    L = [cg.PRELUDE, SM_STRUCT, "typedef unsigned u4v __attribute__((ext_vector_type(4)));",
+         "typedef double d2v __attribute__((ext_vector_type(2)));",
+         "typedef double d4v __attribute__((ext_vector_type(4)));",
+         "template <typename T> __device__ __forceinline__ T shfl_down_(T v, int d) {\n"
+         "  if constexpr (sizeof(T) == 8) { union { T t; int i[2]; } u; u.t = v;\n"
+         "    u.i[0] = __shfl_down(u.i[0], d, 64); u.i[1] = __shfl_down(u.i[1], d, 64); return u.t; }\n"
+         "  else { union { T t; int i; } u; u.t = v; u.i = __shfl_down(u.i, d, 64); return u.t; } }"]
     keys = []
     for ph in pr.phases:
         for a_, x in ph["dots"]:
@@ -517,11 +534,11 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
             if key not in keys:
                 keys.append(key)
     K = N
-    Q = K // 64                       # float4 fragments per lane per operand block
+    Q = K // (16 * PV)                # 16-byte fragments per lane per operand block
     PW = NJ // 4                      # producers (column slices) feeding one wavefront's K quarter
     ndots_max = max(len(ph["dots"]) for ph in pr.phases)
     L.append('extern "C" __global__ __launch_bounds__(256) void %s(SmArgs a) {' % name)
-    L.append("  __shared__ float part[2][%d][4][256];" % max(ndots_max, 1))
+    L.append("  __shared__ %s part[2][%d][4][256];" % (T, max(ndots_max, 1)))
     L.append("  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;")
     L.append("  const int r16 = lane & 15, grp = lane >> 4;")
     L.append("  const int bi = blockIdx.x %% %d, nj = blockIdx.x / %d;" % (NB, NB))
@@ -534,10 +551,10 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
     L.append("  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.xch, 0, %du, 0x00020000);"
              % (xtot * 8))
     # where this workgroup's 16 columns live in a consumer's fragment order
-    L.append("  const int pk = nj * 16 + (ecol & ~3);                       // first of 4 consecutive k")
+    L.append("  const int pk = nj * 16 + (ecol & ~%d);                      // first of %d consecutive k" % (PV - 1, PV))
     L.append("  const int pw = pk / %d, pkk = pk %% %d;" % (K // 4, K // 4))
-    L.append("  const unsigned pub_off = (unsigned)((((pw * %d + (pkk %% %d) / 4) * 64) + (pkk / %d) * 16 + erow) * 16);"
-             % (Q, K // 16, K // 16))
+    L.append("  const unsigned pub_off = (unsigned)((((pw * %d + (pkk %% %d) / %d) * 64) + (pkk / %d) * 16 + erow) * 16);"
+             % (Q, K // 16, PV, K // 16))
     L.append("  const unsigned ld_off = (unsigned)(((wave * %d) * 64 + lane) * 16);" % Q)
     marks = []
 
@@ -561,38 +578,38 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
         assert Km == K
         L.append("  const i64 wk%d = (i64)wave * %d + grp * %d;" % (slot, Km // 4, Km // 16))
         for s_ in range(Km // 16):
-            L.append("  const float w%d_%d = ((const float*)a.mat[%d])[(wk%d + %d) * a.mat_rs[%d] + nj * 16 + r16];"
-                     % (slot, s_, slot, slot, s_, slot))
+            L.append("  const %s w%d_%d = ((const %s*)a.mat[%d])[(wk%d + %d) * a.mat_rs[%d] + nj * 16 + r16];"
+                     % (T, slot, s_, T, slot, slot, s_, slot))
     out_of = {}
     for o, kind, j in pr.outs:
         out_of.setdefault(o, []).append((kind, j))
     for v, k in pr.state.items():
-        L.append("  float own_%d = 0.f;" % v)
-        L.append("  if (owner) own_%d = ((const float*)a.out[%d])[((a.out_pos0[%d] + a.out_store[%d] - 1) %% "
-                 "a.out_store[%d]) * a.out_ts[%d] + eb * a.out_rs[%d] + en];" % (v, k, k, k, k, k, k))
+        L.append("  %s own_%d = %s;" % (T, v, ZERO))
+        L.append("  if (owner) own_%d = ((const %s*)a.out[%d])[((a.out_pos0[%d] + a.out_store[%d] - 1) %% "
+                 "a.out_store[%d]) * a.out_ts[%d] + eb * a.out_rs[%d] + en];" % (v, T, k, k, k, k, k, k))
     pw_nsq = sorted({v for ph in pr.phases for v in ph["ins"] if v in pr.nsq})
     for v in pw_nsq:
         s_ = pr.nsq[v]
-        L.append("  float own_%d = 0.f;" % v)
-        L.append("  if (owner) own_%d = ((const float*)a.nsq[%d])[eb * a.nsq_rs[%d] + en * a.nsq_cs[%d]];"
-                 % (v, s_, s_, s_))
+        L.append("  %s own_%d = %s;" % (T, v, ZERO))
+        L.append("  if (owner) own_%d = ((const %s*)a.nsq[%d])[eb * a.nsq_rs[%d] + en * a.nsq_cs[%d]];"
+                 % (v, T, s_, s_, s_))
     pw_seq = sorted({v for ph in pr.phases for v in ph["ins"] if v in pr.seq})
     for v in pw_seq:
         s_ = pr.seq[v]
-        L.append("  float nxt_%d = 0.f, own_%d = 0.f;" % (v, v))
-        L.append("  if (owner && a.T > 0) nxt_%d = ((const float*)a.seq[%d])[eb * a.seq_rs[%d] + en * a.seq_cs[%d]];"
-                 % (v, s_, s_, s_))
+        L.append("  %s nxt_%d = %s, own_%d = %s;" % (T, v, ZERO, v, ZERO))
+        L.append("  if (owner && a.T > 0) nxt_%d = ((const %s*)a.seq[%d])[eb * a.seq_rs[%d] + en * a.seq_cs[%d]];"
+                 % (v, T, s_, s_, s_))
     for ph in pr.phases:
         for o in ph["outs"]:
-            L.append("  float own_%d = 0.f;" % o)
+            L.append("  %s own_%d = %s;" % (T, o, ZERO))
     for ki in range(len(keys)):
-        L.append("  f4 fr%d[%d];" % (ki, Q))
+        L.append("  %s fr%d[%d];" % (VT, ki, Q))
     L.append("  for (i64 t = 0; t < a.T; ++t) {")
     for v in pw_seq:
         s_ = pr.seq[v]
         L.append("    own_%d = nxt_%d;" % (v, v))
-        L.append("    if (owner && t + 1 < a.T) nxt_%d = ((const float*)a.seq[%d])[(t + 1) * a.seq_ts[%d] + "
-                 "eb * a.seq_rs[%d] + en * a.seq_cs[%d]];" % (v, s_, s_, s_, s_))
+        L.append("    if (owner && t + 1 < a.T) nxt_%d = ((const %s*)a.seq[%d])[(t + 1) * a.seq_ts[%d] + "
+                 "eb * a.seq_rs[%d] + en * a.seq_cs[%d]];" % (v, T, s_, s_, s_, s_))
     staged_this_step = set()
 
     def emit_mfma(pi, d, a_, x):
@@ -601,14 +618,15 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
         slot = pr.mats[a_]
         ki = keys.index((x, "prev" if x in pr.state else "cur"))
         L.append("    {")
-        L.append("      f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};")
+        L.append("      %s acc0 = {%s, %s, %s, %s}, acc1 = {%s, %s, %s, %s};" % ((AT,) + (ZERO,) * 8))
         for q in range(Q):
-            for e, c in enumerate("xyzw"):
-                acc = "acc%d" % ((4 * q + e) & 1)
-                L.append("      %s = __builtin_amdgcn_mfma_f32_16x16x4f32(fr%d[%d].%s, w%d_%d, %s, 0, 0, 0);"
-                         % (acc, ki, q, c, slot, 4 * q + e, acc))
-        L.append("      for (int i = 0; i < 4; ++i) part[pp%d][%d][wave][(4 * grp + i) * 16 + r16] = acc0[i] + acc1[i];"
-                 % (pi, d))
+            for e, c in enumerate("xyzw"[:PV]):
+                acc = "acc%d" % ((PV * q + e) & 1)
+                L.append("      %s = %s(fr%d[%d].%s, w%d_%d, %s, 0, 0, 0);"
+                         % (acc, MFMA, ki, q, c, slot, PV * q + e, acc))
+        # C/D rows of a lane: f32 16x16x4 -> 4 * grp + i ; f64 16x16x4 -> grp + 4 * i
+        L.append("      for (int i = 0; i < 4; ++i) part[pp%d][%d][wave][(%s) * 16 + r16] = acc0[i] + acc1[i];"
+                 % (pi, d, "grp + 4 * i" if F64 else "4 * grp + i"))
         L.append("    }")
 
     def emit_fetch(pi, x, kind):
@@ -619,14 +637,14 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
         if kind == "prev":
             k_out = pr.state[x]
             L.append("    if (t == 0) {")
-            L.append("      const float* ini = (const float*)a.out[%d] + ((a.out_pos0[%d] + a.out_store[%d] - 1) %% "
+            L.append("      const %s* ini = (const %s*)a.out[%d] + ((a.out_pos0[%d] + a.out_store[%d] - 1) %% "
                      "a.out_store[%d]) * a.out_ts[%d] + ((i64)bi * 16 + r16) * a.out_rs[%d] + wave * %d + grp * %d;"
-                     % (k_out, k_out, k_out, k_out, k_out, k_out, K // 4, K // 16))
+                     % (T, T, k_out, k_out, k_out, k_out, k_out, k_out, K // 4, K // 16))
             L.append("      const int c0 = wave * %d + grp * %d;" % (K // 4, K // 16))
             for q in range(Q):
-                L.append("      { f4 v = {0.f, 0.f, 0.f, 0.f};")
-                L.append("        if (r16 < vrows) { for (int e = 0; e < 4; ++e) if (c0 + %d + e < %d) v[e] = ini[%d + e]; }"
-                         % (4 * q, spec.Nt, 4 * q))
+                L.append("      { %s v = {%s};" % (VT, ", ".join([ZERO] * PV)))
+                L.append("        if (r16 < vrows) { for (int e = 0; e < %d; ++e) if (c0 + %d + e < %d) v[e] = ini[%d + e]; }"
+                         % (PV, PV * q, spec.Nt, PV * q))
                 L.append("        fr%d[%d] = v; }" % (ki, q))
             L.append("    } else {")
             step_expr = "(t - 1)"
@@ -646,10 +664,10 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
         L.append(ind + "  __builtin_amdgcn_s_sleep(1);")
         L.append(ind + "}")
         L.append(ind + "const unsigned so_ = (unsigned)((%d + (%s & 3) * %d + (i64)bi * %d) * 8);"
-                 % (po_, step_expr, lpp, 16 * K // 2))
+                 % (po_, step_expr, lpp, 16 * K * ISZ // 8))
         for q in range(Q):
             L.append(ind + "{ const u4v g = __builtin_amdgcn_raw_buffer_load_b128(xr, ld_off + %du, so_, 16);"
-                     " fr%d[%d] = __builtin_bit_cast(f4, g); }" % (q * 64 * 16, ki, q))
+                     " fr%d[%d] = __builtin_bit_cast(%s, g); }" % (q * 64 * 16, ki, q, VT))
         L.append("    }")
 
     pending_pub = []
@@ -692,15 +710,15 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
             L.append("    __syncthreads();")
             stamp("p%d products done" % pi)
         for d in range(D):
-            L.append("    const float dot_%d_%d = part[pp%d][%d][0][tid] + part[pp%d][%d][1][tid] + part[pp%d][%d][2][tid] + part[pp%d][%d][3][tid];"
-                     % (pi, d, pi, d, pi, d, pi, d, pi, d))
+            L.append("    const %s dot_%d_%d = part[pp%d][%d][0][tid] + part[pp%d][%d][1][tid] + part[pp%d][%d][2][tid] + part[pp%d][%d][3][tid];"
+                     % (T, pi, d, pi, d, pi, d, pi, d, pi, d))
         L.append("    if (owner) {")
         ins = ["dot_%d_%d" % (pi, d) for d in range(D)] + ["own_%d" % v for v in ph["ins"]]
-        lines, outs, odts = cg.emit_scalar_body(ph["scalar"], ins, ["float32"] * len(ins),
+        lines, outs, odts = cg.emit_scalar_body(ph["scalar"], ins, [spec.dtype] * len(ins),
                                                 indent="      ", suffix="_p%d" % pi)
         L.extend(lines)
         for o, ri in zip(ph["outs"], ph["out_refs"]):
-            L.append("      own_%d = %s;" % (o, cg._cast(outs[ri], odts[ri], "float32")))
+            L.append("      own_%d = %s;" % (o, cg._cast(outs[ri], odts[ri], spec.dtype)))
         L.append("    }")
         # publish first (the hand-off is the critical path), the stores into the output buffers after
         pending_pub.extend(o for o in ph["outs"] if o in xoff)
@@ -710,20 +728,20 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
             pending_pub = []
         for o in pub:
             po_, lpp, fo_, lpf = xoff[o]
-            L.append("    { const float v0_ = owner ? own_%d : 0.f;" % o)
-            L.append("      const float v1_ = __shfl_down(v0_, 1, 64), v2_ = __shfl_down(v0_, 2, 64), v3_ = __shfl_down(v0_, 3, 64);")
-            L.append("      if ((ecol & 3) == 0 && eb < %d) {" % B)
-            L.append("        const f4 pv = {v0_, v1_, v2_, v3_};")
+            L.append("    { const %s v0_ = owner ? own_%d : %s;" % (T, o, ZERO))
+            L.append("      " + " ".join("const %s v%d_ = shfl_down_<%s>(v0_, %d);" % (T, e, T, e) for e in range(1, PV)))
+            L.append("      if ((ecol & %d) == 0 && eb < %d) {" % (PV - 1, B))
+            L.append("        const %s pv = {%s};" % (VT, ", ".join("v%d_" % e for e in range(PV))))
             L.append("        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, pv), xr, pub_off, "
-                     "(unsigned)((%d + (t & 3) * %d + (i64)bi * %d) * 8), 16);" % (po_, lpp, 16 * K // 2))
+                     "(unsigned)((%d + (t & 3) * %d + (i64)bi * %d) * 8), 16);" % (po_, lpp, 16 * K * ISZ // 8))
             L.append("      } }")
         if pub:
             stamp("p%d epilogue + payload stores issued" % pi)
         L.append("    if (owner) {")
         for o in ph["outs"]:
             for _kind, j in out_of.get(o, []):
-                L.append("      ((float*)a.out[%d])[((a.out_pos0[%d] + t) %% a.out_store[%d]) * a.out_ts[%d] + "
-                         "eb * a.out_rs[%d] + en] = own_%d;" % (j, j, j, j, j, o))
+                L.append("      ((%s*)a.out[%d])[((a.out_pos0[%d] + t) %% a.out_store[%d]) * a.out_ts[%d] + "
+                         "eb * a.out_rs[%d] + en] = own_%d;" % (T, j, j, j, j, j, o))
         L.append("    }")
         if pub:
             L.append('    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");')

@@ -127,6 +127,9 @@ def main():
                     help="comma list of secondary workloads to run (default: all)")
     ap.add_argument("--cfg5-log2n", type=int, default=24, help="config 5 rows = 2**k (total)")
     ap.add_argument("--eager", action="store_true", help="no launch-list replay (per-node launches)")
+    ap.add_argument("--no-warm", action="store_true",
+                    help="skip the same-buffer and through-Function legs (rocprofv3 passes: every "
+                         "profiled eval of the headline kernel is then a MALL-cold one)")
     ap.add_argument("--rotate", type=int, default=8,
                     help="distinct input buffers the timed region cycles through (1 = same buffer)")
     args = ap.parse_args()
@@ -273,12 +276,13 @@ def main():
                      "note": "same rotation over %d buffers, longer run" % NROT}
         # the figure of rounds 1-2: ONE 128 MiB buffer re-read every eval, i.e. partly served by the
         # 256 MiB memory-side cache (MALL) — an L2-fabric number, not an HBM number
-        d_ms, w_ms = timer.time(lambda: ex(x, mu, sigma), n_long, warmup=20)
-        warm = {"evals": n_long, "kernel_ms": d_ms, "evals_per_s": 1e3 / max(d_ms, w_ms),
-                "frac": ALGO_BYTES / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "note": "same buffer every eval (MALL-assisted); not the roofline figure"}
-        if rank == 0:
-            through = through_function(timer, xs, torch, np, n_long)
+        if not args.no_warm:
+            d_ms, w_ms = timer.time(lambda: ex(x, mu, sigma), n_long, warmup=20)
+            warm = {"evals": n_long, "kernel_ms": d_ms, "evals_per_s": 1e3 / max(d_ms, w_ms),
+                    "frac": ALGO_BYTES / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "note": "same buffer every eval (MALL-assisted); not the roofline figure"}
+            if rank == 0:
+                through = through_function(timer, xs, torch, np, n_long)
 
     secondary = []
     if not args.no_secondary:
