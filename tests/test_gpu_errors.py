@@ -194,3 +194,42 @@ def test_rebinding_only_touches_declared_pointer_words():
         check(lib.ahip_list_end(C.byref(lst)))
     assert lib.ahip_list_bind_bases(lst, lo, hi, 1) == -2
     lib.ahip_list_destroy(lst)
+
+
+def test_more_nonmergeable_dims_than_a_kernel_takes_and_2d_batched_dot():
+    """two `NotImplementedError`s of the hot path are gone — an Elemwise over
+    8 dims whose operands alternate broadcast / full extents (nothing merges: one launch per index
+    of the outermost dims), and `BatchedDot` with 2-d operands (a batch of vectors,
+    tensor/blas.py:2196-2224)."""
+    import torch
+    from aesara_amd.executor import PlanExecutor
+    from aesara_amd.plan import Node, Plan
+    p = Plan("many_dims", {}, [], [], [])
+    a = p.new_var("float64", [None, 1, None, 1, None, 1, None, 1])
+    b = p.new_var("float64", [1, None, 1, None, 1, None, 1, None])
+    o = p.new_var("float64", [None] * 8)
+    p.inputs, p.outputs = [a, b], [o]
+    p.nodes = [Node("Elemwise", [a, b], [o], {"scalar": {"n_in": 2, "nodes": [
+        {"op": "mul", "in": [["i", 0], ["i", 1]], "dtype": "float64"},
+        {"op": "add", "in": [["t", 0], ["i", 0]], "dtype": "float64"}], "out": [["t", 1]]}})]
+    rng = np.random.default_rng(0)
+    av, bv = rng.standard_normal((2, 1, 3, 1, 2, 1, 3, 1)), rng.standard_normal((1, 3, 1, 2, 1, 3, 1, 2))
+    for use_graph in (False, True):
+        ex = PlanExecutor(p, use_graph=use_graph)
+        for _ in range(2):
+            (r,) = ex(_t(av), _t(bv))
+            np.testing.assert_allclose(r.cpu().numpy(), av * bv + av, rtol=1e-15)
+    for xs, ys in (((5, 7), (5, 7, 3)), ((5, 4, 7), (5, 7)), ((5, 7), (5, 7))):
+        q = Plan("bd", {}, [], [], [])
+        x = q.new_var("float32", [None] * len(xs))
+        y = q.new_var("float32", [None] * len(ys))
+        z = q.new_var("float32", [None] * (len(xs) + len(ys) - 3))
+        q.inputs, q.outputs = [x, y], [z]
+        q.nodes = [Node("BatchedDot", [x, y], [z], {})]
+        xv, yv = rng.standard_normal(xs).astype("float32"), rng.standard_normal(ys).astype("float32")
+        want = np.stack([np.dot(xv[i], yv[i]) for i in range(5)])
+        (r,) = PlanExecutor(q)(_t(xv), _t(yv))
+        assert tuple(r.shape) == want.shape
+        np.testing.assert_allclose(r.cpu().numpy(), want, rtol=2e-5, atol=1e-5)
+    with pytest.raises(TypeError):
+        PlanExecutor(q)(_t(xv[:4]), _t(yv))

@@ -9,11 +9,13 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/profiles_r03; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --no-cpu-baseline"
 ROWS=${@:-cfg2 cfg3a cfg1b cfg5 cfg3b cfg4}
-prof() {   # name, bench args, kernel regex, algorithmic bytes per launch (0 = n/a)
-  local name=$1 args=$2 rx=$3 algo=$4
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/${name}_kt -o p -- $B $args > $O/${name}_bench.json 2> $O/${name}_kt.err
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${name}_fetch -o p -- $B $args > /dev/null 2> $O/${name}_fetch.err
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${name}_write -o p -- $B $args > /dev/null 2> $O/${name}_write.err
+prof() {   # name, bench args, kernel regex, algorithmic bytes per launch (0 = n/a), [nopmc]
+  local name=$1 args=$2 rx=$3 algo=$4 nopmc=${5:-}
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${name}_kt -o p -- $B $args > $O/${name}_bench.json 2> $O/${name}_kt.err
+  if [ -z "$nopmc" ]; then
+  timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${name}_fetch -o p -- $B $args > /dev/null 2> $O/${name}_fetch.err
+  timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${name}_write -o p -- $B $args > /dev/null 2> $O/${name}_write.err
+  fi
   python - "$O" "$name" "$rx" "$algo" <<'PY'
 import csv, glob, json, os, re, sys, collections
 O, name, rx, algo = sys.argv[1], sys.argv[2], re.compile(sys.argv[3]), int(sys.argv[4])
@@ -61,8 +63,12 @@ for r in $ROWS; do case $r in
   cfg2)  prof cfg2_rotated "--no-secondary --no-warm --steps 1000 --warmup 50" "^ew_" 134217728 ;;
   cfg3a) prof cfg3a_gemv "--steps 20 --warmup 5 --only-secondary cfg3a" "gemv|gv_|ge_" 134283264 ;;
   cfg1b) prof cfg1b_add "--steps 20 --warmup 5 --only-secondary cfg1b" "^ew_" 402653184 ;;
-  cfg5)  prof cfg5_rowpass "--steps 20 --warmup 5 --only-secondary cfg5" "^rp_" 17246978048 ;;
-  cfg3b) prof cfg3b_gemm "--steps 20 --warmup 5 --only-secondary cfg3b" "gemm" 0 ;;
-  cfg4)  prof cfg4_scan "--steps 20 --warmup 5 --only-secondary cfg4" "^s[mp]_|gemm" 0 ;;
+  # config 5 under the profiler at N = 2^22 (4 GiB of X; the ratio counter bytes : algorithmic bytes
+  # is what shows "X is read once", and it does not depend on N); full size: cfg5full
+  cfg5)  prof cfg5_rowpass "--steps 20 --warmup 5 --only-secondary cfg5 --cfg5-log2n 22" "^rp_" 4311744512 ;;
+  cfg5full) prof cfg5_rowpass_full "--steps 20 --warmup 5 --only-secondary cfg5" "^rp_" 17246978048 ;;
+  cfg3b) prof cfg3b_gemm "--steps 20 --warmup 5 --only-secondary cfg3b" "gemm" 0 nopmc ;;
+  # persistent (spinning) kernels: kernel trace only, no counter passes
+  cfg4)  prof cfg4_scan "--steps 20 --warmup 5 --only-secondary cfg4" "^s[mp]_|gemm" 0 nopmc ;;
 esac; done
 ls $O
