@@ -42,11 +42,19 @@ def counter(d, cname):
     return {k: {"n": len(v), "avg": sum(v) / len(v)} for k, v in acc.items()}
 fe, wr = counter(name + "_fetch", "FETCH_SIZE"), counter(name + "_write", "WRITE_SIZE")
 out["FETCH_SIZE_KB_raw"], out["WRITE_SIZE_KB_raw"] = fe, wr
-tot = 0.0
-for k, v in fe.items(): tot += v["avg"] * 2 * 1024          # gfx950: x2 for wide coalesced reads
-for k, v in wr.items(): tot += v["avg"] * 1024
-out["hbm_bytes_per_launch_corrected"] = int(tot) if tot else None
-out["correction"] = "FETCH_SIZE x2 (gfx950 reports 1/2 of wide coalesced reads, MI355X_MICROARCH.md HBM) + WRITE_SIZE; summed over the matching kernels"
+per = {}
+for k in out.get("kernels", []):
+    f = fe.get(k["name"], {}).get("avg"); w = wr.get(k["name"], {}).get("avg")
+    per[k["name"]] = dict(k, FETCH_SIZE_KB_raw=f, WRITE_SIZE_KB_raw=w,
+                          hbm_bytes_per_launch_corrected=None if f is None else int(f * 2 * 1024 + (w or 0) * 1024))
+out["per_kernel"] = per
+# the row's own kernel: the matching kernel with the largest share of GPU time that is not the
+# headline kernel every bench process also runs (cfg2's own row excepted)
+cands = sorted(out.get("kernels", []), key=lambda k: -k["pct_of_gpu_time"])
+out["row_kernel"] = cands[0]["name"] if cands else None
+tot = per.get(out["row_kernel"], {}).get("hbm_bytes_per_launch_corrected") if cands else None
+out["hbm_bytes_per_launch_corrected"] = tot
+out["correction"] = "FETCH_SIZE x2 (gfx950 reports 1/2 of wide coalesced reads, MI355X_MICROARCH.md HBM) + WRITE_SIZE, of row_kernel"
 if algo and tot: out["traffic_over_algorithmic"] = tot / algo
 try:
     line = json.loads([l for l in open(os.path.join(O, name + "_bench.json")) if l.startswith("{")][-1])
