@@ -107,7 +107,10 @@ class SpecMat:
         K0 = max(Ks.values()) if Ks else 64
         wpr = 2 if dtype == "float64" else 1          # 32-bit registers per value
         regs = wpr * (sum(K // 16 for K in Ks.values()) + (K0 // 16) * nstaged)
-        self.xmode = os.environ.get("AESARA_HIP_SM_XMODE", "frag" if regs <= 384 else "flag")
+        # measured (r03, T = 512, H = 1024, B = 64): the two-operand forward GRU kernel (320
+        # registers of weights + fragments) 6.09 -> 5.7 ms in the fragment form; the three-operand
+        # gradient kernel (384) is 1 ms FASTER in the LDS form (training step 21.0 vs 22.0 ms)
+        self.xmode = os.environ.get("AESARA_HIP_SM_XMODE", "frag" if regs <= 320 else "flag")
         if dtype == "float64":
             self.xmode = "frag" if regs <= 384 else "none"     # float64 exists in the fragment form only
         # products on operands that are already in registers run BEFORE the wait for the new
