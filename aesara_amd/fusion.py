@@ -606,6 +606,60 @@ def push_out_accumulators(plan: Plan) -> Plan:
     return plan
 
 
+def merge_shared_left_dots(plan: Plan) -> Plan:
+    """Several ``Dot22(x, W_k)`` with the SAME left operand and plan-input right operands (the
+    ``x_t @ W_gate`` products of every gate, lifted over a whole sequence: ``[T*B, K] @ [K, H]``
+    three times) become ONE product against the weights side by side —
+    ``P = Dot22(x, Join(1, W_1, .., W_G))``, each result a column view ``P[:, c_{k-1}:c_k]`` (no
+    copies of P; the 12 MiB of weights are joined once per call).  A wider N keeps more of the chip
+    busy per tile wave and saves G - 1 launch boundaries.  Returns the plan unchanged when no group
+    of >= 2 such products exists."""
+    groups: Dict[int, list] = {}
+    ins = set(plan.inputs)
+    for ni, n in enumerate(plan.nodes):
+        if n.op == "Dot22" and n.inputs[1] in ins and plan.vars[n.inputs[1]].ndim == 2:
+            groups.setdefault(n.inputs[0], []).append(ni)
+    groups = {x: g for x, g in groups.items() if len(g) >= 2 and
+              len({plan.vars[plan.nodes[ni].inputs[1]].dtype for ni in g}) == 1}
+    if not groups:
+        return plan
+    work = Plan(plan.name + "_wide", dict(plan.vars), list(plan.inputs), list(plan.outputs), [])
+    V = work.vars
+    drop, emitted_at = set(), {}
+    for x, g in groups.items():
+        first = min(g)
+        dt = V[plan.nodes[first].outputs[0]].dtype
+        Ws = [plan.nodes[ni].inputs[1] for ni in g]
+        new = []
+        wcat = work.new_var(dt, [None, None])
+        new.append(Node("Join", [work.add_const(1, "int8")] + Ws, [wcat], {}))
+        P = work.new_var(dt, [None, None])
+        new.append(Node("Dot22", [x, wcat], [P], {}))
+        lo = None
+        for k, ni in enumerate(g):
+            nk = work.new_var("int64", [])
+            new.append(Node("Shape_i", [Ws[k]], [nk], {"i": 1}))
+            if lo is None:
+                hi = nk
+            else:
+                hi = work.new_var("int64", [])
+                new.append(Node("Elemwise", [lo, nk], [hi], {"scalar": {
+                    "n_in": 2, "nodes": [{"op": "add", "in": [["i", 0], ["i", 1]], "dtype": "int64"}],
+                    "out": [["t", 0]]}}))
+            out = plan.nodes[ni].outputs[0]
+            idx = [{"slice": [None, None, None]}, {"slice": [None if lo is None else "in", "in", None]}]
+            new.append(Node("Subtensor", [P] + ([] if lo is None else [lo]) + [hi], [out], {"idx_list": idx}))
+            lo = hi
+            drop.add(ni)
+        emitted_at[first] = new
+    for ni, n in enumerate(plan.nodes):
+        if ni in emitted_at:
+            work.nodes.extend(emitted_at[ni])
+        if ni not in drop:
+            work.nodes.append(n)
+    return work
+
+
 def split_assembled_columns(plan: Plan) -> Plan:
     """The gradient step of a fused-gate recurrence assembles the gate gradients into ONE wide
     value — ``X = zeros(B, 4H); X[:, 0:H] = p_i; X[:, H:2H] = p_f; ...`` (a vector of length 4H for

@@ -474,3 +474,33 @@ def test_accumulator_push_out_with_a_buffer_longer_than_the_loop():
     assert want[-1].shape == got[-1].shape and np.all(want[-1][-3:] == 0) and np.any(want[-1][:-12] != 0)
     for g, w_ in zip(got, want):
         np.testing.assert_allclose(np.asarray(g, "float64"), np.asarray(w_, "float64"), rtol=1e-6, atol=1e-7)
+
+
+def test_shared_left_dots_become_one_wide_product():
+    """fusion.merge_shared_left_dots: three ``Dot22(x, W_k)`` of one operand -> one product against
+    the joined weights + column views; same values through the oracle, other nodes untouched."""
+    import interp
+    from aesara_amd.fusion import merge_shared_left_dots
+    from aesara_amd.plan import Node, Plan
+    p = Plan("gates", {}, [], [], [])
+    x = p.new_var("float64", [None, None], "x")
+    Ws = [p.new_var("float64", [None, None], "W%d" % k) for k in range(3)]
+    y = p.new_var("float64", [None, None], "y")
+    p.inputs = [x] + Ws + [y]
+    outs = []
+    for W in Ws:
+        o = p.new_var("float64", [None, None])
+        p.nodes.append(Node("Dot22", [x, W], [o], {}))
+        outs.append(o)
+    lone = p.new_var("float64", [None, None])
+    p.nodes.append(Node("Dot22", [y, Ws[0]], [lone], {}))          # another left operand: kept
+    p.outputs = outs + [lone]
+    rng = np.random.default_rng(0)
+    ins = [rng.standard_normal((7, 5))] + [rng.standard_normal((5, n)) for n in (4, 6, 3)] + \
+        [rng.standard_normal((2, 5))]
+    q = merge_shared_left_dots(p)
+    assert q is not p and sum(n.op == "Dot22" for n in q.nodes) == 2 and any(n.op == "Join" for n in q.nodes)
+    for g, w in zip(interp.run_plan(q, ins), interp.run_plan(p, ins)):
+        np.testing.assert_allclose(g, w, rtol=1e-13)
+    single = Plan("one", dict(p.vars), list(p.inputs), [lone], [p.nodes[3]])
+    assert merge_shared_left_dots(single) is single
