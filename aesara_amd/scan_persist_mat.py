@@ -123,7 +123,7 @@ class SpecMat:
 
     def key(self):
         pr = self.prog
-        blob = json.dumps(["sm8" + ("t" if self.trace else ""), self.dtype, self.chunk, self.xmode, self.early_first, self.B, self.N, self.Nt, sorted(self.Ks.items()), sorted(pr.seq.items()),
+        blob = json.dumps(["sm9" + ("t" if self.trace else ""), self.dtype, self.chunk, self.xmode, self.early_first, self.B, self.N, self.Nt, sorted(self.Ks.items()), sorted(pr.seq.items()),
                            sorted(pr.state.items()), sorted(pr.nsq.items()), sorted(pr.mats.items()),
                            [[ph["dots"], ph["ins"], ph["outs"], ph["scalar"], ph["out_refs"]]
                             for ph in pr.phases], pr.outs, pr.exchanged, sorted(pr.tap_seq.items())],
@@ -185,7 +185,7 @@ def generate(spec: SpecMat):
     pr, B, N, NB, NJ = spec.prog, spec.B, spec.N, spec.NB, spec.NJ
     name = "sm_" + spec.key()
     AG = "__ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT"
-    L = [cg.PRELUDE, SM_STRUCT]
+    L = [cg.PRELUDE, SM_STRUCT, "typedef unsigned u4v __attribute__((ext_vector_type(4)));"]
     xoff, _tot = xch_layout(pr, NB, N, spec.xmode, 8 if spec.dtype == "float64" else 4)
     FRAG = spec.xmode == "frag"
     FLAG = spec.xmode in ("flag", "frag")
@@ -207,6 +207,9 @@ def generate(spec: SpecMat):
     L.append("  const int vrows = (%d - bi * 16) < 16 ? (%d - bi * 16) : 16;   // valid rows of this batch block" % (B, B))
     L.append("  const unsigned base = __hip_atomic_load(a.ctl, %s);" % AG)
     L.append("  unsigned* errp = a.ctl + 1;")
+    if FLAG:
+        L.append("  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.xch, 0, %du, 0x00020000);"
+                 % (_tot * 8))
     if spec.trace:
         L.append("  const bool tr_on = tid == 0 && (blockIdx.x == 0 || blockIdx.x == %d);" % (NB * NJ // 2))
         L.append("  unsigned long long* tr = (unsigned long long*)(a.ctl + 16) + (blockIdx.x == 0 ? 0 : %d);"
@@ -258,16 +261,22 @@ def generate(spec: SpecMat):
         kind = "prev" if x in pr.state else "cur"
         so, _k = stage[(x, kind)]
         P = K + 4
+        # r03: the fragment fetches of a product are issued together (their LDS latency used to
+        # be exposed once per 4 MFMAs) and the k-steps alternate between two accumulator chains
+        # (a chain of dependent 16x16x4 MFMAs issues every 40 cycles, two interleaved every 32)
+        Qn = K // 64
         L.append("    {")
-        L.append("      f4 acc = {0.f, 0.f, 0.f, 0.f};")
+        L.append("      f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};")
         L.append("      const float* hp = Hl + %d + r16 * %d + wave * %d + grp * %d;" % (so, P, K // 4, K // 16))
-        for q in range(K // 64):
-            L.append("      { const f4 av = *(const f4*)(hp + %d);" % (4 * q))
+        L.append("      f4 av[%d];" % Qn)
+        for q in range(Qn):
+            L.append("      av[%d] = *(const f4*)(hp + %d);" % (q, 4 * q))
+        for q in range(Qn):
             for e, c in enumerate("xyzw"):
-                L.append("        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.%s, w%d_%d, acc, 0, 0, 0);"
-                         % (c, slot, 4 * q + e))
-            L.append("      }")
-        L.append("      for (int i = 0; i < 4; ++i) part[%d][wave][(4 * grp + i) * 16 + r16] = acc[i];" % d)
+                acc = "acc%d" % ((4 * q + e) & 1)
+                L.append("      %s = __builtin_amdgcn_mfma_f32_16x16x4f32(av[%d].%s, w%d_%d, %s, 0, 0, 0);"
+                         % (acc, q, c, slot, 4 * q + e, acc))
+        L.append("      for (int i = 0; i < 4; ++i) part[%d][wave][(4 * grp + i) * 16 + r16] = acc0[i] + acc1[i];" % d)
         L.append("    }")
 
     marks = []
@@ -328,25 +337,28 @@ def generate(spec: SpecMat):
             L.append(ind + "  }")
             L.append(ind + "}")
             L.append(ind + "__syncthreads();")
+            # payload as 16-byte sc1 loads (r03; guide: 8-byte accesses run at 0.54-0.70x the
+            # 16-byte rate): thread tid takes float4 number u * 256 + tid of the 16 x K block
             for q, (x, kind) in enumerate(fresh):
                 so, K = stage[(x, kind)]
                 po_, lpp, fo_, lpf = xoff[pr.new_of_state.get(x, x)]
-                PT = 16 * K // 2 // 256
-                L.append(ind + "const u64* src%d_%d = a.xch + %d + (t & 3) * %d + (i64)bi * %d;"
+                PT = 16 * K // 4 // 256
+                L.append(ind + "const unsigned so%d_%d = (unsigned)((%d + (t & 3) * %d + (i64)bi * %d) * 8);"
                          % (pi, q, po_, lpp, 16 * K // 2))
-                L.append(ind + "u64 g%d_%d[%d];" % (pi, q, PT))
+                L.append(ind + "u4v g%d_%d[%d];" % (pi, q, PT))
                 for u in range(PT):
-                    L.append(ind + "{ const int idx = %d * 256 + tid; g%d_%d[%d] = (idx / %d < vrows) ? "
-                             "__hip_atomic_load(src%d_%d + idx, %s) : 0ull; }" % (u, pi, q, u, K // 2, pi, q, AG))
+                    L.append(ind + "{ const int idx = %d * 256 + tid; const u4v z_ = {0u, 0u, 0u, 0u}; g%d_%d[%d] = (idx / %d < vrows) ? "
+                             "__builtin_amdgcn_raw_buffer_load_b128(xr, (unsigned)idx * 16u, so%d_%d, 16) : z_; }"
+                             % (u, pi, q, u, K // 4, pi, q))
             done = set()
             for q, (x, kind) in enumerate(fresh):
                 so, K = stage[(x, kind)]
                 P = K + 4
-                PT = 16 * K // 2 // 256
+                PT = 16 * K // 4 // 256
                 for u in range(PT):
                     L.append(ind + "{ const int idx = %d * 256 + tid; "
-                             "*(u64*)(Hl + %d + (idx / %d) * %d + 2 * (idx %% %d)) = g%d_%d[%d]; }"
-                             % (u, so, K // 2, P, K // 2, pi, q, u))
+                             "*(u4v*)(Hl + %d + (idx / %d) * %d + 4 * (idx %% %d)) = g%d_%d[%d]; }"
+                             % (u, so, K // 4, P, K // 4, pi, q, u))
                 L.append(ind + "__syncthreads();")
                 for d, a_, x2 in late:
                     if x2 == x and d not in done:
@@ -404,15 +416,18 @@ def generate(spec: SpecMat):
                 L.append(ind + "}")
                 L.append(ind + "__syncthreads();")
                 stamp("p%d flags seen" % pi)
-                L.append(ind + "const u64* src = a.xch + %d + (%s & 3) * %d + (i64)bi * %d;" % (po_, step_expr, lpp, 16 * K // 2))
-                L.append(ind + "u64 g[%d];" % PT)
+                PT = 16 * K // 4 // 256          # float4 per thread
+                L.append(ind + "const unsigned so_ = (unsigned)((%d + (%s & 3) * %d + (i64)bi * %d) * 8);"
+                         % (po_, step_expr, lpp, 16 * K // 2))
+                L.append(ind + "u4v g[%d];" % PT)
                 for u in range(PT):
-                    L.append(ind + "{ const int idx = %d * 256 + tid; g[%d] = (idx / %d < vrows) ? "
-                             "__hip_atomic_load(src + idx, %s) : 0ull; }" % (u, u, K // 2, AG))
+                    L.append(ind + "{ const int idx = %d * 256 + tid; const u4v z_ = {0u, 0u, 0u, 0u}; g[%d] = (idx / %d < vrows) ? "
+                             "__builtin_amdgcn_raw_buffer_load_b128(xr, (unsigned)idx * 16u, so_, 16) : z_; }"
+                             % (u, u, K // 4))
                 for u in range(PT):
                     L.append(ind + "{ const int idx = %d * 256 + tid; "
-                             "*(u64*)(Hl + %d + (idx / %d) * %d + 2 * (idx %% %d)) = g[%d]; }"
-                             % (u, so, K // 2, P, K // 2, u))
+                             "*(u4v*)(Hl + %d + (idx / %d) * %d + 4 * (idx %% %d)) = g[%d]; }"
+                             % (u, so, K // 4, P, K // 4, u))
                 L.append("    }")
                 continue
             xo, lp = xoff[src]
