@@ -283,8 +283,24 @@ def _register_handlers():
 
     @hip_lower.register(Dot)
     def _(op, node, ctx):
-        # reference: tensor/math.py:1879 Dot (1-d/2-d only)
-        ctx.emit("Dot", node)
+        # reference: tensor/math.py:1879 Dot (1-d/2-d only; perform = np.dot, which upcasts mixed
+        # operands).  The BLAS kernels take ONE float dtype: a float32 operand next to a float64
+        # one is cast first (what np.dot does); integer / bool products have no kernel on this
+        # path and are refused HERE, at compile time — never at run time, never on the host
+        dts = [str(i.type.dtype) for i in node.inputs]
+        odt = str(node.outputs[0].type.dtype)
+        if any(not d.startswith("float") for d in dts + [odt]):
+            raise UnsupportedOp(f"Dot over {dts} -> {odt}: only float32 / float64 products are on the "
+                                "HIP BLAS path (SURVEY §8a H5/H6)")
+        ins = []
+        for i, d in zip(node.inputs, dts):
+            vid = ctx.vid(i)
+            if d != odt:
+                vid = ctx.raw("Elemwise", [vid], odt, _static_shape(i.type), {"scalar": {
+                    "n_in": 1, "nodes": [{"op": "cast", "in": [["i", 0]], "dtype": odt}], "out": [["t", 0]]}})
+            ins.append(vid)
+        outs = [ctx.new(o) for o in node.outputs]
+        ctx.plan.nodes.append(Node("Dot", ins, outs, {}))
 
     @hip_lower.register(Dot22)
     def _(op, node, ctx):

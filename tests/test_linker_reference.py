@@ -241,6 +241,27 @@ def test_accept_keeps_linker_options(ae):
     assert l2 is not l1 and l2.return_numpy and not l2.use_graph and l2.fgraph is not l1.fgraph
 
 
+def test_mixed_dtype_dot_is_cast_and_integer_dot_is_refused_at_compile_time(ae):
+    """no dtype surprise at run time — a float32 x float64 ``Dot`` (np.dot
+    upcasts, tensor/math.py:1879) is lowered with a cast, an integer ``Dot`` (no kernel on the BLAS
+    path) raises ``UnsupportedOp`` when the function is compiled."""
+    import aesara.tensor as at
+    from aesara.compile.mode import Mode
+    from aesara_amd.linker import HIP_QUERY
+    from aesara_amd.lower import UnsupportedOp
+    x, y = at.fmatrix("x"), at.dmatrix("y")
+    f = ae.function([x, y], [at.dot(x, y), at.dot(y.T, x.T)], mode=Mode(_oracle_linker(), HIP_QUERY))
+    xv = np.random.default_rng(0).standard_normal((4, 5)).astype("float32")
+    yv = np.random.default_rng(1).standard_normal((5, 3))
+    r1, r2 = f(xv, yv)
+    assert r1.dtype == np.float64
+    np.testing.assert_allclose(r1, xv @ yv, rtol=1e-12)
+    np.testing.assert_allclose(r2, yv.T @ xv.T, rtol=1e-12)
+    i, j = at.lmatrix("i"), at.lmatrix("j")
+    with pytest.raises(UnsupportedOp, match="only float32 / float64"):
+        ae.function([i, j], at.dot(i, j), mode=Mode(_oracle_linker(), HIP_QUERY))
+
+
 def test_linker_clone_and_scan_inner_mode(ae):
     """Linker.clone(allow_gc=…) is used by Scan/Mode.clone (link/basic.py:190)."""
     from aesara_amd.linker import HipLinker
