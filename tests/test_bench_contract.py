@@ -27,16 +27,21 @@ def _check(line, need_cpu):
         c = line["cpu_baseline"]
         assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     for s in line.get("secondary", []):
+        assert "error" not in s, s
         rr = s["roofline"]
+        if rr["bound"] == "latency":      # config 4 with a vector state: us/step against the hand-off floor
+            assert rr["us_per_step"] > 0 and rr["us_per_step_vs_handoff_floor"] > 0.5
+            assert "frac" not in rr and 0 < rr["vs_restreamed_bound"] < 2
+            continue
         assert rr["bound"] in ("hbm", "mfma") and abs(rr["frac"] - rr["achieved"] / rr["peak"]) < 1e-9
 
 
 def test_committed_bench_line_meets_the_contract():
-    with open(os.path.join(ROOT, "profiles", "r02_bench_line.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r03_bench_line.json")) as f:
         line = json.loads(f.read())
     _check(line, need_cpu=True)
     names = " ".join(s["config"] for s in line["secondary"])
-    for cfg in ("cfg3b", "cfg3a", "cfg1b", "cfg4", "cfg5"):      # every other BASELINE config
+    for cfg in ("cfg3b", "cfg3a", "cfg1b", "cfg4", "cfg5", "placed"):    # every other BASELINE config
         assert cfg in names, cfg
 
 
@@ -51,3 +56,36 @@ def test_live_bench_line_meets_the_contract():
     line = json.loads(lines[0])
     assert line["steps"] == 20 and line["warmup"] == 5
     _check(line, need_cpu=False)
+
+
+@pytest.mark.gpu
+def test_two_rank_bench_control_flow_on_one_device():
+    """What the driver launches for N > 1 (`torch.distributed.run --nproc-per-node N bench.py
+    --gpus N`), here with 2 ranks sharing cuda:0 over gloo (test hooks AESARA_BENCH_BACKEND /
+    AESARA_BENCH_ONE_DEVICE): rotating inputs + ring slots + bucketed async all-reduce of the
+    headline, the batch-sharded config-4 row, config 5 row-sharded with its packed fp64
+    all-reduce, the placed-outputs row; max-over-ranks timing; ONE JSON line from rank 0."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, AESARA_BENCH_BACKEND="gloo", AESARA_BENCH_ONE_DEVICE="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "24", "--warmup", "8",
+                          "--cfg5-log2n", "20"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 24 and line["scaling"] == "weak"
+    assert abs(line["value"] - 2 * 1e3 / line["ms_per_step"]) / line["value"] < 1e-6     # whole-job evals/s
+    assert "cpu_baseline" not in line
+    rows = {r["config"].split(":")[0].split(" ")[0]: r for r in line["secondary"]}
+    assert {"cfg4", "cfg5", "placed"} <= set(rows), list(rows)
+    for r in line["secondary"]:
+        assert "error" not in r, r
+        assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["evals_per_s"] > 0
+    assert rows["placed"]["placement"] == [[0, 2, 4, 6], [1, 3, 5, 7]]
+    assert rows["cfg5"]["check"]["logp_rel_err"] <= 1e-6
