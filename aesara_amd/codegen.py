@@ -503,8 +503,12 @@ class KernelSpec:
     """
 
     def __init__(self, scalar, in_dtypes, out_dtypes, out_refs, inner, nd, vec, block=256,
-                 idx64=False, reduce=None, unroll=1, nt=False, invariant=None, tile_dim=None):
+                 idx64=False, reduce=None, unroll=1, nt=False, invariant=None, tile_dim=None, pipe=0):
         self.scalar = scalar
+        # flat 1-d streams only: ping-pong software pipeline — the loads of the NEXT group of
+        # `unroll` vectors are in flight while the current group is evaluated (every wave keeps
+        # loads outstanding through its ALU phase, which a load-all / compute-all body does not)
+        self.pipe = int(pipe)
         self.in_dtypes = list(in_dtypes)
         self.out_dtypes = list(out_dtypes)
         self.out_refs = list(out_refs)
@@ -527,7 +531,7 @@ class KernelSpec:
     def key(self):
         fields = [self.in_dtypes, self.out_dtypes, self.out_refs, self.inner, self.nd, self.vec,
                   self.block, self.idx64, self.reduce, self.unroll, self.nt, self.invariant,
-                  self.tile_dim, "v11" if self.tile_dim else "v10"]
+                  self.tile_dim, "v11" if self.tile_dim else "v10"] + (["pipe"] if self.pipe else [])
         return _memo_key([self.scalar], fields, self._key)
 
     def _key(self):
@@ -535,7 +539,8 @@ class KernelSpec:
         blob = json.dumps([self.scalar, self.in_dtypes, self.out_dtypes, self.out_refs,
                            self.inner, self.nd, self.vec, self.block, self.idx64, self.reduce,
                            self.unroll, self.nt, self.invariant, "v10"] +
-                          ([["tile2", self.tile_dim]] if self.tile_dim is not None else []),
+                          ([["tile2", self.tile_dim]] if self.tile_dim is not None else []) +
+                          (["pipe"] if self.pipe else []),
                           sort_keys=True)
         return hashlib.sha256(blob.encode()).hexdigest()[:24]
 
@@ -928,7 +933,47 @@ def generate(spec: KernelSpec):
         L.append("  const %s items = (%s)(a.n / %d);" % (idx_t, idx_t, V))
         L.append("  const %s step = (%s)gridDim.x * %d;" % (idx_t, idx_t, spec.block))
         L.append("  %s item = (%s)blockIdx.x * %d + threadIdx.x;" % (idx_t, idx_t, spec.block))
-        if nd == 1 and U > 1:
+        if nd == 1 and spec.pipe and V > 1 and all(
+                spec.inner[k] == "c" or k in inv_in for k in range(nin)):
+            # ping-pong pipeline over groups of U vectors: A = [item, item + U) is loaded; per
+            # round: load B = next group, evaluate A, load A' = the group after, evaluate B
+            G = max(U, 1)
+            streamed = [k for k in range(nin) if k not in inv_in]
+            flatx = ["(i64)%%s * %d" % V if spec.inner[k] == "c" else "0" for k in range(nops)]
+
+            def ld(grp, base):
+                out = []
+                for u in range(G):
+                    it = "(item + %d * step)" % (base + u)
+                    for k in streamed:
+                        ct = CTYPE[spec.in_dtypes[k]]
+                        ptr = "(const Pack<%s, %d>*)(p%d + (i64)%s * %d)" % (ct, V, k, it, V)
+                        out.append("      x%d_%s%d = %s;" % (k, grp, u, ("nt_load(%s)" % ptr) if int(spec.nt) & 1
+                                                            else "*" + ptr))
+                return out
+
+            def ev(grp, base):
+                out = []
+                for u in range(G):
+                    it = "(item + %d * step)" % (base + u)
+                    out.extend(compute([f % it if "%s" in f else f for f in flatx], "_%s%d" % (grp, u)))
+                return out
+            for grp in "AB":
+                for u in range(G):
+                    for k in streamed:
+                        L.append("  Pack<%s, %d> x%d_%s%d;" % (CTYPE[spec.in_dtypes[k]], V, k, grp, u))
+            L.append("  if (item + %d * step < items) {" % (G - 1))
+            L.extend(ld("A", 0))
+            L.append("    for (; item + %d * step < items; item += %d * step) {" % (3 * G - 1, 2 * G))
+            L.extend(ld("B", G))
+            L.extend(ev("A", 0))
+            L.extend(ld("A", 2 * G))
+            L.extend(ev("B", G))
+            L.append("    }")
+            L.extend(ev("A", 0))
+            L.append("    item += %d * step;" % G)
+            L.append("  }")
+        elif nd == 1 and U > 1:
             # flat streaming shape: U independent vectors in flight per lane, loads first
             flat = []
             for k in range(nops):
