@@ -84,8 +84,11 @@ typedef unsigned long long u64;
 class SpecMat:
     """Shape-specialised kernel: B batch rows, N state columns, K per weight matrix."""
 
-    def __init__(self, prog, B, N, Ks, Nt=None, dtype="float32"):
+    def __init__(self, prog, B, N, Ks, Nt=None, dtype="float32", xfold=None):
         self.dtype = dtype
+        # xfold: None, or {"sx": sequence slot of the fragment-ordered x, "items": [(v, phase,
+        # dot, mat slot, "lds" | "reg")]} — sequence products x_t @ W computed inside the loop
+        self.xfold = xfold
         # N: state width the tiles cover (a multiple of 64); Nt: the true width (<= N) when the
         # executor zero-padded the weights — columns Nt .. N-1 are never owned, never published
         # (they read as the zeros the exchange buffer starts with) and hit zero weight rows
@@ -107,11 +110,16 @@ class SpecMat:
         K0 = max(Ks.values()) if Ks else 64
         wpr = 2 if dtype == "float64" else 1          # 32-bit registers per value
         regs = wpr * (sum(K // 16 for K in Ks.values()) + (K0 // 16) * nstaged)
+        if xfold:
+            regs = None     # decided by the executor (fragment form, its own register budget)
         # measured (r03, T = 512, H = 1024, B = 64): the two-operand forward GRU kernel (320
         # registers of weights + fragments) 6.09 -> 5.7 ms in the fragment form; the three-operand
         # gradient kernel (384) is 1 ms FASTER in the LDS form (training step 21.0 vs 22.0 ms)
-        self.xmode = os.environ.get("AESARA_HIP_SM_XMODE", "frag" if regs <= 320 else "flag")
-        if dtype == "float64":
+        if xfold:
+            self.xmode = "frag"
+        else:
+            self.xmode = os.environ.get("AESARA_HIP_SM_XMODE", "frag" if regs <= 320 else "flag")
+        if dtype == "float64" and not xfold:
             self.xmode = "frag" if regs <= 384 else "none"     # float64 exists in the fragment form only
         # products on operands that are already in registers run BEFORE the wait for the new
         # operand's tags (r03 timeline, config 4 B = 64: 6.7 us per step; issuing them after the
@@ -123,12 +131,78 @@ class SpecMat:
 
     def key(self):
         pr = self.prog
-        blob = json.dumps(["sm9" + ("t" if self.trace else ""), self.dtype, self.chunk, self.xmode, self.early_first, self.B, self.N, self.Nt, sorted(self.Ks.items()), sorted(pr.seq.items()),
+        blob = json.dumps(["sm9" + ("t" if self.trace else ""), self.xfold, self.dtype, self.chunk, self.xmode, self.early_first, self.B, self.N, self.Nt, sorted(self.Ks.items()), sorted(pr.seq.items()),
                            sorted(pr.state.items()), sorted(pr.nsq.items()), sorted(pr.mats.items()),
                            [[ph["dots"], ph["ins"], ph["outs"], ph["scalar"], ph["out_refs"]]
                             for ph in pr.phases], pr.outs, pr.exchanged, sorted(pr.tap_seq.items())],
                           sort_keys=True)
         return hashlib.sha256(blob.encode()).hexdigest()[:24]
+
+
+def xfold_pairs(prog, lifted_outs):
+    """In-kernel sequence products (round 3).  ``lifted_outs``: loop-plan variables that are rows of
+    whole-sequence products ``x_t @ W_k`` (what ``fusion.hoist_sequence_only`` lifted out).  The
+    product can move INTO the persistent loop — accumulated on the matrix cores by the same
+    wavefronts, in the shadow of the hand-off latency, feeding the accumulator of the recurrent
+    product it is added to — when the step uses it in exactly one place: ``dot_d + v`` (possibly
+    through ``mul(1.0, .)`` wrappers of a Gemm's alpha).  Returns ``[(v, phase, dot index)]`` in
+    ``lifted_outs`` order, or None when some variable does not have that form."""
+    def const1(r):
+        return r[0] == "c" and float(r[1]) == 1.0
+
+    pairs = []
+    for v in lifted_outs:
+        where = [pi for pi, ph in enumerate(prog.phases) if v in ph["ins"]]
+        if len(where) != 1 or any(v == x for ph in prog.phases for _a, x in ph["dots"]) or \
+                any(v == o for o, _k, _j in prog.outs) or v in prog.passthru.values():
+            return None
+        pi = where[0]
+        ph = prog.phases[pi]
+        if ph["ins"].count(v) != 1:
+            return None
+        D = len(ph["dots"])
+        nodes = ph["scalar"]["nodes"]
+        me = ["i", D + ph["ins"].index(v)]
+
+        def users(ref):
+            return [k for k, n in enumerate(nodes) if any(list(r) == list(ref) for r in n["in"])] + \
+                   (["out"] if any(list(r) == list(ref) for r in ph["scalar"]["out"]) else [])
+
+        def through_unit_mul(ref):
+            """follow ref through mul(1.0, ref) wrappers that have no other user"""
+            while True:
+                us = users(ref)
+                if len(us) != 1 or us[0] == "out":
+                    return ref, us
+                n = nodes[us[0]]
+                if n["op"] == "mul" and len(n["in"]) == 2 and any(const1(r) for r in n["in"]):
+                    ref = ["t", us[0]]
+                    continue
+                return ref, us
+        ref, us = through_unit_mul(me)
+        if len(us) != 1 or us[0] == "out":
+            return None
+        add = nodes[us[0]]
+        if add["op"] != "add" or len(add["in"]) != 2 or add["dtype"] != "float32":
+            return None
+        other = [r for r in add["in"] if list(r) != list(ref)]
+        if len(other) != 1:
+            return None
+        # the other operand must be dot_d (possibly behind its own unit mul, used only here)
+        o = other[0]
+        while o[0] == "t":
+            n = nodes[o[1]]
+            if n["op"] == "mul" and len(n["in"]) == 2 and any(const1(r) for r in n["in"]) and \
+                    len(users(o)) == 1:
+                o = [r for r in n["in"] if not const1(r)][0]
+            else:
+                return None
+        if o[0] != "i" or o[1] >= D or len(users(o)) != 1:
+            return None
+        if any(q[1] == pi and q[2] == o[1] for q in pairs):
+            return None
+        pairs.append((v, pi, o[1]))
+    return pairs
 
 
 def xch_layout(prog, NB, N, xmode="flag", itemsize=4):
@@ -555,8 +629,14 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
     Q = K // (16 * PV)                # 16-byte fragments per lane per operand block
     PW = NJ // 4                      # producers (column slices) feeding one wavefront's K quarter
     ndots_max = max(len(ph["dots"]) for ph in pr.phases)
+    XF = spec.xfold["items"] if spec.xfold else []
+    xf_of = {(pi, d): (gi, slot, place) for gi, (_v, pi, d, slot, place) in enumerate(XF)}
+    folded = {v for v, _pi, _d, _s, _pl in XF}
+    lds_items = [gi for gi, it in enumerate(XF) if it[4] == "lds"]
     L.append('extern "C" __global__ __launch_bounds__(256) void %s(SmArgs a) {' % name)
     L.append("  __shared__ %s part[2][%d][4][256];" % (T, max(ndots_max, 1)))
+    if lds_items:
+        L.append("  __shared__ __attribute__((aligned(16))) float Wl[%d];" % (len(lds_items) * K * 16))
     L.append("  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;")
     L.append("  const int r16 = lane & 15, grp = lane >> 4;")
     L.append("  const int bi = blockIdx.x %% %d, nj = blockIdx.x / %d;" % (NB, NB))
@@ -598,6 +678,34 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
         for s_ in range(Km // 16):
             L.append("  const %s w%d_%d = ((const %s*)a.mat[%d])[(wk%d + %d) * a.mat_rs[%d] + nj * 16 + r16];"
                      % (T, slot, s_, T, slot, slot, s_, slot))
+    # ---- in-kernel sequence products (xfold): weight columns of x_t @ W_g — in registers like
+    #      the recurrent weights, or in LDS in MFMA B-fragment order: float4 (w*Q + q)*64 + lane =
+    #      W_g[w*K/4 + grp*K/16 + 4q .. +3][nj*16 + r16]
+    for gi, (_v, _pi, _d, slot, place) in enumerate(XF):
+        if place == "reg":
+            L.append("  const i64 wkx%d = (i64)wave * %d + grp * %d;" % (gi, K // 4, K // 16))
+            for s_ in range(K // 16):
+                L.append("  const float wx%d_%d = ((const float*)a.mat[%d])[(wkx%d + %d) * a.mat_rs[%d] + nj * 16 + r16];"
+                         % (gi, s_, slot, gi, s_, slot))
+        else:
+            li = lds_items.index(gi)
+            L.append("  for (int f = tid; f < %d; f += 256) {" % (K * 16 // 4))
+            L.append("    const int ln = f & 63, qq = (f >> 6) %% %d, ww = (f >> 6) / %d;" % (Q, Q))
+            L.append("    const i64 k0 = (i64)ww * %d + (ln >> 4) * %d + 4 * qq;" % (K // 4, K // 16))
+            L.append("    const float* wp = (const float*)a.mat[%d] + k0 * a.mat_rs[%d] + nj * 16 + (ln & 15);" % (slot, slot))
+            L.append("    const f4 wv = {wp[0], wp[a.mat_rs[%d]], wp[2 * a.mat_rs[%d]], wp[3 * a.mat_rs[%d]]};" % (slot, slot, slot))
+            L.append("    *(f4*)(Wl + %d + 4 * f) = wv;" % (li * K * 16))
+            L.append("  }")
+    if XF:
+        sx = spec.xfold["sx"]
+        L.append("  f4 xfr[%d];" % Q)
+        L.append("  const f4* xpp = (const f4*)a.seq[%d] + (i64)bi * %d + (wave * %d) * 64 + lane;" % (sx, K * 16 // 4, Q))
+        for q in range(Q):
+            L.append("  xfr[%d] = xpp[%d];" % (q, q * 64))
+        for gi in range(len(XF)):
+            L.append("  f4 accx%d_0 = {0.f, 0.f, 0.f, 0.f}, accx%d_1 = {0.f, 0.f, 0.f, 0.f};" % (gi, gi))
+        if lds_items:
+            L.append("  __syncthreads();")
     out_of = {}
     for o, kind, j in pr.outs:
         out_of.setdefault(o, []).append((kind, j))
@@ -611,7 +719,7 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
         L.append("  %s own_%d = %s;" % (T, v, ZERO))
         L.append("  if (owner) own_%d = ((const %s*)a.nsq[%d])[eb * a.nsq_rs[%d] + en * a.nsq_cs[%d]];"
                  % (v, T, s_, s_, s_))
-    pw_seq = sorted({v for ph in pr.phases for v in ph["ins"] if v in pr.seq})
+    pw_seq = sorted({v for ph in pr.phases for v in ph["ins"] if v in pr.seq and v not in folded})
     for v in pw_seq:
         s_ = pr.seq[v]
         L.append("  %s nxt_%d = %s, own_%d = %s;" % (T, v, ZERO, v, ZERO))
@@ -636,7 +744,11 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
         slot = pr.mats[a_]
         ki = keys.index((x, "prev" if x in pr.state else "cur"))
         L.append("    {")
-        L.append("      %s acc0 = {%s, %s, %s, %s}, acc1 = {%s, %s, %s, %s};" % ((AT,) + (ZERO,) * 8))
+        if (pi, d) in xf_of:        # continue the accumulation the sequence product started
+            gi_ = xf_of[(pi, d)][0]
+            L.append("      %s acc0 = accx%d_0, acc1 = accx%d_1;" % (AT, gi_, gi_))
+        else:
+            L.append("      %s acc0 = {%s, %s, %s, %s}, acc1 = {%s, %s, %s, %s};" % ((AT,) + (ZERO,) * 8))
         for q in range(Q):
             for e, c in enumerate("xyzw"[:PV]):
                 acc = "acc%d" % ((PV * q + e) & 1)
@@ -688,6 +800,28 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
                      " fr%d[%d] = __builtin_bit_cast(%s, g); }" % (q * 64 * 16, ki, q, VT))
         L.append("    }")
 
+    def emit_xpart(gi):
+        """x_t @ W_g on this wavefront's K quarter into accx<gi> (two chains)"""
+        _v, _pi, _d, slot, place = XF[gi]
+        L.append("    { f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};")
+        if place == "lds":
+            li = lds_items.index(gi)
+            L.append("      const f4* wl = (const f4*)(Wl + %d) + (wave * %d) * 64 + lane;" % (li * K * 16, Q))
+        for q in range(Q):
+            if place == "lds":
+                L.append("      { const f4 bw = wl[%d];" % (q * 64))
+                bs = ["bw.%s" % c for c in "xyzw"]
+            else:
+                L.append("      {")
+                bs = ["wx%d_%d" % (gi, 4 * q + e) for e in range(4)]
+            for e, c in enumerate("xyzw"):
+                acc = "a%d" % ((4 * q + e) & 1)
+                L.append("        %s = __builtin_amdgcn_mfma_f32_16x16x4f32(xfr[%d].%s, %s, %s, 0, 0, 0);"
+                         % (acc, q, c, bs[e], acc))
+            L.append("      }")
+        L.append("      accx%d_0 = a0; accx%d_1 = a1; }" % (gi, gi))
+
+    last_x_phase = max([it[1] for it in XF], default=-1)
     pending_pub = []
     # `part` is double-buffered by the running count of product phases (across steps): a phase's
     # epilogue reads never meet the next product phase's writes, and the barrier of the phase in
@@ -707,6 +841,15 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
                 late.append((d, a_, x))
                 if (x, kind) not in fresh:
                     fresh.append((x, kind))
+        # sequence products of this phase: those feeding an early product (or a phase that stages
+        # nothing) run first — in the shadow of the tag latency; those feeding a product on the
+        # operand being fetched run after its loads are issued — in the shadow of the load latency
+        x_early = [xf_of[(pi, d)][0] for d, _a, _x in early if (pi, d) in xf_of]
+        x_late = [xf_of[(pi, d)][0] for d, _a, _x in late if (pi, d) in xf_of]
+        if not fresh:
+            x_early, x_late = x_early + x_late, []
+        for gi_ in x_early:
+            emit_xpart(gi_)
         if spec.early_first:
             for d, a_, x in early:
                 emit_mfma(pi, d, a_, x)
@@ -715,6 +858,14 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
             staged_this_step.add((x, kind))
         if fresh:
             stamp("p%d tags seen, loads issued" % pi)
+        for gi_ in x_late:
+            emit_xpart(gi_)
+        if XF and pi == last_x_phase:
+            # x_{t+1}: same registers, in flight through the rest of this step
+            L.append("    if (t + 1 < a.T) {")
+            for q in range(Q):
+                L.append("      xfr[%d] = xpp[(t + 1) * a.seq_ts[%d] / 4 + %d];" % (q, spec.xfold["sx"], q * 64))
+            L.append("    }")
         if not spec.early_first:
             # the products on operands already in registers run while the new operand is in flight
             for d, a_, x in early:
@@ -731,7 +882,8 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
             L.append("    const %s dot_%d_%d = part[pp%d][%d][0][tid] + part[pp%d][%d][1][tid] + part[pp%d][%d][2][tid] + part[pp%d][%d][3][tid];"
                      % (T, pi, d, pi, d, pi, d, pi, d, pi, d))
         L.append("    if (owner) {")
-        ins = ["dot_%d_%d" % (pi, d) for d in range(D)] + ["own_%d" % v for v in ph["ins"]]
+        ins = ["dot_%d_%d" % (pi, d) for d in range(D)] + \
+            [("0.f" if v in folded else "own_%d" % v) for v in ph["ins"]]     # folded: already in the dot
         lines, outs, odts = cg.emit_scalar_body(ph["scalar"], ins, [spec.dtype] * len(ins),
                                                 indent="      ", suffix="_p%d" % pi)
         L.extend(lines)

@@ -513,3 +513,50 @@ def test_persistent_scan_next_to_a_saturating_stream_and_occupancy_refusal():
     finally:
         _Kernels.cache.clear()
         _Kernels.cache.update(saved)
+
+
+@pytest.mark.parametrize("T,H,B", [(7, 64, 16), (33, 128, 32), (12, 256, 48), (64, 1024, 64)])
+def test_sequence_products_inside_the_persistent_loop(T, H, B, monkeypatch):
+    """Round 3: the ``x_t @ W`` products of a batched recurrence are computed INSIDE the persistent
+    matrix kernel (fragment-ordered x, weight columns in LDS / registers, accumulated into the
+    recurrent products' accumulators) instead of as a GEMM over the whole sequence up front.
+    Same results as with the products up front (AESARA_HIP_SM_XFOLD=0) up to fp32 summation
+    order, every step within 1e-5 of fp64, eager and replayed; an ineligible batch (B % 16 != 0)
+    keeps the up-front form."""
+    import torch
+    from aesara_amd.executor import PlanExecutor
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    x = torch.randn(T, B, H, dtype=torch.float32, device="cuda", generator=g) * 0.3
+    h0 = torch.randn(B, H, dtype=torch.float32, device="cuda", generator=g) * 0.5
+    Ws = [torch.randn(H, H, dtype=torch.float32, device="cuda", generator=g) / np.sqrt(H) for _ in range(6)]
+    Wz, Uz, Wr, Ur, Wh, Uh = [W.double() for W in Ws]
+    h, ref = h0.double(), []
+    for t in range(T):
+        xt = x[t].double()
+        z = torch.sigmoid(xt @ Wz + h @ Uz)
+        r = torch.sigmoid(xt @ Wr + h @ Ur)
+        h = (1 - z) * h + z * torch.tanh(xt @ Wh + (r * h) @ Uh)
+        ref.append(h)
+    ref = torch.stack(ref)
+    plan = case_plan(_case("cfg4_gru_b8_f32"))
+    res = {}
+    for fold in ("1", "0"):
+        monkeypatch.setenv("AESARA_HIP_SM_XFOLD", fold)
+        for use_graph in (False, True):
+            ex = PlanExecutor(plan, use_graph=use_graph)
+            for _ in range(3):
+                hs, hT = ex(x, h0, *Ws)
+            assert list(ex.scan_modes.values()) == ["persistent"], ex.scan_modes
+            notes = list(ex.scan_notes.values())
+            assert notes == (["sequence products in the loop"] if fold == "1" else []), notes
+            err = ((hs.double() - ref).abs().max() / ref.abs().max()).item()
+            assert err <= 1e-5, (fold, use_graph, err)
+            res[(fold, use_graph)] = hs.clone()
+            ex.check()
+    assert torch.allclose(res[("1", False)], res[("0", False)], rtol=2e-5, atol=2e-6)
+    assert torch.equal(res[("1", False)], res[("1", True)])
+    monkeypatch.setenv("AESARA_HIP_SM_XFOLD", "1")
+    ex = PlanExecutor(plan)
+    ex(x[:, :B - 3].contiguous(), h0[:B - 3].contiguous(), *Ws)             # ragged batch: up front
+    assert list(ex.scan_modes.values()) == ["persistent"] and not ex.scan_notes
