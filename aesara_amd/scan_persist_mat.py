@@ -87,7 +87,7 @@ class SpecMat:
     def __init__(self, prog, B, N, Ks, Nt=None, dtype="float32", xfold=None):
         self.dtype = dtype
         # xfold: None, or {"sx": sequence slot of the fragment-ordered x, "items": [(v, phase,
-        # dot, mat slot, "lds" | "reg")]} — sequence products x_t @ W computed inside the loop
+        # dot, mat slot)]} — sequence products x_t @ W computed inside the loop (columns in LDS)
         self.xfold = xfold
         # N: state width the tiles cover (a multiple of 64); Nt: the true width (<= N) when the
         # executor zero-padded the weights — columns Nt .. N-1 are never owned, never published
@@ -125,13 +125,19 @@ class SpecMat:
         # operand's tags (r03 timeline, config 4 B = 64: 6.7 us per step; issuing them after the
         # loads — to cover the load latency instead of the tag latency — measured 8.5)
         self.early_first = os.environ.get("AESARA_HIP_SM_EARLY", "first") == "first"
+        # fragment form: the weight columns pinned to ARCHITECTURAL registers (the fragments the
+        # loads deliver then live in accumulation registers).  Left to the allocator, products
+        # end up with A and B both in AGPRs and get a v_accvgpr_read through ONE temporary in
+        # front of every MFMA (r03 timeline: 64 such MFMAs 1.2 us, 64 plain ones 0.93)
+        self.pin = (self.xmode == "frag" and os.environ.get("AESARA_HIP_SM_PIN", "1") != "0" and
+                    wpr * sum(K // 16 for K in Ks.values()) <= 192)
         # per-phase timeline (tools/sm_trace.py): thread 0 of workgroups 0 and NB*NJ/2 stamps
         # s_memtime at every mark of steps TRACE_T0 .. TRACE_T0+TRACE_NT-1 into ctl[16..]
         self.trace = bool(int(os.environ.get("AESARA_HIP_SM_TRACE", "0")))
 
     def key(self):
         pr = self.prog
-        blob = json.dumps(["sm9" + ("t" if self.trace else ""), self.xfold, self.dtype, self.chunk, self.xmode, self.early_first, self.B, self.N, self.Nt, sorted(self.Ks.items()), sorted(pr.seq.items()),
+        blob = json.dumps(["sm9" + ("t" if self.trace else "") + ("/f2p%d" % self.pin if self.xmode == "frag" else ""), self.xfold and [self.xfold, "w14", os.environ.get("AESARA_HIP_SM_XTAIL", "8"), os.environ.get("AESARA_HIP_SM_XDBG", "")], self.dtype, self.chunk, self.xmode, self.early_first, self.B, self.N, self.Nt, sorted(self.Ks.items()), sorted(pr.seq.items()),
                            sorted(pr.state.items()), sorted(pr.nsq.items()), sorted(pr.mats.items()),
                            [[ph["dots"], ph["ins"], ph["outs"], ph["scalar"], ph["out_refs"]]
                             for ph in pr.phases], pr.outs, pr.exchanged, sorted(pr.tap_seq.items())],
@@ -203,6 +209,53 @@ def xfold_pairs(prog, lifted_outs):
             return None
         pairs.append((v, pi, o[1]))
     return pairs
+
+
+def phase_fetches(prog):
+    """Per phase of the step: (early, late, fresh) — the products on operands staged earlier in
+    the step, the products on operands this phase fetches, and those operands [(var, kind)]."""
+    staged, res = set(), []
+    for ph in prog.phases:
+        early, late, fresh = [], [], []
+        for d, (a_, x) in enumerate(ph["dots"]):
+            kind = "prev" if x in prog.state else "cur"
+            if (x, kind) in staged:
+                early.append((d, a_, x))
+            else:
+                late.append((d, a_, x))
+                if (x, kind) not in fresh:
+                    fresh.append((x, kind))
+        staged.update(fresh)
+        res.append((early, late, fresh))
+    return res
+
+
+def xfold_windows(prog, pairs):
+    """Where the in-kernel sequence products run.  The free issue slots of a step are the WINDOWS
+    in front of each operand fetch: a wavefront that has raised its tag waits there for its
+    producers' tags and then for the payload.  The sequence product feeding recurrent product
+    (phase p, d) runs in the window of the last fetch strictly before p — for the products of the
+    first fetching phase that is the last window of the PREVIOUS step, computed from x_{t+1}
+    ("wrapped").  -> {"win": {phase: [pair index]}, "wrapped": set, "reload": phase after whose
+    window x moves on, "ahead": how many steps ahead that load reaches} or None when one window
+    would need two different x."""
+    fetch = [pi for pi, (_e, _l, fresh) in enumerate(phase_fetches(prog)) if fresh]
+    if not fetch or not pairs:
+        return None
+    win, wrapped = {f: [] for f in fetch}, set()
+    for gi, (_v, pi, _d) in enumerate(pairs):
+        prev = [f for f in fetch if f < pi]
+        if prev:
+            win[prev[-1]].append(gi)
+        else:
+            win[fetch[-1]].append(gi)
+            wrapped.add(gi)
+    plain = [f for f in fetch if any(gi not in wrapped for gi in win[f])]
+    if wrapped and plain and plain[-1] >= fetch[-1]:
+        return None
+    if plain:
+        return {"win": win, "wrapped": wrapped, "reload": plain[-1], "ahead": 1}
+    return {"win": win, "wrapped": wrapped, "reload": fetch[-1], "ahead": 2}
 
 
 def xch_layout(prog, NB, N, xmode="flag", itemsize=4):
@@ -630,13 +683,12 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
     PW = NJ // 4                      # producers (column slices) feeding one wavefront's K quarter
     ndots_max = max(len(ph["dots"]) for ph in pr.phases)
     XF = spec.xfold["items"] if spec.xfold else []
-    xf_of = {(pi, d): (gi, slot, place) for gi, (_v, pi, d, slot, place) in enumerate(XF)}
-    folded = {v for v, _pi, _d, _s, _pl in XF}
-    lds_items = [gi for gi, it in enumerate(XF) if it[4] == "lds"]
+    xf_of = {(pi, d): (gi, slot) for gi, (_v, pi, d, slot) in enumerate(XF)}
+    folded = {v for v, _pi, _d, _s in XF}
     L.append('extern "C" __global__ __launch_bounds__(256) void %s(SmArgs a) {' % name)
     L.append("  __shared__ %s part[2][%d][4][256];" % (T, max(ndots_max, 1)))
-    if lds_items:
-        L.append("  __shared__ __attribute__((aligned(16))) float Wl[%d];" % (len(lds_items) * K * 16))
+    if XF:
+        L.append("  __shared__ __attribute__((aligned(16))) float Wl[%d];" % (len(XF) * K * 16))
     L.append("  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;")
     L.append("  const int r16 = lane & 15, grp = lane >> 4;")
     L.append("  const int bi = blockIdx.x %% %d, nj = blockIdx.x / %d;" % (NB, NB))
@@ -676,36 +728,72 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
         assert Km == K
         L.append("  const i64 wk%d = (i64)wave * %d + grp * %d;" % (slot, Km // 4, Km // 16))
         for s_ in range(Km // 16):
-            L.append("  const %s w%d_%d = ((const %s*)a.mat[%d])[(wk%d + %d) * a.mat_rs[%d] + nj * 16 + r16];"
-                     % (T, slot, s_, T, slot, slot, s_, slot))
-    # ---- in-kernel sequence products (xfold): weight columns of x_t @ W_g — in registers like
-    #      the recurrent weights, or in LDS in MFMA B-fragment order: float4 (w*Q + q)*64 + lane =
-    #      W_g[w*K/4 + grp*K/16 + 4q .. +3][nj*16 + r16]
-    for gi, (_v, _pi, _d, slot, place) in enumerate(XF):
-        if place == "reg":
-            L.append("  const i64 wkx%d = (i64)wave * %d + grp * %d;" % (gi, K // 4, K // 16))
-            for s_ in range(K // 16):
-                L.append("  const float wx%d_%d = ((const float*)a.mat[%d])[(wkx%d + %d) * a.mat_rs[%d] + nj * 16 + r16];"
-                         % (gi, s_, slot, gi, s_, slot))
-        else:
-            li = lds_items.index(gi)
-            L.append("  for (int f = tid; f < %d; f += 256) {" % (K * 16 // 4))
-            L.append("    const int ln = f & 63, qq = (f >> 6) %% %d, ww = (f >> 6) / %d;" % (Q, Q))
-            L.append("    const i64 k0 = (i64)ww * %d + (ln >> 4) * %d + 4 * qq;" % (K // 4, K // 16))
-            L.append("    const float* wp = (const float*)a.mat[%d] + k0 * a.mat_rs[%d] + nj * 16 + (ln & 15);" % (slot, slot))
-            L.append("    const f4 wv = {wp[0], wp[a.mat_rs[%d]], wp[2 * a.mat_rs[%d]], wp[3 * a.mat_rs[%d]]};" % (slot, slot, slot))
-            L.append("    *(f4*)(Wl + %d + 4 * f) = wv;" % (li * K * 16))
-            L.append("  }")
+            L.append("  %s%s w%d_%d = ((const %s*)a.mat[%d])[(wk%d + %d) * a.mat_rs[%d] + nj * 16 + r16];"
+                     % ("" if spec.pin else "const ", T, slot, s_, T, slot, slot, s_, slot))
+    # ---- in-kernel sequence products (xfold): the weight columns of x_t @ W_g in LDS, in MFMA
+    #      B-fragment order: float4 (w*Q + q)*64 + lane = W_g[w*K/4 + grp*K/16 + 4q .. +3][nj*16 + r16]
+    for gi, (_v, _pi, _d, slot) in enumerate(XF):
+        L.append("  for (int f = tid; f < %d; f += 256) {" % (K * 16 // 4))
+        L.append("    const int ln = f & 63, qq = (f >> 6) %% %d, ww = (f >> 6) / %d;" % (Q, Q))
+        L.append("    const i64 k0 = (i64)ww * %d + (ln >> 4) * %d + 4 * qq;" % (K // 4, K // 16))
+        L.append("    const float* wp = (const float*)a.mat[%d] + k0 * a.mat_rs[%d] + nj * 16 + (ln & 15);" % (slot, slot))
+        L.append("    const f4 wv = {wp[0], wp[a.mat_rs[%d]], wp[2 * a.mat_rs[%d]], wp[3 * a.mat_rs[%d]]};" % (slot, slot, slot))
+        L.append("    *(f4*)(Wl + %d + 4 * f) = wv;" % (gi * K * 16))
+        L.append("  }")
+    XW = None
+    XDBG = os.environ.get("AESARA_HIP_SM_XDBG", "")      # timing experiments only (wrong results)
+    XTAIL = max(1, int(os.environ.get("AESARA_HIP_SM_XTAIL", "8")))  # fragments (4 MFMAs each) behind the payload loads
+
+    def emit_xload(step_expr, ind):
+        """x of step ``step_expr`` -> xfr: one buffer over that step's x (uniform base, the
+        fragment index in the scalar offset: no per-load address registers)"""
+        L.append(ind + "{ const __amdgpu_buffer_rsrc_t xs_ = __builtin_amdgcn_make_buffer_rsrc("
+                 "(void*)((const float*)a.seq[%d] + (i64)(%s) * a.seq_ts[%d]), 0, %du, 0x00020000);"
+                 % (spec.xfold["sx"], step_expr, spec.xfold["sx"], NB * 16 * K * 4))
+        for q in range(Q):
+            L.append(ind + "  xfr[%d] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(xs_, xl_off, %du, 0));"
+                     % (q, q * 64 * 16))
+        L.append(ind + "}")
+
+    def emit_xunits(units, ind, between=None):
+        """The MFMA k-steps 4q .. 4q+3 of x @ W_<gi> on this wavefront's K quarter into accx<gi>,
+        for every (gi, q) of ``units``.  Weight columns in LDS are read one unit AHEAD into the
+        other of two registers quads (an LDS read in front of each group of four MFMAs, waited for
+        at once, costs as much as the MFMAs).  ``between(i)``: code emitted in front of unit i."""
+        if units:
+            L.append(ind + "bw0 = wl%d[%d];" % (units[0][0], units[0][1] * 64))
+        for i, (gi, q) in enumerate(units):
+            if between is not None:
+                between(i)
+            if q == 0:
+                L.append(ind + "accx%d_0 = zero4; accx%d_1 = zero4;" % (gi, gi))
+            if i + 1 < len(units):
+                gj, qj = units[i + 1]
+                L.append(ind + "bw%d = wl%d[%d];" % ((i + 1) & 1, gj, qj * 64))
+                L.append(ind + "__builtin_amdgcn_sched_barrier(0);     // (the scheduler sinks the read to its use)")
+            bs = ["bw%d.%s" % (i & 1, c) for c in "xyzw"]
+            for e, c in enumerate("xyzw"):
+                L.append(ind + "accx%d_%d = __builtin_amdgcn_mfma_f32_16x16x4f32(xfr[%d].%s, %s, accx%d_%d, 0, 0, 0);"
+                         % (gi, e & 1, q, c, bs[e], gi, e & 1))
     if XF:
         sx = spec.xfold["sx"]
-        L.append("  f4 xfr[%d];" % Q)
-        L.append("  const f4* xpp = (const f4*)a.seq[%d] + (i64)bi * %d + (wave * %d) * 64 + lane;" % (sx, K * 16 // 4, Q))
-        for q in range(Q):
-            L.append("  xfr[%d] = xpp[%d];" % (q, q * 64))
+        XW = xfold_windows(pr, [(v, pi, d) for v, pi, d, _s in XF])
+        assert XW is not None
+        L.append("  const f4 zero4 = {0.f, 0.f, 0.f, 0.f};")
+        L.append("  f4 xfr[%d], bw0 = zero4, bw1 = zero4;" % Q)
+        L.append("  const unsigned xl_off = (unsigned)((((i64)bi * %d) + (wave * %d) * 64 + lane) * 16);" % (K * 16 // 4, Q))
+        emit_xload("0", "  ")
         for gi in range(len(XF)):
-            L.append("  f4 accx%d_0 = {0.f, 0.f, 0.f, 0.f}, accx%d_1 = {0.f, 0.f, 0.f, 0.f};" % (gi, gi))
-        if lds_items:
-            L.append("  __syncthreads();")
+            L.append("  f4 accx%d_0 = zero4, accx%d_1 = zero4;" % (gi, gi))
+            L.append("  const f4* wl%d = (const f4*)(Wl + %d) + (wave * %d) * 64 + lane;" % (gi, gi * K * 16, Q))
+        L.append("  __syncthreads();")
+        # the products the first fetching phase of step 0 needs (later steps get theirs from the
+        # last window of the step before)
+        emit_xunits([(gi, q) for gi in sorted(XW["wrapped"]) for q in range(Q)], "  ")
+        if XW["ahead"] == 2:
+            L.append("  if (a.T > 1) {")
+            emit_xload("1", "    ")
+            L.append("  }")
     out_of = {}
     for o, kind, j in pr.outs:
         out_of.setdefault(o, []).append((kind, j))
@@ -728,9 +816,18 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
     for ph in pr.phases:
         for o in ph["outs"]:
             L.append("  %s own_%d = %s;" % (T, o, ZERO))
-    for ki in range(len(keys)):
-        L.append("  %s fr%d[%d];" % (VT, ki, Q))
+    if not XF:
+        for ki in range(len(keys)):
+            L.append("  %s fr%d[%d];" % (VT, ki, Q))
     L.append("  for (i64 t = 0; t < a.T; ++t) {")
+    if XF:      # per step: the windowed fetch assigns them on one of several paths
+        for ki in range(len(keys)):
+            L.append("    %s fr%d[%d];" % (VT, ki, Q))
+    if spec.pin:
+        for av, slot in sorted(pr.mats.items(), key=lambda t: t[1]):
+            for s0 in range(0, spec.Ks[av] // 16, 16):
+                ops = ", ".join('"+v"(w%d_%d)' % (slot, s_) for s_ in range(s0, min(s0 + 16, spec.Ks[av] // 16)))
+                L.append('    asm volatile("" : %s);' % ops)
     for v in pw_seq:
         s_ = pr.seq[v]
         L.append("    own_%d = nxt_%d;" % (v, v))
@@ -738,7 +835,7 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
                  "eb * a.seq_rs[%d] + en * a.seq_cs[%d]];" % (v, T, s_, s_, s_, s_))
     staged_this_step = set()
 
-    def emit_mfma(pi, d, a_, x):
+    def emit_mfma(pi, d, a_, x, after_q=None):
         """one product on this wavefront's K quarter: two independent accumulator chains (a chain
         of dependent 16x16x4 MFMAs issues every 40 cycles, two interleaved ones every 32)"""
         slot = pr.mats[a_]
@@ -746,7 +843,8 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
         L.append("    {")
         if (pi, d) in xf_of:        # continue the accumulation the sequence product started
             gi_ = xf_of[(pi, d)][0]
-            L.append("      %s acc0 = accx%d_0, acc1 = accx%d_1;" % (AT, gi_, gi_))
+            nm = "accs" if gi_ in snap else "accx"
+            L.append("      %s acc0 = %s%d_0, acc1 = %s%d_1;" % (AT, nm, gi_, nm, gi_))
         else:
             L.append("      %s acc0 = {%s, %s, %s, %s}, acc1 = {%s, %s, %s, %s};" % ((AT,) + (ZERO,) * 8))
         for q in range(Q):
@@ -754,6 +852,8 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
                 acc = "acc%d" % ((PV * q + e) & 1)
                 L.append("      %s = %s(fr%d[%d].%s, w%d_%d, %s, 0, 0, 0);"
                          % (acc, MFMA, ki, q, c, slot, PV * q + e, acc))
+            if after_q is not None:
+                after_q(q)
         # C/D rows of a lane: f32 16x16x4 -> 4 * grp + i ; f64 16x16x4 -> grp + 4 * i
         L.append("      for (int i = 0; i < 4; ++i) part[pp%d][%d][wave][(%s) * 16 + r16] = acc0[i] + acc1[i];"
                  % (pi, d, "grp + 4 * i" if F64 else "4 * grp + i"))
@@ -776,6 +876,9 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
                 L.append("        if (r16 < vrows) { for (int e = 0; e < %d; ++e) if (c0 + %d + e < %d) v[e] = ini[%d + e]; }"
                          % (PV, PV * q, spec.Nt, PV * q))
                 L.append("        fr%d[%d] = v; }" % (ki, q))
+            # nothing of this path pending where the two meet: the compiler merges the two load
+            # orders into an s_waitcnt vmcnt(0) in front of the SECOND MFMA of every step
+            L.append("      __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)")
             L.append("    } else {")
             step_expr = "(t - 1)"
         else:
@@ -800,29 +903,97 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
                      " fr%d[%d] = __builtin_bit_cast(%s, g); }" % (q * 64 * 16, ki, q, VT))
         L.append("    }")
 
-    def emit_xpart(gi):
-        """x_t @ W_g on this wavefront's K quarter into accx<gi> (two chains)"""
-        _v, _pi, _d, slot, place = XF[gi]
-        L.append("    { f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};")
-        if place == "lds":
-            li = lds_items.index(gi)
-            L.append("      const f4* wl = (const f4*)(Wl + %d) + (wave * %d) * 64 + lane;" % (li * K * 16, Q))
-        for q in range(Q):
-            if place == "lds":
-                L.append("      { const f4 bw = wl[%d];" % (q * 64))
-                bs = ["bw.%s" % c for c in "xyzw"]
-            else:
-                L.append("      {")
-                bs = ["wx%d_%d" % (gi, 4 * q + e) for e in range(4)]
-            for e, c in enumerate("xyzw"):
-                acc = "a%d" % ((4 * q + e) & 1)
-                L.append("        %s = __builtin_amdgcn_mfma_f32_16x16x4f32(xfr[%d].%s, %s, %s, 0, 0, 0);"
-                         % (acc, q, c, bs[e], acc))
-            L.append("      }")
-        L.append("      accx%d_0 = a0; accx%d_1 = a1; }" % (gi, gi))
+    def window_begin(pi, x, kind):
+        """(sequence products in the loop) the first look at the tags of this phase's operand:
+        started here — in front of the products on operands already in registers — and examined
+        when the head of the window has been issued"""
+        src = pr.new_of_state.get(x, x)
+        po_, lpp, fo_, lpf = xoff[src]
+        step_expr = "(t - 1)" if kind == "prev" else "t"
+        ind = "    "
+        L.append(ind + "const unsigned want32_w%d = base + (unsigned)%s + 1u;" % (pi, step_expr))
+        L.append(ind + "const u64* fl_w%d = a.xch + %d + (%s & 3) * %d + (i64)bi * %d + wave * %d;"
+                 % (pi, fo_, step_expr, lpf, NJ, PW))
+        L.append(ind + "const unsigned so_w%d = (unsigned)((%d + (%s & 3) * %d + (i64)bi * %d) * 8);"
+                 % (pi, po_, step_expr, lpp, 16 * K * ISZ // 8))
+        # every lane loads (a clamped address): no branch, no copy the compiler would wait for
+        L.append(ind + "const unsigned tg0_w%d = __hip_atomic_load((const unsigned*)(fl_w%d + (lane < %d ? lane : 0)), %s);"
+                 % (pi, pi, PW, AG))
 
-    last_x_phase = max([it[1] for it in XF], default=-1)
+    def emit_window(pi, x, kind, xunits):
+        """The fetch of a phase with sequence products to run (r03 timelines of this kernel): a
+        wavefront has two idle stretches here — until its producers' tags are visible (~1 us
+        after its own tag) and while the payload is in flight (16 KiB per wavefront: ~0.4 us of
+        load issue, which stalls the instruction stream when issued back to back, + ~0.7 us).
+        HEAD: the fragments beyond the last XTAIL, issued while the first look at the tags is in
+        flight; then the usual spin if that look did not find every tag.  TAIL: one payload load
+        in front of each of the remaining fragments' four MFMAs."""
+        assert PW <= 64
+        ki = keys.index((x, kind))
+        xunits = list(xunits)
+        n_head = max(0, len(xunits) - XTAIL)
+        tail = xunits[n_head:]
+        per = -(-Q // max(len(tail), 1))       # payload loads in front of each tail fragment
+
+        def load(q, ind2):
+            L.append(ind2 + "{ const u4v g = __builtin_amdgcn_raw_buffer_load_b128(xr, ld_off, so_w%d + %du, 16);"
+                     " fr%d[%d] = __builtin_bit_cast(%s, g); }" % (pi, q * 64 * 16, ki, q, VT))
+        if kind == "prev":
+            k_out = pr.state[x]
+            L.append("    if (t == 0) {")
+            L.append("      const %s* ini = (const %s*)a.out[%d] + ((a.out_pos0[%d] + a.out_store[%d] - 1) %% "
+                     "a.out_store[%d]) * a.out_ts[%d] + ((i64)bi * 16 + r16) * a.out_rs[%d] + wave * %d + grp * %d;"
+                     % (T, T, k_out, k_out, k_out, k_out, k_out, k_out, K // 4, K // 16))
+            L.append("      const int c0 = wave * %d + grp * %d;" % (K // 4, K // 16))
+            for q in range(Q):
+                L.append("      { %s v = {%s};" % (VT, ", ".join([ZERO] * PV)))
+                L.append("        if (r16 < vrows) { for (int e = 0; e < %d; ++e) if (c0 + %d + e < %d) v[e] = ini[%d + e]; }"
+                         % (PV, PV * q, spec.Nt, PV * q))
+                L.append("        fr%d[%d] = v; }" % (ki, q))
+            emit_xunits(xunits, "      ")
+            # nothing of this path pending where the two meet: the compiler merges the two
+            # load orders into an s_waitcnt vmcnt(0) in front of the SECOND MFMA of every step
+            L.append("      __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)")
+            L.append("    } else {")
+        else:
+            L.append("    {")
+        ind = "      "
+        emit_xunits(xunits[:n_head], ind)
+        L.append(ind + "__builtin_amdgcn_sched_barrier(0);")
+        if n_head:
+            stamp("p%d window head issued" % pi)
+        L.append(ind + "if (!__all(tg0_w%d == want32_w%d)) {" % (pi, pi))
+        L.append(ind + "  const unsigned long long want64 = (unsigned long long)want32_w%d;" % pi)
+        L.append(ind + "  for (int spin = 0;; ++spin) {")
+        L.append(ind + "    bool ok = true;")
+        L.append(ind + "    for (int j = lane; j < %d; j += 64) ok = ok && (__hip_atomic_load(fl_w%d + j, %s) == want64);" % (PW, pi, AG))
+        L.append(ind + "    if (__all(ok)) break;")
+        L.append(ind + "    if (spin > %d || ((spin & 255) == 255 && __hip_atomic_load(errp, %s) != 0u)) "
+                 "{ __hip_atomic_store(errp, 1u, %s); break; }" % (SPIN_LIMIT, AG, AG))
+        L.append(ind + "    __builtin_amdgcn_s_sleep(1);")
+        L.append(ind + "  }")
+        L.append(ind + "}")
+        L.append(ind + "__builtin_amdgcn_sched_barrier(0);")
+        stamp("p%d tags seen" % pi)
+        def between(i):
+            qs = range(i * per, min(Q, (i + 1) * per))
+            if qs:
+                L.append(ind + "__builtin_amdgcn_sched_barrier(0);")
+                for q in qs:
+                    load(q, ind)
+                L.append(ind + "__builtin_amdgcn_sched_barrier(0);")
+        emit_xunits(tail, ind, between)
+        for q in range(len(tail) * per, Q):
+            load(q, ind)
+        L.append(ind + "__builtin_amdgcn_sched_barrier(0);")
+        L.append("    }")
+
     pending_pub = []
+    fetches = phase_fetches(pr)
+    snap = set()
+    if XW:
+        last_f = max(XW["win"])
+        snap = {gi for gi in XW["wrapped"] if XF[gi][1] == last_f}
     # `part` is double-buffered by the running count of product phases (across steps): a phase's
     # epilogue reads never meet the next product phase's writes, and the barrier of the phase in
     # between orders everything two phases apart — no barrier between hand-off and products
@@ -832,50 +1003,57 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
         if ph["dots"]:
             L.append("    const int pp%d = (int)((t * %d + %d) & 1);" % (pi, len(dot_phases), dot_phases.index(pi)))
         stamp("p%d start" % pi)
-        early, late, fresh = [], [], []
-        for d, (a_, x) in enumerate(ph["dots"]):
-            kind = "prev" if x in pr.state else "cur"
-            if (x, kind) in staged_this_step:
-                early.append((d, a_, x))
-            else:
-                late.append((d, a_, x))
-                if (x, kind) not in fresh:
-                    fresh.append((x, kind))
-        # sequence products of this phase: those feeding an early product (or a phase that stages
-        # nothing) run first — in the shadow of the tag latency; those feeding a product on the
-        # operand being fetched run after its loads are issued — in the shadow of the load latency
-        x_early = [xf_of[(pi, d)][0] for d, _a, _x in early if (pi, d) in xf_of]
-        x_late = [xf_of[(pi, d)][0] for d, _a, _x in late if (pi, d) in xf_of]
-        if not fresh:
-            x_early, x_late = x_early + x_late, []
-        for gi_ in x_early:
-            emit_xpart(gi_)
+        early, late, fresh = fetches[pi]
+        if XW and pi == max(XW["win"]):
+            for gi_ in sorted(snap):     # this window overwrites what this phase's products start from
+                L.append("    const f4 accs%d_0 = accx%d_0, accs%d_1 = accx%d_1;" % (gi_, gi_, gi_, gi_))
+        win_units = [(gi_, q) for gi_ in XW["win"][pi] for q in range(Q)] if (XW and fresh) else []
+        if "nounits" in XDBG:
+            win_units = []
+        if win_units:
+            window_begin(pi, *fresh[0])
         if spec.early_first:
             for d, a_, x in early:
                 emit_mfma(pi, d, a_, x)
-        for x, kind in fresh:
-            emit_fetch(pi, x, kind)
+        for fi, (x, kind) in enumerate(fresh):
+            if win_units and fi == 0:
+                emit_window(pi, x, kind, win_units)
+            else:
+                emit_fetch(pi, x, kind)
             staged_this_step.add((x, kind))
         if fresh:
             stamp("p%d tags seen, loads issued" % pi)
-        for gi_ in x_late:
-            emit_xpart(gi_)
-        if XF and pi == last_x_phase:
-            # x_{t+1}: same registers, in flight through the rest of this step
-            L.append("    if (t + 1 < a.T) {")
-            for q in range(Q):
-                L.append("      xfr[%d] = xpp[(t + 1) * a.seq_ts[%d] / 4 + %d];" % (q, spec.xfold["sx"], q * 64))
-            L.append("    }")
+        reload_here = bool(XW) and pi == XW["reload"] and "noxload" not in XDBG and bool(late)
+        if reload_here:
+            # the next x: same registers; the step index clamped (no branch); one load behind
+            # each fragment's MFMAs of the first product below (issued back to back, 16 loads of
+            # 1 KiB stall the wavefront's instruction stream for ~0.4 us)
+            L.append("    const i64 xt_ = (t + %d < a.T) ? t + %d : a.T - 1;" % (XW["ahead"], XW["ahead"]))
+            L.append("    const __amdgpu_buffer_rsrc_t xs_ = __builtin_amdgcn_make_buffer_rsrc("
+                     "(void*)((const float*)a.seq[%d] + xt_ * a.seq_ts[%d]), 0, %du, 0x00020000);"
+                     % (spec.xfold["sx"], spec.xfold["sx"], NB * 16 * K * 4))
         if not spec.early_first:
             # the products on operands already in registers run while the new operand is in flight
             for d, a_, x in early:
                 emit_mfma(pi, d, a_, x)
         if early:
             stamp("p%d early products done" % pi)
-        for d, a_, x in late:
-            emit_mfma(pi, d, a_, x)
+        for li, (d, a_, x) in enumerate(late):
+            if reload_here and li == 0:
+                def xl(q):
+                    L.append("      __builtin_amdgcn_sched_barrier(0);")
+                    L.append("      xfr[%d] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(xs_, xl_off, %du, 0));"
+                             % (q, q * 64 * 16))
+                    L.append("      __builtin_amdgcn_sched_barrier(0);")
+                emit_mfma(pi, d, a_, x, xl)
+            else:
+                emit_mfma(pi, d, a_, x)
+        if reload_here:
+            stamp("p%d next x requested" % pi)
         D = len(ph["dots"])
         if D:
+            if XW:
+                stamp("p%d own products written" % pi)
             L.append("    __syncthreads();")
             stamp("p%d products done" % pi)
         for d in range(D):
