@@ -137,7 +137,7 @@ class SpecMat:
 
     def key(self):
         pr = self.prog
-        blob = json.dumps(["sm9" + ("t" if self.trace else "") + ("/f2p%d" % self.pin if self.xmode == "frag" else ""), self.xfold and [self.xfold, "w14", os.environ.get("AESARA_HIP_SM_XTAIL", "8"), os.environ.get("AESARA_HIP_SM_XDBG", "")], self.dtype, self.chunk, self.xmode, self.early_first, self.B, self.N, self.Nt, sorted(self.Ks.items()), sorted(pr.seq.items()),
+        blob = json.dumps(["sm9" + ("t" if self.trace else "") + ("/f2p%d" % self.pin if self.xmode == "frag" else ""), self.xfold and [self.xfold, "w15", os.environ.get("AESARA_HIP_SM_XTAIL", "8")], self.dtype, self.chunk, self.xmode, self.early_first, self.B, self.N, self.Nt, sorted(self.Ks.items()), sorted(pr.seq.items()),
                            sorted(pr.state.items()), sorted(pr.nsq.items()), sorted(pr.mats.items()),
                            [[ph["dots"], ph["ins"], ph["outs"], ph["scalar"], ph["out_refs"]]
                             for ph in pr.phases], pr.outs, pr.exchanged, sorted(pr.tap_seq.items())],
@@ -741,7 +741,6 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
         L.append("    *(f4*)(Wl + %d + 4 * f) = wv;" % (gi * K * 16))
         L.append("  }")
     XW = None
-    XDBG = os.environ.get("AESARA_HIP_SM_XDBG", "")      # timing experiments only (wrong results)
     XTAIL = max(1, int(os.environ.get("AESARA_HIP_SM_XTAIL", "8")))  # fragments (4 MFMAs each) behind the payload loads
 
     def emit_xload(step_expr, ind):
@@ -1008,8 +1007,6 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
             for gi_ in sorted(snap):     # this window overwrites what this phase's products start from
                 L.append("    const f4 accs%d_0 = accx%d_0, accs%d_1 = accx%d_1;" % (gi_, gi_, gi_, gi_))
         win_units = [(gi_, q) for gi_ in XW["win"][pi] for q in range(Q)] if (XW and fresh) else []
-        if "nounits" in XDBG:
-            win_units = []
         if win_units:
             window_begin(pi, *fresh[0])
         if spec.early_first:
@@ -1023,7 +1020,7 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
             staged_this_step.add((x, kind))
         if fresh:
             stamp("p%d tags seen, loads issued" % pi)
-        reload_here = bool(XW) and pi == XW["reload"] and "noxload" not in XDBG and bool(late)
+        reload_here = bool(XW) and pi == XW["reload"] and bool(late)
         if reload_here:
             # the next x: same registers; the step index clamped (no branch); one load behind
             # each fragment's MFMAs of the first product below (issued back to back, 16 loads of
@@ -1041,6 +1038,8 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
         for li, (d, a_, x) in enumerate(late):
             if reload_here and li == 0:
                 def xl(q):
+                    if spec.trace and q in (3, 7, 11):
+                        stamp("p%d product, %d MFMAs issued" % (pi, 4 * q + 4))
                     L.append("      __builtin_amdgcn_sched_barrier(0);")
                     L.append("      xfr[%d] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(xs_, xl_off, %du, 0));"
                              % (q, q * 64 * 16))

@@ -1043,6 +1043,24 @@ case("gru_bptt_b4_f32", rtol=3e-4, atol=3e-5)(_gru_bptt("float32", 10, 16, 4))
 case("cfg4_gru_b1_f32", rtol=1e-5, atol=1e-5)(_gru("float32", 32, 64, 1, 1e-5))
 case("cfg4_gru_b8_f32", rtol=1e-5, atol=1e-5)(_gru("float32", 16, 64, 8, 1e-5))
 case("gru_b1_f64", rtol=1e-11, atol=1e-11)(_gru("float64", 10, 24, 1, 1e-11))
+# batch a multiple of 16, state a multiple of 64: the shapes at which the persistent matrix kernel
+# computes the sequence products x_t @ W itself (scan_persist_mat.xfold_windows) — three products
+# over the two windows of a GRU step, one of them a step ahead
+case("xfold_gru_b16_f32", rtol=1e-5, atol=1e-5)(_gru("float32", 12, 64, 16, 1e-5))
+
+
+@case("xfold_rnn_b16_f32", rtol=1e-5, atol=1e-5)
+def _():
+    """Elman recurrence with a batch: ONE fetching phase per step, so its sequence product runs a
+    whole step ahead (x_{t+1} in the window of step t, x_{t+2} requested behind it)."""
+    x, h0, W, U = at.ftensor3("x"), at.fmatrix("h0"), at.fmatrix("W"), at.fmatrix("U")
+
+    def step(x_t, h, W, U):
+        return at.tanh(at.dot(x_t, W) + at.dot(h, U))
+    hs, _ = ae.scan(step, sequences=[x], outputs_info=[h0], non_sequences=[W, U])
+    return [x, h0, W, U], [hs, hs[-1]], \
+        [N((9, 16, 64), "float32", 4, 0.5), N((16, 64), "float32", 3, 0.5),
+         N((64, 64), "float32", 5, 0.125), N((64, 64), "float32", 6, 0.125)]
 
 
 

@@ -560,3 +560,48 @@ def test_sequence_products_inside_the_persistent_loop(T, H, B, monkeypatch):
     ex = PlanExecutor(plan)
     ex(x[:, :B - 3].contiguous(), h0[:B - 3].contiguous(), *Ws)             # ragged batch: up front
     assert list(ex.scan_modes.values()) == ["persistent"] and not ex.scan_notes
+
+
+@pytest.mark.parametrize("name", ["xfold_gru_b16_f32", "xfold_rnn_b16_f32"])
+def test_golden_recurrences_with_the_products_in_the_loop(name):
+    """The two golden recurrences whose shapes let the kernel take the sequence products in
+    (batch % 16 == 0, state % 64 == 0) against the REFERENCE's outputs: the GRU spreads three
+    products over its two windows (one of them computed a step ahead, from x_{t+1}); the Elman
+    step has a single fetching phase, so its product runs a whole step ahead."""
+    from aesara_amd.executor import PlanExecutor
+    c = _case(name)
+    plan, ins, want = case_plan(c), case_inputs(c), case_expected(c)
+    for use_graph in (False, True):
+        ex = PlanExecutor(plan, use_graph=use_graph)
+        for _ in range(2):
+            got = ex(*ins)
+        assert list(ex.scan_modes.values()) == ["persistent"], ex.scan_modes
+        assert list(ex.scan_notes.values()) == ["sequence products in the loop"], ex.scan_notes
+        assert_matches(c, [g_.cpu().numpy() for g_ in got], want)
+        ex.check()
+
+
+@pytest.mark.parametrize("T,H,B", [(5, 64, 16), (40, 256, 32), (24, 1024, 64)])
+def test_elman_sequence_product_a_step_ahead(T, H, B):
+    """h_t = tanh(x_t W + h_{t-1} U) at sizes up to the benchmark's: the product for step t + 1 is
+    accumulated in the window of step t (x_{t+2} requested behind it); every step within 1e-5 of
+    fp64."""
+    import torch
+    from aesara_amd.executor import PlanExecutor
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    x = torch.randn(T, B, H, dtype=torch.float32, device="cuda", generator=g) * 0.5
+    h0 = torch.randn(B, H, dtype=torch.float32, device="cuda", generator=g) * 0.5
+    W, U = [torch.randn(H, H, dtype=torch.float32, device="cuda", generator=g) / np.sqrt(H) for _ in range(2)]
+    h, ref = h0.double(), []
+    for t in range(T):
+        h = torch.tanh(x[t].double() @ W.double() + h @ U.double())
+        ref.append(h)
+    ref = torch.stack(ref)
+    ex = PlanExecutor(case_plan(_case("xfold_rnn_b16_f32")))
+    for _ in range(2):
+        hs, hT = ex(x, h0, W, U)
+    assert list(ex.scan_notes.values()) == ["sequence products in the loop"], (ex.scan_modes, ex.scan_notes)
+    err = ((hs.double() - ref).abs().max() / ref.abs().max()).item()
+    assert err <= 1e-5, err
+    assert torch.equal(hT, hs[-1])
