@@ -106,7 +106,16 @@ class SpecMat:
         #   registers the MFMAs read — no LDS image, no staging pass, no barrier between hand-off
         #   and product (round 3: the r03 timeline showed 2.5 of 8.6 us per step in the LDS staging
         #   of the payload and 3.6 us in LDS-latency-serialised dependent MFMA chains)
-        nstaged = len({(x, "prev" if x in prog.state else "cur") for ph in prog.phases for _a, x in ph["dots"]})
+        # operand fragments alive at the same time: an operand is fetched in the phase of its first
+        # product and dead after its last
+        first, last = {}, {}
+        for pi, ph in enumerate(prog.phases):
+            for _a, x in ph["dots"]:
+                k_ = (x, "prev" if x in prog.state else "cur")
+                first.setdefault(k_, pi)
+                last[k_] = pi
+        nstaged = max([sum(1 for k_ in first if first[k_] <= pi <= last[k_]) for pi in range(len(prog.phases))],
+                      default=0)
         K0 = max(Ks.values()) if Ks else 64
         wpr = 2 if dtype == "float64" else 1          # 32-bit registers per value
         regs = wpr * (sum(K // 16 for K in Ks.values()) + (K0 // 16) * nstaged)
@@ -137,7 +146,7 @@ class SpecMat:
 
     def key(self):
         pr = self.prog
-        blob = json.dumps(["sm9" + ("t" if self.trace else "") + ("/f2p%d" % self.pin if self.xmode == "frag" else ""), self.xfold and [self.xfold, "w15", os.environ.get("AESARA_HIP_SM_XTAIL", "8")], self.dtype, self.chunk, self.xmode, self.early_first, self.B, self.N, self.Nt, sorted(self.Ks.items()), sorted(pr.seq.items()),
+        blob = json.dumps(["sm9" + ("t" if self.trace else "") + ("/f4p%d%s" % (self.pin, os.environ.get("AESARA_HIP_SM_FENCE", "1")) if self.xmode == "frag" else ""), self.xfold and [self.xfold, "w15", os.environ.get("AESARA_HIP_SM_XTAIL", "8")], self.dtype, self.chunk, self.xmode, self.early_first, self.B, self.N, self.Nt, sorted(self.Ks.items()), sorted(pr.seq.items()),
                            sorted(pr.state.items()), sorted(pr.nsq.items()), sorted(pr.mats.items()),
                            [[ph["dots"], ph["ins"], ph["outs"], ph["scalar"], ph["out_refs"]]
                             for ph in pr.phases], pr.outs, pr.exchanged, sorted(pr.tap_seq.items())],
@@ -707,9 +716,12 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
              % (Q, K // 16, PV, K // 16))
     L.append("  const unsigned ld_off = (unsigned)(((wave * %d) * 64 + lane) * 16);" % Q)
     marks = []
+    FENCE = os.environ.get("AESARA_HIP_SM_FENCE", "1") != "0"
 
     def stamp(label):
         if not spec.trace:
+            if FENCE:
+                L.append("    __builtin_amdgcn_sched_barrier(0);")
             return
         k = len(marks)
         marks.append(label)
@@ -815,13 +827,11 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
     for ph in pr.phases:
         for o in ph["outs"]:
             L.append("  %s own_%d = %s;" % (T, o, ZERO))
-    if not XF:
-        for ki in range(len(keys)):
-            L.append("  %s fr%d[%d];" % (VT, ki, Q))
     L.append("  for (i64 t = 0; t < a.T; ++t) {")
-    if XF:      # per step: the windowed fetch assigns them on one of several paths
-        for ki in range(len(keys)):
-            L.append("    %s fr%d[%d];" % (VT, ki, Q))
+    # the operand fragments are per-step values: declared here, one whose last product lies
+    # before another's fetch lends it its registers (a gradient step fetches three, two at a time)
+    for ki in range(len(keys)):
+        L.append("    %s fr%d[%d];" % (VT, ki, Q))
     if spec.pin:
         for av, slot in sorted(pr.mats.items(), key=lambda t: t[1]):
             for s0 in range(0, spec.Ks[av] // 16, 16):
