@@ -25,7 +25,7 @@ pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(not ref_overlay.available(),
                                  reason="no reference front end (oracle/_ref overlay not packed)")]
 
-# default: EVERY golden case (269 graphs, ~2.5 min on the MI355X); AESARA_E2E_SUBSET=1 restricts
+# default: EVERY golden case (271 graphs, ~2.5 min on the MI355X); AESARA_E2E_SUBSET=1 restricts
 # the run to the BASELINE configs + one case per Op family
 SUBSET = [
     "cfg1a_scalar_add", "cfg1b_matrix_add", "cfg2_gauss_sum", "cfg3a_gemv", "cfg3b_gemm_update",
