@@ -29,6 +29,14 @@ no barrier, publishes deferred to the next hand-off), plain ``Dot22`` / ``Gemm``
 phases, several operands published together (one polling pass, loads in flight together),
 operand blocks that lend each other their LDS slot, and state widths that are not a multiple of
 64 (``SpecMat.Nt``: the executor zero-pads the weights, unowned columns are never published).
+
+Round 3 added the FRAGMENT form of the exchange (``_generate_frag``: payload in MFMA A-fragment
+order, pulled straight into the registers the MFMAs read — the default whenever the weight columns
+and the operand fragments alive at the same time fit in 320 registers, which now includes the
+gradient kernels) and, on it, the sequence products ``x_t @ W`` computed INSIDE the loop
+(``xfold_pairs`` / ``xfold_windows`` / ``emit_window``: weight columns in LDS, ``x`` in fragment
+order a step ahead, the work placed in the idle windows in front of each operand fetch).
+DESIGN.md §3.3b has the timelines each of these decisions came from.
 """
 from __future__ import annotations
 
@@ -119,11 +127,10 @@ class SpecMat:
         K0 = max(Ks.values()) if Ks else 64
         wpr = 2 if dtype == "float64" else 1          # 32-bit registers per value
         regs = wpr * (sum(K // 16 for K in Ks.values()) + (K0 // 16) * nstaged)
-        if xfold:
-            regs = None     # decided by the executor (fragment form, its own register budget)
-        # measured (r03, T = 512, H = 1024, B = 64): the two-operand forward GRU kernel (320
-        # registers of weights + fragments) 6.09 -> 5.7 ms in the fragment form; the three-operand
-        # gradient kernel (384) is 1 ms FASTER in the LDS form (training step 21.0 vs 22.0 ms)
+        # measured (r03, T = 512, H = 1024, B = 64): the forward GRU kernel (192 registers of
+        # weights + two fragments) 6.09 -> 5.7 ms in the fragment form; the backward kernel (three
+        # operands, two alive at a time: 320 as well) 6.4 -> 5.8 ms.  In-loop sequence products
+        # exist in the fragment form only (their weights live in LDS, one more fragment for x)
         if xfold:
             self.xmode = "frag"
         else:

@@ -518,8 +518,9 @@ def test_persistent_scan_next_to_a_saturating_stream_and_occupancy_refusal():
 @pytest.mark.parametrize("T,H,B", [(7, 64, 16), (33, 128, 32), (12, 256, 48), (64, 1024, 64)])
 def test_sequence_products_inside_the_persistent_loop(T, H, B, monkeypatch):
     """Round 3: the ``x_t @ W`` products of a batched recurrence are computed INSIDE the persistent
-    matrix kernel (fragment-ordered x, weight columns in LDS / registers, accumulated into the
-    recurrent products' accumulators) instead of as a GEMM over the whole sequence up front.
+    matrix kernel (fragment-ordered x, weight columns in LDS — as many products as fit, the others
+    stay up front: two of three at H = 1024 —, accumulated into the recurrent products'
+    accumulators) instead of as a GEMM over the whole sequence up front.
     Same results as with the products up front (AESARA_HIP_SM_XFOLD=0) up to fp32 summation
     order, every step within 1e-5 of fp64, eager and replayed; an ineligible batch (B % 16 != 0)
     keeps the up-front form."""
