@@ -153,7 +153,7 @@ class SpecMat:
 
     def key(self):
         pr = self.prog
-        blob = json.dumps(["sm9" + ("t" if self.trace else "") + ("/f4p%d%s" % (self.pin, os.environ.get("AESARA_HIP_SM_FENCE", "1")) if self.xmode == "frag" else ""), self.xfold and [self.xfold, "w15", os.environ.get("AESARA_HIP_SM_XTAIL", "8")], self.dtype, self.chunk, self.xmode, self.early_first, self.B, self.N, self.Nt, sorted(self.Ks.items()), sorted(pr.seq.items()),
+        blob = json.dumps(["sm9" + ("t" if self.trace else "") + ("/f4p%d%s" % (self.pin, os.environ.get("AESARA_HIP_SM_FENCE", "1")) if self.xmode == "frag" else ""), self.xfold and [self.xfold, "w15", os.environ.get("AESARA_HIP_SM_XTAIL", "10")], self.dtype, self.chunk, self.xmode, self.early_first, self.B, self.N, self.Nt, sorted(self.Ks.items()), sorted(pr.seq.items()),
                            sorted(pr.state.items()), sorted(pr.nsq.items()), sorted(pr.mats.items()),
                            [[ph["dots"], ph["ins"], ph["outs"], ph["scalar"], ph["out_refs"]]
                             for ph in pr.phases], pr.outs, pr.exchanged, sorted(pr.tap_seq.items())],
@@ -760,7 +760,7 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
         L.append("    *(f4*)(Wl + %d + 4 * f) = wv;" % (gi * K * 16))
         L.append("  }")
     XW = None
-    XTAIL = max(1, int(os.environ.get("AESARA_HIP_SM_XTAIL", "8")))  # fragments (4 MFMAs each) behind the payload loads
+    XTAIL = max(1, int(os.environ.get("AESARA_HIP_SM_XTAIL", "10")))  # fragments (4 MFMAs each) behind the payload loads
 
     def emit_xload(step_expr, ind):
         """x of step ``step_expr`` -> xfr: one buffer over that step's x (uniform base, the

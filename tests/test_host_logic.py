@@ -504,3 +504,53 @@ def test_shared_left_dots_become_one_wide_product():
         np.testing.assert_allclose(g, w, rtol=1e-13)
     single = Plan("one", dict(p.vars), list(p.inputs), [lone], [p.nodes[3]])
     assert merge_shared_left_dots(single) is single
+
+
+def test_sequence_product_windows():
+    """scan_persist_mat.xfold_windows: which window of the step each in-loop sequence product runs
+    in.  GRU (phase 0: r on h; phase 1: z on h — already in registers — and the candidate on r*h):
+    the products of phase 1 run in front of phase 0's fetch, phase 0's own in the LAST window of
+    the step before (from x_{t+1}); a recurrence with one fetching phase runs a whole step ahead;
+    a product that would put x_t and x_{t+1} into one window is refused."""
+    from types import SimpleNamespace
+    from aesara_amd import scan_persist_mat as sm
+    gru = SimpleNamespace(state={1: 0}, phases=[{"dots": [(5, 1)]}, {"dots": [(3, 1), (7, 11)]}])
+    assert [(len(e), len(l), f) for e, l, f in sm.phase_fetches(gru)] == \
+        [(0, 1, [(1, "prev")]), (1, 1, [(11, "cur")])]
+    w = sm.xfold_windows(gru, [("r", 0, 0), ("h", 1, 1), ("z", 1, 0)])
+    assert w == {"win": {0: [1, 2], 1: [0]}, "wrapped": {0}, "reload": 0, "ahead": 1}
+    # only phase-0 products folded: everything a step ahead, x moves on behind the last window
+    assert sm.xfold_windows(gru, [("r", 0, 0)]) == {"win": {0: [], 1: [0]}, "wrapped": {0}, "reload": 1, "ahead": 2}
+    elman = SimpleNamespace(state={1: 0}, phases=[{"dots": [(2, 1)]}])
+    assert sm.xfold_windows(elman, [("x", 0, 0)]) == {"win": {0: [0]}, "wrapped": {0}, "reload": 0, "ahead": 2}
+    # phase 2 (no fetch of its own) would share the window of phase 1 with phase 0's wrapped product
+    three = SimpleNamespace(state={1: 0}, phases=[{"dots": [(5, 1)]}, {"dots": [(7, 11)]}, {"dots": [(3, 1)]}])
+    assert sm.xfold_windows(three, [("a", 0, 0), ("c", 2, 0)]) is None
+    assert sm.xfold_windows(gru, []) is None
+
+
+@pytest.mark.parametrize("name,folded", [("xfold_gru_b16_f32", 3), ("xfold_rnn_b16_f32", 1)])
+def test_sequence_products_move_into_the_loop_at_eligible_shapes(name, folded, monkeypatch):
+    """Dry run of the two golden recurrences with batch % 16 == 0 and state % 64 == 0: the Scan
+    takes the persistent matrix kernel with the sequence products inside (every weight block fits
+    in LDS at H = 64; the kernel is generated and compiled on the way) and AESARA_HIP_SM_XFOLD=0
+    keeps them up front."""
+    from aesara_amd import scan_persist_mat as sm
+    c = _case(name)
+    seen = []
+
+    class Spy(sm.SpecMat):            # (a cached kernel is not generated again: watch the specs)
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            seen.append(self)
+    monkeypatch.setattr(sm, "SpecMat", Spy)
+    ex = PlanExecutor(case_plan(c), dry_run=True)
+    ex(*case_inputs(c))
+    assert list(ex.scan_modes.values()) == ["persistent"]
+    assert list(ex.scan_notes.values()) == ["sequence products in the loop"]
+    xf = [s for s in seen if s.xfold]
+    assert xf and len(xf[-1].xfold["items"]) == folded and xf[-1].xmode == "frag"
+    monkeypatch.setenv("AESARA_HIP_SM_XFOLD", "0")
+    ex = PlanExecutor(case_plan(c), dry_run=True)
+    ex(*case_inputs(c))
+    assert list(ex.scan_modes.values()) == ["persistent"] and not ex.scan_notes
