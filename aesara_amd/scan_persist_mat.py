@@ -153,7 +153,7 @@ class SpecMat:
 
     def key(self):
         pr = self.prog
-        blob = json.dumps(["sm9" + ("t" if self.trace else "") + ("/f4p%d%s" % (self.pin, os.environ.get("AESARA_HIP_SM_FENCE", "1")) if self.xmode == "frag" else ""), self.xfold and [self.xfold, "w15", os.environ.get("AESARA_HIP_SM_XTAIL", "10")], self.dtype, self.chunk, self.xmode, self.early_first, self.B, self.N, self.Nt, sorted(self.Ks.items()), sorted(pr.seq.items()),
+        blob = json.dumps(["sm9" + ("t" if self.trace else "") + ("/f5p%d%s" % (self.pin, os.environ.get("AESARA_HIP_SM_FENCE", "1")) if self.xmode == "frag" else ""), self.xfold and [self.xfold, "w15", os.environ.get("AESARA_HIP_SM_XTAIL", "10")], self.dtype, self.chunk, self.xmode, self.early_first, self.B, self.N, self.Nt, sorted(self.Ks.items()), sorted(pr.seq.items()),
                            sorted(pr.state.items()), sorted(pr.nsq.items()), sorted(pr.mats.items()),
                            [[ph["dots"], ph["ins"], ph["outs"], ph["scalar"], ph["out_refs"]]
                             for ph in pr.phases], pr.outs, pr.exchanged, sorted(pr.tap_seq.items())],
@@ -919,6 +919,38 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
                      " fr%d[%d] = __builtin_bit_cast(%s, g); }" % (q * 64 * 16, ki, q, VT))
         L.append("    }")
 
+    def emit_fetch_joint(pi, ops):
+        """Several operands of the current step published by the same epilogue (the two
+        last-phase products of a gradient step): ONE polling pass over all their tags — fetched
+        one after the other, the second wait costs a tag round trip (0.6 us) although its tags
+        are there — then all the loads in flight together."""
+        ind = "      "
+        L.append("    {")
+        L.append(ind + "const unsigned long long want64 = (unsigned long long)(base + (unsigned)t + 1u);")
+        for n, (x, kind) in enumerate(ops):
+            po_, lpp, fo_, lpf = xoff[pr.new_of_state.get(x, x)]
+            L.append(ind + "const u64* fl%d = a.xch + %d + (t & 3) * %d + (i64)bi * %d + wave * %d;"
+                     % (n, fo_, lpf, NJ, PW))
+        L.append(ind + "for (int spin = 0;; ++spin) {")
+        L.append(ind + "  bool ok = true;")
+        for n in range(len(ops)):
+            L.append(ind + "  for (int j = lane; j < %d; j += 64) ok = ok && (__hip_atomic_load(fl%d + j, %s) == want64);"
+                     % (PW, n, AG))
+        L.append(ind + "  if (__all(ok)) break;")
+        L.append(ind + "  if (spin > %d || ((spin & 255) == 255 && __hip_atomic_load(errp, %s) != 0u)) "
+                 "{ __hip_atomic_store(errp, 1u, %s); break; }" % (SPIN_LIMIT, AG, AG))
+        L.append(ind + "  __builtin_amdgcn_s_sleep(1);")
+        L.append(ind + "}")
+        for n, (x, kind) in enumerate(ops):
+            ki = keys.index((x, kind))
+            po_, lpp, fo_, lpf = xoff[pr.new_of_state.get(x, x)]
+            L.append(ind + "const unsigned so%d_ = (unsigned)((%d + (t & 3) * %d + (i64)bi * %d) * 8);"
+                     % (n, po_, lpp, 16 * K * ISZ // 8))
+            for q in range(Q):
+                L.append(ind + "{ const u4v g = __builtin_amdgcn_raw_buffer_load_b128(xr, ld_off + %du, so%d_, 16);"
+                         " fr%d[%d] = __builtin_bit_cast(%s, g); }" % (q * 64 * 16, n, ki, q, VT))
+        L.append("    }")
+
     def window_begin(pi, x, kind):
         """(sequence products in the loop) the first look at the tags of this phase's operand:
         started here — in front of the products on operands already in registers — and examined
@@ -1029,12 +1061,16 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
         if spec.early_first:
             for d, a_, x in early:
                 emit_mfma(pi, d, a_, x)
-        for fi, (x, kind) in enumerate(fresh):
-            if win_units and fi == 0:
-                emit_window(pi, x, kind, win_units)
-            else:
-                emit_fetch(pi, x, kind)
-            staged_this_step.add((x, kind))
+        if not win_units and len(fresh) >= 2 and all(kind == "cur" for _x, kind in fresh):
+            emit_fetch_joint(pi, fresh)
+            staged_this_step.update(fresh)
+        else:
+            for fi, (x, kind) in enumerate(fresh):
+                if win_units and fi == 0:
+                    emit_window(pi, x, kind, win_units)
+                else:
+                    emit_fetch(pi, x, kind)
+                staged_this_step.add((x, kind))
         if fresh:
             stamp("p%d tags seen, loads issued" % pi)
         reload_here = bool(XW) and pi == XW["reload"] and bool(late)
