@@ -124,6 +124,7 @@ class SpecMat:
                 last[k_] = pi
         nstaged = max([sum(1 for k_ in first if first[k_] <= pi <= last[k_]) for pi in range(len(prog.phases))],
                       default=0)
+        self.nstaged = nstaged
         K0 = max(Ks.values()) if Ks else 64
         wpr = 2 if dtype == "float64" else 1          # 32-bit registers per value
         regs = wpr * (sum(K // 16 for K in Ks.values()) + (K0 // 16) * nstaged)
