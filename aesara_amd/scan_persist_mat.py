@@ -795,7 +795,6 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
                 L.append(ind + "accx%d_%d = __builtin_amdgcn_mfma_f32_16x16x4f32(xfr[%d].%s, %s, accx%d_%d, 0, 0, 0);"
                          % (gi, e & 1, q, c, bs[e], gi, e & 1))
     if XF:
-        sx = spec.xfold["sx"]
         XW = xfold_windows(pr, [(v, pi, d) for v, pi, d, _s in XF])
         assert XW is not None
         L.append("  const f4 zero4 = {0.f, 0.f, 0.f, 0.f};")
