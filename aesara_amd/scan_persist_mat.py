@@ -92,8 +92,12 @@ typedef unsigned long long u64;
 class SpecMat:
     """Shape-specialised kernel: B batch rows, N state columns, K per weight matrix."""
 
-    def __init__(self, prog, B, N, Ks, Nt=None, dtype="float32", xfold=None):
+    def __init__(self, prog, B, N, Ks, Nt=None, dtype="float32", xfold=None, nblk=1):
         self.dtype = dtype
+        # nblk: batch blocks (of 16 rows) per workgroup.  A workgroup owns ONE 16 x 16 tile per
+        # block; when B * N / 256 exceeds the CU count it takes two blocks (independent
+        # recurrences: the whole step body runs once per block, sharing the weight registers)
+        self.nblk = nblk
         # xfold: None, or {"sx": sequence slot of the fragment-ordered x, "items": [(v, phase,
         # dot, mat slot)]} — sequence products x_t @ W computed inside the loop (columns in LDS)
         self.xfold = xfold
@@ -157,7 +161,8 @@ class SpecMat:
         blob = json.dumps(["sm9" + ("t" if self.trace else "") + ("/f5p%d%s" % (self.pin, os.environ.get("AESARA_HIP_SM_FENCE", "1")) if self.xmode == "frag" else ""), self.xfold and [self.xfold, "w15", os.environ.get("AESARA_HIP_SM_XTAIL", "10")], self.dtype, self.chunk, self.xmode, self.early_first, self.B, self.N, self.Nt, sorted(self.Ks.items()), sorted(pr.seq.items()),
                            sorted(pr.state.items()), sorted(pr.nsq.items()), sorted(pr.mats.items()),
                            [[ph["dots"], ph["ins"], ph["outs"], ph["scalar"], ph["out_refs"]]
-                            for ph in pr.phases], pr.outs, pr.exchanged, sorted(pr.tap_seq.items())],
+                            for ph in pr.phases], pr.outs, pr.exchanged, sorted(pr.tap_seq.items())] +
+                          ([["nblk", self.nblk]] if self.nblk != 1 else []),
                           sort_keys=True)
         return hashlib.sha256(blob.encode()).hexdigest()[:24]
 
@@ -708,11 +713,32 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
         L.append("  __shared__ __attribute__((aligned(16))) float Wl[%d];" % (len(XF) * K * 16))
     L.append("  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;")
     L.append("  const int r16 = lane & 15, grp = lane >> 4;")
-    L.append("  const int bi = blockIdx.x %% %d, nj = blockIdx.x / %d;" % (NB, NB))
-    L.append("  const int erow = tid >> 4, ecol = tid & 15;        // tile element owned by this thread")
-    L.append("  const i64 eb = (i64)bi * 16 + erow, en = (i64)nj * 16 + ecol;")
-    L.append("  const bool owner = eb < %d && en < %d;" % (B, spec.Nt))
-    L.append("  const int vrows = (%d - bi * 16) < 16 ? (%d - bi * 16) : 16;   // valid rows of this batch block" % (B, B))
+    NBLK = spec.nblk
+    assert NBLK == 1 or (not XF and not spec.trace and NB % NBLK == 0)
+
+    def per_block(lines):
+        """instantiate template lines per batch block of the workgroup: '§' = the block's name
+        suffix ('' with one block per workgroup), '¤' = its number"""
+        out = []
+        for blk in range(NBLK):
+            sfx = "" if NBLK == 1 else "_b%d" % blk
+            out.extend(l.replace("§", sfx).replace("¤", str(blk)) for l in lines)
+        return out
+    if NBLK == 1:
+        L.append("  const int bi = blockIdx.x %% %d, nj = blockIdx.x / %d;" % (NB, NB))
+        L.append("  const int erow = tid >> 4, ecol = tid & 15;        // tile element owned by this thread")
+        L.append("  const i64 eb = (i64)bi * 16 + erow, en = (i64)nj * 16 + ecol;")
+        L.append("  const bool owner = eb < %d && en < %d;" % (B, spec.Nt))
+        L.append("  const int vrows = (%d - bi * 16) < 16 ? (%d - bi * 16) : 16;   // valid rows of this batch block" % (B, B))
+    else:
+        L.append("  const int nj = blockIdx.x / %d;" % (NB // NBLK))
+        L.append("  const int erow = tid >> 4, ecol = tid & 15;        // tile element owned by this thread")
+        L.append("  const i64 en = (i64)nj * 16 + ecol;")
+        L.extend(per_block([
+            "  const int bi§ = (blockIdx.x %% %d) * %d + ¤;" % (NB // NBLK, NBLK),
+            "  const i64 eb§ = (i64)bi§ * 16 + erow;",
+            "  const bool owner§ = eb§ < %d && en < %d;" % (B, spec.Nt),
+            "  const int vrows§ = (%d - bi§ * 16) < 16 ? (%d - bi§ * 16) : 16;" % (B, B)]))
     L.append("  const unsigned base = __hip_atomic_load(a.ctl, %s);" % AG)
     L.append("  unsigned* errp = a.ctl + 1;")
     L.append("  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.xch, 0, %du, 0x00020000);"
@@ -815,25 +841,27 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
     out_of = {}
     for o, kind, j in pr.outs:
         out_of.setdefault(o, []).append((kind, j))
+    i_tpl = len(L)
     for v, k in pr.state.items():
-        L.append("  %s own_%d = %s;" % (T, v, ZERO))
-        L.append("  if (owner) own_%d = ((const %s*)a.out[%d])[((a.out_pos0[%d] + a.out_store[%d] - 1) %% "
-                 "a.out_store[%d]) * a.out_ts[%d] + eb * a.out_rs[%d] + en];" % (v, T, k, k, k, k, k, k))
+        L.append("  %s own_%d§ = %s;" % (T, v, ZERO))
+        L.append("  if (owner§) own_%d§ = ((const %s*)a.out[%d])[((a.out_pos0[%d] + a.out_store[%d] - 1) %% "
+                 "a.out_store[%d]) * a.out_ts[%d] + eb§ * a.out_rs[%d] + en];" % (v, T, k, k, k, k, k, k))
     pw_nsq = sorted({v for ph in pr.phases for v in ph["ins"] if v in pr.nsq})
     for v in pw_nsq:
         s_ = pr.nsq[v]
-        L.append("  %s own_%d = %s;" % (T, v, ZERO))
-        L.append("  if (owner) own_%d = ((const %s*)a.nsq[%d])[eb * a.nsq_rs[%d] + en * a.nsq_cs[%d]];"
+        L.append("  %s own_%d§ = %s;" % (T, v, ZERO))
+        L.append("  if (owner§) own_%d§ = ((const %s*)a.nsq[%d])[eb§ * a.nsq_rs[%d] + en * a.nsq_cs[%d]];"
                  % (v, T, s_, s_, s_))
     pw_seq = sorted({v for ph in pr.phases for v in ph["ins"] if v in pr.seq and v not in folded})
     for v in pw_seq:
         s_ = pr.seq[v]
-        L.append("  %s nxt_%d = %s, own_%d = %s;" % (T, v, ZERO, v, ZERO))
-        L.append("  if (owner && a.T > 0) nxt_%d = ((const %s*)a.seq[%d])[eb * a.seq_rs[%d] + en * a.seq_cs[%d]];"
+        L.append("  %s nxt_%d§ = %s, own_%d§ = %s;" % (T, v, ZERO, v, ZERO))
+        L.append("  if (owner§ && a.T > 0) nxt_%d§ = ((const %s*)a.seq[%d])[eb§ * a.seq_rs[%d] + en * a.seq_cs[%d]];"
                  % (v, T, s_, s_, s_))
     for ph in pr.phases:
         for o in ph["outs"]:
-            L.append("  %s own_%d = %s;" % (T, o, ZERO))
+            L.append("  %s own_%d§ = %s;" % (T, o, ZERO))
+    L[i_tpl:] = per_block(L[i_tpl:])
     L.append("  for (i64 t = 0; t < a.T; ++t) {")
     # the operand fragments are per-step values: declared here, one whose last product lies
     # before another's fetch lends it its registers (a gradient step fetches three, two at a time)
@@ -844,11 +872,12 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
             for s0 in range(0, spec.Ks[av] // 16, 16):
                 ops = ", ".join('"+v"(w%d_%d)' % (slot, s_) for s_ in range(s0, min(s0 + 16, spec.Ks[av] // 16)))
                 L.append('    asm volatile("" : %s);' % ops)
+    i_body = len(L)              # the step body: a template, instantiated per batch block below
     for v in pw_seq:
         s_ = pr.seq[v]
-        L.append("    own_%d = nxt_%d;" % (v, v))
-        L.append("    if (owner && t + 1 < a.T) nxt_%d = ((const %s*)a.seq[%d])[(t + 1) * a.seq_ts[%d] + "
-                 "eb * a.seq_rs[%d] + en * a.seq_cs[%d]];" % (v, T, s_, s_, s_, s_))
+        L.append("    own_%d§ = nxt_%d§;" % (v, v))
+        L.append("    if (owner§ && t + 1 < a.T) nxt_%d§ = ((const %s*)a.seq[%d])[(t + 1) * a.seq_ts[%d] + "
+                 "eb§ * a.seq_rs[%d] + en * a.seq_cs[%d]];" % (v, T, s_, s_, s_, s_))
     staged_this_step = set()
 
     def emit_mfma(pi, d, a_, x, after_q=None):
@@ -884,12 +913,12 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
             k_out = pr.state[x]
             L.append("    if (t == 0) {")
             L.append("      const %s* ini = (const %s*)a.out[%d] + ((a.out_pos0[%d] + a.out_store[%d] - 1) %% "
-                     "a.out_store[%d]) * a.out_ts[%d] + ((i64)bi * 16 + r16) * a.out_rs[%d] + wave * %d + grp * %d;"
+                     "a.out_store[%d]) * a.out_ts[%d] + ((i64)bi§ * 16 + r16) * a.out_rs[%d] + wave * %d + grp * %d;"
                      % (T, T, k_out, k_out, k_out, k_out, k_out, k_out, K // 4, K // 16))
             L.append("      const int c0 = wave * %d + grp * %d;" % (K // 4, K // 16))
             for q in range(Q):
                 L.append("      { %s v = {%s};" % (VT, ", ".join([ZERO] * PV)))
-                L.append("        if (r16 < vrows) { for (int e = 0; e < %d; ++e) if (c0 + %d + e < %d) v[e] = ini[%d + e]; }"
+                L.append("        if (r16 < vrows§) { for (int e = 0; e < %d; ++e) if (c0 + %d + e < %d) v[e] = ini[%d + e]; }"
                          % (PV, PV * q, spec.Nt, PV * q))
                 L.append("        fr%d[%d] = v; }" % (ki, q))
             # nothing of this path pending where the two meet: the compiler merges the two load
@@ -902,7 +931,7 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
             step_expr = "t"
         ind = "      "
         L.append(ind + "const unsigned long long want64 = (unsigned long long)(base + (unsigned)%s + 1u);" % step_expr)
-        L.append(ind + "const u64* fl = a.xch + %d + (%s & 3) * %d + (i64)bi * %d + wave * %d;"
+        L.append(ind + "const u64* fl = a.xch + %d + (%s & 3) * %d + (i64)bi§ * %d + wave * %d;"
                  % (fo_, step_expr, lpf, NJ, PW))
         L.append(ind + "for (int spin = 0;; ++spin) {")
         L.append(ind + "  bool ok = true;")
@@ -912,7 +941,7 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
                  "{ __hip_atomic_store(errp, 1u, %s); break; }" % (SPIN_LIMIT, AG, AG))
         L.append(ind + "  __builtin_amdgcn_s_sleep(1);")
         L.append(ind + "}")
-        L.append(ind + "const unsigned so_ = (unsigned)((%d + (%s & 3) * %d + (i64)bi * %d) * 8);"
+        L.append(ind + "const unsigned so_ = (unsigned)((%d + (%s & 3) * %d + (i64)bi§ * %d) * 8);"
                  % (po_, step_expr, lpp, 16 * K * ISZ // 8))
         for q in range(Q):
             L.append(ind + "{ const u4v g = __builtin_amdgcn_raw_buffer_load_b128(xr, ld_off + %du, so_, 16);"
@@ -929,7 +958,7 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
         L.append(ind + "const unsigned long long want64 = (unsigned long long)(base + (unsigned)t + 1u);")
         for n, (x, kind) in enumerate(ops):
             po_, lpp, fo_, lpf = xoff[pr.new_of_state.get(x, x)]
-            L.append(ind + "const u64* fl%d = a.xch + %d + (t & 3) * %d + (i64)bi * %d + wave * %d;"
+            L.append(ind + "const u64* fl%d = a.xch + %d + (t & 3) * %d + (i64)bi§ * %d + wave * %d;"
                      % (n, fo_, lpf, NJ, PW))
         L.append(ind + "for (int spin = 0;; ++spin) {")
         L.append(ind + "  bool ok = true;")
@@ -944,7 +973,7 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
         for n, (x, kind) in enumerate(ops):
             ki = keys.index((x, kind))
             po_, lpp, fo_, lpf = xoff[pr.new_of_state.get(x, x)]
-            L.append(ind + "const unsigned so%d_ = (unsigned)((%d + (t & 3) * %d + (i64)bi * %d) * 8);"
+            L.append(ind + "const unsigned so%d_ = (unsigned)((%d + (t & 3) * %d + (i64)bi§ * %d) * 8);"
                      % (n, po_, lpp, 16 * K * ISZ // 8))
             for q in range(Q):
                 L.append(ind + "{ const u4v g = __builtin_amdgcn_raw_buffer_load_b128(xr, ld_off + %du, so%d_, 16);"
@@ -1049,7 +1078,11 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
     for pi, ph in enumerate(pr.phases):
         L.append("    // ---- phase %d" % pi)
         if ph["dots"]:
-            L.append("    const int pp%d = (int)((t * %d + %d) & 1);" % (pi, len(dot_phases), dot_phases.index(pi)))
+            if NBLK == 1:
+                L.append("    const int pp%d = (int)((t * %d + %d) & 1);" % (pi, len(dot_phases), dot_phases.index(pi)))
+            else:       # product phases counted across the blocks of the workgroup
+                L.append("    const int pp%d = (int)((t * %d + ¤ * %d + %d) & 1);"
+                         % (pi, NBLK * len(dot_phases), len(dot_phases), dot_phases.index(pi)))
         stamp("p%d start" % pi)
         early, late, fresh = fetches[pi]
         if XW and pi == max(XW["win"]):
@@ -1111,14 +1144,14 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
         for d in range(D):
             L.append("    const %s dot_%d_%d = part[pp%d][%d][0][tid] + part[pp%d][%d][1][tid] + part[pp%d][%d][2][tid] + part[pp%d][%d][3][tid];"
                      % (T, pi, d, pi, d, pi, d, pi, d, pi, d))
-        L.append("    if (owner) {")
+        L.append("    if (owner§) {")
         ins = ["dot_%d_%d" % (pi, d) for d in range(D)] + \
-            [("0.f" if v in folded else "own_%d" % v) for v in ph["ins"]]     # folded: already in the dot
+            [("0.f" if v in folded else "own_%d§" % v) for v in ph["ins"]]     # folded: already in the dot
         lines, outs, odts = cg.emit_scalar_body(ph["scalar"], ins, [spec.dtype] * len(ins),
                                                 indent="      ", suffix="_p%d" % pi)
         L.extend(lines)
         for o, ri in zip(ph["outs"], ph["out_refs"]):
-            L.append("      own_%d = %s;" % (o, cg._cast(outs[ri], odts[ri], spec.dtype)))
+            L.append("      own_%d§ = %s;" % (o, cg._cast(outs[ri], odts[ri], spec.dtype)))
         L.append("    }")
         # publish first (the hand-off is the critical path), the stores into the output buffers after
         pending_pub.extend(o for o in ph["outs"] if o in xoff)
@@ -1128,20 +1161,20 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
             pending_pub = []
         for o in pub:
             po_, lpp, fo_, lpf = xoff[o]
-            L.append("    { const %s v0_ = owner ? own_%d : %s;" % (T, o, ZERO))
+            L.append("    { const %s v0_ = owner§ ? own_%d§ : %s;" % (T, o, ZERO))
             L.append("      " + " ".join("const %s v%d_ = shfl_down_<%s>(v0_, %d);" % (T, e, T, e) for e in range(1, PV)))
-            L.append("      if ((ecol & %d) == 0 && eb < %d) {" % (PV - 1, B))
+            L.append("      if ((ecol & %d) == 0 && eb§ < %d) {" % (PV - 1, B))
             L.append("        const %s pv = {%s};" % (VT, ", ".join("v%d_" % e for e in range(PV))))
             L.append("        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, pv), xr, pub_off, "
-                     "(unsigned)((%d + (t & 3) * %d + (i64)bi * %d) * 8), 16);" % (po_, lpp, 16 * K * ISZ // 8))
+                     "(unsigned)((%d + (t & 3) * %d + (i64)bi§ * %d) * 8), 16);" % (po_, lpp, 16 * K * ISZ // 8))
             L.append("      } }")
         if pub:
             stamp("p%d epilogue + payload stores issued" % pi)
-        L.append("    if (owner) {")
+        L.append("    if (owner§) {")
         for o in ph["outs"]:
             for _kind, j in out_of.get(o, []):
                 L.append("      ((%s*)a.out[%d])[((a.out_pos0[%d] + t) %% a.out_store[%d]) * a.out_ts[%d] + "
-                         "eb * a.out_rs[%d] + en] = own_%d;" % (T, j, j, j, j, j, o))
+                         "eb§ * a.out_rs[%d] + en] = own_%d§;" % (T, j, j, j, j, j, o))
         L.append("    }")
         if pub:
             L.append('    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");')
@@ -1149,7 +1182,7 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
             L.append("    __syncthreads();")
             for o in pub:
                 po_, lpp, fo_, lpf = xoff[o]
-                L.append("    if (tid == 0) __hip_atomic_store(a.xch + %d + (t & 3) * %d + (i64)bi * %d + nj, "
+                L.append("    if (tid == 0) __hip_atomic_store(a.xch + %d + (t & 3) * %d + (i64)bi§ * %d + nj, "
                          "(unsigned long long)(base + (unsigned)t + 1u), %s);" % (fo_, lpf, NJ, AG))
             stamp("p%d tag raised" % pi)
         elif D:
@@ -1158,7 +1191,16 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
             pass
     stamp("step end")
     for v, nv in pr.new_of_state.items():
-        L.append("    own_%d = own_%d;" % (v, nv))
+        L.append("    own_%d§ = own_%d§;" % (v, nv))
+    body = L[i_body:]
+    del L[i_body:]
+    for blk_ in range(NBLK):
+        sfx = "" if NBLK == 1 else "_b%d" % blk_
+        if NBLK > 1:
+            L.append("    {   // ---- batch block %d of this workgroup" % blk_)
+        L.extend(l.replace("§", sfx).replace("¤", str(blk_)) for l in body)
+        if NBLK > 1:
+            L.append("    }")
     L.append("  }")
     if spec.trace:
         L.append("  if (tr_on) { tr[%d] = __builtin_amdgcn_s_memtime(); tr[%d] = __builtin_amdgcn_s_memrealtime(); }"
