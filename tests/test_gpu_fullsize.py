@@ -535,8 +535,9 @@ def test_sort_and_argsort_rows_against_torch_stable_sort():
 
 @pytest.mark.parametrize("T,H,B,name", [(64, 256, 1, "gru_bptt_b1_f32"), (24, 128, 16, "gru_bptt_b4_f64"),
                                          (40, 256, 48, "gru_bptt_b4_f32"), (9, 64, 5, "gru_bptt_b4_f32"),
-                                         # more 16 x 16 tiles than CUs: two batch blocks per workgroup
-                                         (12, 1024, 128, "gru_bptt_b4_f32"), (10, 512, 256, "gru_bptt_b4_f32")])
+                                         # more 16 x 16 tiles than CUs: two (or four) batch blocks per workgroup
+                                         (12, 1024, 128, "gru_bptt_b4_f32"), (10, 512, 256, "gru_bptt_b4_f32"),
+                                         (6, 1024, 256, "gru_bptt_b4_f32")])      # four blocks
 def test_gru_bptt_against_torch_autograd(T, H, B, name):
     """SURVEY §8(f3) at a real shape: loss and gradients of the GRU recurrence (forward Scan +
     gradient Scan with mit-mot accumulators, lowered from aesara.grad) against torch.autograd of an
