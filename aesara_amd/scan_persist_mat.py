@@ -162,7 +162,7 @@ class SpecMat:
                            sorted(pr.state.items()), sorted(pr.nsq.items()), sorted(pr.mats.items()),
                            [[ph["dots"], ph["ins"], ph["outs"], ph["scalar"], ph["out_refs"]]
                             for ph in pr.phases], pr.outs, pr.exchanged, sorted(pr.tap_seq.items())] +
-                          ([["nblk", self.nblk]] if self.nblk != 1 else []),
+                          ([["nblk", self.nblk, os.environ.get("AESARA_HIP_SM_INTERLEAVE", "1")]] if self.nblk != 1 else []),
                           sort_keys=True)
         return hashlib.sha256(blob.encode()).hexdigest()[:24]
 
@@ -865,8 +865,24 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
     L.append("  for (i64 t = 0; t < a.T; ++t) {")
     # the operand fragments are per-step values: declared here, one whose last product lies
     # before another's fetch lends it its registers (a gradient step fetches three, two at a time)
+    # (several blocks per workgroup, phases interleaved: an operand used by a later phase too must
+    # survive the other blocks' fetches in between -> its own registers per block)
+    ph_of = {}
+    for pi_, ph_ in enumerate(pr.phases):
+        for _a, x_ in ph_["dots"]:
+            ph_of.setdefault((x_, "prev" if x_ in pr.state else "cur"), set()).add(pi_)
+    # measured (B = 128, H = 1024): the backward GRU kernel (every operand used by one phase)
+    # gains 11 % on the training step interleaved; the forward kernel (h feeds two phases: 64 more
+    # registers per block, and its early product already covered the wait) loses 5 % -> interleave
+    # only when no operand needs registers per block ("2" forces it, "0" turns it off)
+    ilv_env = os.environ.get("AESARA_HIP_SM_INTERLEAVE", "1")
+    ILV = NBLK > 1 and (ilv_env == "2" or (ilv_env == "1" and all(len(v_) == 1 for v_ in ph_of.values())))
+    frs = ["fr%d%s" % (ki, "§" if (ILV and len(ph_of[keys[ki]]) > 1) else "") for ki in range(len(keys))]
     for ki in range(len(keys)):
-        L.append("    %s fr%d[%d];" % (VT, ki, Q))
+        if frs[ki].endswith("§"):
+            L.extend(per_block(["    %s %s[%d];" % (VT, frs[ki], Q)]))
+        else:
+            L.append("    %s fr%d[%d];" % (VT, ki, Q))
     if spec.pin:
         for av, slot in sorted(pr.mats.items(), key=lambda t: t[1]):
             for s0 in range(0, spec.Ks[av] // 16, 16):
@@ -895,8 +911,8 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
         for q in range(Q):
             for e, c in enumerate("xyzw"[:PV]):
                 acc = "acc%d" % ((PV * q + e) & 1)
-                L.append("      %s = %s(fr%d[%d].%s, w%d_%d, %s, 0, 0, 0);"
-                         % (acc, MFMA, ki, q, c, slot, PV * q + e, acc))
+                L.append("      %s = %s(%s[%d].%s, w%d_%d, %s, 0, 0, 0);"
+                         % (acc, MFMA, frs[ki], q, c, slot, PV * q + e, acc))
             if after_q is not None:
                 after_q(q)
         # C/D rows of a lane: f32 16x16x4 -> 4 * grp + i ; f64 16x16x4 -> grp + 4 * i
@@ -920,7 +936,7 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
                 L.append("      { %s v = {%s};" % (VT, ", ".join([ZERO] * PV)))
                 L.append("        if (r16 < vrows§) { for (int e = 0; e < %d; ++e) if (c0 + %d + e < %d) v[e] = ini[%d + e]; }"
                          % (PV, PV * q, spec.Nt, PV * q))
-                L.append("        fr%d[%d] = v; }" % (ki, q))
+                L.append("        %s[%d] = v; }" % (frs[ki], q))
             # nothing of this path pending where the two meet: the compiler merges the two load
             # orders into an s_waitcnt vmcnt(0) in front of the SECOND MFMA of every step
             L.append("      __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)")
@@ -945,7 +961,7 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
                  % (po_, step_expr, lpp, 16 * K * ISZ // 8))
         for q in range(Q):
             L.append(ind + "{ const u4v g = __builtin_amdgcn_raw_buffer_load_b128(xr, ld_off + %du, so_, 16);"
-                     " fr%d[%d] = __builtin_bit_cast(%s, g); }" % (q * 64 * 16, ki, q, VT))
+                     " %s[%d] = __builtin_bit_cast(%s, g); }" % (q * 64 * 16, frs[ki], q, VT))
         L.append("    }")
 
     def emit_fetch_joint(pi, ops):
@@ -977,7 +993,7 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
                      % (n, po_, lpp, 16 * K * ISZ // 8))
             for q in range(Q):
                 L.append(ind + "{ const u4v g = __builtin_amdgcn_raw_buffer_load_b128(xr, ld_off + %du, so%d_, 16);"
-                         " fr%d[%d] = __builtin_bit_cast(%s, g); }" % (q * 64 * 16, n, ki, q, VT))
+                         " %s[%d] = __builtin_bit_cast(%s, g); }" % (q * 64 * 16, n, frs[ki], q, VT))
         L.append("    }")
 
     def window_begin(pi, x, kind):
@@ -1075,11 +1091,16 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
     # epilogue reads never meet the next product phase's writes, and the barrier of the phase in
     # between orders everything two phases apart — no barrier between hand-off and products
     dot_phases = [pi for pi, ph in enumerate(pr.phases) if ph["dots"]]
+    i_phase = []
     for pi, ph in enumerate(pr.phases):
+        i_phase.append(len(L))
         L.append("    // ---- phase %d" % pi)
         if ph["dots"]:
             if NBLK == 1:
                 L.append("    const int pp%d = (int)((t * %d + %d) & 1);" % (pi, len(dot_phases), dot_phases.index(pi)))
+            elif ILV:   # product events in program order: phase by phase, block by block
+                L.append("    const int pp%d = (int)((t * %d + %d + ¤) & 1);"
+                         % (pi, NBLK * len(dot_phases), NBLK * dot_phases.index(pi)))
             else:       # product phases counted across the blocks of the workgroup
                 L.append("    const int pp%d = (int)((t * %d + ¤ * %d + %d) & 1);"
                          % (pi, NBLK * len(dot_phases), len(dot_phases), dot_phases.index(pi)))
@@ -1189,12 +1210,25 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
             # no publish between this phase's `part` reads and the next writes of the same parity
             # two phases on: the products-done barrier of the next phase orders them
             pass
+    i_phase.append(len(L))
     stamp("step end")
     for v, nv in pr.new_of_state.items():
         L.append("    own_%d§ = own_%d§;" % (v, nv))
     body = L[i_body:]
     del L[i_body:]
-    for blk_ in range(NBLK):
+    if ILV:
+        # phase by phase over the blocks: while block b's hand-off is in flight the workgroup works
+        # on block b + 1 — by the time it comes back to b the tags are there (what the round-2
+        # review asked for; possible because batch blocks are independent recurrences)
+        cuts = [0] + [i - i_body for i in i_phase] + [len(body)]
+        for k in range(len(cuts) - 1):
+            seg = body[cuts[k]:cuts[k + 1]]
+            for blk_ in range(NBLK):
+                sfx = "_b%d" % blk_
+                L.append("    {   // ---- batch block %d" % blk_)
+                L.extend(l.replace("§", sfx).replace("¤", str(blk_)) for l in seg)
+                L.append("    }")
+    for blk_ in range(0 if ILV else NBLK):
         sfx = "" if NBLK == 1 else "_b%d" % blk_
         if NBLK > 1:
             L.append("    {   // ---- batch block %d of this workgroup" % blk_)
