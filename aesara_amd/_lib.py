@@ -127,6 +127,7 @@ SIGNATURES = {
     "ahip_elemwise": (i32, [vp, i32, p_i64, i32, p_vp, p_i64, i32, i32, vp]),
     "ahip_elemwise_tiled": (i32, [vp, i32, p_i64, i32, p_vp, p_i64, i32, i32, vp, vp, sz, vp]),
     "ahip_reduce_ws_bytes": (sz, []),
+    "ahip_reduce_partials_bytes": (sz, []),
     "ahip_elemwise_reduce_all": (i32, [vp, i32, p_i64, i32, p_vp, p_i64, i32, i32, vp, vp, sz,
                                        vp]),
     "ahip_set_param": (i32, [C.c_char_p, i64]),

@@ -22,6 +22,7 @@ import hashlib
 
 import numpy as np
 
+from . import knobs
 from ._lib import AHIP_MAXD, AHIP_MAXOPS
 
 CTYPE = {
@@ -184,6 +185,67 @@ __device__ __forceinline__ double log1mexp_(double x) { return x < -0.6931471805
 __device__ __forceinline__ float round_away(float x) { return x < 0 ? ceilf(x - 0.5f) : floorf(x + 0.5f); }
 __device__ __forceinline__ double round_away(double x) { return x < 0 ? ceil(x - 0.5) : floor(x + 0.5); }
 
+// ---- float64 exp through a 64-entry table (Tang's scheme; tools/gen_exp_table.py prints the
+// constants): x = (64 k + j) ln2/64 + r with |r| <= ln2/128, exp(x) = 2^k * T[j] * (1 + p(r)).
+// T = 2^(j/64) correctly rounded, one copy per wavefront in LDS (no barrier: a wave reads only
+// what it wrote).  |x| >= 708, infinities and NaN: the argument is clamped first and 2^k applied
+// by v_ldexp_f64 (denormal results, overflow, underflow), behind a rare branch.  Measured
+// against expl over 2e7 arguments: <= 1.02 ulp (the C library: 0.51, ocml's exp: 1).  Replaces
+// Exp.c_code (scalar/basic.py:3102) `exp(x)` for float64 only.
+__device__ const double AHIP_EXP2_64[64] = {
+  0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
+  0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
+  0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,
+  0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0,
+  0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0,
+  0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cd0p+0,
+  0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0,
+  0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0,
+  0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,
+  0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0,
+  0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e50p+0,
+  0x1.9c49182a3f090p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,
+  0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,
+  0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
+  0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
+  0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0,
+};
+__device__ __forceinline__ double exp_tbl64(double x, const double* tbl) {
+  const bool big = ((unsigned)__double2hiint(x) & 0x7fffffffu) >= 0x40862000u;   // |x| >= 708, inf, NaN
+  double xc = x;
+  if (__builtin_expect(big, 0)) {
+    asm volatile("" ::: "memory");   // rare: keep it a branch (no if-conversion into the hot path)
+    xc = fmin(fmax(x, -1000.0), 1000.0);
+  }
+  double s;                                                     // x * 64/ln2 + 1.5 * 2^52: k lands in the low word
+  asm("v_fma_f64 %%0, %%1, %%2, %%3" : "=v"(s) : "v"(xc), "v"(0x1.71547652b82fep+6), "s"(0x1.8p+52));
+  const int ki = __double2loint(s);
+  const double kd = s - 0x1.8p+52;
+  double r = fma(kd, -0x1.62e42ff000000p-7, xc);                // k * C1 is exact (33-bit C1)
+  r = fma(kd, 0x1.718432a1b0e26p-41, r);
+  const double T = tbl[ki & 63];
+  const double r2 = r * r;
+  // Horner steps with a constant addend as three-address v_fma_f64 with the constant in an
+  // SGPR pair (the compiler's two-address v_fmac_f64 copies the constant into the destination
+  // first: one v_mov_b64 per step)
+  double q;
+  asm("v_fma_f64 %%0, %%1, %%2, %%3" : "=v"(q) : "v"(r), "s"(0x1.11111d8fbe766p-7), "v"(0x1.55556b3304ec0p-5));
+  asm("v_fma_f64 %%0, %%1, %%2, %%3" : "=v"(q) : "v"(q), "v"(r), "s"(0x1.5555555555255p-3));
+  asm("v_fma_f64 %%0, %%1, %%2, %%3" : "=v"(q) : "v"(q), "v"(r), "s"(0x1.ffffffffff57fp-2));
+  const double p = fma(r2, q, r);
+  const double m = fma(T, p, T);                                // T * e^r, in [0.99, 2.01)
+  // |x| < 708: the result is a normal number and 2^k is an add into the exponent field
+  int hi;
+  asm("v_lshl_add_u32 %%0, %%1, 14, %%2" : "=v"(hi) : "v"(ki & ~63), "v"(__double2hiint(m)));
+  double res = __hiloint2double(hi, __double2loint(m));
+  if (__builtin_expect(big, 0)) {
+    asm volatile("" ::: "memory");
+    res = ldexp(m, ki >> 6);        // denormal results, overflow to inf, underflow to 0
+    if (x != x) res = x;
+  }
+  return res;
+}
+
 // ---- cross-lane reduction plumbing (64-wide wavefronts) ----
 template <typename T> __device__ __forceinline__ T shfl_xor_(T v, int m) {
   if constexpr (sizeof(T) == 8) {
@@ -194,6 +256,34 @@ template <typename T> __device__ __forceinline__ T shfl_xor_(T v, int m) {
     union { T t; int i; } u; u.t = v; u.i = __shfl_xor(u.i, m, 64); return u.t;
   } else {
     int i = (int)v; i = __shfl_xor(i, m, 64); return (T)i;
+  }
+}
+// DPP move of a whole value (32-bit pieces): ctrl 0xB1 / 0x4E = quad_perm [1,0,3,2] / [2,3,0,1],
+// 0x141 = row_half_mirror, 0x140 = row_mirror.  After combining with these four in turn every lane
+// of a 16-lane row holds the row's fold; lane_get_ then reads the four row leaders (uniform).
+template <typename T, int CTRL> __device__ __forceinline__ T dpp_mov_(T v) {
+  if constexpr (sizeof(T) == 8) {
+    union { T t; int i[2]; } u; u.t = v;
+    u.i[0] = __builtin_amdgcn_update_dpp(u.i[0], u.i[0], CTRL, 0xf, 0xf, false);
+    u.i[1] = __builtin_amdgcn_update_dpp(u.i[1], u.i[1], CTRL, 0xf, 0xf, false);
+    return u.t;
+  } else if constexpr (sizeof(T) == 4) {
+    union { T t; int i; } u; u.t = v;
+    u.i = __builtin_amdgcn_update_dpp(u.i, u.i, CTRL, 0xf, 0xf, false);
+    return u.t;
+  } else {
+    int i = (int)v; i = __builtin_amdgcn_update_dpp(i, i, CTRL, 0xf, 0xf, false); return (T)i;
+  }
+}
+template <typename T> __device__ __forceinline__ T lane_get_(T v, int lane) {
+  if constexpr (sizeof(T) == 8) {
+    union { T t; int i[2]; } u; u.t = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], lane); u.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
+    return u.t;
+  } else if constexpr (sizeof(T) == 4) {
+    union { T t; int i; } u; u.t = v; u.i = __builtin_amdgcn_readlane(u.i, lane); return u.t;
+  } else {
+    int i = (int)v; i = __builtin_amdgcn_readlane(i, lane); return (T)i;
   }
 }
 """ % (AHIP_MAXD, AHIP_MAXOPS)
@@ -387,11 +477,12 @@ def invariant_nodes(scalar, inv_inputs):
 
 
 def emit_scalar_body(scalar, in_exprs, in_dts, indent="      ", suffix="", hoisted=None,
-                     only=None):
+                     only=None, exp_tbl=None):
     """Lines computing the temporaries of a plan scalar expression; returns (lines, out_exprs,
     out_dtypes).  ``hoisted``: {node index: (name, recip_name | None)} of temporaries already
     computed before the loop (loop-invariant sub-expressions); ``only``: restrict emission to
-    that set of nodes (used to emit the invariant prologue itself)."""
+    that set of nodes (used to emit the invariant prologue itself); ``exp_tbl``: name of the
+    wave's 2^(j/64) table in LDS — float64 ``exp`` nodes then go through ``exp_tbl64``."""
     lines = []
     tdt = [n["dtype"] for n in scalar["nodes"]]
     hoisted = hoisted or {}
@@ -417,6 +508,8 @@ def emit_scalar_body(scalar, in_exprs, in_dts, indent="      ", suffix="", hoist
             # reciprocal (q = x*r; q += r*fma(-q, c, x)) instead of the full v_div_* sequence
             e = "fdiv_inv(%s, %s, %s)" % (_cast(refs[0][0], refs[0][1], dt), refs[1][0],
                                           hoisted[div[1]][1])
+        elif exp_tbl and n["op"] == "exp" and dt == "float64":
+            e = "exp_tbl64(%s, %s)" % (_cast(refs[0][0], refs[0][1], dt), exp_tbl)
         else:
             e = scalar_node_expr(n["op"], [x[0] for x in refs], [x[1] for x in refs], dt)
         lines.append("%sconst %s t%d%s = %s;" % (indent, RTYPE[dt], k, suffix, e))
@@ -503,8 +596,23 @@ class KernelSpec:
     """
 
     def __init__(self, scalar, in_dtypes, out_dtypes, out_refs, inner, nd, vec, block=256,
-                 idx64=False, reduce=None, unroll=1, nt=False, invariant=None, tile_dim=None, pipe=0):
+                 idx64=False, reduce=None, unroll=1, nt=False, invariant=None, tile_dim=None, pipe=0,
+                 early=None, blocked=None, trace=None, fast_exp=None):
         self.scalar = scalar
+        flat_all = (reduce is not None and reduce.get("kind") == "all" and tile_dim is None
+                    and nd == 1 and vec > 1)
+        # flat full reductions: the first group of loads is issued before the invariant prologue
+        # (its dependent scalar loads and the reciprocal would otherwise delay them ~0.3 us)
+        self.early = bool(knobs.get("EARLY") if early is None else early) and flat_all and not pipe
+        # one contiguous chunk of the stream per workgroup instead of a grid-stride walk
+        self.blocked = int(knobs.get("RED_BLOCKED") if blocked is None else blocked) if flat_all else 0
+        # per-workgroup s_memrealtime stamps into the reduce workspace (tools/ew_trace.py)
+        self.trace = bool(knobs.get("EW_TRACE") if trace is None else trace) and \
+            reduce is not None and reduce.get("kind") == "all" and tile_dim is None
+        # float64 exp through the LDS table (exp_tbl64); only where the scalar program has one
+        self.fast_exp = bool(knobs.get("FASTEXP") if fast_exp is None else fast_exp) and \
+            tile_dim is None and any(n["op"] == "exp" and n["dtype"] == "float64"
+                                     for n in scalar["nodes"])
         # flat 1-d streams only: ping-pong software pipeline — the loads of the NEXT group of
         # `unroll` vectors are in flight while the current group is evaluated (every wave keeps
         # loads outstanding through its ALU phase, which a load-all / compute-all body does not)
@@ -531,14 +639,18 @@ class KernelSpec:
     def key(self):
         fields = [self.in_dtypes, self.out_dtypes, self.out_refs, self.inner, self.nd, self.vec,
                   self.block, self.idx64, self.reduce, self.unroll, self.nt, self.invariant,
-                  self.tile_dim, "v11" if self.tile_dim else "v10"] + (["pipe"] if self.pipe else [])
+                  self.tile_dim, "v11" if self.tile_dim else "v10", self._variant()] + \
+            (["pipe"] if self.pipe else [])
         return _memo_key([self.scalar], fields, self._key)
+
+    def _variant(self):
+        return "r4%d%d%d%d" % (self.early, self.blocked, self.trace, self.fast_exp)
 
     def _key(self):
         import json
         blob = json.dumps([self.scalar, self.in_dtypes, self.out_dtypes, self.out_refs,
                            self.inner, self.nd, self.vec, self.block, self.idx64, self.reduce,
-                           self.unroll, self.nt, self.invariant, "v10"] +
+                           self.unroll, self.nt, self.invariant, "v10", self._variant()] +
                           ([["tile2", self.tile_dim]] if self.tile_dim is not None else []) +
                           (["pipe"] if self.pipe else []),
                           sort_keys=True)
@@ -570,10 +682,15 @@ def _offset_code(spec, nops, nd_lo, nd_hi, var, idx_t, inner_vecs=None):
     return L
 
 
-def _kernel_prologue(spec, name, L):
+TRACE_SLOTS = 8          # 8-byte stamps per workgroup of an EW_TRACE build (after the 4 KiB tail of ws)
+
+
+def _kernel_prologue(spec, name, L, mid=None, pre=None):
     """Kernel head shared by generate / generate_tiled: operand pointers, accumulator, and the
     loop-invariant part (scalar operands, sub-expressions of them, reciprocals of invariant
-    divisors).  Returns (hoisted, inv_in) for emit_scalar_body."""
+    divisors).  ``pre(L)`` / ``mid(L)`` may emit code right after the operand pointers (index
+    arithmetic on kernel arguments) and after the small loads of the head (the early first loads
+    of a flat reduction).  Returns (hoisted, inv_in) for emit_scalar_body."""
     nin = len(spec.in_dtypes)
     nout = len(spec.out_dtypes)
     nops = nin + nout
@@ -593,16 +710,22 @@ def _kernel_prologue(spec, name, L):
             if spec.inner[k] == "s":
                 L.append("  const i64 is%d = a.stride[%d][%d];" % (k, k, spec.nd - 1))
 
-    if red is not None:
-        acc_t = RTYPE[red["acc"]]
-        L.append("  %s acc = %s;" % (acc_t, red_identity(red["op"], red["acc"])))
-        if red["kind"] == "all":
-            # launch epoch of the finalize (read early: its latency hides under the streaming loop)
-            L.append("  const unsigned ep0 = __hip_atomic_load((unsigned*)((char*)a.ws + a.aux1 + 2048 + 64), "
-                     "__ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);")
-
-    # loop-invariant prologue: scalar operands are loaded once, sub-expressions that depend only
-    # on them are computed once per thread, and reciprocals of invariant divisors are hoisted
+    if getattr(spec, "trace", False):
+        L.append("  unsigned long long* const tr_ = (unsigned long long*)((char*)a.ws + a.aux1 + 4096) + "
+                 "%d * (size_t)blockIdx.x;" % TRACE_SLOTS)
+        L.append("  if (threadIdx.x == 0) { tr_[0] = __builtin_readcyclecounter(); tr_[1] = wall_clock64(); "
+                 "unsigned hw_; asm volatile(\"s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\" : \"=s\"(hw_)); "
+                 "unsigned xcc_; asm volatile(\"s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)\" : \"=s\"(xcc_)); "
+                 "tr_[7] = ((unsigned long long)xcc_ << 32) | hw_; }")
+    # every load the head of the kernel depends on is ISSUED before anything waits: the small
+    # ones first (exp-table entry, scalar operands, launch epoch: they come back from the
+    # memory-side cache), then — ``mid`` — the first group of a flat reduction's stream, so the
+    # invariant arithmetic below runs while the stream's first bytes are in flight
+    if pre is not None:
+        pre(L)
+    fast_exp = getattr(spec, "fast_exp", False)
+    if fast_exp:
+        L.append("  const double etv_ = AHIP_EXP2_64[threadIdx.x & 63];")
     hoisted = {}
     inv_in = {}
     if any(spec.invariant):
@@ -611,6 +734,27 @@ def _kernel_prologue(spec, name, L):
                 e = "xinv%d" % k
                 L.append("  const %s %s = p%d[0];" % (CTYPE[spec.in_dtypes[k]], e, k))
                 inv_in[k] = "(%s != 0)" % e if spec.in_dtypes[k] == "bool" else e
+    if red is not None and red["kind"] == "all":
+        # launch epoch of the finalize (read early: its latency hides under the streaming loop)
+        L.append("  const unsigned ep0 = __hip_atomic_load((unsigned*)((char*)a.ws + a.aux1 + 2048 + 64), "
+                 "__ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);")
+    if mid is not None:
+        mid(L)
+    if fast_exp:
+        # one copy of the 2^(j/64) table per wavefront: lane j writes entry j of its wave's copy
+        # and the wave reads only that copy, so there is no workgroup barrier (LDS operations of
+        # one wave complete in order; the asm keeps the compiler from moving reads above it)
+        L.append("  __shared__ double exptbl_[%d];" % spec.block)
+        L.append("  exptbl_[threadIdx.x] = etv_;")
+        L.append("  asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");")
+        L.append("  const double* const etbl_ = exptbl_ + (threadIdx.x & ~63u);")
+    if red is not None:
+        acc_t = RTYPE[red["acc"]]
+        L.append("  %s acc = %s;" % (acc_t, red_identity(red["op"], red["acc"])))
+
+    # loop-invariant prologue: sub-expressions that depend only on scalar operands are computed
+    # once per thread, and reciprocals of invariant divisors are hoisted
+    if any(spec.invariant):
         inv_nodes = invariant_nodes(spec.scalar, spec.invariant)
         if inv_nodes:
             ins0 = [inv_in.get(k, "0") for k in range(nin)]
@@ -631,97 +775,145 @@ def _kernel_prologue(spec, name, L):
 
 
 REDUCE_ERR_OFF = 128     # error word of the in-kernel finalize: bytes past the shard sums (epoch at +64)
+REDUCE_HOSTFLAG_OFF = 192  # 8-byte pointer to a host-mapped (pinned) flag the failing launch also raises
+
+
+def wave_fold_lines(acc_t, comb, var="acc", indent="    "):
+    """Fold `var` over the 64 lanes of a wavefront in a fixed tree, without LDS round trips: four
+    DPP steps leave every lane of a 16-lane row with the row's fold, the four row leaders are
+    then combined in lane order (uniform reads).  Every lane ends with the wave's fold."""
+    out = []
+    for ctrl in ("0xB1", "0x4E", "0x141", "0x140"):
+        out.append("%s%s = %s;" % (indent, var, comb(var, "dpp_mov_<%s, %s>(%s)" % (acc_t, ctrl, var))))
+    rows = ["lane_get_<%s>(%s, %d)" % (acc_t, var, 16 * r) for r in range(4)]
+    out.append("%s%s = %s;" % (indent, var, comb(comb(comb(rows[0], rows[1]), rows[2]), rows[3])))
+    return out
+
+
+COLLECT_K = 4            # partials per lane per polling round of the finalize (8 granule loads in flight;
+#                          8 per lane would put the kernel above 64 VGPRs = one 1024-thread workgroup per CU)
 
 
 def _reduce_all_finalize(spec, red, L):
     """Deterministic in-kernel finalize of a full reduction (appended after the streaming loop:
-    `acc` holds the thread's partial)."""
+    `acc` holds the thread's partial).
+
+    ONE hop on a static tree, no tickets and no fences: every workgroup folds its threads (DPP
+    inside a wavefront, the waves in order through LDS) and publishes its partial as two
+    epoch-tagged 8-byte granules {hi32 | epoch}, {lo32 | epoch} (agent-scope write-through
+    stores, single-copy atomic).  Workgroup 0 then collects: wavefront w takes the partials
+    [256 w, 256 w + 256), four per lane and all eight granule loads of a lane in flight at
+    once, re-reading until every tag carries this launch's epoch; lanes fold their four in index
+    order, the wave folds by DPP, the collecting waves in order through LDS (the other waves of
+    workgroup 0 have exited: the barrier counts live waves only).  With the default 1024-thread
+    workgroups a launch has <= 512 partials: two wavefronts collect side by side and the critical
+    path after the last workgroup has streamed is one store -> load visibility latency.  The
+    workspace is zero-initialised once; epoch 0 never matches a live tag; every spin is bounded
+    and a partial that never arrives raises the error word (a float result is NaN)."""
     acc_t = RTYPE[red["acc"]]
     sm_t = acc_t if acc_t != "bool" else "unsigned char"
     comb = lambda a_, b_: red_combine(red["op"], red["acc"], a_, b_)  # noqa: E731
-    wave_red = ["  for (int m = 32; m > 0; m >>= 1) acc = %s;" %
-                comb("acc", "shfl_xor_<%s>(acc, m)" % acc_t)]
-    # K2 single pass, two-level deterministic finalize on a STATIC tree, no tickets:
-    #   every workgroup publishes its 8-byte partial as two epoch-tagged granules
-    #   {hi32 | epoch}, {lo32 | epoch} (8-byte agent-scope stores: single-copy atomic,
-    #   write-through).  The first workgroup of each run of 32 consecutive workgroups
-    #   re-reads its siblings' granules until they carry this launch's epoch, folds them
-    #   in index order and publishes the shard sum the same way; workgroup 0 does the
-    #   same over the shard sums, stores the result and advances the epoch.  Critical
-    #   path after the last workgroup finishes: granule store -> read -> fold -> granule
-    #   store -> read -> fold (two visibility latencies — one when the grid is small enough
-    #   for workgroup 0 to hold a thread per partial; the ticket form had five
-    #   dependent round trips).  Combiners are 1/32 of the grid, so spinning ones can
-    #   never starve the workgroups they wait for; every spin is bounded.  The workspace
-    #   is zero-initialised once and epoch 0 never matches a live tag.
     nw = spec.block // 64
     AG = "__ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT"
-    SH = 32
+    K = COLLECT_K
     ident = red_identity(red["op"], red["acc"])
+    tr = getattr(spec, "trace", False)
 
     L.append("  __shared__ %s sm[%d];" % (sm_t, nw))
     L.append("  unsigned long long* wsp = (unsigned long long*)a.ws;")
-    L.append("  unsigned long long* shard_sum = (unsigned long long*)((char*)a.ws + a.aux1);")
     L.append("  unsigned* epochp = (unsigned*)((char*)a.ws + a.aux1 + 2048 + 64);")
     L.append("  unsigned* errp = (unsigned*)((char*)a.ws + a.aux1 + 2048 + %d);" % REDUCE_ERR_OFF)
     L.append("  const unsigned ep = ep0 + 1u;")
-    L.append("  auto publish = [&](unsigned long long* slot, %s v) {" % acc_t)
-    L.append("    union { unsigned long long u; %s v; } cv; cv.u = 0; cv.v = v;" % acc_t)
-    L.append("    __hip_atomic_store(slot, ((cv.u >> 32) << 32) | ep, %s);" % AG)
-    L.append("    __hip_atomic_store(slot + 1, (cv.u << 32) | ep, %s);" % AG)
-    L.append("  };")
-    L.append("  auto collect = [&](unsigned long long* slot) -> %s {" % acc_t)
-    L.append("    unsigned long long g0 = 0, g1 = 0;")
+    L.append("  const unsigned wv_ = threadIdx.x >> 6, ln_ = threadIdx.x & 63u;")
+    # workgroup partial: wave folds, then the waves in order
+    L.append("  {")
+    L.extend(wave_fold_lines(acc_t, comb))
+    if nw > 1:
+        L.append("    if (ln_ == 0) sm[wv_] = acc;")
+        L.append("    __syncthreads();")
+    L.append("    if (threadIdx.x == 0) {")
+    if nw > 1:
+        L.append("      %s r = sm[0];" % acc_t)
+        L.append("      for (int w = 1; w < %d; ++w) r = %s;" % (nw, comb("r", "(%s)sm[w]" % acc_t)))
+    else:
+        L.append("      %s r = acc;" % acc_t)
+    L.append("      union { unsigned long long u; %s v; } cv; cv.u = 0; cv.v = r;" % acc_t)
+    L.append("      unsigned long long* slot = wsp + 2 * (size_t)blockIdx.x;")
+    L.append("      __hip_atomic_store(slot, ((cv.u >> 32) << 32) | ep, %s);" % AG)
+    L.append("      __hip_atomic_store(slot + 1, (cv.u << 32) | ep, %s);" % AG)
+    if tr:
+        L.append("      tr_[4] = wall_clock64();")
+    L.append("    }")
+    L.append("  }")
+    L.append("  if (blockIdx.x != 0) return;")
+    # ---- workgroup 0: collect
+    L.append("  const unsigned G_ = gridDim.x;")
+    L.append("  const unsigned ncol_ = (G_ + %du) / %du < %du ? (G_ + %du) / %du : %du;   // collecting waves" %
+             (64 * K - 1, 64 * K, nw, 64 * K - 1, 64 * K, nw))
+    L.append("  const bool one_wave = ncol_ <= 1u;")
+    L.append("  if (wv_ >= ncol_) return;")
+    if nw > 1:
+        L.append("  if (!one_wave) __syncthreads();        // sm[] is reused below (live waves only)")
+    L.append("  acc = %s;" % ident)
+    L.append("  for (unsigned c0 = wv_ * %du; c0 < G_; c0 += %du) {" % (64 * K, 64 * K * nw))
+    L.append("    unsigned long long g0[%d], g1[%d];" % (K, K))
     L.append("    bool seen = false;")
     L.append("    for (int spin = 0; spin < (1 << 24); ++spin) {")
-    L.append("      g0 = __hip_atomic_load(slot, %s);" % AG)
-    L.append("      g1 = __hip_atomic_load(slot + 1, %s);" % AG)
-    L.append("      if ((unsigned)g0 == ep && (unsigned)g1 == ep) { seen = true; break; }")
+    L.append("      bool all_ = true;")
+    L.append("#pragma unroll")
+    L.append("      for (int k = 0; k < %d; ++k) {" % K)
+    L.append("        const unsigned idx = c0 + (unsigned)k * 64u + ln_;")
+    L.append("        if (idx < G_) {")
+    L.append("          g0[k] = __hip_atomic_load(wsp + 2 * (size_t)idx, %s);" % AG)
+    L.append("          g1[k] = __hip_atomic_load(wsp + 2 * (size_t)idx + 1, %s);" % AG)
+    L.append("        }")
+    L.append("      }")
+    L.append("#pragma unroll")
+    L.append("      for (int k = 0; k < %d; ++k) {" % K)
+    L.append("        const unsigned idx = c0 + (unsigned)k * 64u + ln_;")
+    L.append("        if (idx < G_) all_ = all_ && (unsigned)g0[k] == ep && (unsigned)g1[k] == ep;")
+    L.append("      }")
+    L.append("      if (all_) { seen = true; break; }")
+    L.append("      __builtin_amdgcn_s_sleep(1);")
     L.append("    }")
     # a partial that never arrived (the producing workgroup starved for ~2^24 polls: a device
-    # shared with something that never yields) must not become a silently wrong sum: the error
-    # word is what the host reports (executor.check / deferred check), a float result is NaN
-    L.append("    if (!seen) __hip_atomic_store(errp, 1u, %s);" % AG)
-    L.append("    union { unsigned long long u; %s v; } cv; cv.u = ((g0 >> 32) << 32) | (g1 >> 32);" % acc_t)
-    L.append("    return cv.v;")
-    L.append("  };")
-    # fold `acc` over the workgroup in a fixed tree (wave shuffles, then the waves in
-    # order); the result is valid in thread 0
-    L.append("  auto block_fold = [&]() -> %s {" % acc_t)
-    L.extend("  " + x for x in wave_red)
-    L.append("    __syncthreads();")
-    L.append("    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;")
-    L.append("    __syncthreads();")
-    L.append("    %s r = sm[0];" % acc_t)
-    L.append("    for (int w = 1; w < %d; ++w) r = %s;" % (nw, comb("r", "(%s)sm[w]" % acc_t)))
-    L.append("    return r;")
-    L.append("  };")
-    L.append("  {")
-    L.append("    const %s part = block_fold();" % acc_t)
-    L.append("    if (threadIdx.x == 0) publish(wsp + 2 * (size_t)blockIdx.x, part);")
+    # shared with something that never yields) must not become a silently wrong sum: the launch
+    # tags the device error word with ITS epoch (so only its own float result becomes NaN: later
+    # launches carry other epochs and nothing has to be cleared) and raises a flag in pinned host
+    # memory, which the executor looks at after every call without touching the device
+    L.append("    if (!seen) {")
+    L.append("      __hip_atomic_store(errp, ep, %s);" % AG)
+    L.append("      unsigned* hostp = *(unsigned* volatile*)((char*)a.ws + a.aux1 + 2048 + %d);" % REDUCE_HOSTFLAG_OFF)
+    L.append("      if (hostp) __hip_atomic_store(hostp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);")
+    L.append("    }")
+    L.append("#pragma unroll")
+    L.append("    for (int k = 0; k < %d; ++k) {" % K)
+    L.append("      const unsigned idx = c0 + (unsigned)k * 64u + ln_;")
+    L.append("      if (idx < G_) {")
+    L.append("        union { unsigned long long u; %s v; } cv; cv.u = ((g0[k] >> 32) << 32) | (g1[k] >> 32);" % acc_t)
+    L.append("        acc = %s;" % comb("acc", "cv.v"))
+    L.append("      }")
+    L.append("    }")
     L.append("  }")
-    # one level when a single workgroup has a thread per partial, else shards of SH
-    L.append("  const bool one_level = gridDim.x <= %du;" % spec.block)
-    L.append("  if (one_level) {")
-    L.append("    if (blockIdx.x != 0) return;")
-    L.append("    acc = threadIdx.x < gridDim.x ? collect(wsp + 2 * (size_t)threadIdx.x) : %s;" % ident)
-    L.append("  } else {")
-    L.append("    if (blockIdx.x %% %du != 0) return;" % SH)
-    L.append("    acc = (threadIdx.x < %du && blockIdx.x + threadIdx.x < gridDim.x)" % SH)
-    L.append("        ? collect(wsp + 2 * (size_t)(blockIdx.x + threadIdx.x)) : %s;" % ident)
-    L.append("    const %s ssum = block_fold();" % acc_t)
-    L.append("    if (threadIdx.x == 0) publish(shard_sum + 2 * (size_t)(blockIdx.x / %du), ssum);" % SH)
-    L.append("    if (blockIdx.x != 0) return;")
-    L.append("    const unsigned nsh = (gridDim.x + %du) / %du;" % (SH - 1, SH))
-    L.append("    acc = threadIdx.x < nsh ? collect(shard_sum + 2 * (size_t)threadIdx.x) : %s;" % ident)
-    L.append("  }")
+    if tr:
+        L.append("  if (threadIdx.x == 0) tr_[5] = wall_clock64();")
     L.append("  {")
-    L.append("    %s r = block_fold();" % acc_t)
+    L.extend(wave_fold_lines(acc_t, comb))
+    if nw > 1:
+        L.append("    if (!one_wave) {")
+        L.append("      if (ln_ == 0) sm[wv_] = acc;")
+        L.append("      __syncthreads();")
+        L.append("      acc = sm[0];")
+        L.append("      for (unsigned w = 1; w < ncol_; ++w) acc = %s;" % comb("acc", "(%s)sm[w]" % acc_t))
+        L.append("    }")
     L.append("    if (threadIdx.x == 0) {")
+    L.append("      %s r = acc;" % acc_t)
     if _is_float(red["acc"]):
-        L.append("      if (__hip_atomic_load(errp, %s) != 0u) r = (%s)__builtin_nan(\"\");" % (AG, acc_t))
+        L.append("      if (__hip_atomic_load(errp, %s) == ep) r = (%s)__builtin_nan(\"\");" % (AG, acc_t))
     L.append("      *(%s*)a.out = %s;" % (CTYPE[red["out"]], _store_val("r", red["acc"], red["out"])))
     L.append("      __hip_atomic_store(epochp, ep, %s);" % AG)
+    if tr:
+        L.append("      tr_[6] = wall_clock64();")
     L.append("    }")
     L.append("  }")
 
@@ -853,24 +1045,83 @@ def generate(spec: KernelSpec):
     red = spec.reduce
     name = "ew_" + spec.key()
     L = []
-    hoisted, inv_in = _kernel_prologue(spec, name, L)
+    etbl = "etbl_" if spec.fast_exp else None
+    flat_u = (red is None or red["kind"] == "all") and spec.nd == 1 and U > 1 and not (
+        spec.pipe and V > 1)
+    early = spec.early and flat_u
+    inv_set = {k for k in range(nin) if spec.invariant[k]}
 
-    def loads(elem_off_exprs, sfx=""):
+    def index_setup(L_):
+        # the walk over the items (vectors of V elements): grid-stride, or (blocked) one
+        # contiguous chunk per workgroup, rounded to whole groups of U vectors per thread
+        L_.append("  const %s inner_vecs = (%s)(a.shape[%d] / %d);" % (idx_t, idx_t, spec.nd - 1, V))
+        if spec.blocked:
+            L_.append("  const %s items_all = (%s)(a.n / %d);" % (idx_t, idx_t, V))
+            L_.append("  const %s chunk_ = ((items_all + (%s)gridDim.x - 1) / (%s)gridDim.x + %d) / %d * %d;" %
+                      (idx_t, idx_t, idx_t, spec.block * U - 1, spec.block * U, spec.block * U))
+            if spec.blocked == 2:
+                # workgroup b runs on XCD b % 8 (observed dispatch order, a speed hint only): give
+                # every XCD one contiguous eighth of the stream, so an XCD's L2 / TLB sees 1/8 of
+                # the pages instead of all of them
+                L_.append("  const unsigned vb_ = (gridDim.x % 8u == 0u) ? (blockIdx.x % 8u) * (gridDim.x / 8u) + "
+                          "blockIdx.x / 8u : blockIdx.x;")
+            else:
+                L_.append("  const unsigned vb_ = blockIdx.x;")
+            L_.append("  const %s beg_ = (%s)vb_ * chunk_;" % (idx_t, idx_t))
+            L_.append("  const %s items = beg_ + chunk_ < items_all ? beg_ + chunk_ : items_all;" % idx_t)
+            L_.append("  const %s step = %d;" % (idx_t, spec.block))
+            L_.append("  %s item = beg_ + threadIdx.x;" % idx_t)
+        else:
+            L_.append("  const %s items = (%s)(a.n / %d);" % (idx_t, idx_t, V))
+            L_.append("  const %s step = (%s)gridDim.x * %d;" % (idx_t, idx_t, spec.block))
+            L_.append("  %s item = (%s)blockIdx.x * %d + threadIdx.x;" % (idx_t, idx_t, spec.block))
+
+    flat = [{"c": "(i64)%%s * %d" % V, "b": "0", "s": "(i64)%%s * is%d" % k}[spec.inner[k]]
+            for k in range(nops)]
+
+    def loads(elem_off_exprs, sfx="", decl=True):
         B = []
         for k in range(nin):
             ct = CTYPE[spec.in_dtypes[k]]
             cls = spec.inner[k]
-            if k in inv_in:
+            if k in inv_set:
                 continue
             if cls == "c" and V > 1:
                 ptr = "(const Pack<%s, %d>*)(p%d + %s)" % (ct, V, k, elem_off_exprs[k])
+                head = "const Pack<%s, %d> " % (ct, V) if decl else ""
                 if int(spec.nt) & 1:
-                    B.append("      const Pack<%s, %d> x%d%s = nt_load(%s);" % (ct, V, k, sfx, ptr))
+                    B.append("      %sx%d%s = nt_load(%s);" % (head, k, sfx, ptr))
                 else:
-                    B.append("      const Pack<%s, %d> x%d%s = *%s;" % (ct, V, k, sfx, ptr))
+                    B.append("      %sx%d%s = *%s;" % (head, k, sfx, ptr))
             else:
-                B.append("      const %s x%d%s = p%d[%s];" % (ct, k, sfx, k, elem_off_exprs[k]))
+                B.append("      %sx%d%s = p%d[%s];" % ("const %s " % ct if decl else "", k, sfx, k,
+                                                     elem_off_exprs[k]))
         return B
+
+    def early_loads(L_):
+        # the first group of U vectors per lane, issued straight after the kernel arguments: the
+        # invariant prologue below (dependent scalar loads of mu / sigma, a full-precision
+        # reciprocal, the exp table) then runs while they are in flight
+        for u in range(U):
+            for k in range(nin):
+                if k in inv_set:
+                    continue
+                ct = CTYPE[spec.in_dtypes[k]]
+                L_.append("  %s x%d_e%d;" % ("Pack<%s, %d>" % (ct, V) if spec.inner[k] == "c" and V > 1
+                                              else ct, k, u))
+        # issued unconditionally, at clamped positions (no branch: the compiler then knows how
+        # many loads are outstanding and waits for the exp table / scalars only); an empty
+        # operand is re-pointed at the workspace by the launcher, so position 0 is always readable
+        L_.append("  const bool first_ = item + %d * step < items;" % (U - 1))
+        L_.append("  const %s last_ = items > 0 ? items - 1 : 0;" % idx_t)
+        for u in range(U):
+            L_.append("  const %s ie%d_ = item + %d * step < last_ ? item + %d * step : last_;" %
+                      (idx_t, u, u, u))
+            it = "ie%d_" % u
+            L_.extend(loads([f % it if "%s" in f else f for f in flat], "_e%d" % u, decl=False))
+
+    hoisted, inv_in = _kernel_prologue(spec, name, L, mid=early_loads if early else None,
+                                       pre=index_setup if early else None)
 
     def compute(elem_off_exprs, sfx="", accs=None):
         B = []
@@ -892,7 +1143,8 @@ def generate(spec: KernelSpec):
                     e = "(%s != 0)" % e
                 ins.append(e)
             lines, outs, odts = emit_scalar_body(spec.scalar, ins, spec.in_dtypes,
-                                                 suffix="_%d%s" % (v, sfx), hoisted=hoisted)
+                                                 suffix="_%d%s" % (v, sfx), hoisted=hoisted,
+                                                 exp_tbl=etbl)
             B.extend(lines)
             for k, ri in enumerate(spec.out_refs):
                 val = _cast(outs[ri], odts[ri], spec.out_dtypes[k])
@@ -927,12 +1179,12 @@ def generate(spec: KernelSpec):
                 out.append("off%d%s + (i64)%s * is%d" % (k, off_sfx, inner, k))
         return out
 
+    tstamp = (lambda k: L.append("  if (threadIdx.x == 0) tr_[%d] = wall_clock64();" % k)) \
+        if spec.trace else (lambda k: None)
     if red is None or red["kind"] == "all":
         nd = spec.nd
-        L.append("  const %s inner_vecs = (%s)(a.shape[%d] / %d);" % (idx_t, idx_t, nd - 1, V))
-        L.append("  const %s items = (%s)(a.n / %d);" % (idx_t, idx_t, V))
-        L.append("  const %s step = (%s)gridDim.x * %d;" % (idx_t, idx_t, spec.block))
-        L.append("  %s item = (%s)blockIdx.x * %d + threadIdx.x;" % (idx_t, idx_t, spec.block))
+        if not early:
+            index_setup(L)
         if nd == 1 and spec.pipe and V > 1 and all(
                 spec.inner[k] == "c" or k in inv_in for k in range(nin)):
             # ping-pong pipeline over groups of U vectors: A = [item, item + U) is loaded; per
@@ -975,9 +1227,14 @@ def generate(spec: KernelSpec):
             L.append("  }")
         elif nd == 1 and U > 1:
             # flat streaming shape: U independent vectors in flight per lane, loads first
-            flat = []
-            for k in range(nops):
-                flat.append({"c": "(i64)%%s * %d" % V, "b": "0", "s": "(i64)%%s * is%d" % k}[spec.inner[k]])
+            if early:
+                L.append("  if (first_) {")
+                for u in range(U):
+                    it = "(item + %d * step)" % u
+                    L.extend(compute([f % it if "%s" in f else f for f in flat], "_e%d" % u))
+                L.append("    item += %d * step;" % U)
+                L.append("  }")
+                tstamp(2)
             L.append("  for (; item + %d * step < items; item += %d * step) {" % (U - 1, U))
             for u in range(U):
                 it = "(item + %d * step)" % u
@@ -994,6 +1251,7 @@ def generate(spec: KernelSpec):
         L.extend(loads(eo))
         L.extend(compute(eo))
         L.append("  }")
+        tstamp(3)
     else:
         # K2 axis reductions.  Dims are [kept (nk) | reduced (nr)]; `lanes` threads cooperate:
         #   row: the unit stride is in the reduced group.  `lanes` (<= 64, power of two) adjacent

@@ -52,7 +52,9 @@ static uint32_t stream_grid(int64_t items, int block) {
 
 extern "C" {
 
-size_t ahip_reduce_ws_bytes(void) { return (size_t)AHIP_MAX_PARTIALS * 16 + 4096; }
+size_t ahip_reduce_partials_bytes(void) { return (size_t)AHIP_MAX_PARTIALS * 16; }
+// granules + 4 KiB tail (epoch, error word, host-flag pointer) + 64 B of trace stamps per workgroup
+size_t ahip_reduce_ws_bytes(void) { return (size_t)AHIP_MAX_PARTIALS * (16 + 64) + 4096; }
 
 int ahip_set_param(const char* name, int64_t value) {
   AHIP_REQUIRE(name != nullptr && value > 0, "bad parameter");
@@ -112,6 +114,10 @@ int ahip_elemwise_reduce_all(ahip_fn_t k, int nd, const int64_t* shape, int nops
     if (cap > AHIP_MAX_PARTIALS) cap = AHIP_MAX_PARTIALS;
     if (want > cap) want = cap;
     if (want < 1) want = 1;
+  } else {
+    // an empty operand may have no storage at all: the kernel's first (clamped, unconditional)
+    // loads read position 0 of every operand, so point them at readable memory
+    for (int k = 0; k < nops; ++k) a.ptr[k] = ws;
   }
   return launch(k, (uint32_t)want, 1, block, &a, stream);
 }

@@ -37,6 +37,127 @@ def check_device_value(typ, data):
     return data
 
 
+_CASTERS = {}
+
+
+def _device_cast(data, dtype):
+    """``data`` (device tensor) converted to ``dtype`` by the generated cast kernel (the device
+    counterpart of the ``_asarray(data, dtype)`` in ``TensorType.filter``): a one-node Elemwise
+    plan through the HIP executor, cached per (source dtype, target dtype, rank)."""
+    from .executor import PlanExecutor
+    from .plan import Plan
+
+    src = DTYPE_NAMES[data.dtype]
+    key = (src, dtype, data.ndim)
+    ex = _CASTERS.get(key)
+    if ex is None:
+        shape = [None] * data.ndim
+        ex = _CASTERS[key] = PlanExecutor(Plan.from_json({
+            "version": 1, "name": "filter_cast_%s_%s" % (src, dtype),
+            "vars": [{"id": 0, "dtype": src, "shape": shape}, {"id": 1, "dtype": dtype, "shape": shape}],
+            "inputs": [0], "outputs": [1],
+            "nodes": [{"op": "Elemwise", "inputs": [0], "outputs": [1], "params": {"scalar": {
+                "n_in": 1, "nodes": [{"op": "cast", "in": [["i", 0]], "dtype": dtype}],
+                "out": [["t", 0]]}}}]}), use_graph=False)
+    (out,) = ex(data)
+    return out
+
+
+def filter_device_value(typ, data, strict=False, allow_downcast=None):
+    """``TensorType.filter`` (tensor/type.py:135-256) for a value that already is a device tensor:
+    the same decisions, taken without bringing the data to the host.  ``strict``: the dtype must
+    be the type's (:163-173).  Otherwise a value whose dtype the type can represent exactly is
+    converted (on the device), any other dtype only with ``allow_downcast`` (:175-203, same
+    message); then the rank / static-shape checks (:236-251)."""
+    src = DTYPE_NAMES.get(data.dtype)
+    if src is None:
+        raise TypeError(f"{typ}: device tensors of dtype {data.dtype} have no counterpart here")
+    if src != typ.dtype:
+        if strict:
+            raise TypeError(f"{typ} expected a tensor with dtype={typ.dtype} (got {src}).")
+        if not allow_downcast and np.promote_types(src, typ.dtype).name != typ.dtype:
+            raise TypeError(
+                f"{typ} cannot store a value of dtype {src} without risking loss of precision. "
+                f"If you do not mind this loss, you can: 1) explicitly cast your data to "
+                f'{typ.dtype}, or 2) set "allow_input_downcast=True" when calling "function". '
+                f"Value: device tensor of shape {tuple(data.shape)}")
+        if data.ndim != typ.ndim:
+            raise TypeError(f"Wrong number of dimensions: expected {typ.ndim}, "
+                            f"got {data.ndim} with shape {tuple(data.shape)}.")
+        data = _device_cast(data, typ.dtype)
+    return check_device_value(typ, data)
+
+
+class DeviceFilterType:
+    """What the input cells of a HIP-linked ``Function`` carry as ``.type``.
+
+    ``Function.__call__`` filters every positional argument with
+    ``s.type.filter(arg, strict=s.strict, allow_downcast=s.allow_downcast)`` where ``s`` is the
+    input *container* (compile/function/types.py:853-863) — and ``TensorType.filter`` starts
+    with ``np.asarray``, which a device tensor cannot survive.  The graph-level ``Type`` has to
+    stay the plain ``TensorType`` (``DenseTypeMeta``, tensor/type.py:632), so the container's type
+    is wrapped instead: ``filter`` keeps a device tensor on the device (``filter_device_value``:
+    same strict / downcast / rank / shape decisions) and sends everything else to the wrapped
+    type; every other attribute, equality and hashing are the wrapped type's.
+
+    The aliased-input copy of ``Function.__call__`` (:898-938) asks the *variable's* type —
+    ``TensorType.may_share_memory`` is False for anything but two ndarrays — so two device
+    arguments over the same memory are passed as they are.  That check protects inputs an
+    in-place Op would destroy; this linker's rewrite query excludes ``inplace`` and the executor
+    only ever writes into buffers it allocated itself, so there is nothing for it to protect.
+    """
+    __slots__ = ("_t",)
+
+    def __init__(self, t):
+        object.__setattr__(self, "_t", t._t if isinstance(t, DeviceFilterType) else t)
+
+    def filter(self, value, strict=False, allow_downcast=None):
+        if isinstance(value, torch.Tensor):
+            if value.device.type == "cpu":
+                value = value.numpy()
+            else:
+                return filter_device_value(self._t, value, strict=strict,
+                                           allow_downcast=allow_downcast)
+        return self._t.filter(value, strict=strict, allow_downcast=allow_downcast)
+
+    def is_valid_value(self, value, strict=True):
+        if isinstance(value, torch.Tensor) and value.device.type != "cpu":
+            try:
+                filter_device_value(self._t, value, strict=strict)
+                return True
+            except TypeError:
+                return False
+        return self._t.is_valid_value(value, strict)
+
+    def __getattr__(self, name):
+        return getattr(object.__getattribute__(self, "_t"), name)
+
+    def __setattr__(self, name, value):
+        setattr(self._t, name, value)
+
+    def __eq__(self, other):
+        return self._t == (other._t if isinstance(other, DeviceFilterType) else other)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    def __hash__(self):
+        return hash(self._t)
+
+    def __repr__(self):
+        return repr(self._t)
+
+    def __str__(self):
+        return str(self._t)
+
+    def __deepcopy__(self, memo):
+        from copy import deepcopy
+        return DeviceFilterType(deepcopy(self._t, memo))
+
+    def __reduce__(self):
+        return (DeviceFilterType, (self._t,))
+
+
 class DeviceCellMixin:
     """``__set__`` of a storage cell that accepts device tensors as they are.  The host class
     supplies ``type``, ``storage`` (one-element list), ``readonly``, ``name`` and

@@ -1,0 +1,100 @@
+"""One registry for every ``AESARA_HIP_*`` environment switch of the package.
+
+The defaults are the measured ones (DESIGN §3.5 lists them with the sweep each came from); the
+environment overrides exist for the sweeps under ``tools/`` and for A/B runs on the GPU box.  A
+switch is read when it is asked for (``get``), never cached here, so a test may flip one with
+``monkeypatch.setenv``.  Nothing outside this module reads ``os.environ["AESARA_HIP_..."]``.
+"""
+from __future__ import annotations
+
+import os
+
+_REG = {}     # name -> (default, type, doc)
+
+
+def _def(name, default, typ, doc):
+    _REG[name] = (default, typ, doc)
+
+
+# ---- library / caches --------------------------------------------------------------------------
+_def("LIB", None, str, "path of libaesara_hip.so (default: next to the package)")
+_def("KCACHE", None, str, "directory of the generated-kernel cache (default: aesara_amd/_kcache)")
+_def("RCCL", None, str, "path of the RCCL library the C-ABI communicator dlopens")
+_def("ARENA_CAP_GB", 64.0, float, "replay arenas of all signatures together, GiB, before eviction")
+# ---- generated Elemwise / CAReduce kernels -----------------------------------------------------
+_def("UNROLL", None, int, "vectors in flight per lane of a flat stream (default: 2 up to 256 MiB, else 1)")
+_def("NT", 0, int, "bit 0: non-temporal loads, bit 1: non-temporal stores (flat streams)")
+_def("VECBYTES", 32, int, "bytes per lane per iteration of a flat stream")
+_def("BLOCK", 256, int, "threads per workgroup of Elemwise kernels")
+_def("RED_BLOCK", None, int, "threads per workgroup of full reductions (default 1024)")
+_def("RED_UNROLL", 1, int, "axis-reduce loop unroll (1 = the default 8)")
+_def("COL_LANES", 128, int, "column-reduce strip width in lanes")
+_def("TILED", 1, int, "LDS-tiled form for transposed operands")
+_def("PIPE", 0, int, "ping-pong software pipeline for flat streams (measured null, r03)")
+_def("FASTEXP", 1, int, "float64 exp through the 64-entry table in LDS (0: ocml's exp)")
+_def("EARLY", 1, int, "flat full reductions issue their first loads before the invariant prologue")
+_def("RED_BLOCKED", 0, int, "flat full reductions: one contiguous chunk per workgroup instead of grid-stride")
+_def("EW_TRACE", 0, int, "full reductions stamp s_memrealtime per workgroup into the workspace (tools/ew_trace.py)")
+_def("HFUSE", 1, int, "horizontal fusion of independent same-shape Elemwise/CAReduce steps into one launch")
+# ---- launch shapes owned by the C side (ahip_set_param) ----------------------------------------
+_def("RED_BPC", None, int, "256-thread blocks per CU of full reductions")
+_def("STREAM_BPC", None, int, "256-thread blocks per CU of streaming Elemwise kernels")
+_def("GEMV_COL_BPC", None, int, "blocks per CU of the COL gemv")
+_def("GEMV_COL_LANES", None, int, "strip width (lanes) of the COL gemv")
+_def("ARGMAX_SLICES", None, int, "maximum slices of a column argmax")
+_def("GEMM_GROUP", None, int, "tile-group width of the GEMM's XCD-aware block order")
+_def("GEMM_HALF_MAX", None, int, "largest 128x128-tile count that still takes the 64x64 tile")
+_def("GEMM_HALF_MIN", None, int, "smallest 128x128-tile count that takes the 64x64 tile")
+_def("GE_WAVES", 0, int, "waves per workgroup of the generated GEMM epilogue (0: automatic)")
+# ---- Scan ---------------------------------------------------------------------------------------
+_def("SCAN_PERSIST", 1, int, "Scan loops as ONE persistent kernel where the class allows")
+_def("COOP", 0, int, "persistent kernels through hipLaunchCooperativeKernel (launch-time size check)")
+_def("SCAN_ROWS", None, str, "rows x waves geometry of the vector-state persistent kernel")
+_def("SCAN_WAVES", 4, int, "waves per workgroup of the vector-state persistent kernel")
+_def("SP_POLLW", 2, int, "polling waves of the vector-state kernel")
+_def("SP_SLEEP", 1, int, "s_sleep between polls of the vector-state kernel")
+_def("SP_REPOLL", 0, int, "re-poll only the granules that were missing")
+_def("SM_CHUNK", 32, int, "k-chunk of the matrix-state kernel's exchange")
+_def("SM_XMODE", None, str, "exchange form of the matrix-state kernel: frag | flag (default by registers)")
+_def("SM_EARLY", "first", str, "which product of a step starts before the hand-off: first | none")
+_def("SM_PIN", 1, int, "pin the recurrent weights to architectural registers (fragment form)")
+_def("SM_TRACE", 0, int, "stamp s_memtime at the phase marks (tools/sm_trace.py)")
+_def("SM_FENCE", 1, int, "scheduler fences at the phase marks")
+_def("SM_XTAIL", 10, int, "fragments of the sequence product behind the payload loads")
+_def("SM_XFOLD", 1, int, "sequence products x_t @ W inside the loop")
+_def("SM_INTERLEAVE", 1, int, "interleave the phases of the batch blocks of one workgroup")
+_def("SM_DEPTH", 8, int, "16-byte payload loads in flight per lane of the fragment fetch")
+
+
+def names():
+    return sorted(_REG)
+
+
+def doc(name):
+    return _REG[name][2]
+
+
+def raw(name):
+    """The environment string of a switch, or None when it is not set."""
+    if name not in _REG:
+        raise KeyError("unknown switch AESARA_HIP_%s (add it to aesara_amd/knobs.py)" % name)
+    return os.environ.get("AESARA_HIP_" + name)
+
+
+def is_set(name):
+    return bool(raw(name))
+
+
+def get(name, default=None):
+    """Value of a switch: the environment override parsed with the registered type, else the
+    registered default (or ``default`` when the registry leaves it to the caller)."""
+    dflt, typ, _ = _REG[name] if name in _REG else (None, None, None)
+    v = raw(name)
+    if v is None or v == "":
+        return dflt if default is None else default
+    return typ(v)
+
+
+def table():
+    """Rows (name, default, current, doc) for DESIGN §3.5 / debugging."""
+    return [("AESARA_HIP_" + n, _REG[n][0], raw(n), _REG[n][2]) for n in names()]

@@ -119,13 +119,15 @@ class HipLinker(JITLinker):
     def make_all(self, *args, **kwargs):
         """``JITLinker.make_all`` (link/basic.py:684-747) plus one change: the input cells handed
         to ``Function`` accept device tensors as they are (``sharedvar.DeviceContainer``), so an
-        ``updates=`` output is stored back into its shared variable without leaving HBM."""
+        ``updates=`` output is stored back into its shared variable without leaving HBM, and
+        their ``type`` filters a device-tensor ARGUMENT on the device (``devcell.DeviceFilterType``:
+        ``Function.__call__`` needs no ``trust_input`` for device inputs)."""
         from .sharedvar import DeviceContainer
 
         fn, ins, outs, thunks, nodes = super().make_all(*args, **kwargs)
         if self.fast_call and len(thunks) == 1:
             fn = self._fast_vm(fn, thunks[0])
-        return fn, [DeviceContainer.adopt(c) for c in ins], outs, thunks, nodes
+        return fn, [DeviceContainer.adopt_input(c) for c in ins], outs, thunks, nodes
 
     def _fast_vm(self, slow_fn, thunk):
         """What ``Function.__call__`` invokes as ``self.vm()`` (compile/function/types.py:967-973).

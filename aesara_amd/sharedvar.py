@@ -25,7 +25,7 @@ from aesara.tensor.type import TensorType
 
 from .devcell import DTYPE_NAMES as _DTYPE_NAMES
 from .devcell import TORCH_DTYPES as _TORCH_DTYPES
-from .devcell import DeviceCellMixin, check_device_value  # noqa: F401  (re-exported)
+from .devcell import DeviceCellMixin, DeviceFilterType, check_device_value  # noqa: F401  (re-exported)
 
 
 def _default_device():
@@ -55,6 +55,17 @@ class DeviceContainer(DeviceCellMixin, Container):
             return c
         return cls(c.type, c.storage, readonly=c.readonly, strict=c.strict,
                    allow_downcast=c.allow_downcast, name=c.name)
+
+    @classmethod
+    def adopt_input(cls, c: Container) -> "DeviceContainer":
+        """``adopt`` for a cell ``Function.__call__`` filters arguments through
+        (compile/function/types.py:853-863 ``s.type.filter(arg, ...)``): its ``type`` becomes the
+        ``DeviceFilterType`` wrapper, which keeps device tensors on the device (no
+        ``trust_input`` needed) and is the wrapped ``TensorType`` for everything else."""
+        new = cls.adopt(c)
+        if not isinstance(new.type, DeviceFilterType):
+            new.type = DeviceFilterType(new.type)
+        return new
 
 
 class HipTensorSharedVariable(TensorSharedVariable):

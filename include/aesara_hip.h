@@ -216,12 +216,17 @@ int ahip_elemwise_tiled(ahip_fn_t k, int nd, const int64_t* shape, int nops, voi
 /* ---- K2: Elemwise fused into a full CAReduce (axis=None) --------------------------------
  * replaces: tensor/elemwise.py:1495 CAReduce.perform / :1522 _c_all (make_loop_careduce,
  * elemwise_cgen.py:502) applied to the output of the Elemwise above, without materialising
- * the intermediate.  ONE generated kernel: every workgroup writes its partial into `ws`, takes
- * an agent-scope arrival ticket, and the last workgroup to arrive folds the partials in index
- * order (deterministic) and stores the cast result to `out`.  `ws` (>= ahip_reduce_ws_bytes())
- * must be ZERO-INITIALISED once by the caller; the kernel leaves the ticket word zero again, so
- * the same workspace serves every later launch on the same stream (graph replays included).  */
+ * the intermediate.  ONE generated kernel: every workgroup publishes its partial into `ws` as
+ * two epoch-tagged 8-byte granules and workgroup 0 collects them, folds them in index order
+ * (deterministic) and stores the cast result to `out`.  `ws` (>= ahip_reduce_ws_bytes()) must be
+ * ZERO-INITIALISED once by the caller; the kernel advances the epoch word, so the same
+ * workspace serves every later launch on the same stream (graph replays included).  Layout:
+ * [0, ahip_reduce_partials_bytes()) the granules; then a 4 KiB tail (epoch at +2048+64, the
+ * epoch-tagged error word at +2048+128, at +2048+192 an optional pointer to a 4-byte flag in
+ * device-visible host memory that a launch whose finalize timed out sets to 1); then 64 bytes
+ * per workgroup for the time stamps of AESARA_HIP_EW_TRACE builds.  */
 size_t ahip_reduce_ws_bytes(void);
+size_t ahip_reduce_partials_bytes(void);
 int ahip_elemwise_reduce_all(ahip_fn_t k, int nd, const int64_t* shape, int nops,
                              void* const* ptrs, const int64_t* strides, int vec, int block,
                              void* out, void* ws, size_t ws_bytes, void* stream);

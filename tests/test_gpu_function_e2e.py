@@ -75,7 +75,8 @@ def _host(outs):
 @pytest.mark.parametrize("name", NAMES)
 def test_golden_case_through_aesara_function(gg, ae, name):
     """mode="HIP" by NAME, real executor: (1) host inputs through Function's own filter,
-    (2) the replayed second call, (3) device tensors with ``trust_input``."""
+    (2) the replayed second call, (3) device tensors as ordinary (untrusted) arguments,
+    (4) the same with ``trust_input``."""
     import torch
     c = BY_NAME[name]
     ins, outs, _specs = _builder(gg, name)()
@@ -91,11 +92,11 @@ def test_golden_case_through_aesara_function(gg, ae, name):
                    for o in (got if isinstance(got, list) else [got])), "outputs stay in HBM"
     assert_matches(c, _host(got), want, "call 1 (host inputs)")
     assert_matches(c, _host(f(*xs)), want, "call 2 (replay)")
-    f.trust_input = True
     dev = [x if (x.ndim == 0 and x.dtype.kind in "iub") or not x.flags.c_contiguous
            else torch.from_numpy(np.array(x, order="C")).cuda() for x in xs]     # (0-d stays 0-d)
-    assert_matches(c, _host(f(*dev)), want, "call 3 (device inputs, trust_input)")
-    assert_matches(c, _host(f(*dev)), want, "call 4")
+    assert_matches(c, _host(f(*dev)), want, "call 3 (device inputs through Function's filter)")
+    f.trust_input = True
+    assert_matches(c, _host(f(*dev)), want, "call 4 (device inputs, trust_input)")
     ex.check()
 
 
@@ -216,13 +217,64 @@ def test_free_allow_gc_copy_and_numpy_mode(ae, gg):
     rn = fn(xv, vv)
     assert all(isinstance(o, np.ndarray) for o in rn)
     np.testing.assert_allclose(rn[0], xv @ vv + 1.0, rtol=1e-12)
-    # device tensors need ``trust_input`` (Function filters untrusted arguments through
-    # ``TensorType.filter`` = ``np.asarray``, types.py:860): a clear TypeError
-    with pytest.raises(TypeError, match="Bad input argument"):
-        f(torch.from_numpy(xv).cuda(), torch.from_numpy(vv).cuda())
-    f.trust_input = True
+    # device tensors are ordinary arguments of an UNTRUSTED function: ``Function.__call__`` filters
+    # them through the input cell's type (types.py:853-863), which is ``devcell.DeviceFilterType``
+    # here — no ``trust_input`` escape hatch
+    assert f.trust_input is False
     rd = f(torch.from_numpy(xv).cuda(), torch.from_numpy(vv).cuda())
     np.testing.assert_allclose(_host(rd)[0], xv @ vv + 1.0, rtol=1e-12)
+    np.testing.assert_allclose(_host(rd)[1], (xv * 2).sum(axis=0), rtol=1e-12)
+
+
+def test_untrusted_function_filters_device_tensors(ae, gg):
+    """The decisions of ``TensorType.filter`` (tensor/type.py:135-256) for device-tensor
+    arguments of an untrusted ``Function`` (types.py:853-863): exact dtype passes untouched,
+    a safe upcast is converted ON THE DEVICE, a downcast is refused unless
+    ``allow_input_downcast``, ``strict`` inputs take no conversion, wrong rank is a TypeError
+    with the reference's "Bad input argument" prefix; mixed host / device arguments and a
+    device tensor passed twice (aliased inputs, types.py:898-938) work."""
+    import torch
+    import aesara.tensor as at
+    from aesara.compile.io import In
+    x, v = at.dmatrix("x"), at.dvector("v")
+    f = ae.function([x, v], at.dot(x, v) + x.sum(axis=0), mode="HIP")
+    assert f.trust_input is False
+    rng = np.random.default_rng(11)
+    xv, vv = rng.standard_normal((30, 30)), rng.standard_normal(30)
+    want = xv @ vv + xv.sum(axis=0)
+    xd, vd = torch.from_numpy(xv).cuda(), torch.from_numpy(vv).cuda()
+    np.testing.assert_allclose(_host(f(xd, vd))[0], want, rtol=1e-12)
+    np.testing.assert_allclose(_host(f(xd, vv))[0], want, rtol=1e-12)        # device + host
+    np.testing.assert_allclose(_host(f(xv, vd))[0], want, rtol=1e-12)
+    # float32 device tensor into a float64 input: exact upcast, done by the cast kernel
+    x32 = torch.from_numpy(xv.astype("float32")).cuda()
+    got = _host(f(x32, vd))[0]
+    np.testing.assert_allclose(got, xv.astype("float32").astype("float64") @ vv
+                               + xv.astype("float32").astype("float64").sum(axis=0), rtol=1e-12)
+    # wrong rank: the reference's message
+    with pytest.raises(TypeError, match="Bad input argument.*Wrong number of dimensions"):
+        f(vd, vd)
+    # float64 -> float32 input: refused (precision), accepted with allow_input_downcast
+    x4 = at.fmatrix("x4")
+    g = ae.function([x4], (x4 * 2).sum(), mode="HIP")
+    with pytest.raises(TypeError, match="Bad input argument.*without risking loss of precision"):
+        g(xd)
+    g2 = ae.function([x4], (x4 * 2).sum(), mode="HIP", allow_input_downcast=True)
+    np.testing.assert_allclose(_host(g2(xd))[0], (xv.astype("float32") * 2).sum(), rtol=1e-5)
+    # strict input: no conversion at all
+    g3 = ae.function([In(x4, strict=True)], (x4 * 2).sum(), mode="HIP")
+    with pytest.raises(TypeError, match="Bad input argument.*expected a tensor with dtype=float32"):
+        g3(xd)
+    np.testing.assert_allclose(_host(g3(x32))[0], (xv.astype("float32") * 2).sum(), rtol=1e-5)
+    # the same device tensor as two arguments (aliased inputs): nothing is destroyed in place
+    a, b = at.dmatrix("a"), at.dmatrix("b")
+    h = ae.function([a, b], [a + b, a * b], mode="HIP")
+    r = _host(h(xd, xd))
+    np.testing.assert_allclose(r[0], 2 * xv, rtol=1e-15)
+    np.testing.assert_allclose(r[1], xv * xv, rtol=1e-15)
+    np.testing.assert_array_equal(xd.cpu().numpy(), xv)
+    # keyword arguments go through Container.__set__ (types.py:894 ``self[k] = arg``)
+    np.testing.assert_allclose(_host(f(x=xd, v=vd))[0], want, rtol=1e-12)
 
 
 def test_errors_name_the_apply_node(ae, gg):

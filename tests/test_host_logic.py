@@ -250,6 +250,43 @@ def test_device_cell_checks_without_the_reference():
         ro.value = torch.zeros(3)
 
 
+def test_device_filter_type_decisions():
+    """``devcell.DeviceFilterType`` / ``filter_device_value``: the decisions of
+    ``TensorType.filter`` (reference tensor/type.py:135-256) for a value that is already a tensor
+    — strict dtype, refused downcast, rank, static shape — and delegation of everything else to
+    the wrapped type (CPU tensors stand in for device tensors: no conversion kernel is reached)."""
+    import copy
+    import pickle
+    import torch
+    from aesara_amd.devcell import DeviceFilterType, PlainType, filter_device_value
+    base = PlainType("float32", (None, 3))
+    t = DeviceFilterType(base)
+    ok = torch.zeros(5, 3)
+    assert filter_device_value(base, ok) is ok and filter_device_value(base, ok, strict=True) is ok
+    with pytest.raises(TypeError, match="expected a tensor with dtype=float32"):
+        filter_device_value(base, ok.double(), strict=True)
+    with pytest.raises(TypeError, match="without risking loss of precision"):
+        filter_device_value(base, ok.double())                 # float64 -> float32 is a downcast
+    with pytest.raises(TypeError, match="Wrong number of dimensions"):
+        filter_device_value(base, torch.zeros(3))
+    with pytest.raises(TypeError, match="not compatible"):
+        filter_device_value(base, torch.zeros(5, 4))
+    with pytest.raises(TypeError, match="Wrong number of dimensions"):
+        filter_device_value(base, torch.zeros(3, dtype=torch.int8))   # rank is checked before a cast
+    # a CPU tensor goes to the wrapped type's host filter (np.asarray works on it), as do arrays
+    out = t.filter(torch.ones(2, 3, dtype=torch.float64), allow_downcast=True)
+    assert isinstance(out, np.ndarray) and out.dtype == np.float32
+    assert t.filter(np.ones((2, 3), "float32")).shape == (2, 3)
+    # the wrapper IS the wrapped type for everything but filter
+    assert t == base and base == t._t and hash(t) == hash(base) and repr(t) == repr(base)
+    assert t.dtype == "float32" and t.ndim == 2 and t.shape == (None, 3)
+    assert DeviceFilterType(t)._t is base                     # never nested
+    t2 = copy.deepcopy(t)
+    assert isinstance(t2, DeviceFilterType) and t2._t is not base and t2.dtype == "float32"
+    t3 = pickle.loads(pickle.dumps(t))
+    assert isinstance(t3, DeviceFilterType) and t3.shape == (None, 3)
+
+
 @pytest.mark.parametrize("name", ["gru_bptt_b1_f32", "gru_bptt_b4_f32", "lstm_bptt_vec_f32", "cfg4_gru_b1_f32"])
 def test_sequence_only_hoisting_preserves_the_step(name):
     """fusion.hoist_sequence_only on the Scan inner plans of the golden recurrences and their
