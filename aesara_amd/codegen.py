@@ -606,6 +606,9 @@ class KernelSpec:
         self.early = bool(knobs.get("EARLY") if early is None else early) and flat_all and not pipe
         # one contiguous chunk of the stream per workgroup instead of a grid-stride walk
         self.blocked = int(knobs.get("RED_BLOCKED") if blocked is None else blocked) if flat_all else 0
+        # the second workgroup a CU receives loses every issue arbitration to the older one
+        # (oldest first): static priority for the second half of the grid evens their progress
+        self.prio = int(knobs.get("RED_PRIO")) if flat_all else 0
         # per-workgroup s_memrealtime stamps into the reduce workspace (tools/ew_trace.py)
         self.trace = bool(knobs.get("EW_TRACE") if trace is None else trace) and \
             reduce is not None and reduce.get("kind") == "all" and tile_dim is None
@@ -644,7 +647,7 @@ class KernelSpec:
         return _memo_key([self.scalar], fields, self._key)
 
     def _variant(self):
-        return "r4%d%d%d%d" % (self.early, self.blocked, self.trace, self.fast_exp)
+        return "r4%d%d%d%d%d" % (self.early, self.blocked, self.trace, self.fast_exp, self.prio)
 
     def _key(self):
         import json
@@ -721,6 +724,8 @@ def _kernel_prologue(spec, name, L, mid=None, pre=None):
     # ones first (exp-table entry, scalar operands, launch epoch: they come back from the
     # memory-side cache), then — ``mid`` — the first group of a flat reduction's stream, so the
     # invariant arithmetic below runs while the stream's first bytes are in flight
+    if getattr(spec, "prio", 0):
+        L.append("  if (blockIdx.x >= gridDim.x / 2) __builtin_amdgcn_s_setprio(%d);" % min(3, spec.prio))
     if pre is not None:
         pre(L)
     fast_exp = getattr(spec, "fast_exp", False)
@@ -1053,12 +1058,12 @@ def generate(spec: KernelSpec):
 
     def index_setup(L_):
         # the walk over the items (vectors of V elements): grid-stride, or (blocked) one
-        # contiguous chunk per workgroup, rounded to whole groups of U vectors per thread
+        # contiguous chunk per workgroup, a whole number of vectors per thread
         L_.append("  const %s inner_vecs = (%s)(a.shape[%d] / %d);" % (idx_t, idx_t, spec.nd - 1, V))
         if spec.blocked:
             L_.append("  const %s items_all = (%s)(a.n / %d);" % (idx_t, idx_t, V))
             L_.append("  const %s chunk_ = ((items_all + (%s)gridDim.x - 1) / (%s)gridDim.x + %d) / %d * %d;" %
-                      (idx_t, idx_t, idx_t, spec.block * U - 1, spec.block * U, spec.block * U))
+                      (idx_t, idx_t, idx_t, spec.block - 1, spec.block, spec.block))
             if spec.blocked == 2:
                 # workgroup b runs on XCD b % 8 (observed dispatch order, a speed hint only): give
                 # every XCD one contiguous eighth of the stream, so an XCD's L2 / TLB sees 1/8 of

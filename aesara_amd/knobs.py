@@ -33,7 +33,9 @@ _def("TILED", 1, int, "LDS-tiled form for transposed operands")
 _def("PIPE", 0, int, "ping-pong software pipeline for flat streams (measured null, r03)")
 _def("FASTEXP", 1, int, "float64 exp through the 64-entry table in LDS (0: ocml's exp)")
 _def("EARLY", 1, int, "flat full reductions issue their first loads before the invariant prologue")
-_def("RED_BLOCKED", 0, int, "flat full reductions: one contiguous chunk per workgroup instead of grid-stride")
+_def("RED_BLOCKED", 2, int, "flat full reductions: 0 grid-stride walk, 1 one contiguous chunk per workgroup, "
+     "2 (default) chunks ordered so that every XCD streams one contiguous eighth (r04 sweeps: 27.1 vs 27.7 us)")
+_def("RED_PRIO", 0, int, "flat full reductions: s_setprio for the second half of the grid (the younger workgroup of a CU)")
 _def("EW_TRACE", 0, int, "full reductions stamp s_memrealtime per workgroup into the workspace (tools/ew_trace.py)")
 _def("HFUSE", 1, int, "horizontal fusion of independent same-shape Elemwise/CAReduce steps into one launch")
 # ---- launch shapes owned by the C side (ahip_set_param) ----------------------------------------

@@ -124,6 +124,14 @@ class HipLinker(JITLinker):
         ``Function.__call__`` needs no ``trust_input`` for device inputs)."""
         from .sharedvar import DeviceContainer
 
+        if not self.fgraph.apply_nodes:
+            # nothing to compute (outputs are inputs / constants, e.g. a statically known shape):
+            # ``JITLinker.make_all`` hands ``streamline`` one thunk for zero nodes and raises
+            # (link/basic.py:747, link/utils.py:183) — the per-node loop of its parent class is
+            # the empty loop, which is all such a graph needs
+            from aesara.link.basic import PerformLinker
+            fn, ins, outs, thunks, nodes = PerformLinker.make_all(self, *args, **kwargs)
+            return fn, [DeviceContainer.adopt_input(c) for c in ins], outs, thunks, nodes
         fn, ins, outs, thunks, nodes = super().make_all(*args, **kwargs)
         if self.fast_call and len(thunks) == 1:
             fn = self._fast_vm(fn, thunks[0])
@@ -255,8 +263,11 @@ class HipLinker(JITLinker):
         return [storage_map[n] for n in self.fgraph.inputs]
 
     def output_filter(self, var, out):
+        # return_numpy=True: results handed to the caller become ndarrays, ``updates=`` results stay
+        # device tensors (they go back into shared-variable cells); "all": those too — for host
+        # ``aesara.shared`` state, e.g. the reference's own test-suite (tests/reference_suites.py)
         if self.return_numpy and hasattr(out, "detach") \
-                and var not in getattr(self, "_update_outputs", ()):
+                and (self.return_numpy == "all" or var not in getattr(self, "_update_outputs", ())):
             return out.detach().cpu().numpy()
         return out
 

@@ -33,7 +33,7 @@ stream.  ``cpu_baseline`` (rank 0, N=1 only): the REFERENCE itself — its ``Mod
 C linker on this host (``oracle/time_reference.py`` in a child process, ``kind: "reference"``) when
 the reference front end is available (``/root/reference`` or the packed overlay ``oracle/_ref/``),
 else the oracle's C port of the same loops (``kind: "port"``).  With the front end available the
-line also carries ``config.through_function``: the same workload driven through the real
+line also carries ``through_function`` (top level): the headline itself is then driven through the real
 ``aesara.function(..., mode="HIP")`` -> ``Function.__call__`` instead of the bare executor.
 """
 import argparse
@@ -130,6 +130,8 @@ def main():
     ap.add_argument("--no-warm", action="store_true",
                     help="skip the same-buffer and through-Function legs (rocprofv3 passes: every "
                          "profiled eval of the headline kernel is then a MALL-cold one)")
+    ap.add_argument("--executor-level", action="store_true",
+                    help="time the bare PlanExecutor even when the reference front end is present")
     ap.add_argument("--no-clock-warmup", action="store_true",
                     help="skip the untimed clock warm-up in front of the timed region")
     ap.add_argument("--rotate", type=int, default=8,
@@ -205,11 +207,23 @@ def main():
     state = {"i": 0}
     reducer = ShardedFunction(lambda bucket: [bucket], kinds)
 
+    # N = 1 with the reference front end present (the packed overlay travels to the GPU box): the
+    # timed step is ``f(x, mu, sigma)`` of ``f = aesara.function([x, mu, sigma], expr, mode="HIP")``
+    # — Function.__call__ with its own input filtering (no trust_input), device tensor in, device
+    # tensor out: the "compiled-fn evals/sec" of the metric.  The bare executor rides in
+    # ``config.executor_level``; ``--executor-level`` (and N > 1: ring slots need ``out=``) times it.
+    fn, fn_info = (None, None)
+    if world == 1 and not args.executor_level:
+        fn, fn_info = make_function(xs[0], torch, np)
+
     def step():
         i = state["i"]
         state["i"] = i + 1
         if world == 1:
-            ex(xs[i % NROT], mu, sigma)
+            if fn is not None:
+                fn(xs[i % NROT])
+            else:
+                ex(xs[i % NROT], mu, sigma)
             return None
         ex(xs[i % NROT], mu, sigma, out=[slots[i % R]])
         if (i + 1) % BUCKET == 0:
@@ -279,7 +293,7 @@ def main():
 
     # the driver's --steps may be small (20 evals = 0.55 ms): a longer untimed-by-contract run
     # of the same step gives the sustained figure next to it
-    sustained = warm = through = None
+    sustained = warm = through = exec_level = None
     if world == 1:
         n_long = max(args.steps, 2000)
         state["i"] = 0
@@ -287,6 +301,27 @@ def main():
         sustained = {"evals": n_long, "kernel_ms": d_ms, "evals_per_s": 1e3 / max(d_ms, w_ms),
                      "frac": ALGO_BYTES / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "note": "same rotation over %d buffers, longer run" % NROT}
+        if fn is not None:
+            # the same rotation through the bare executor (no Function.__call__ around it)
+            est = {"i": 0}
+
+            def estep():
+                est["i"] += 1
+                ex(xs[est["i"] % NROT], mu, sigma)
+            d2, w2 = timer.time(estep, n_long, warmup=NROT)
+            exec_level = {"evals": n_long, "kernel_ms": d2, "evals_per_s": 1e3 / max(d2, w2),
+                          "frac": ALGO_BYTES / (d2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "note": "PlanExecutor called directly (borrowed outputs), same rotation"}
+            # host cost of one call alone: the same calls with nothing to wait for in between
+            t0h = time.perf_counter()
+            for _ in range(200):
+                step()
+            host_us = (time.perf_counter() - t0h) / 200 * 1e6
+            torch.cuda.synchronize()
+            through = dict(fn_info, evals_per_s=sustained["evals_per_s"], kernel_ms=sustained["kernel_ms"],
+                           frac=sustained["frac"], host_us_per_call=host_us)
+        elif fn_info is not None:
+            through = fn_info
         # the figure of rounds 1-2: ONE 128 MiB buffer re-read every eval, i.e. partly served by the
         # 256 MiB memory-side cache (MALL) — an L2-fabric number, not an HBM number
         if not args.no_warm:
@@ -294,8 +329,6 @@ def main():
             warm = {"evals": n_long, "kernel_ms": d_ms, "evals_per_s": 1e3 / max(d_ms, w_ms),
                     "frac": ALGO_BYTES / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "note": "same buffer every eval (MALL-assisted); not the roofline figure"}
-            if rank == 0:
-                through = through_function(timer, xs, torch, np, n_long)
 
     # what the hardware allows at this size with this launch shape: the same rotation through a
     # kernel that only loads and sums (no exp, no division) — the read-only ceiling of the headline
@@ -410,7 +443,11 @@ def main():
                        # north_star: >= 60 % of the HBM roofline on this graph.  Met on a cache-warm
                        # input (config.warm), NOT on MALL-cold inputs (DESIGN §5 says why)
                        "target_frac": 0.60, "target_met_cold": bool(achieved / HBM_PEAK_GBS >= 0.60),
-                       "warm": warm, "through_function": through, "read_only_ceiling": ceiling,
+                       "warm": warm, "executor_level": exec_level, "read_only_ceiling": ceiling,
+                       "headline_path": "aesara.function(mode='HIP') -> Function.__call__ (untrusted: its own "
+                                        "input filter, device tensors in / out)" if fn is not None
+                                        else "PlanExecutor (no reference front end here, N > 1, or "
+                                             "--executor-level)",
                        "parallelism": "row-sharded x%d, bucketed async RCCL all-reduce of the CAReduce "
                                       "partials (8 evals per collective)" % world
                                       if world > 1 else "single GPU",
@@ -420,10 +457,15 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": dev_ms_per_eval, "algorithmic_bytes": ALGO_BYTES},
         }
+        if through is not None:
+            res["through_function"] = through    # top level: the driver's record keeps top-level keys
         if secondary:
             res["secondary"] = secondary
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(np, ref_warm, secondary)
+            vs = res["cpu_baseline"].pop("vs_reference", None)
+            if vs is not None:
+                res["vs_reference"] = vs        # top level: the driver's record keeps top-level keys
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
@@ -762,12 +804,13 @@ def start_reference_warm():
         return None
 
 
-def reference_rows(budget, configs, openmp=False, timeout=420):
+def reference_rows(budget, configs, openmp=False, timeout=420, dump_dir=None):
     import subprocess
     env = dict(os.environ)
     env.pop("AESARA_FLAGS", None)
     cmd = [sys.executable, os.path.join(ROOT, "oracle", "time_reference.py"), "--budget", str(budget),
-           "--configs", ",".join(configs)] + (["--openmp"] if openmp else [])
+           "--configs", ",".join(configs)] + (["--openmp"] if openmp else []) + \
+        (["--dump-dir", dump_dir] if dump_dir else [])
     p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout)
     line = next((ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")), None)
     if line is None:
@@ -775,47 +818,36 @@ def reference_rows(budget, configs, openmp=False, timeout=420):
     return json.loads(line[7:])
 
 
-def through_function(timer, xs, torch, np, iters):
-    """The headline workload through the REAL front end: ``aesara.function([...], expr,
-    mode="HIP")`` -> ``Function.__call__`` (trust_input, device-resident rotating inputs, fresh
-    outputs as a user gets them) -> HipLinker VM -> PlanExecutor.  None when the reference front
-    end is not available here."""
+def make_function(x0, torch, np):
+    """The headline workload through the REAL front end: ``aesara.function([x, mu, sigma], expr,
+    mode="HIP")``; returns (callable taking the device matrix, info) — the callable is an ordinary
+    UNTRUSTED ``Function.__call__`` (types.py:791-1082: its own input filter — a device tensor is
+    filtered on the device by ``devcell.DeviceFilterType`` — then HipLinker's VM -> PlanExecutor
+    replay -> ``ahip_list_run_rebased``; mu / sigma are host scalars as a user passes them; the
+    result is a fresh device tensor).  (None, why) when the front end is not available here."""
     try:
         import ref_overlay
         if not ref_overlay.available():
-            return None
+            return None, None
         ae = ref_overlay.import_reference()
         import aesara.tensor as at
         import aesara_amd
         aesara_amd.get_mode()
         x, mu, sg = at.dmatrix("x"), at.dscalar("mu"), at.dscalar("sigma")
         f = ae.function([x, mu, sg], at.exp(-(x - mu) ** 2 / (2 * sg ** 2)).sum(), mode="HIP")
-        f.trust_input = True
+        assert f.trust_input is False
         m, s_ = np.asarray(0.1), np.asarray(1.3)
-        out = f(xs[0], m, s_)
-        want = torch.exp(-(xs[0] - 0.1) ** 2 / (2 * 1.3 ** 2)).sum()
+        out = f(x0, m, s_)
+        want = torch.exp(-(x0 - 0.1) ** 2 / (2 * 1.3 ** 2)).sum()
         rel = abs(out.item() - want.item()) / abs(want.item())
         assert rel < 1e-9, rel
-        st = {"i": 0}
-        n = len(xs)
-
-        def step():
-            st["i"] += 1
-            f(xs[st["i"] % n], m, s_)
-        d, w = timer.time(step, iters, warmup=2 * n)
-        # host cost alone: the same calls with nothing to wait for in between
-        t0 = time.perf_counter()
-        for _ in range(200):
-            step()
-        host_us = (time.perf_counter() - t0) / 200 * 1e6
-        torch.cuda.synchronize()
-        return {"evals_per_s": 1e3 / max(d, w), "kernel_ms": d, "wall_ms_per_eval": w,
-                "host_us_per_call": host_us, "frac": ALGO_BYTES / (d * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "rel_err_vs_fp64": rel, "source": ref_overlay.source(),
-                "path": "aesara.function(mode='HIP') -> Function.__call__ (trust_input) -> HipLinker "
-                        "fast VM -> PlanExecutor replay -> ahip_list_run_rebased; fresh outputs"}
-    except Exception as e:                              # noqa: BLE001  (an extra leg must not cost the line)
-        return {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        info = {"path": "aesara.function(mode='HIP') -> Function.__call__ (trust_input=False: "
+                        "DeviceFilterType) -> HipLinker fast VM -> PlanExecutor replay -> "
+                        "ahip_list_run_rebased; fresh outputs",
+                "trust_input": False, "rel_err_vs_fp64": rel, "front_end": ref_overlay.source()}
+        return (lambda xd: f(xd, m, s_)), info
+    except Exception as e:                              # noqa: BLE001  (fall back to the executor)
+        return None, {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
 
 
 def cpu_baseline(np, ref_warm=None, secondary=None):
@@ -831,7 +863,10 @@ def cpu_baseline(np, ref_warm=None, secondary=None):
         try:
             if ref_warm is not None:
                 ref_warm.wait(timeout=300)
-            r = reference_rows(4.0, ["cfg2", "cfg1b", "cfg3a", "cfg3b", "cfg4_b1", "cfg4_b64", "cfg5"])
+            import tempfile
+            dump = tempfile.mkdtemp(prefix="aesara_ref_out_")
+            r = reference_rows(4.0, ["cfg2", "cfg1b", "cfg3a", "cfg3b", "cfg4_b1", "cfg4_b64", "cfg5"],
+                               dump_dir=dump)
             row = r["rows"]["cfg2"]
             res = {"value": 1e3 / row["ms_per_eval"], "unit": "evals/s", "cores": row["cores"],
                    "kind": "reference", "ms_per_eval": row["ms_per_eval"],
@@ -853,6 +888,22 @@ def cpu_baseline(np, ref_warm=None, secondary=None):
                 else:
                     others[k] = v
             res["other_configs"] = others
+            # the HIP path on the SAME seeded inputs against what the reference's C linker returned
+            # (full BASELINE shapes for cfg 1b / 2 / 3a / 3b, the timed samples for cfg 4 / 5):
+            # north_star "results equal to the C linker within 1e-6 rel"
+            try:
+                import shutil
+                import refcheck
+                vs = refcheck.hip_vs_reference(dump)
+                shutil.rmtree(dump, ignore_errors=True)
+                res["vs_reference"] = {"bar": refcheck.BAR, "rel_err": {k: v["max"] for k, v in vs.items()},
+                                       "per_output": {k: v["rel_err"] for k, v in vs.items()},
+                                       "ok": bool(vs) and all(v["max"] <= refcheck.BAR for v in vs.values()),
+                                       "what": "max |hip - ref| / max |ref| per output, same seeded inputs "
+                                               "(oracle/time_reference.make_inputs); ref = the reference's "
+                                               "Mode('cvm','fast_run') on this host"}
+            except Exception as e:                      # noqa: BLE001  (a check row must not cost the line)
+                res["vs_reference"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
             # next to every secondary row: the reference's time for the same config on this host
             key = {"cfg3b": "cfg3b", "cfg3a": "cfg3a", "cfg1b": "cfg1b", "cfg5": "cfg5"}
             for srow in secondary or ():
@@ -864,6 +915,8 @@ def cpu_baseline(np, ref_warm=None, secondary=None):
                     k = "cfg4_b64"
                 if k and k in others and "ms_per_eval_full_config" in others[k]:
                     srow["cpu_reference_ms_per_eval"] = others[k]["ms_per_eval_full_config"]
+                if k and k in res["vs_reference"].get("rel_err", {}):
+                    srow.setdefault("check", {})["vs_reference_rel_err"] = res["vs_reference"]["rel_err"][k]
             try:
                 ro = reference_rows(4.0, ["cfg2"], openmp=True, timeout=240)["rows"]["cfg2"]
                 res["openmp"] = {"value": 1e3 / ro["ms_per_eval"], "unit": "evals/s", "cores": ro["cores"],

@@ -5,7 +5,7 @@ TEST INFRASTRUCTURE ONLY.  Only tests/, oracle/ scripts and bench.py's ``cpu_bas
 
 Where the reference front end comes from, in this order:
 
-1. an overlay that is already built (``$AESARA_REF_OVERLAY/.built``);
+1. an overlay that is already built (``$AESARA_REF_OVERLAY/.built2``);
 2. ``/root/reference`` (authoring container): ``build_ref_overlay.sh`` builds the overlay;
 3. ``oracle/_ref/aesara_ref_overlay.tar.gz`` — the packed overlay ``pack_ref_overlay.sh`` writes
    (git-ignored build artefact, never committed; it travels to the GPU box with the snapshot the
@@ -33,7 +33,7 @@ _CXXFLAGS = (
 
 
 def _built():
-    return os.path.isfile(os.path.join(OVERLAY, ".built"))
+    return os.path.isfile(os.path.join(OVERLAY, ".built2"))
 
 
 def source():

@@ -24,47 +24,82 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ALL = ["cfg2", "cfg1b", "cfg3a", "cfg3b", "cfg4_b1", "cfg4_b64", "cfg5"]
 
 
-def build(ae, name, np, tiny=False):
-    """-> (function, args, sample description, cores used).  ``tiny``: small shapes (same graph
-    and dtypes — the compiled modules are shape-independent), used by --warm."""
-    import aesara.tensor as at
-    from aesara.compile.mode import Mode
-    mode = Mode("cvm", "fast_run")
-    nthreads = os.cpu_count()
+def make_inputs(name, np, tiny=False):
+    """The seeded input arrays of one config — a dict; no front end needed, so ``bench.py`` and the
+    GPU tests regenerate exactly what the reference child evaluated and compare results.
+    ``tiny``: small shapes (same graph and dtypes), used by --warm."""
     n = 64 if tiny else 4096
     if name == "cfg2":
-        x, mu, sg = at.dmatrix("x"), at.dscalar("mu"), at.dscalar("sigma")
-        f = ae.function([x, mu, sg], at.exp(-((x - mu) ** 2) / (2 * sg ** 2)).sum(), mode=mode)
-        xv = np.random.default_rng(1).standard_normal((n, n))
-        return f, (xv, np.asarray(0.1), np.asarray(1.3)), "fp64 %dx%d exp-sum graph" % (n, n), \
-            (nthreads if ae.config.openmp else 1)
+        return {"x": np.random.default_rng(1).standard_normal((n, n)), "mu": np.asarray(0.1),
+                "sigma": np.asarray(1.3)}
     if name == "cfg1b":
-        x, y = at.dmatrix("x"), at.dmatrix("y")
-        f = ae.function([x, y], x + y, mode=mode)
-        return f, (np.random.default_rng(0).random((n, n)), np.random.default_rng(1).random((n, n))), \
-            "fp64 %dx%d add" % (n, n), (nthreads if ae.config.openmp else 1)
+        return {"x": np.random.default_rng(0).random((n, n)), "y": np.random.default_rng(1).random((n, n))}
     if name == "cfg3a":
-        M, v, a = at.dmatrix("M"), at.dvector("v"), at.dscalar("a")
-        f = ae.function([M, v, a], at.dot(M, v) + a, mode=mode)
-        return f, (np.random.default_rng(2).standard_normal((n, n)),
-                   np.random.default_rng(3).standard_normal(n), np.asarray(2.0)), \
-            "fp64 %dx%d M.dot(v)+a (Gemv through SciPy fblas)" % (n, n), nthreads
+        return {"M": np.random.default_rng(2).standard_normal((n, n)),
+                "v": np.random.default_rng(3).standard_normal(n), "a": np.asarray(2.0)}
     if name == "cfg3b":
-        A = ae.shared(np.random.default_rng(3).standard_normal((n, n)).astype("float32"), "A")
-        B = ae.shared(np.random.default_rng(4).standard_normal((n, n)).astype("float32"), "B")
-        Cs = ae.shared(np.zeros((n, n), "float32"), "C")
-        f = ae.function([], [], updates=[(Cs, np.float32(0.4) * Cs + np.float32(0.8) * at.dot(A, B))],
-                        mode=mode)
-        return f, (), "fp32 %d^3 Gemm update (alt-BLAS -> NumPy's OpenBLAS)" % n, nthreads
+        return {"A": np.random.default_rng(3).standard_normal((n, n)).astype("float32"),
+                "B": np.random.default_rng(4).standard_normal((n, n)).astype("float32"),
+                "C": np.zeros((n, n), "float32")}
     if name in ("cfg4_b1", "cfg4_b64"):
         B_ = 1 if name == "cfg4_b1" else 64
         T_, H = (8, 32) if tiny else (64, 1024)       # 1/8 of the config's 512 steps (bounded sample)
         if tiny and B_ > 1:
             B_ = 4
+        xs = (T_, H) if B_ == 1 else (T_, B_, H)
+        d = {"x": (np.random.default_rng(4).standard_normal(xs) * 0.1).astype("float32"),
+             "h0": np.zeros(xs[1:], "float32")}
+        for k, nm in enumerate(("Wz", "Uz", "Wr", "Ur", "Wh", "Uh")):
+            d[nm] = (np.random.default_rng(5 + k).standard_normal((H, H)) / np.sqrt(H)).astype("float32")
+        return d
+    if name == "cfg5":
+        N, D = (256, 16) if tiny else (1 << 20, 256)
+        return {"X": np.random.default_rng(6).standard_normal((N, D), dtype="float32"),
+                "w": (np.random.default_rng(7).standard_normal(D) / 16).astype("float32"),
+                "b": np.asarray(0.1, "float32"),
+                "y": (np.random.default_rng(8).random(N) < 0.5).astype("float32")}
+    raise ValueError(name)
+
+
+def build(ae, name, np, tiny=False):
+    """-> (function, args, sample description, cores used, result getter).  ``tiny``: small shapes
+    (same graph and dtypes — the compiled modules are shape-independent), used by --warm."""
+    import aesara.tensor as at
+    from aesara.compile.mode import Mode
+    mode = Mode("cvm", "fast_run")
+    nthreads = os.cpu_count()
+    n = 64 if tiny else 4096
+    d = make_inputs(name, np, tiny)
+    if name == "cfg2":
+        x, mu, sg = at.dmatrix("x"), at.dscalar("mu"), at.dscalar("sigma")
+        f = ae.function([x, mu, sg], at.exp(-((x - mu) ** 2) / (2 * sg ** 2)).sum(), mode=mode)
+        return f, (d["x"], d["mu"], d["sigma"]), "fp64 %dx%d exp-sum graph" % (n, n), \
+            (nthreads if ae.config.openmp else 1)
+    if name == "cfg1b":
+        x, y = at.dmatrix("x"), at.dmatrix("y")
+        f = ae.function([x, y], x + y, mode=mode)
+        return f, (d["x"], d["y"]), "fp64 %dx%d add" % (n, n), (nthreads if ae.config.openmp else 1)
+    if name == "cfg3a":
+        M, v, a = at.dmatrix("M"), at.dvector("v"), at.dscalar("a")
+        f = ae.function([M, v, a], at.dot(M, v) + a, mode=mode)
+        return f, (d["M"], d["v"], d["a"]), \
+            "fp64 %dx%d M.dot(v)+a (Gemv through SciPy fblas)" % (n, n), nthreads
+    if name == "cfg3b":
+        A = ae.shared(d["A"], "A")
+        B = ae.shared(d["B"], "B")
+        Cs = ae.shared(d["C"], "C")
+        f = ae.function([], [], updates=[(Cs, np.float32(0.4) * Cs + np.float32(0.8) * at.dot(A, B))],
+                        mode=mode)
+        f.result_of_first_eval = lambda: [Cs.get_value()]
+        return f, (), "fp32 %d^3 Gemm update (alt-BLAS -> NumPy's OpenBLAS)" % n, nthreads
+    if name in ("cfg4_b1", "cfg4_b64"):
+        B_ = 1 if name == "cfg4_b1" else 64
+        T_, H = d["x"].shape[0], d["x"].shape[-1]
+        if tiny and B_ > 1:
+            B_ = 4
         x = at.fmatrix("x") if B_ == 1 else at.ftensor3("x")
         h0 = at.fvector("h0") if B_ == 1 else at.fmatrix("h0")
-        Ws = [ae.shared((np.random.default_rng(5 + k).standard_normal((H, H)) / np.sqrt(H)).astype("float32"),
-                        nm) for k, nm in enumerate(("Wz", "Uz", "Wr", "Ur", "Wh", "Uh"))]
+        Ws = [ae.shared(d[nm], nm) for nm in ("Wz", "Uz", "Wr", "Ur", "Wh", "Uh")]
 
         def step(x_t, h, Wz, Uz, Wr, Ur, Wh, Uh):
             z = at.sigmoid(at.dot(x_t, Wz) + at.dot(h, Uz))
@@ -73,22 +108,17 @@ def build(ae, name, np, tiny=False):
             return (1 - z) * h + z * hh
         hs, _ = ae.scan(step, sequences=[x], outputs_info=[h0], non_sequences=Ws)
         f = ae.function([x, h0], hs[-1], mode=mode)
-        xs = (T_, H) if B_ == 1 else (T_, B_, H)
-        xv = (np.random.default_rng(4).standard_normal(xs) * 0.1).astype("float32")
-        return f, (xv, np.zeros(xs[1:], "float32")), \
+        return f, (d["x"], d["h0"]), \
             "fp32 Scan GRU T=%d of 512 steps (x8 for the config), H=%d B=%d (scan_perform.pyx loop, inner cvm " \
             "function)" % (T_, H, B_), nthreads
     if name == "cfg5":
-        N, D = (256, 16) if tiny else (1 << 20, 256)
+        N, D = d["X"].shape
         X, w, b, y = at.fmatrix("X"), at.fvector("w"), at.fscalar("b"), at.fvector("y")
         p = at.sigmoid(at.dot(X, w) + b)
         logp = (y * at.log(p) + (1 - y) * at.log(1 - p)).sum()
         gw, gb = ae.grad(logp, [w, b])
         f = ae.function([X, w, b, y], [logp, gw, gb], mode=mode)
-        rng = np.random.default_rng(6)
-        return f, (rng.standard_normal((N, D), dtype="float32"),
-                   (np.random.default_rng(7).standard_normal(D) / 16).astype("float32"),
-                   np.asarray(0.1, "float32"), (np.random.default_rng(8).random(N) < 0.5).astype("float32")), \
+        return f, (d["X"], d["w"], d["b"], d["y"]), \
             "fp32 logistic logp+grad N=2^%d D=%d (1/16 of the config's rows: x16 for the full batch)" % (
                 N.bit_length() - 1, D), nthreads
     raise ValueError(name)
@@ -100,6 +130,9 @@ def main():
     ap.add_argument("--budget", type=float, default=5.0, help="seconds of timed evals per config")
     ap.add_argument("--warm", action="store_true")
     ap.add_argument("--openmp", action="store_true")
+    ap.add_argument("--dump-dir", default="",
+                    help="save what the FIRST evaluation of every config returned (npy files "
+                         "<cfg>_out<i>.npy): the values bench.py / the GPU tests check the HIP path against")
     args = ap.parse_args()
     if args.openmp:
         os.environ["AESARA_FLAGS"] = "openmp=True"
@@ -119,8 +152,15 @@ def main():
             f.trust_input = True
             row = {"cores": cores, "sample": sample}
             t = time.perf_counter()
-            f(*fargs)                                   # first eval (page faults, lazy imports)
+            res = f(*fargs)                             # first eval (page faults, lazy imports)
             first = time.perf_counter() - t
+            if args.dump_dir and not args.warm:
+                getter = getattr(f, "result_of_first_eval", None)
+                vals = getter() if getter else (res if isinstance(res, (list, tuple)) else [res])
+                os.makedirs(args.dump_dir, exist_ok=True)
+                for i, v in enumerate(vals):
+                    np.save(os.path.join(args.dump_dir, "%s_out%d.npy" % (name, i)), np.asarray(v))
+                row["dumped_outputs"] = len(vals)
             row["build_s"] = time.perf_counter() - t0 - first
             if not args.warm:
                 ts = []

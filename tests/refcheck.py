@@ -1,0 +1,76 @@
+"""HIP results against the REFERENCE's own outputs at the BASELINE shapes (checker; used by
+``bench.py``'s baseline leg and ``tests/test_gpu_fullsize.py`` only).
+
+``oracle/time_reference.py --dump-dir D`` makes the reference's ``Mode("cvm","fast_run")`` C linker
+save what the first evaluation of every config returned; the inputs are seeded
+(``time_reference.make_inputs``), so this module regenerates them, runs the HIP executor on the
+same data and reports the relative error of every output (max |dx| / max |ref| for arrays,
+|dx| / |ref| for scalars).  north_star: "results equal to the C linker within 1e-6 rel".
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE = os.path.join(os.path.dirname(HERE), "oracle")
+for p in (HERE, ORACLE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+BAR = 1e-6
+# config of time_reference.py -> (golden plan, input names in plan order, plan outputs compared
+# with the dumped reference outputs in that order)
+CONFIGS = {
+    "cfg2": ("cfg2_gauss_sum", ("x", "mu", "sigma"), (0,)),
+    "cfg1b": ("cfg1b_matrix_add", ("x", "y"), (0,)),
+    "cfg3a": ("cfg3a_gemv", ("M", "v", "a"), (1,)),                 # output 1 is dot(M, v) + a
+    "cfg3b": ("cfg3b_gemm_update", ("C", "A", "B"), (0,)),          # C after the first update
+    "cfg4_b1": ("cfg4_gru_b1_f32", ("x", "h0", "Wz", "Uz", "Wr", "Ur", "Wh", "Uh"), (-1,)),
+    "cfg4_b64": ("cfg4_gru_b8_f32", ("x", "h0", "Wz", "Uz", "Wr", "Ur", "Wh", "Uh"), (-1,)),
+    "cfg5": ("cfg5_logistic", ("X", "w", "b", "y"), (0, 1, 2)),
+}
+
+
+def rel_err(got, ref):
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    if got.shape != ref.shape:
+        return float("inf")
+    if ref.size == 0:
+        return 0.0
+    den = np.abs(ref).max()
+    return float(np.abs(got - ref).max() / (den if den > 0 else 1.0))
+
+
+def hip_vs_reference(dump_dir, configs=None):
+    """{config: {"rel_err": [...], "max": worst, "outputs": n}} for every config whose dumped
+    reference outputs are in ``dump_dir`` (needs a HIP device)."""
+    import torch
+    import time_reference
+    from golden_util import CASES, case_plan
+    from aesara_amd.executor import PlanExecutor
+
+    out = {}
+    for cfg in configs or CONFIGS:
+        case, names, outs = CONFIGS[cfg]
+        refs = []
+        for i in range(len(outs)):
+            p = os.path.join(dump_dir, "%s_out%d.npy" % (cfg, i))
+            if not os.path.exists(p):
+                break
+            refs.append(np.load(p))
+        if len(refs) != len(outs):
+            continue
+        d = time_reference.make_inputs(cfg, np)
+        args = []
+        for n in names:
+            a = d[n]
+            # 0-d values stay host scalars (mu, sigma, a, b: what a user passes), arrays go to HBM
+            args.append(a if a.ndim == 0 else torch.from_numpy(np.ascontiguousarray(a)).cuda())
+        ex = PlanExecutor(case_plan(next(c for c in CASES if c["name"] == case)))
+        got = ex(*args)
+        errs = [rel_err(got[o].detach().cpu().numpy(), r) for o, r in zip(outs, refs)]
+        out[cfg] = {"rel_err": errs, "max": max(errs), "outputs": len(errs)}
+        del ex, got, args
+        torch.cuda.empty_cache()
+    return out

@@ -648,3 +648,32 @@ def test_fused_gate_lstm_bptt_against_torch_autograd():
         for k, (gv, wv) in enumerate(zip(got, want)):
             err = ((gv.double() - wv).abs().max() / wv.abs().max().clamp_min(1e-30)).item()
             assert gv.shape == wv.shape and err <= 2e-4, (use_graph, k, err)
+
+
+def test_baseline_configs_against_the_reference_c_linker(tmp_path):
+    """north_star: "results equal to the C linker within 1e-6 rel" — checked against the REFERENCE
+    ITSELF, not a restatement: ``oracle/time_reference.py --dump-dir`` (child process, the
+    reference's ``Mode("cvm","fast_run")`` from the packed overlay) evaluates cfg 2 / 1b / 3a / 3b at
+    the full 4096 shapes, cfg 4 (B = 1 and B = 64) on a T = 64 sample and cfg 5 on N = 2^20 rows;
+    ``tests/refcheck.py`` regenerates the same seeded inputs, runs the HIP path and compares
+    every output (max |dx| / max |ref|).  ``bench.py`` puts the same numbers on its line."""
+    import os
+    import subprocess
+    import sys
+    import ref_overlay
+    if not ref_overlay.available():
+        pytest.skip("no reference front end (oracle/_ref overlay not packed)")
+    import refcheck
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("AESARA_FLAGS", None)
+    cfgs = ["cfg2", "cfg1b", "cfg3a", "cfg3b", "cfg4_b1", "cfg4_b64", "cfg5"]
+    p = subprocess.run([sys.executable, os.path.join(root, "oracle", "time_reference.py"),
+                        "--budget", "0.01", "--configs", ",".join(cfgs), "--dump-dir", str(tmp_path)],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert "RESULT " in p.stdout, (p.stdout + p.stderr)[-2000:]
+    got = refcheck.hip_vs_reference(str(tmp_path), cfgs)
+    assert sorted(got) == sorted(cfgs), (sorted(got), p.stdout[-1500:])
+    assert got["cfg1b"]["max"] == 0.0                          # an add is exact
+    for k, v in got.items():
+        assert v["max"] <= refcheck.BAR, (k, v)

@@ -252,18 +252,18 @@ def test_untrusted_function_filters_device_tensors(ae, gg):
     np.testing.assert_allclose(got, xv.astype("float32").astype("float64") @ vv
                                + xv.astype("float32").astype("float64").sum(axis=0), rtol=1e-12)
     # wrong rank: the reference's message
-    with pytest.raises(TypeError, match="Bad input argument.*Wrong number of dimensions"):
+    with pytest.raises(TypeError, match="(?s)Bad input argument.*Wrong number of dimensions"):
         f(vd, vd)
     # float64 -> float32 input: refused (precision), accepted with allow_input_downcast
     x4 = at.fmatrix("x4")
     g = ae.function([x4], (x4 * 2).sum(), mode="HIP")
-    with pytest.raises(TypeError, match="Bad input argument.*without risking loss of precision"):
+    with pytest.raises(TypeError, match="(?s)Bad input argument.*without risking loss of precision"):
         g(xd)
     g2 = ae.function([x4], (x4 * 2).sum(), mode="HIP", allow_input_downcast=True)
     np.testing.assert_allclose(_host(g2(xd))[0], (xv.astype("float32") * 2).sum(), rtol=1e-5)
     # strict input: no conversion at all
     g3 = ae.function([In(x4, strict=True)], (x4 * 2).sum(), mode="HIP")
-    with pytest.raises(TypeError, match="Bad input argument.*expected a tensor with dtype=float32"):
+    with pytest.raises(TypeError, match="(?s)Bad input argument.*expected a tensor with dtype=float32"):
         g3(xd)
     np.testing.assert_allclose(_host(g3(x32))[0], (xv.astype("float32") * 2).sum(), rtol=1e-5)
     # the same device tensor as two arguments (aliased inputs): nothing is destroyed in place
