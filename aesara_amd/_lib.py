@@ -140,6 +140,8 @@ SIGNATURES = {
                                vp, i64, i64, vp, sz, vp]),
     "ahip_gemm_batched": (i32, [i32, i64, i64, i64, i64, vp, vp, i64, i64, i64, vp, i64, i64,
                                 i64, vp, vp, i64, i64, i64, vp, i64, i64, i64, vp]),
+    "ahip_igemm_batched": (i32, [i32, i64, i64, i64, i64, vp, i64, i64, i64, vp, i64, i64, i64, vp,
+                                 i64, i64, i64, vp]),
     "ahip_gemv_ws_bytes": (sz, [i32, i64, i64]),
     "ahip_gemv": (i32, [i32, i64, i64, vp, vp, i64, i64, vp, i64, vp, vp, i64, vp, i64, vp, sz,
                         vp]),

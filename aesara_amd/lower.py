@@ -283,15 +283,19 @@ def _register_handlers():
 
     @hip_lower.register(Dot)
     def _(op, node, ctx):
-        # reference: tensor/math.py:1879 Dot (1-d/2-d only; perform = np.dot, which upcasts mixed
-        # operands).  The BLAS kernels take ONE float dtype: a float32 operand next to a float64
-        # one is cast first (what np.dot does); integer / bool products have no kernel on this
-        # path and are refused HERE, at compile time — never at run time, never on the host
+        # reference: tensor/math.py:1879 Dot (1-d/2-d only; make_node :1903 upcasts the output dtype,
+        # perform :1929 = np.dot, which converts mixed operands to the common type first).  The
+        # kernels take ONE dtype: operands are cast to the node's output dtype (exact for every
+        # pair NumPy promotes: the common type holds both), then float32 / float64 products run on
+        # the MFMA kernels and bool / integer products on the vector-ALU kernel (csrc/igemm.hip,
+        # NumPy's wrap-around arithmetic bit for bit).  float16 / complex: refused at compile time.
         dts = [str(i.type.dtype) for i in node.inputs]
         odt = str(node.outputs[0].type.dtype)
-        if any(not d.startswith("float") for d in dts + [odt]):
-            raise UnsupportedOp(f"Dot over {dts} -> {odt}: only float32 / float64 products are on the "
-                                "HIP BLAS path (SURVEY §8a H5/H6)")
+        _ok = ("float32", "float64", "bool", "int8", "int16", "int32", "int64", "uint8", "uint16",
+               "uint32", "uint64")
+        if any(d not in _ok for d in dts + [odt]):
+            raise UnsupportedOp(f"Dot over {dts} -> {odt}: float16 / complex products are not on the HIP "
+                                "path (SURVEY §2)")
         ins = []
         for i, d in zip(node.inputs, dts):
             vid = ctx.vid(i)
@@ -329,8 +333,26 @@ def _register_handlers():
 
     @hip_lower.register(BatchedDot)
     def _(op, node, ctx):
-        # reference: tensor/blas.py:2179 BatchedDot
-        ctx.emit("BatchedDot", node)
+        # reference: tensor/blas.py:2179 BatchedDot (make_node :2196 upcasts the output dtype;
+        # perform :2224 z[i] = np.dot(x[i], y[i])): operands cast to the output dtype like Dot
+        dts = [str(i.type.dtype) for i in node.inputs]
+        odt = str(node.outputs[0].type.dtype)
+        if all(d == odt for d in dts):
+            ctx.emit("BatchedDot", node)
+            return
+        _ok = ("float32", "float64", "bool", "int8", "int16", "int32", "int64", "uint8", "uint16",
+               "uint32", "uint64")
+        if any(d not in _ok for d in dts + [odt]):
+            raise UnsupportedOp(f"BatchedDot over {dts} -> {odt}")
+        ins = []
+        for i, d in zip(node.inputs, dts):
+            vid = ctx.vid(i)
+            if d != odt:
+                vid = ctx.raw("Elemwise", [vid], odt, _static_shape(i.type), {"scalar": {
+                    "n_in": 1, "nodes": [{"op": "cast", "in": [["i", 0]], "dtype": odt}], "out": [["t", 0]]}})
+            ins.append(vid)
+        outs = [ctx.new(o) for o in node.outputs]
+        ctx.plan.nodes.append(Node("BatchedDot", ins, outs, {}))
 
     @hip_lower.register(Alloc)
     def _(op, node, ctx):

@@ -261,6 +261,14 @@ int ahip_gemm_batched(int dtype, int64_t batch, int64_t M, int64_t N, int64_t K,
                       const void* B, int64_t b_bs, int64_t b_rs, int64_t b_cs, const void* beta,
                       const void* Cin, int64_t ci_bs, int64_t ci_rs, int64_t ci_cs, void* C,
                       int64_t c_bs, int64_t c_rs, int64_t c_cs, void* stream);
+/* Integer / bool products (vector ALU, bit-exact with NumPy's wrap-around arithmetic):
+ * replaces tensor/math.py:1879 Dot.perform (np.dot) and tensor/blas.py:2224 BatchedDot.perform for
+ * AHIP_BOOL / AHIP_I8..AHIP_U64 operands of ONE dtype (mixed operands are cast by the caller, as
+ * Dot.make_node :1903 upcasts).  C[b] = A[b] @ B[b]; element strides, zero batch stride = broadcast. */
+int ahip_igemm_batched(int dtype, int64_t batch, int64_t M, int64_t N, int64_t K, const void* A,
+                       int64_t a_bs, int64_t a_rs, int64_t a_cs, const void* B, int64_t b_bs,
+                       int64_t b_rs, int64_t b_cs, void* C, int64_t c_bs, int64_t c_rs, int64_t c_cs,
+                       void* stream);
 /* Split-K form for few output tiles and a very long K (weight gradients X.T @ dY): the K range runs
  * as S slices of the 128x128 kernel into the caller-provided workspace [S][M][N], then one pass
  * sums the slices in order and applies alpha / beta (deterministic).  ahip_gemm_ws_bytes returns

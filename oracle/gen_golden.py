@@ -397,6 +397,43 @@ def _():
         [N((40, 60), seed=1), N((60,), seed=2), N((40,), seed=3)]
 
 
+# integer / bool / mixed-dtype Dot (tensor/math.py:1879; tests/tensor/test_math.py TestDot): NumPy's
+# wrap-around arithmetic, bit for bit; a mixed pair is computed in the common type
+for _dt, _lo, _hi in (("int8", -128, 127), ("int16", -3000, 3000), ("int32", -70000, 70000),
+                      ("int64", -(2 ** 40), 2 ** 40), ("uint8", 0, 255), ("uint32", 0, 2 ** 31)):
+    def _mkID(dt=_dt, lo=_lo, hi=_hi):
+        A, Bm, v, w = T(dt, (2, 2), "A"), T(dt, (2, 2), "B"), T(dt, (2,), "v"), T(dt, (2,), "w")
+        return [A, Bm, v, w], [at.dot(A, Bm), at.dot(A, v), at.dot(w, A), at.dot(w, at.dot(A, v)),
+                               at.dot(Bm.T[::2], A.T[:, ::-1])], \
+            [I((70, 45), dt, 1, lo, hi), I((45, 83), dt, 2, lo, hi), I((45,), dt, 3, lo, hi),
+             I((70,), dt, 4, lo, hi)]
+    case(f"dot_{_dt}", exact=True)(_mkID)
+
+
+@case("dot_bool", exact=True)
+def _():
+    A, Bm, v = T("bool", (2, 2), "A"), T("bool", (2, 2), "B"), T("bool", (2,), "v")
+    return [A, Bm, v], [at.dot(A, Bm), at.dot(A, v)], [B((33, 70), 1, 0.05), B((70, 20), 2, 0.05),
+                                                      B((70,), 3, 0.05)]
+
+
+@case("dot_mixed", rtol=1e-12, atol=1e-9)
+def _():
+    Ai, Bf, Cd, Dl, v8 = at.imatrix("Ai"), at.fmatrix("Bf"), at.dmatrix("Cd"), at.lmatrix("Dl"), \
+        at.bvector("v8")
+    return [Ai, Bf, Cd, Dl, v8], [at.dot(Ai, Bf), at.dot(Bf.T, Cd), at.dot(Ai, Dl), at.dot(Dl.T, v8),
+                                  at.dot(Cd.T, Dl)], \
+        [I((30, 40), "int32", 1, -1000, 1000), N((40, 30), "float32", 2), N((40, 25), "float64", 3),
+         I((40, 30), "int64", 4, -(2 ** 36), 2 ** 36), I((40,), "int8", 5, -100, 100)]
+
+
+@case("batched_dot_int32", exact=True, ref_py=True)
+def _():
+    x, y = at.itensor3("x"), at.itensor3("y")
+    return [x, y], [at.batched_dot(x, y)], [I((5, 17, 40), "int32", 1, -70000, 70000),
+                                            I((5, 40, 9), "int32", 2, -70000, 70000)]
+
+
 def _gemv_case(name, dt, M, Nn, alpha, beta, tA=False, rtol=None):
     def mk():
         y, A, x = T(dt, (2,), "y"), T(dt, (2, 2), "A"), T(dt, (2,), "x")

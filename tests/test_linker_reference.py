@@ -241,10 +241,12 @@ def test_accept_keeps_linker_options(ae):
     assert l2 is not l1 and l2.return_numpy and not l2.use_graph and l2.fgraph is not l1.fgraph
 
 
-def test_mixed_dtype_dot_is_cast_and_integer_dot_is_refused_at_compile_time(ae):
-    """no dtype surprise at run time — a float32 x float64 ``Dot`` (np.dot
-    upcasts, tensor/math.py:1879) is lowered with a cast, an integer ``Dot`` (no kernel on the BLAS
-    path) raises ``UnsupportedOp`` when the function is compiled."""
+def test_mixed_dtype_and_integer_dot_are_lowered_float16_is_refused_at_compile_time(ae):
+    """No dtype surprise at run time: the operands of a ``Dot`` are cast to the node's output
+    dtype when it is lowered (``Dot.make_node`` upcasts, ``np.dot`` converts to the common type:
+    tensor/math.py:1903 / :1929) — float32 x float64 -> float64, int32 x float32 -> float64,
+    int8 x int64 -> int64 — and an integer product keeps NumPy's wrap-around arithmetic; a
+    float16 ``Dot`` (no kernel) raises ``UnsupportedOp`` when the function is compiled."""
     import aesara.tensor as at
     from aesara.compile.mode import Mode
     from aesara_amd.linker import HIP_QUERY
@@ -257,9 +259,20 @@ def test_mixed_dtype_dot_is_cast_and_integer_dot_is_refused_at_compile_time(ae):
     assert r1.dtype == np.float64
     np.testing.assert_allclose(r1, xv @ yv, rtol=1e-12)
     np.testing.assert_allclose(r2, yv.T @ xv.T, rtol=1e-12)
-    i, j = at.lmatrix("i"), at.lmatrix("j")
-    with pytest.raises(UnsupportedOp, match="only float32 / float64"):
-        ae.function([i, j], at.dot(i, j), mode=Mode(_oracle_linker(), HIP_QUERY))
+    i, j, b = at.lmatrix("i"), at.lmatrix("j"), at.bmatrix("b")
+    g = ae.function([i, j, b, x], [at.dot(i, j), at.dot(b, b.T), at.dot(i, x.T)],
+                    mode=Mode(_oracle_linker(), HIP_QUERY))
+    rng = np.random.default_rng(2)
+    iv, jv = rng.integers(-2 ** 40, 2 ** 40, (4, 5)), rng.integers(-2 ** 40, 2 ** 40, (5, 4))
+    bv = rng.integers(-128, 127, (4, 5)).astype("int8")
+    o1, o2, o3 = g(iv, jv, bv, xv)
+    assert o1.dtype == np.int64 and o2.dtype == np.int8 and o3.dtype == np.float64
+    np.testing.assert_array_equal(o1, iv @ jv)                  # wraps like NumPy
+    np.testing.assert_array_equal(o2, bv @ bv.T)
+    np.testing.assert_allclose(o3, iv @ xv.T.astype("float64"), rtol=1e-12)
+    h1, h2 = at.matrix("h1", dtype="float16"), at.matrix("h2", dtype="float16")
+    with pytest.raises(UnsupportedOp, match="float16"):
+        ae.function([h1, h2], at.dot(h1, h2), mode=Mode(_oracle_linker(), HIP_QUERY))
 
 
 def test_linker_clone_and_scan_inner_mode(ae):
