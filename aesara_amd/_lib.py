@@ -130,6 +130,7 @@ SIGNATURES = {
     "ahip_reduce_partials_bytes": (sz, []),
     "ahip_elemwise_reduce_all": (i32, [vp, i32, p_i64, i32, p_vp, p_i64, i32, i32, vp, vp, sz,
                                        vp]),
+    "ahip_elemwise_reduce_all_multi": (i32, [vp, i32, i32, p_vp, p_i64, i32, i32, p_vp, vp, sz, vp]),
     "ahip_set_param": (i32, [C.c_char_p, i64]),
     "ahip_elemwise_reduce_axis": (i32, [vp, i32, i32, i32, p_i64, i32, p_vp, p_i64, i32, vp,
                                         i32, i32, i32, vp]),

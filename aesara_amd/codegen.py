@@ -48,6 +48,13 @@ struct Args {
   i64 n; i64 shape[AHIP_MAXD]; i64 stride[AHIP_MAXOPS][AHIP_MAXD]; void* ptr[AHIP_MAXOPS];
   void* ws; void* out; i64 aux0; i64 aux1; int nd; int nops;
 };
+// horizontally fused full reductions (ahip_ewh_args): jobs share one grid
+#define AHIP_HJOBS 16
+#define AHIP_HOPS 6
+struct ArgsH {
+  i64 n[AHIP_HJOBS]; void* ptr[AHIP_HJOBS][AHIP_HOPS]; void* out[AHIP_HJOBS];
+  unsigned wg0[AHIP_HJOBS + 1]; int njobs; void* ws; i64 aux1;
+};
 template <typename T, int N> struct alignas((sizeof(T) * N) >= 16 ? 16 : (sizeof(T) * N)) Pack { T v[N]; };
 
 template <typename T, int N> __device__ __forceinline__ Pack<T, N> nt_load(const Pack<T, N>* p) {
@@ -597,8 +604,11 @@ class KernelSpec:
 
     def __init__(self, scalar, in_dtypes, out_dtypes, out_refs, inner, nd, vec, block=256,
                  idx64=False, reduce=None, unroll=1, nt=False, invariant=None, tile_dim=None, pipe=0,
-                 early=None, blocked=None, trace=None, fast_exp=None):
+                 early=None, blocked=None, trace=None, fast_exp=None, hjobs=False):
         self.scalar = scalar
+        # horizontal fusion: the kernel takes an ArgsH block — several independent jobs of this
+        # one specialisation in one grid (flat full reductions only)
+        self.hjobs = bool(hjobs)
         flat_all = (reduce is not None and reduce.get("kind") == "all" and tile_dim is None
                     and nd == 1 and vec > 1)
         # flat full reductions: the first group of loads is issued before the invariant prologue
@@ -609,6 +619,9 @@ class KernelSpec:
         # the second workgroup a CU receives loses every issue arbitration to the older one
         # (oldest first): static priority for the second half of the grid evens their progress
         self.prio = int(knobs.get("RED_PRIO")) if flat_all else 0
+        if self.hjobs:
+            assert flat_all and len(in_dtypes) + len(out_dtypes) <= 6, "hjobs: flat full reductions only"
+            self.blocked, self.prio = 1, 0      # a contiguous chunk per workgroup inside its job
         # per-workgroup s_memrealtime stamps into the reduce workspace (tools/ew_trace.py)
         self.trace = bool(knobs.get("EW_TRACE") if trace is None else trace) and \
             reduce is not None and reduce.get("kind") == "all" and tile_dim is None
@@ -647,7 +660,8 @@ class KernelSpec:
         return _memo_key([self.scalar], fields, self._key)
 
     def _variant(self):
-        return "r4%d%d%d%d%d" % (self.early, self.blocked, self.trace, self.fast_exp, self.prio)
+        return "r4%d%d%d%d%d%s" % (self.early, self.blocked, self.trace, self.fast_exp, self.prio,
+                                   "H" if self.hjobs else "")
 
     def _key(self):
         import json
@@ -686,6 +700,7 @@ def _offset_code(spec, nops, nd_lo, nd_hi, var, idx_t, inner_vecs=None):
 
 
 TRACE_SLOTS = 8          # 8-byte stamps per workgroup of an EW_TRACE build (after the 4 KiB tail of ws)
+TRACE_HALF = 2048        # workgroup slots per half of the trace area (even / odd launch epochs)
 
 
 def _kernel_prologue(spec, name, L, mid=None, pre=None):
@@ -700,7 +715,20 @@ def _kernel_prologue(spec, name, L, mid=None, pre=None):
     V = spec.vec
     red = spec.reduce
     L.append(PRELUDE)
-    L.append('extern "C" __global__ __launch_bounds__(%d) void %s(Args a) {' % (spec.block, name))
+    hj = getattr(spec, "hjobs", False)
+    if hj:
+        # horizontally fused form: find this workgroup's job, then build the single-job view `a`
+        # the rest of the kernel is written against (flat operands: shape[0] = n, no strides)
+        L.append('extern "C" __global__ __launch_bounds__(%d) void %s(ArgsH h) {' % (spec.block, name))
+        L.append("  unsigned job_ = 0;")
+        L.append("  for (int j = 1; j < h.njobs; ++j) if (blockIdx.x >= h.wg0[j]) job_ = j;")
+        L.append("  const unsigned lb_ = blockIdx.x - h.wg0[job_], gj_ = h.wg0[job_ + 1] - h.wg0[job_];")
+        L.append("  const unsigned slot0_ = h.wg0[job_];")
+        L.append("  struct { i64 n; i64 shape[1]; void* ptr[AHIP_HOPS]; void* ws; void* out; i64 aux1; } a;")
+        L.append("  a.n = h.n[job_]; a.shape[0] = a.n; a.ws = h.ws; a.out = h.out[job_]; a.aux1 = h.aux1;")
+        L.append("  for (int k = 0; k < %d; ++k) a.ptr[k] = h.ptr[job_][k];" % nops)
+    else:
+        L.append('extern "C" __global__ __launch_bounds__(%d) void %s(Args a) {' % (spec.block, name))
     for k in range(nin):
         L.append("  const %s* __restrict__ p%d = (const %s*)a.ptr[%d];" %
                  (CTYPE[spec.in_dtypes[k]], k, CTYPE[spec.in_dtypes[k]], k))
@@ -714,12 +742,14 @@ def _kernel_prologue(spec, name, L, mid=None, pre=None):
                 L.append("  const i64 is%d = a.stride[%d][%d];" % (k, k, spec.nd - 1))
 
     if getattr(spec, "trace", False):
-        L.append("  unsigned long long* const tr_ = (unsigned long long*)((char*)a.ws + a.aux1 + 4096) + "
-                 "%d * (size_t)blockIdx.x;" % TRACE_SLOTS)
-        L.append("  if (threadIdx.x == 0) { tr_[0] = __builtin_readcyclecounter(); tr_[1] = wall_clock64(); "
+        # stamps are kept in registers until the launch epoch is known: even and odd epochs write
+        # to two halves of the trace area, so the stamps of two CONSECUTIVE launches survive
+        # (end of one launch -> first wavefront of the next, on one clock)
+        L.append("  unsigned long long tr_s_[8] = {0, 0, 0, 0, 0, 0, 0, 0};")
+        L.append("  if (threadIdx.x == 0) { tr_s_[0] = __builtin_readcyclecounter(); tr_s_[1] = wall_clock64(); "
                  "unsigned hw_; asm volatile(\"s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\" : \"=s\"(hw_)); "
                  "unsigned xcc_; asm volatile(\"s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)\" : \"=s\"(xcc_)); "
-                 "tr_[7] = ((unsigned long long)xcc_ << 32) | hw_; }")
+                 "tr_s_[7] = ((unsigned long long)xcc_ << 32) | hw_; }")
     # every load the head of the kernel depends on is ISSUED before anything waits: the small
     # ones first (exp-table entry, scalar operands, launch epoch: they come back from the
     # memory-side cache), then — ``mid`` — the first group of a flat reduction's stream, so the
@@ -740,9 +770,12 @@ def _kernel_prologue(spec, name, L, mid=None, pre=None):
                 L.append("  const %s %s = p%d[0];" % (CTYPE[spec.in_dtypes[k]], e, k))
                 inv_in[k] = "(%s != 0)" % e if spec.in_dtypes[k] == "bool" else e
     if red is not None and red["kind"] == "all":
-        # launch epoch of the finalize (read early: its latency hides under the streaming loop)
-        L.append("  const unsigned ep0 = __hip_atomic_load((unsigned*)((char*)a.ws + a.aux1 + 2048 + 64), "
-                 "__ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);")
+        # launch epoch of the finalize (read early: its latency hides under the streaming loop);
+        # a fused launch keeps one epoch word per job (a job's collector advances it when all of
+        # THAT job's workgroups have published, i.e. have read it)
+        L.append("  unsigned* const epochp = (unsigned*)((char*)a.ws + a.aux1 + 2048 + %s);" %
+                 ("256 + 4 * job_" if hj else "64"))
+        L.append("  const unsigned ep0 = __hip_atomic_load(epochp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);")
     if mid is not None:
         mid(L)
     if fast_exp:
@@ -826,7 +859,6 @@ def _reduce_all_finalize(spec, red, L):
 
     L.append("  __shared__ %s sm[%d];" % (sm_t, nw))
     L.append("  unsigned long long* wsp = (unsigned long long*)a.ws;")
-    L.append("  unsigned* epochp = (unsigned*)((char*)a.ws + a.aux1 + 2048 + 64);")
     L.append("  unsigned* errp = (unsigned*)((char*)a.ws + a.aux1 + 2048 + %d);" % REDUCE_ERR_OFF)
     L.append("  const unsigned ep = ep0 + 1u;")
     L.append("  const unsigned wv_ = threadIdx.x >> 6, ln_ = threadIdx.x & 63u;")
@@ -847,12 +879,18 @@ def _reduce_all_finalize(spec, red, L):
     L.append("      __hip_atomic_store(slot, ((cv.u >> 32) << 32) | ep, %s);" % AG)
     L.append("      __hip_atomic_store(slot + 1, (cv.u << 32) | ep, %s);" % AG)
     if tr:
-        L.append("      tr_[4] = wall_clock64();")
+        L.append("      tr_s_[4] = wall_clock64();")
+        L.append("      unsigned long long* const tr_ = (unsigned long long*)((char*)a.ws + a.aux1 + 4096) + "
+                 "%d * ((size_t)blockIdx.x + (ep & 1u) * %d);" % (TRACE_SLOTS, TRACE_HALF))
+        L.append("      for (int q = 0; q < 8; ++q) if (q < 5 || q == 7) tr_[q] = tr_s_[q];")
     L.append("    }")
     L.append("  }")
-    L.append("  if (blockIdx.x != 0) return;")
-    # ---- workgroup 0: collect
-    L.append("  const unsigned G_ = gridDim.x;")
+    hj = getattr(spec, "hjobs", False)
+    L.append("  if (%s != 0) return;" % ("lb_" if hj else "blockIdx.x"))
+    # ---- workgroup 0 (of the job): collect
+    L.append("  const unsigned G_ = %s;" % ("gj_" if hj else "gridDim.x"))
+    if hj:
+        L.append("  wsp += 2 * (size_t)slot0_;             // this job's partial slots")
     L.append("  const unsigned ncol_ = (G_ + %du) / %du < %du ? (G_ + %du) / %du : %du;   // collecting waves" %
              (64 * K - 1, 64 * K, nw, 64 * K - 1, 64 * K, nw))
     L.append("  const bool one_wave = ncol_ <= 1u;")
@@ -901,7 +939,7 @@ def _reduce_all_finalize(spec, red, L):
     L.append("    }")
     L.append("  }")
     if tr:
-        L.append("  if (threadIdx.x == 0) tr_[5] = wall_clock64();")
+        L.append("  if (threadIdx.x == 0) tr_s_[5] = wall_clock64();")
     L.append("  {")
     L.extend(wave_fold_lines(acc_t, comb))
     if nw > 1:
@@ -918,7 +956,10 @@ def _reduce_all_finalize(spec, red, L):
     L.append("      *(%s*)a.out = %s;" % (CTYPE[red["out"]], _store_val("r", red["acc"], red["out"])))
     L.append("      __hip_atomic_store(epochp, ep, %s);" % AG)
     if tr:
-        L.append("      tr_[6] = wall_clock64();")
+        L.append("      tr_s_[6] = wall_clock64();")
+        L.append("      unsigned long long* const tr_ = (unsigned long long*)((char*)a.ws + a.aux1 + 4096) + "
+                 "%d * ((size_t)blockIdx.x + (ep & 1u) * %d);" % (TRACE_SLOTS, TRACE_HALF))
+        L.append("      tr_[5] = tr_s_[5]; tr_[6] = tr_s_[6];")
     L.append("    }")
     L.append("  }")
 
@@ -1062,8 +1103,9 @@ def generate(spec: KernelSpec):
         L_.append("  const %s inner_vecs = (%s)(a.shape[%d] / %d);" % (idx_t, idx_t, spec.nd - 1, V))
         if spec.blocked:
             L_.append("  const %s items_all = (%s)(a.n / %d);" % (idx_t, idx_t, V))
-            L_.append("  const %s chunk_ = ((items_all + (%s)gridDim.x - 1) / (%s)gridDim.x + %d) / %d * %d;" %
-                      (idx_t, idx_t, idx_t, spec.block - 1, spec.block, spec.block))
+            grd = "gj_" if spec.hjobs else "gridDim.x"
+            L_.append("  const %s chunk_ = ((items_all + (%s)%s - 1) / (%s)%s + %d) / %d * %d;" %
+                      (idx_t, idx_t, grd, idx_t, grd, spec.block - 1, spec.block, spec.block))
             if spec.blocked == 2:
                 # workgroup b runs on XCD b % 8 (observed dispatch order, a speed hint only): give
                 # every XCD one contiguous eighth of the stream, so an XCD's L2 / TLB sees 1/8 of
@@ -1071,7 +1113,7 @@ def generate(spec: KernelSpec):
                 L_.append("  const unsigned vb_ = (gridDim.x % 8u == 0u) ? (blockIdx.x % 8u) * (gridDim.x / 8u) + "
                           "blockIdx.x / 8u : blockIdx.x;")
             else:
-                L_.append("  const unsigned vb_ = blockIdx.x;")
+                L_.append("  const unsigned vb_ = %s;" % ("lb_" if spec.hjobs else "blockIdx.x"))
             L_.append("  const %s beg_ = (%s)vb_ * chunk_;" % (idx_t, idx_t))
             L_.append("  const %s items = beg_ + chunk_ < items_all ? beg_ + chunk_ : items_all;" % idx_t)
             L_.append("  const %s step = %d;" % (idx_t, spec.block))
@@ -1184,7 +1226,7 @@ def generate(spec: KernelSpec):
                 out.append("off%d%s + (i64)%s * is%d" % (k, off_sfx, inner, k))
         return out
 
-    tstamp = (lambda k: L.append("  if (threadIdx.x == 0) tr_[%d] = wall_clock64();" % k)) \
+    tstamp = (lambda k: L.append("  if (threadIdx.x == 0) tr_s_[%d] = wall_clock64();" % k)) \
         if spec.trace else (lambda k: None)
     if red is None or red["kind"] == "all":
         nd = spec.nd

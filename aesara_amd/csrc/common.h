@@ -79,6 +79,8 @@ int ahip_launch_module(hipFunction_t f, dim3 grid, dim3 block, size_t shmem, hip
   }
 
 AHIP_PTRS_BEGIN(ahip_ew_args) AHIP_PTRA(ptr, AHIP_MAXOPS) AHIP_PTR1(ws) AHIP_PTR1(out) AHIP_PTRS_END
+AHIP_PTRS_BEGIN(ahip_ewh_args) AHIP_PTRA(ptr, AHIP_HJOBS * AHIP_HOPS) AHIP_PTRA(out, AHIP_HJOBS) AHIP_PTR1(ws)
+AHIP_PTRS_END
 AHIP_PTRS_BEGIN(ahip_gv_args) AHIP_PTRA(A, AHIP_MAXDOTS) AHIP_PTRA(x, AHIP_MAXDOTS)
   AHIP_PTRA(ptr, AHIP_GV_MAXOPS) AHIP_PTRA(xin, AHIP_MAXDOTS * AHIP_GV_MAXXIN) AHIP_PTRA(xout, AHIP_MAXDOTS)
 AHIP_PTRS_END

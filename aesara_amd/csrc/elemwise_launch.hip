@@ -122,6 +122,53 @@ int ahip_elemwise_reduce_all(ahip_fn_t k, int nd, const int64_t* shape, int nops
   return launch(k, (uint32_t)want, 1, block, &a, stream);
 }
 
+int ahip_elemwise_reduce_all_multi(ahip_fn_t k, int njobs, int nops, void* const* ptrs,
+                                   const int64_t* n, int vec, int block, void* const* outs, void* ws,
+                                   size_t ws_bytes, void* stream) {
+  AHIP_REQUIRE(k && ptrs && n && outs && ws, "null argument");
+  AHIP_REQUIRE(njobs >= 1 && njobs <= AHIP_HJOBS, "njobs=%d outside [1,%d]", njobs, AHIP_HJOBS);
+  AHIP_REQUIRE(nops >= 1 && nops <= AHIP_HOPS, "nops=%d outside [1,%d]", nops, AHIP_HOPS);
+  AHIP_REQUIRE(ws_bytes >= ahip_reduce_ws_bytes(), "workspace too small");
+  AHIP_REQUIRE(vec >= 1 && block >= 64 && block % 64 == 0, "bad vec/block");
+  ahip_ewh_args h;
+  memset(&h, 0, sizeof(h));
+  h.njobs = njobs;
+  h.ws = ws;
+  h.aux1 = (int64_t)AHIP_MAX_PARTIALS * 16;
+  int64_t per_cu = g_reduce_blocks_per_cu * 256 / block;
+  if (per_cu < 1) per_cu = 1;
+  int64_t cap = (int64_t)ahip_cu_count() * per_cu;
+  if (cap > AHIP_MAX_PARTIALS) cap = AHIP_MAX_PARTIALS;
+  if (cap < njobs) cap = njobs;
+  int64_t total = 0;
+  for (int j = 0; j < njobs; ++j) {
+    AHIP_REQUIRE(n[j] >= 0 && n[j] % vec == 0, "job %d: %lld elements not divisible by vec %d", j,
+                 (long long)n[j], vec);
+    total += n[j] / vec;
+  }
+  // the grid is shared in proportion to the items of each job, one workgroup at least, and never
+  // more workgroups than a job has block-sized pieces
+  uint32_t at = 0;
+  for (int j = 0; j < njobs; ++j) {
+    const int64_t items = n[j] / vec;
+    int64_t want = (items + block - 1) / block;
+    int64_t share = total > 0 ? (cap * items + total - 1) / total : 1;
+    if (want > share) want = share;
+    if (want < 1) want = 1;
+    h.n[j] = n[j];
+    h.out[j] = outs[j];
+    for (int kx = 0; kx < nops; ++kx) h.ptr[j][kx] = n[j] > 0 ? ptrs[(size_t)j * nops + kx] : ws;
+    h.wg0[j] = at;
+    at += (uint32_t)want;
+  }
+  AHIP_REQUIRE(at <= AHIP_MAX_PARTIALS, "too many workgroups");
+  for (int j = njobs; j <= AHIP_HJOBS; ++j) h.wg0[j] = at;
+  uint16_t po[AHIP_MAX_PTRS];
+  const int np = ahip_ptrs(&h, po);
+  return ahip_launch_module(k->fn, dim3(at, 1, 1), dim3(block, 1, 1), 0, as_stream(stream), &h,
+                            sizeof(h), po, np);
+}
+
 int ahip_elemwise_tiled(ahip_fn_t k, int nd, const int64_t* shape, int nops, void* const* ptrs,
                         const int64_t* strides, int tile_dim, int tile, void* out, void* ws,
                         size_t ws_bytes, void* stream) {

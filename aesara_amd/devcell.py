@@ -106,12 +106,21 @@ class DeviceFilterType:
     in-place Op would destroy; this linker's rewrite query excludes ``inplace`` and the executor
     only ever writes into buffers it allocated itself, so there is nothing for it to protect.
     """
-    __slots__ = ("_t",)
+    __slots__ = ("_t", "_want", "_ndim", "_static")
 
     def __init__(self, t):
-        object.__setattr__(self, "_t", t._t if isinstance(t, DeviceFilterType) else t)
+        t = t._t if isinstance(t, DeviceFilterType) else t
+        object.__setattr__(self, "_t", t)
+        # what a device tensor must look like to pass untouched (checked per call, in this order)
+        object.__setattr__(self, "_want", TORCH_DTYPES.get(getattr(t, "dtype", None)))
+        object.__setattr__(self, "_ndim", getattr(t, "ndim", None))
+        object.__setattr__(self, "_static", any(x is not None for x in getattr(t, "shape", ())))
 
     def filter(self, value, strict=False, allow_downcast=None):
+        if type(value) is torch.Tensor:
+            if value.dtype is self._want and value.ndim == self._ndim and not self._static \
+                    and value.device.type != "cpu":
+                return value                     # the common case: right dtype and rank, on the device
         if isinstance(value, torch.Tensor):
             if value.device.type == "cpu":
                 value = value.numpy()
@@ -133,7 +142,10 @@ class DeviceFilterType:
         return getattr(object.__getattribute__(self, "_t"), name)
 
     def __setattr__(self, name, value):
-        setattr(self._t, name, value)
+        if name in DeviceFilterType.__slots__:
+            object.__setattr__(self, name, value)
+        else:
+            setattr(self._t, name, value)
 
     def __eq__(self, other):
         return self._t == (other._t if isinstance(other, DeviceFilterType) else other)

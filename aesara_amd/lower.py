@@ -794,8 +794,9 @@ def _register_handlers():
         # reference: tensor/math.py:2871 MatMul (perform :2941 np.matmul): stacks of matrices in
         # the last two dims, batch dims broadcast, 1-d operands promoted
         dts = {v.type.dtype for v in node.inputs} | {node.outputs[0].type.dtype}
-        if len(dts) != 1 or dts.pop() not in ("float32", "float64"):
-            raise UnsupportedOp("MatMul is lowered for float32 / float64 operands of one dtype")
+        if len(dts) != 1 or dts.pop() not in ("float32", "float64", "bool", "int8", "int16", "int32",
+                                              "int64", "uint8", "uint16", "uint32", "uint64"):
+            raise UnsupportedOp("MatMul is lowered for operands of ONE float32 / float64 / integer dtype")
         ctx.emit("MatMul", node)
 
     from aesara.ifelse import IfElse

@@ -245,6 +245,11 @@ def main():
         assert rel < 1e-9, f"benchmark result mismatch: rel err {rel}"
     del want
 
+    stream = timer.stream()
+    ev0, ev1 = C.c_void_p(), C.c_void_p()
+    check(lib.ahip_event_create(C.byref(ev0)))
+    check(lib.ahip_event_create(C.byref(ev1)))
+
     h = None
     for _ in range(args.warmup):
         h = step()
@@ -261,12 +266,6 @@ def main():
         if h is not None:
             h.wait()
     state["i"] = ((state["i"] + BUCKET - 1) // BUCKET) * BUCKET if world > 1 else state["i"]
-    barrier()
-
-    stream = timer.stream()
-    ev0, ev1 = C.c_void_p(), C.c_void_p()
-    check(lib.ahip_event_create(C.byref(ev0)))
-    check(lib.ahip_event_create(C.byref(ev1)))
 
     barrier()
     t0 = time.perf_counter()
@@ -899,7 +898,7 @@ def cpu_baseline(np, ref_warm=None, secondary=None):
                 res["vs_reference"] = {"bar": refcheck.BAR, "rel_err": {k: v["max"] for k, v in vs.items()},
                                        "per_output": {k: v["rel_err"] for k, v in vs.items()},
                                        "ok": bool(vs) and all(v["max"] <= refcheck.BAR for v in vs.values()),
-                                       "what": "max |hip - ref| / max |ref| per output, same seeded inputs "
+                                       "what": "||hip - ref||_2 / ||ref||_2 per output, same seeded inputs "
                                                "(oracle/time_reference.make_inputs); ref = the reference's "
                                                "Mode('cvm','fast_run') on this host"}
             except Exception as e:                      # noqa: BLE001  (a check row must not cost the line)
@@ -916,7 +915,9 @@ def cpu_baseline(np, ref_warm=None, secondary=None):
                 if k and k in others and "ms_per_eval_full_config" in others[k]:
                     srow["cpu_reference_ms_per_eval"] = others[k]["ms_per_eval_full_config"]
                 if k and k in res["vs_reference"].get("rel_err", {}):
-                    srow.setdefault("check", {})["vs_reference_rel_err"] = res["vs_reference"]["rel_err"][k]
+                    if not isinstance(srow.get("check"), dict):
+                        srow["check"] = {}
+                    srow["check"]["vs_reference_rel_err"] = res["vs_reference"]["rel_err"][k]
             try:
                 ro = reference_rows(4.0, ["cfg2"], openmp=True, timeout=240)["rows"]["cfg2"]
                 res["openmp"] = {"value": 1e3 / ro["ms_per_eval"], "unit": "evals/s", "cores": ro["cores"],

@@ -72,6 +72,23 @@ typedef struct ahip_ew_args {
   int32_t nops;
 } ahip_ew_args;
 
+/* Kernel-argument block of a HORIZONTALLY FUSED launch of the generated Elemwise + full-CAReduce
+ * kernel: up to AHIP_HJOBS independent jobs of ONE kernel specialisation (same scalar program,
+ * dtypes, flat contiguous operands) — each job its own operands, length and result — share one
+ * grid: workgroups [wg0[j], wg0[j + 1]) belong to job j.
+ *   extern "C" __global__ void k(ahip_ewh_args h);      (codegen.generate, spec.hjobs)        */
+#define AHIP_HJOBS 16
+#define AHIP_HOPS 6
+typedef struct ahip_ewh_args {
+  int64_t n[AHIP_HJOBS];                   /* elements of job j                                  */
+  void* ptr[AHIP_HJOBS][AHIP_HOPS];        /* operand base pointers of job j (inputs, outputs)   */
+  void* out[AHIP_HJOBS];                   /* reduction result of job j                          */
+  uint32_t wg0[AHIP_HJOBS + 1];            /* first workgroup of job j; wg0[njobs] = grid size   */
+  int32_t njobs;
+  void* ws;                                /* shared reduction workspace                         */
+  int64_t aux1;                            /* byte offset of the workspace tail (epochs, errors) */
+} ahip_ewh_args;
+
 /* Kernel-argument block of the GENERATED fused GEMV-chain + Elemwise epilogue kernels
  *   extern "C" __global__ void k(ahip_gv_args a);       (codegen.generate_gemv_epilogue)
  * y[m] = f(dot_0[m], .., dot_{D-1}[m], operands[m]),  dot_d[m] = sum_k A_d[m*a_rs + k*a_cs] * x_d[k*incx] */
@@ -230,6 +247,15 @@ size_t ahip_reduce_partials_bytes(void);
 int ahip_elemwise_reduce_all(ahip_fn_t k, int nd, const int64_t* shape, int nops,
                              void* const* ptrs, const int64_t* strides, int vec, int block,
                              void* out, void* ws, size_t ws_bytes, void* stream);
+/* Horizontal fusion: `njobs` (2..AHIP_HJOBS) independent full reductions of the SAME generated
+ * kernel (spec.hjobs form) in ONE launch — flat contiguous operands only (`nops` <= AHIP_HOPS
+ * per job, ptrs[j * nops + k]), n[j] elements (multiples of `vec`), results out[j].  The grid is
+ * shared in proportion to the job sizes (at least one workgroup per job); every job runs its own
+ * deterministic finalize (own partial slots and epoch word in `ws`).  What this buys: the fixed
+ * cost of a launch (ramp, finalize hop, kernel boundary: ~5 us) is paid once, not per job.      */
+int ahip_elemwise_reduce_all_multi(ahip_fn_t k, int njobs, int nops, void* const* ptrs,
+                                   const int64_t* n, int vec, int block, void* const* outs, void* ws,
+                                   size_t ws_bytes, void* stream);
 
 /* ---- K2: axis CAReduce (optionally with a fused Elemwise producer) ----------------------
  * The iteration space is [kept dims (nk) | reduced dims (nr)], both already collapsed by the

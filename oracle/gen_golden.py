@@ -397,6 +397,26 @@ def _():
         [N((40, 60), seed=1), N((60,), seed=2), N((40,), seed=3)]
 
 
+# independent outputs of ONE scalar program over operands of different shapes (towers of a model,
+# per-parameter norms): the executor sends them out as one horizontally fused launch
+@case("hfuse_towers_f64", rtol=1e-12, atol=1e-12)
+def _():
+    xs = [at.dmatrix("x%d" % k) for k in range(5)]
+    return xs, [at.exp(-0.5 * x ** 2).sum() for x in xs], \
+        [N((64, 32), seed=1), N((200, 120), seed=2), N((8, 4), seed=3), N((333, 64), seed=4),
+         N((96, 1000), seed=5)]
+
+
+@case("hfuse_norms_f32", rtol=2e-5, atol=1e-6)
+def _():
+    W, b, V, c = at.fmatrix("W"), at.fvector("b"), at.fmatrix("V"), at.fvector("c")
+    ps = [W, b, V, c]
+    sq = [at.sqr(p).sum() for p in ps]
+    return ps, sq + [at.sqrt(sq[0] + sq[1] + sq[2] + sq[3]), abs(W).max(), abs(V).max()], \
+        [N((300, 200), "float32", 1), N((200,), "float32", 2), N((200, 48), "float32", 3),
+         N((48,), "float32", 4)]
+
+
 # integer / bool / mixed-dtype Dot (tensor/math.py:1879; tests/tensor/test_math.py TestDot): NumPy's
 # wrap-around arithmetic, bit for bit; a mixed pair is computed in the common type
 for _dt, _lo, _hi in (("int8", -128, 127), ("int16", -3000, 3000), ("int32", -70000, 70000),

@@ -52,14 +52,29 @@ def available():
 
 
 def _unpack():
+    """Unpack the archive into OVERLAY — once, also when several processes (pytest-xdist workers,
+    bench.py's baseline child next to a test) want it at the same moment: under a file lock, into
+    a private directory that is renamed into place when it is complete."""
+    import fcntl
+    import shutil
     parent = os.path.dirname(OVERLAY.rstrip("/")) or "/"
     os.makedirs(parent, exist_ok=True)
-    with tarfile.open(ARCHIVE) as tf:
-        top = tf.getnames()[0].split("/")[0]
-        tf.extractall(parent)
-    got = os.path.join(parent, top)
-    if os.path.abspath(got) != os.path.abspath(OVERLAY):
-        os.replace(got, OVERLAY)
+    with open(OVERLAY.rstrip("/") + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if _built():
+                return
+            tmp = OVERLAY.rstrip("/") + ".unpack.%d" % os.getpid()
+            shutil.rmtree(tmp, ignore_errors=True)
+            os.makedirs(tmp)
+            with tarfile.open(ARCHIVE) as tf:
+                top = tf.getnames()[0].split("/")[0]
+                tf.extractall(tmp)
+            shutil.rmtree(OVERLAY, ignore_errors=True)
+            os.replace(os.path.join(tmp, top), OVERLAY)
+            shutil.rmtree(tmp, ignore_errors=True)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
 
 
 def import_reference():

@@ -656,7 +656,8 @@ def test_baseline_configs_against_the_reference_c_linker(tmp_path):
     reference's ``Mode("cvm","fast_run")`` from the packed overlay) evaluates cfg 2 / 1b / 3a / 3b at
     the full 4096 shapes, cfg 4 (B = 1 and B = 64) on a T = 64 sample and cfg 5 on N = 2^20 rows;
     ``tests/refcheck.py`` regenerates the same seeded inputs, runs the HIP path and compares
-    every output (max |dx| / max |ref|).  ``bench.py`` puts the same numbers on its line."""
+    every output (norm-wise relative error; |dx| / |ref| for scalars).  ``bench.py`` puts the
+    same numbers on its line."""
     import os
     import subprocess
     import sys

@@ -92,8 +92,10 @@ def test_golden_case_through_aesara_function(gg, ae, name):
                    for o in (got if isinstance(got, list) else [got])), "outputs stay in HBM"
     assert_matches(c, _host(got), want, "call 1 (host inputs)")
     assert_matches(c, _host(f(*xs)), want, "call 2 (replay)")
+    # (0-d index-like values stay 0-d host values; uint16/32/64 have no torch device container)
     dev = [x if (x.ndim == 0 and x.dtype.kind in "iub") or not x.flags.c_contiguous
-           else torch.from_numpy(np.array(x, order="C")).cuda() for x in xs]     # (0-d stays 0-d)
+           or x.dtype.name in ("uint16", "uint32", "uint64")
+           else torch.from_numpy(np.array(x, order="C")).cuda() for x in xs]
     assert_matches(c, _host(f(*dev)), want, "call 3 (device inputs through Function's filter)")
     f.trust_input = True
     assert_matches(c, _host(f(*dev)), want, "call 4 (device inputs, trust_input)")

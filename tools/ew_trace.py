@@ -63,7 +63,7 @@ def main():
     torch.cuda.synchronize()
     off = lib.ahip_reduce_partials_bytes() + 4096
     S = cg.TRACE_SLOTS
-    rows = []
+    rows, gaps = [], []
     for k in range(a.evals):
         # keep the stream busy in front of the traced eval (a launch after an idle stream starts
         # differently from one inside the benchmark's back-to-back sequence)
@@ -72,12 +72,23 @@ def main():
         ex(*args(xs[(k * 5 + 4) % 8]))
         torch.cuda.synchronize()
         raw = ex._ws[off:].view(torch.int64).cpu().numpy()
-        n = 0
-        while n * S < raw.size and raw[n * S + 1] != 0:
-            n += 1
-        st = raw[:n * S].reshape(n, S).copy()
+        raw = raw[:(raw.size // S) * S].reshape(-1, S)
+        halves = []
+        for h in range(2):                     # even / odd launch epochs: two consecutive launches
+            blk = raw[h * cg.TRACE_HALF:(h + 1) * cg.TRACE_HALF]
+            n = 0
+            while n < blk.shape[0] and blk[n, 1] != 0:
+                n += 1
+            halves.append(blk[:n].copy())
+        halves.sort(key=lambda b: b[:, 1].min() if b.size else 0)
+        prev, st = halves
         ex._ws[off:].zero_()
         rows.append(st)
+        if prev.size and st.size:
+            # one clock for both launches: when did the next launch's first wavefront start,
+            # counted from the previous launch's last act (its result store)
+            gaps.append(((st[:, 1].min() - prev[0, 6]) * 0.01, (st[:, 1].min() - prev[:, 4].max()) * 0.01,
+                         (st[0, 6] - prev[0, 6]) * 0.01))
     G = rows[0].shape[0]
     tick_us = 0.01
     out = {"workload": ("sum(x)" if a.sum_only else "exp(-(x-mu)^2/(2 sigma^2)).sum()") +
@@ -112,6 +123,15 @@ def main():
         add("collect_after_last_publish_us", (st[0, 5] - pub.max()) * tick_us)
         add("store_after_collect_us", (st[0, 6] - st[0, 5]) * tick_us)
         add("wg0_loop_done_us", (st[0, 3] - t0) * tick_us)
+    if gaps:
+        g = np.array(gaps)
+        out["consecutive_launches_us"] = {
+            "result_stored(k) -> first_entry(k+1)": {"mean": round(float(g[:, 0].mean()), 3),
+                                                     "min": round(float(g[:, 0].min()), 3),
+                                                     "max": round(float(g[:, 0].max()), 3)},
+            "last_partial_published(k) -> first_entry(k+1)": {"mean": round(float(g[:, 1].mean()), 3)},
+            "result_stored(k) -> result_stored(k+1) (the period)": {"mean": round(float(g[:, 2].mean()), 3),
+                                                                     "min": round(float(g[:, 2].min()), 3)}}
     out["timeline_us_from_first_entry"] = {k: {"mean": round(float(np.mean(v)), 3),
                                                  "min": round(float(np.min(v)), 3),
                                                  "max": round(float(np.max(v)), 3)}
