@@ -14,8 +14,10 @@ import os
 # kernel of this library launched on one of torch's streams fails with "no ROCm-capable device".
 import torch  # noqa: F401,E402
 
+from . import knobs  # noqa: E402
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("AESARA_HIP_LIB", os.path.join(_HERE, "libaesara_hip.so"))
+LIB_PATH = knobs.get("LIB") or os.path.join(_HERE, "libaesara_hip.so")
 
 AHIP_MAXD = 6
 AHIP_MAXOPS = 32

@@ -41,6 +41,12 @@ static int launch(ahip_fn_t k, uint32_t gx, uint32_t gy, uint32_t block, const a
 // grid-stride over the rest (guide: Guideline 11).
 static int64_t g_stream_blocks_per_cu = 8;
 static int64_t g_reduce_blocks_per_cu = 8;
+// flat full reductions (ahip_elemwise_reduce_all): 16 wavefronts per CU = ONE 1024-thread workgroup.
+// r04 timeline (tools/ew_trace.py): of two workgroups per CU the second is dispatched 1-3 us late
+// (8192 wavefronts launch at ~20 cycles each per shader engine) and loses every issue arbitration
+// to the older one (it finishes at 23 us, the first at 15): one workgroup per CU with twice the
+// work per wavefront streams 128 MiB in 26.6-26.8 us instead of 27.0-27.3 (profiles/r04 sweeps 6, 7)
+static int64_t g_reduce_flat_blocks_per_cu = 4;
 
 static uint32_t stream_grid(int64_t items, int block) {
   int64_t want = (items + block - 1) / block;
@@ -59,7 +65,8 @@ size_t ahip_reduce_ws_bytes(void) { return (size_t)AHIP_MAX_PARTIALS * (16 + 64)
 int ahip_set_param(const char* name, int64_t value) {
   AHIP_REQUIRE(name != nullptr && value > 0, "bad parameter");
   if (!strcmp(name, "stream_blocks_per_cu")) g_stream_blocks_per_cu = value;
-  else if (!strcmp(name, "reduce_blocks_per_cu")) g_reduce_blocks_per_cu = value;
+  else if (!strcmp(name, "reduce_blocks_per_cu")) g_reduce_blocks_per_cu = g_reduce_flat_blocks_per_cu = value;
+  else if (!strcmp(name, "reduce_flat_blocks_per_cu")) g_reduce_flat_blocks_per_cu = value;
   else if (!strcmp(name, "gemm_small_max_tiles")) ahip_gemm_set_small_max_tiles(value);
   else if (!strcmp(name, "gemm_skinny_nf")) ahip_gemm_set_skinny_nf(value);
   else if (!strcmp(name, "gemm_half_max_tiles")) ahip_gemm_set_half_max_tiles(value);
@@ -108,7 +115,7 @@ int ahip_elemwise_reduce_all(ahip_fn_t k, int nd, const int64_t* shape, int nops
     // reduce_blocks_per_cu counts 256-thread blocks: the resident thread count per CU stays
     // the same for larger workgroups (1024 threads -> 2 per CU -> 512 partials, which ONE
     // workgroup folds in a single level of the in-kernel finalize)
-    int64_t per_cu = g_reduce_blocks_per_cu * 256 / block;
+    int64_t per_cu = g_reduce_flat_blocks_per_cu * 256 / block;
     if (per_cu < 1) per_cu = 1;
     int64_t cap = (int64_t)ahip_cu_count() * per_cu;
     if (cap > AHIP_MAX_PARTIALS) cap = AHIP_MAX_PARTIALS;

@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from . import knobs
 from ._lib import DTYPE_CODES, check, lib
 
 TORCH_DTYPES = {
@@ -134,8 +135,7 @@ class DevArray:
 # generated-kernel cache: source hash -> code object (disk, in-tree) -> loaded module
 # reference analogue: link/c/cmodule.py:618 ModuleCache keyed by get_module_hash (:419)
 # ---------------------------------------------------------------------------------------
-CACHE_DIR = os.environ.get(
-    "AESARA_HIP_KCACHE", os.path.join(os.path.dirname(os.path.abspath(__file__)), "_kcache"))
+CACHE_DIR = knobs.get("KCACHE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "_kcache")
 _lock = threading.Lock()
 _loaded = {}   # sha -> (module handle, {name: fn handle})
 

@@ -44,6 +44,7 @@ from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
+from . import knobs
 from .plan import Node, Plan
 
 
@@ -529,7 +530,7 @@ class HipComm:
             rank = dist.get_rank(bootstrap_group) if dist.is_initialized() else 0
         self.world, self.rank = int(world), int(rank or 0)
         bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-        if os.path.exists(bundled) and not os.environ.get("AESARA_HIP_RCCL"):
+        if os.path.exists(bundled) and not knobs.get("RCCL"):
             check(lib.ahip_comm_set_library(bundled.encode()))     # the copy torch itself uses
         if unique_id is None:
             buf = C.create_string_buffer(COMM_ID_BYTES)
@@ -558,11 +559,22 @@ class HipComm:
                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         return _Done()
 
-    def close(self):
+    def close(self, force=False):
+        """Destroy the communicator.  Launch lists that recorded an all-reduce hold its raw
+        handle (``REC_ALLREDUCE``): while any is alive (``recorded`` > 0: a ``ShardedPlan`` that
+        replays single lists) the communicator is kept unless ``force``."""
         from ._lib import lib
-        if self._h:
+        if self._h and (force or not self.recorded):
             lib.ahip_comm_destroy(self._h)
             self._h = None
+
+    recorded = 0        # launch lists holding this communicator's handle
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:           # noqa: BLE001  (interpreter shutdown)
+            pass
 
 
 def _dist_reduce(buf, op, group, async_op=False):
@@ -611,6 +623,13 @@ class ShardedPlan:
                 return PlanExecutor(p, use_graph=use_graph, device=device, borrow=True)
         self.execs = [executor_factory(p) for p, _ in self.spec.rounds]
         self._packs: Dict[tuple, list] = {}
+        # ONE launch list per sharded evaluation (use_graph + the C-ABI communicator): round 0's
+        # kernels, the packed all-reduce (a REC_ALLREDUCE entry), round 1's kernels, ... recorded
+        # once per input signature and replayed with one host call — no Python between the rounds
+        self.single_list = bool(use_graph) and isinstance(group, HipComm)
+        self._lists: Dict[tuple, tuple] = {}
+        self._no_list = set()       # signatures that cannot be served from one list
+        self.replays = 0            # evaluations served by a single-list replay (tests, bench)
 
     # -- world size of the group this instance communicates over --------------------------------
     def _world(self):
@@ -657,6 +676,10 @@ class ShardedPlan:
         handles = []
         world = self._world()
         sig = tuple(tuple(getattr(x, "shape", ())) for x in local_inputs)
+        if self.single_list and not async_op:
+            done = self._call_single_list(local_inputs, sig, world)
+            if done is not None:
+                return done
         for k, ((p_k, exchanges), ex) in enumerate(zip(spec.rounds, self.execs)):
             ins = list(local_inputs) + [carried_vals[v] for v in p_k.inputs[n_orig:]]
             if not p_k.nodes:        # nothing left to compute: combined values pass through
@@ -701,6 +724,87 @@ class ShardedPlan:
         if not self.borrow and not async_op:
             final = [o.clone() if isinstance(o, torch.Tensor) else o for o in final]
         return (final, handles) if async_op else final
+
+
+def _call_single_list(self, local_inputs, sig, world):
+    """Serve an evaluation from ONE recorded launch list (rounds + all-reduces).  Returns the
+    outputs, or None when this signature cannot be served that way (yet): the first evaluation of
+    a signature takes the ordinary path (it learns the partial shapes and builds the packed
+    exchange buffers), the second records, later ones replay.  Anything that would need work
+    outside the list — a host input, an input living at a new address, a round whose partial
+    does not land in the packed buffer by itself, data-dependent host control flow — keeps the
+    per-round path."""
+    import ctypes as C
+    import torch
+    from ._lib import check, lib
+    from .executor import HostReadInReplay
+    if not all(isinstance(x, torch.Tensor) and x.is_cuda for x in local_inputs):
+        return None
+    key = (sig, tuple(x.data_ptr() for x in local_inputs))
+    ent = self._lists.get(key)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if ent is not None:
+        check(lib.ahip_list_run(ent[0], stream))
+        self.replays += 1
+        final = ent[1]
+        return final if self.borrow else [o.clone() if isinstance(o, torch.Tensor) else o for o in final]
+    if key in self._no_list:
+        return None
+    spec = self.spec
+    n_orig = len(self.plan.inputs)
+    if any(exchanges and (k, sig) not in self._packs for k, (_p, exchanges) in enumerate(spec.rounds)):
+        return None                       # packed buffers not built yet: ordinary first evaluation
+    if not all(hasattr(ex, "trace_eager") for ex in self.execs):
+        return None
+
+    def run_rounds(recording):
+        carried, results = {}, []
+        for k, ((p_k, exchanges), ex) in enumerate(zip(spec.rounds, self.execs)):
+            ins = list(local_inputs) + [carried[v] for v in p_k.inputs[n_orig:]]
+            if not p_k.nodes:
+                outs = [ins[p_k.inputs.index(v)] for v in p_k.outputs]
+            else:
+                targets = self._packs[(k, sig)][2] if exchanges else None
+                outs = ex.record_external() if recording else ex.trace_eager(ins, out=targets)
+            if exchanges:
+                bufs, views, _ = self._packs[(k, sig)]
+                for pos, _rop, _xdt in exchanges:
+                    o = outs[pos]
+                    if not isinstance(o, torch.Tensor) or o.data_ptr() != views[pos].data_ptr():
+                        raise _NoSingleList("round %d: partial %d is not produced in the packed buffer" % (k, pos))
+                    outs[pos] = views[pos]
+                if world > 1 or self.force_collectives:
+                    for (rop, _xdt), buf in bufs.items():
+                        self.group.all_reduce(buf, rop)       # while recording: a REC_ALLREDUCE entry
+            results.append(outs)
+            for v, o in zip(p_k.outputs, outs):
+                carried[v] = o
+        return [results[r][pos] for r, pos in spec.out_src]
+
+    try:
+        run_rounds(False)                                     # pass 1: eager, allocation traces
+        lst = C.c_void_p()
+        check(lib.ahip_list_begin())
+        try:
+            final = run_rounds(True)                          # pass 2: everything into ONE list
+        finally:
+            rc = lib.ahip_list_end(C.byref(lst))
+        check(rc)
+    except (_NoSingleList, HostReadInReplay, NotImplementedError):
+        self._no_list.add(key)
+        return None
+    check(lib.ahip_list_run(lst, stream))                     # this call's results, from the list
+    self._lists[key] = (lst, final, list(local_inputs))       # inputs kept alive: their addresses are in the list
+    self.group.recorded += 1                                  # the list holds the communicator's handle
+    self.replays += 1
+    return final if self.borrow else [o.clone() if isinstance(o, torch.Tensor) else o for o in final]
+
+
+class _NoSingleList(Exception):
+    pass
+
+
+ShardedPlan._call_single_list = _call_single_list
 
 
 def run_local_shards(plan: Plan, split_inputs: Dict[int, int], shard_inputs: Sequence[Sequence],

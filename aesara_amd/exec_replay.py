@@ -1,0 +1,527 @@
+"""Launch-list / hipGraph replay of a PlanExecutor: input staging, the two-pass record (eager pass ->
+static arena -> recording pass), rebinding of recorded launches to new buffers, fresh outputs,
+error words (reference: the CVM's per-call protocol, link/c/c_code/lazylinker_c.c:752-890).
+
+Part of :class:`aesara_amd.executor.PlanExecutor` (a mixin: the methods run on the executor's
+state; split out of executor.py in round 4, no behaviour change)."""
+from __future__ import annotations
+
+from .exec_common import *  # noqa: F401,F403
+from .exec_common import (_I64, _VP, _i64arr, _Kernels, _FakeBuf, _CAST_SCALARS, _prod, _Arena, _os, _time)  # noqa: F401
+
+
+class ReplayMixin:
+
+    def _signature(self, vals):
+        return tuple((v.ptr, v.shape, v.strides, v.dtype) if isinstance(v, DevArray)
+                     else ("host", dtype_name(v.dtype), v.tobytes()) for v in vals)
+
+    STAGE_MAX_BYTES = 1 << 28   # inputs larger than this are never copied into staging buffers
+
+    def _stage_inputs(self, inputs):
+        """Replay needs the kernels' pointers to stay put, but a training loop hands over a new
+        batch (new tensor / new host array) on every call.  Host arrays always, and device
+        tensors from the second time a layout signature shows up with different pointers, are
+        copied into persistent per-signature staging buffers (one h2d / d2d copy per input per
+        call), so the recorded launch list is replayed instead of re-running the host path.
+        Returns the staged input list, or None to use ``inputs`` as they are."""
+        sig, nbytes, host = [], 0, False
+        for x in inputs:
+            if type(x) is torch.Tensor:
+                sig.append(("d", x.dtype, tuple(x.shape)))
+                nbytes += x.numel() * x.element_size()
+                if not x.is_cuda:
+                    host = True      # a CPU tensor is a host buffer: always staged, like ndarrays
+            elif isinstance(x, DevArray):
+                return None
+            else:
+                a = np.asarray(x)
+                if a.ndim == 0 and a.dtype.kind in "iub":
+                    sig.append(("v", a.dtype.str, a.item()))      # index-like: stays on the host
+                else:
+                    sig.append(("h", a.dtype.str, a.shape))
+                    nbytes += a.nbytes
+                    host = True
+        sig = tuple(sig)
+        bufs = self._stage.get(sig)
+        if bufs is None:
+            seen_ptrs = self._seen_sigs.get(sig)
+            ptrs = tuple(x.data_ptr() for x in inputs if type(x) is torch.Tensor)
+            if seen_ptrs is None:
+                self._seen_sigs[sig] = ptrs
+                if len(self._seen_sigs) > 256:
+                    self._seen_sigs.pop(next(iter(self._seen_sigs)))
+            if nbytes > self.STAGE_MAX_BYTES or not (host or (seen_ptrs is not None
+                                                              and seen_ptrs != ptrs)):
+                return None
+            bufs = []
+            for x, sg in zip(inputs, sig):
+                if sg[0] == "d":
+                    bufs.append(torch.empty(sg[2], dtype=x.dtype, device=self.device))
+                elif sg[0] == "h":
+                    a = np.asarray(x)
+                    bufs.append(torch.empty(a.shape, dtype=TORCH_DTYPES[a.dtype.name],
+                                            device=self.device))
+                else:
+                    bufs.append(None)
+            if len(self._stage) >= 16:
+                self._stage.pop(next(iter(self._stage)))
+            self._stage[sig] = bufs
+        staged = []
+        for x, b in zip(inputs, bufs):
+            if b is None:
+                staged.append(x)
+            elif type(x) is torch.Tensor:
+                if x.data_ptr() != b.data_ptr():
+                    b.copy_(x, non_blocking=True)
+                staged.append(b)
+            else:
+                a = np.asarray(x)    # (np.ascontiguousarray would turn a 0-d value into 1-d)
+                if not a.flags.c_contiguous or not a.flags.writeable:
+                    a = np.array(a, order="C", copy=True)
+                b.copy_(torch.from_numpy(a), non_blocking=True)
+                staged.append(b)
+        return staged
+
+    _SMALL_FLOAT = frozenset("fd")        # dtype.char of the values cached by value
+
+    def _small_host_values(self, inputs):
+        """Small host FLOAT arrays (the ``mu`` / ``sigma`` / learning-rate scalars
+        ``Function.__call__`` hands over as 0-d ndarrays) become device tensors cached BY VALUE:
+        one upload per distinct value, after that an ordinary device input — rebindable, so the
+        big device tensors next to it are never copied into staging buffers.  Integer / bool
+        values (index-like: they steer host control flow) are never cached.  The cached tensor is
+        handed to every later call that passes the same value; nothing on this path writes into a
+        plan input (the rewrite query excludes ``inplace``; in-place writes of the executor touch
+        only its own allocations), so the cache cannot be corrupted through it."""
+        res = None
+        for k, x in enumerate(inputs):
+            if type(x) is torch.Tensor or isinstance(x, DevArray):
+                continue
+            a = x if type(x) is np.ndarray else np.asarray(x)
+            dt = a.dtype
+            if dt.char not in self._SMALL_FLOAT or a.size > 16:      # (dtype.name is slow: NumPy 2)
+                continue
+            key = (dt.char, a.shape, a.tobytes())
+            t = self._host_vals.get(key)
+            if t is None:
+                if len(self._host_vals) >= 1024:
+                    self._host_vals.pop(next(iter(self._host_vals)))
+                t = self._host_vals[key] = torch.from_numpy(np.array(a, order="C", copy=True)).to(self.device)
+            if res is None:
+                res = list(inputs)
+            res[k] = t
+        return inputs if res is None else res
+
+    LIST_MAX = 48   # launches replayed as a plain launch list; longer lists become a hipGraph
+
+    def _call_graph(self, inputs, vals=None, out=None):
+        """Replay path.  First call per input signature: (1) eager pass (real results; records
+        every allocation), (2) recording pass — same host control flow, same buffers, every
+        kernel launch appended to a C-side launch list instead of executed, (3) short lists are
+        replayed as is (one host call, plain launches), long ones (Scan) are turned into a
+        hipGraph by capturing one replay of the list."""
+        okey = tuple(-1 if t is None else t.data_ptr() for t in out) if out else ()
+        ent = None
+        if not all(type(x) is torch.Tensor for x in inputs):
+            inputs = self._small_host_values(inputs)
+        if all(type(x) is torch.Tensor for x in inputs):     # fast path: same tensors as before
+            key = tuple([(id(x), x.data_ptr()) for x in inputs]) + okey
+            ent = self._graphs.get(key)
+            if ent is not None and ent[9] is not None:
+                # a rebound entry holds its inputs weakly (a training loop's batches and updated
+                # weights must not be kept alive by the cache): an id can be reused once its
+                # tensor died, so a hit counts only if these ARE the tensors it was made for
+                for r, x in zip(ent[9], inputs):
+                    if r is None or r() is not x:
+                        ent = None
+                        self._release(self._graphs.pop(key))
+                        break
+        if ent is None and self._reloc:
+            # same layouts, NEW buffers (a training loop's next batch): rebind the recorded
+            # launches to the new addresses instead of copying into staging buffers
+            ent = self._rebind(inputs, out, okey)
+        if ent is None:
+            staged = self._stage_inputs(inputs)
+            if staged is not None:
+                inputs, vals = staged, None
+            key = tuple([(id(x), x.data_ptr()) if type(x) is torch.Tensor else self._slow_key(x)
+                         for x in inputs]) + okey
+            ent = self._graphs.get(key)
+        if ent is not None:
+            stream = torch._C._cuda_getCurrentRawStream(self.device.index)
+            fresh = None
+            if ent[7] is not None:
+                bases = ent[7]
+                if ent[8] and not self.borrow:
+                    # fresh outputs WITHOUT a copy: the launches that produce them are re-pointed
+                    # at newly allocated tensors (slot = position in the rebinding table)
+                    fresh = {}
+                    for k, slot, shape, dtype in ent[8]:
+                        t = torch.empty(shape, dtype=dtype, device=self.device)
+                        fresh[k] = t
+                        bases[slot] = t.data_ptr()
+                rc = lib.ahip_list_run_rebased(ent[0], bases, len(bases), stream)
+            else:
+                rc = (lib.ahip_list_run(ent[0], stream) if ent[1] is None
+                      else lib.ahip_graph_launch(ent[1], stream))
+            if rc:
+                check(rc)
+            # index kernels (and the persistent Scan kernel) flag errors in device words: a
+            # replayed call never skips the check, but it does not stall the pipeline for it —
+            # the words are copied to pinned memory behind the launches and examined when they
+            # have landed (next call at the latest; ``check()`` waits)
+            if (self._bad_index is not None or self._sp_ws) and self.check_indices:
+                if self.check_indices == "deferred":
+                    self._deferred_check()
+                else:
+                    self._raise_bad_index()
+            self._check_reduce_flag()
+            return self._hand_out(ent[2], out, fresh)
+        if vals is None:
+            vals = self._bind_inputs(inputs)
+        # 1. eager pass
+        targets = self._targets(out)
+        self._arena, self._capturing = _Arena(), False
+        try:
+            outs1 = self._positive_strides(self.run(vals, out_targets=targets))
+            self._raise_bad_index()
+            arena = self._arena
+            # static buffer plan from the eager pass's allocation / release trace
+            arena.plan(self.device)
+            self.arena_bytes = (arena.total, arena.naive)
+            # 2. recording pass
+            lst = _VP()
+            self._capturing = True
+            check(lib.ahip_list_begin())
+            try:
+                outs2 = self._positive_strides(self.run(vals, out_targets=targets))
+            except HostReadInReplay:
+                # data-dependent host control flow (do-while Scan, device-valued index or
+                # Assert condition): this plan can never be replayed -> eager from now on;
+                # the eager pass above already produced this call's results
+                self._no_replay = True
+                outs2 = None
+            finally:
+                rc = lib.ahip_list_end(C.byref(lst))
+                self._capturing = False
+            if outs2 is None:
+                if not rc:
+                    lib.ahip_list_destroy(lst)
+                return [self._export(o) for o in outs1]
+            check(rc)
+        finally:
+            self._arena = None
+            self._capturing = False
+        graph = None
+        if lib.ahip_list_length(lst) > self.LIST_MAX:
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream())
+            graph = _VP()
+            with torch.cuda.stream(side):
+                check(lib.ahip_graph_begin(self._stream()))
+                rc1 = lib.ahip_list_run(lst, self._stream())
+                rc2 = lib.ahip_graph_end(self._stream(), C.byref(graph))
+                check(rc1)
+                check(rc2)
+            torch.cuda.current_stream().wait_stream(side)
+        # the eager pass computed in its own buffers; the recorded launches address the packed
+        # arena: run them once so that this call's results are in the buffers it hands out
+        stream = torch._C._cuda_getCurrentRawStream(self.device.index)
+        check(lib.ahip_list_run(lst, stream) if graph is None else lib.ahip_graph_launch(graph, stream))
+        outs = [self._export(o) for o in outs2]
+        if len(self._graphs) >= 64:
+            self._release(self._graphs.pop(next(iter(self._graphs))))
+        # keep inputs and arena alive: ids/pointers in the key stay valid while cached
+        bases, fresh_spec = self._bind_relocations(lst, graph, inputs, out, outs, arena)
+        # every replayed signature owns an arena: shape-varying workloads evict the oldest
+        # signatures once the arenas together exceed the cap (AESARA_HIP_ARENA_CAP_GB, 64)
+        cap = float(knobs.get("ARENA_CAP_GB")) * (1 << 30)
+        while self._graphs:
+            seen, tot = set(), arena.total
+            for e in self._graphs.values():
+                if e[3] is not None and id(e[3]) not in seen:
+                    seen.add(id(e[3]))
+                    tot += e[3].total
+            if tot <= cap:
+                break
+            self._release(self._graphs.pop(next(iter(self._graphs))))
+        self._graphs[key] = (lst, graph, outs, arena, list(inputs), vals, out, bases, fresh_spec, None)
+        self._list_refs[lst.value] = self._list_refs.get(lst.value, 0) + 1
+        return self._hand_out(outs, out)
+
+    # -- recording into a launch list the CALLER owns ------------------------------------------
+    def trace_eager(self, inputs, out=None):
+        """Pass 1 of an externally recorded replay (``dist.ShardedPlan``: ONE launch list per
+        sharded evaluation, the exchange rounds' all-reduces between the rounds' kernels): the
+        ordinary eager evaluation, with the allocation trace kept and packed into an arena so
+        that :meth:`record_external` can repeat the same host control flow over stable buffers."""
+        vals = self._bind_inputs(inputs)
+        targets = self._targets(out)
+        self._arena, self._capturing = _Arena(), False
+        try:
+            outs = self._positive_strides(self.run(vals, out_targets=targets))
+            self._raise_bad_index()
+            self._arena.plan(self.device)
+            self._ext = (self._arena, vals, targets)
+        finally:
+            self._arena = None
+            self._capturing = False
+        return [self._export(o) for o in outs]
+
+    def record_external(self):
+        """Pass 2: the same steps again, every launch going into the launch list the caller has
+        open (``ahip_list_begin`` .. ``ahip_list_end`` around SEVERAL executors and collectives).
+        The results live in this executor's planned arena, which ``self._ext`` keeps alive for as
+        long as the caller replays the list.  Raises ``HostReadInReplay`` for plans whose host
+        control flow depends on device values (never replayable)."""
+        arena, vals, targets = self._ext
+        self._arena, self._capturing = arena, True
+        try:
+            outs = self._positive_strides(self.run(vals, out_targets=targets))
+        finally:
+            self._arena = None
+            self._capturing = False
+        return [self._export(o) for o in outs]
+
+    # -- zero-copy replay for rebound buffers ------------------------------------------------
+    @staticmethod
+    def _extent(t):
+        """[lo, hi) byte range a strided tensor can touch."""
+        if t.numel() == 0:
+            return t.data_ptr(), t.data_ptr()
+        span = 1 + sum((n - 1) * st for n, st in zip(t.shape, t.stride()))
+        return t.data_ptr(), t.data_ptr() + span * t.element_size()
+
+    def _layout_sig(self, inputs, out):
+        sig = []
+        for x in inputs:
+            if type(x) is torch.Tensor:
+                if not x.is_cuda:
+                    return None
+                sig.append((x.dtype, tuple(x.shape), x.stride(), x.data_ptr() & 63))
+            elif isinstance(x, DevArray):
+                return None
+            else:
+                a = np.asarray(x)
+                if not (a.ndim == 0 and a.dtype.kind in "iub"):
+                    return None                     # host arrays are staged (pointer-stable)
+                sig.append(("v", a.dtype.str, a.item()))
+        for t in out or ():
+            sig.append(None if t is None else (t.dtype, tuple(t.shape), t.stride(), t.data_ptr() & 63))
+        return tuple(sig)
+
+    def _bind_relocations(self, lst, graph, inputs, out, outs, arena):
+        """After recording a (short) launch list: declare the device inputs / output targets as
+        rebindable address ranges (``ahip_list_bind_bases``).  Returns the ctypes array of their
+        current bases, or None when the entry cannot be rebound (hipGraph, overlapping buffers,
+        an output that is a view of an input)."""
+        if graph is not None or self.dry_run:
+            return None, None
+        sig = self._layout_sig(inputs, out)
+        if sig is None:
+            return None, None
+        bufs = [x for x in inputs if type(x) is torch.Tensor] + [t for t in (out or ()) if t is not None]
+        rng = [self._extent(t) for t in bufs]
+        srt = sorted(r for r in rng if r[1] > r[0])
+        if any(a[1] > b[0] for a, b in zip(srt, srt[1:])):
+            return None, None
+        targets = {t.data_ptr() for t in (out or ()) if t is not None}
+        for o in outs:
+            if type(o) is torch.Tensor and o.numel() and o.data_ptr() not in targets:
+                lo, hi = self._extent(o)
+                if any(lo < r[1] and r[0] < hi for r in rng):
+                    return None, None               # pass-through output: aliases an input
+        # outputs that are whole, contiguous, exclusive arena allocations can be produced
+        # straight into fresh tensors (see _Arena.plan: their bytes were never anything else)
+        fresh_spec = []
+        if arena is not None and arena.big is not None:
+            base0 = arena.big.data_ptr()
+            excl = {base0 + arena.offsets[i]: arena.sizes[i][0] for i in arena.persistent}
+            ext = [self._extent(o) if type(o) is torch.Tensor and o.numel() else None for o in outs]
+            for k, o in enumerate(outs):
+                if ext[k] is None or o.data_ptr() in targets:
+                    continue
+                nb = excl.get(o.data_ptr())
+                if nb is None or not o.is_contiguous() or o.numel() * o.element_size() != nb:
+                    continue
+                # another output that shares the allocation (the same variable listed twice, a
+                # view of it) would be copied from the arena range the launches no longer write
+                lo_, hi_ = o.data_ptr(), o.data_ptr() + nb
+                if any(j != k and e is not None and e[0] < hi_ and lo_ < e[1] for j, e in enumerate(ext)):
+                    continue
+                fresh_spec.append((k, len(rng), tuple(o.shape), o.dtype))
+                rng.append((lo_, hi_))
+        n = len(rng)
+        if n == 0:
+            return None, None
+        lo = (C.c_uint64 * n)(*[r[0] for r in rng])
+        hi = (C.c_uint64 * n)(*[r[1] for r in rng])
+        rc = lib.ahip_list_bind_bases(lst, lo, hi, n)
+        if rc < 0:
+            return None, None
+        self._reloc[sig] = (lst, None, outs, arena, None, None, None, None, fresh_spec, None)
+        if len(self._reloc) > 32:
+            self._reloc.pop(next(iter(self._reloc)))
+        return lo, fresh_spec
+
+    def _rebind(self, inputs, out, okey):
+        sig = self._layout_sig(inputs, out)
+        core = self._reloc.get(sig) if sig is not None else None
+        if core is None or core[0].value not in self._list_refs:
+            return None
+        bufs = [x for x in inputs if type(x) is torch.Tensor] + [t for t in (out or ()) if t is not None]
+        rng = sorted(r for r in (self._extent(t) for t in bufs) if r[1] > r[0])
+        if any(a[1] > b[0] for a, b in zip(rng, rng[1:])):
+            return None
+        arena = core[3]
+        if arena is not None and arena.big is not None and rng:
+            # a caller may hand a borrowed result (a range of this list's own arena) back as an
+            # input: the launches would read what they are overwriting -> staged copy instead
+            alo, ahi = self._extent(arena.big)
+            if any(r[0] < ahi and alo < r[1] for r in rng):
+                return None
+        fresh_spec = core[8]
+        ptrs = [t.data_ptr() for t in bufs] + [core[2][k].data_ptr() for k, _s, _sh, _dt in fresh_spec]
+        bases = (C.c_uint64 * len(ptrs))(*ptrs)
+        # the recorded launches do not address these buffers (their bases are patched in per
+        # call), so nothing here needs to keep them alive: weak references only (ADVICE r2 —
+        # fresh outputs make every step's updated weights new tensors; pinning them kept up to 64
+        # generations of all parameters and batches in HBM)
+        ent = (core[0], None, core[2], core[3], None, None, None, bases, fresh_spec,
+               [weakref.ref(x) if type(x) is torch.Tensor else None for x in inputs])
+        if all(type(x) is torch.Tensor for x in inputs):
+            key = tuple([(id(x), x.data_ptr()) for x in inputs]) + okey
+            if len(self._graphs) >= 64:
+                self._release(self._graphs.pop(next(iter(self._graphs))))
+            self._graphs[key] = ent
+            self._list_refs[core[0].value] += 1
+        return ent
+
+    def _positive_strides(self, outs):
+        """Outputs that are negative-stride views (``x[::-1]``) cannot be handed out as torch
+        tensors: their copy is part of the recorded launches, so replays refresh it."""
+        return [self.materialize(o) if isinstance(o, DevArray) and any(s < 0 for s in o.strides)
+                else o for o in outs]
+
+    def _hand_out(self, outs, out, fresh=None):
+        """Replay results live in the function-owned arena: hand out fresh tensors unless the
+        caller asked to borrow them or supplied the destination itself (``out=``).  ``fresh``:
+        outputs the launches already wrote into newly allocated tensors (no copy); the others
+        are copied out."""
+        if self.borrow:
+            return outs
+        res = []
+        for k, o in enumerate(outs):
+            if fresh is not None and k in fresh:
+                res.append(fresh[k])
+            elif type(o) is torch.Tensor and not (out and k < len(out) and out[k] is not None):
+                res.append(o.clone())
+            else:
+                res.append(o)
+        return res
+
+    def _release(self, ent):
+        """Free the C-side launch list / hipGraph of an evicted replay entry (a list rebound to
+        several buffer sets is shared by their entries: freed with the last of them)."""
+        lst, graph = ent[0], ent[1]
+        if graph is not None:
+            lib.ahip_graph_destroy(graph)
+        if lst is not None:
+            left = self._list_refs.get(lst.value, 1) - 1
+            if left > 0:
+                self._list_refs[lst.value] = left
+                return
+            self._list_refs.pop(lst.value, None)
+            for sg in [k for k, v in self._reloc.items() if v[0].value == lst.value]:
+                del self._reloc[sg]
+            lib.ahip_list_destroy(lst)
+
+    def close(self):
+        """Free every recorded launch list / hipGraph now (not done from ``__del__``: at
+        interpreter shutdown the HIP runtime may already be gone)."""
+        for ent in self._graphs.values():
+            self._release(ent)
+        self._graphs.clear()
+
+    def _slow_key(self, x):
+        if isinstance(x, DevArray):
+            return ("dev", id(x), x.ptr, x.shape, x.strides)
+        a = np.asarray(x)
+        return ("host", dtype_name(a.dtype), a.shape, a.tobytes())
+
+    def _deferred_check(self, wait=False):
+        st = self._flag_state
+        if st is None:
+            nb = len(self.steps) + 1
+            st = self._flag_state = {"pinned": torch.zeros(1 + nb, dtype=torch.int64).pin_memory(),
+                                     "event": torch.cuda.Event(), "pending": False}
+        if st["pending"] and (wait or st["event"].query()):
+            if wait:
+                st["event"].synchronize()
+            st["pending"] = False
+            scan = int(st["pinned"][0])
+            if scan:
+                for _x, ctl in self._sp_ws.values():
+                    ctl[1].zero_()
+                raise RuntimeError("persistent Scan kernel: a workgroup timed out waiting for "
+                                   "its peers (the device could not keep the grid resident)")
+            codes = st["pinned"][1:]
+            if self._bad_index is not None and bool(codes.any()):
+                self._bad_index.zero_()
+                self._raise_index_error(codes.tolist(), " (reported by a later replayed call)")
+        if not st["pending"]:
+            if self._bad_index is not None:
+                st["pinned"][1:].copy_(self._bad_index, non_blocking=True)
+            ctls = [ctl for _x, ctl in self._sp_ws.values()]
+            if len(ctls) == 1:
+                st["pinned"][0:1].copy_(ctls[0][1:2], non_blocking=True)
+            elif ctls:     # several persistent loops in one plan: any non-zero error word counts
+                worst = ctls[0][1:2].clone()
+                for ctl in ctls[1:]:
+                    torch.maximum(worst, ctl[1:2], out=worst)
+                st["pinned"][0:1].copy_(worst, non_blocking=True)
+            st["event"].record()
+            st["pending"] = True
+
+    def _reduce_err(self):
+        """int32 view of the device error word of the in-kernel reduce finalize
+        (codegen.REDUCE_ERR_OFF): the epoch of the last launch that timed out, 0 if none ever did"""
+        off = lib.ahip_reduce_partials_bytes() + 2048 + cg.REDUCE_ERR_OFF
+        return self._ws[off:off + 4].view(torch.int32)
+
+    def check(self):
+        """Wait for the launches issued so far and raise what their error words report (replay
+        mode defers those checks; eager calls check before they return)."""
+        if self.dry_run:
+            return
+        if self._flag_state is not None or self._bad_index is not None or self._sp_ws:
+            self._deferred_check()          # enqueue a copy behind everything launched so far
+            self._deferred_check(wait=True)
+        if self._ws_flag_np is not None:
+            torch.cuda.current_stream().synchronize()
+            self._check_reduce_flag()
+
+    def _raise_bad_index(self):
+        self._check_reduce_flag()
+        if self._sp_ws and not self._capturing and not self.dry_run:
+            for _xch, ctl in self._sp_ws.values():
+                if int(ctl[1].item()) != 0:
+                    ctl[1].zero_()
+                    raise RuntimeError("persistent Scan kernel: a workgroup timed out waiting for "
+                                       "its peers (the device could not keep the grid resident)")
+        if self._bad_index is not None and self.check_indices and not self._capturing \
+                and not self.dry_run:
+            codes = self._bad_index.tolist()          # one d2h read (waits for the launches)
+            if any(codes):
+                self._bad_index.zero_()
+                self._raise_index_error(codes)
+
+    def _raise_index_error(self, codes, note=""):
+        si = next(i for i, c in enumerate(codes) if c)
+        code = codes[si]
+        idx = code - 1 if code > 0 else code
+        e = IndexError(f"index {idx} is out of bounds{note}")
+        if si < len(self.steps):
+            self._annotate(e, si)
+        raise e

@@ -21,8 +21,10 @@ weight matrix from L2 / HBM on every step; here one launch runs all T steps:
   the next step) stays in registers: lane i of a wavefront owns one output row.
 
 Eligibility (anything else runs the launch-list path, and ``PlanExecutor.scan_modes`` says which
-was taken): no shared outputs / do-while, every sit-sot output has the single tap -1, mit-mot
-groups only of the gradient form ([0, 1] -> [1], see ``analyze``), the fused inner steps are Gemv
+was taken): no shared outputs / do-while, sit- / mit-sot outputs with taps down to -8 (tap -1 is
+the exchanged state; older taps are values the row owner produced itself and stay in its
+registers, usable element-wise), mit-mot groups only of the gradient form ([0, 1] -> [1], see
+``analyze``), the fused inner steps are Gemv
 chains + Elemwise on float32 / float64 vectors of one length M, matrices are loop invariant (rows
 that are not whole 16-byte vectors are zero-padded by the executor), at least one exchanged
 vector, T >= 2, and the matrix rows of a workgroup fit on chip (LDS + VGPRs).
@@ -34,6 +36,7 @@ import hashlib
 import json
 import os
 
+from . import knobs
 from . import codegen as cg
 
 SP_MAXMAT = 12
@@ -313,9 +316,9 @@ class Spec:
         assert R % nw == 0
         self.place = dict(place or {})      # matrix var -> "reg" (rows in VGPRs) | "lds"
         # polling shape (measured defaults; environment overrides for sweeps)
-        self.var = {"pollw": min(nw, int(os.environ.get("AESARA_HIP_SP_POLLW", 2))),
-                    "sleep": int(os.environ.get("AESARA_HIP_SP_SLEEP", "1")),
-                    "repoll": int(os.environ.get("AESARA_HIP_SP_REPOLL", "0"))}
+        self.var = {"pollw": min(nw, int(knobs.get("SP_POLLW"))),
+                    "sleep": int(knobs.get("SP_SLEEP")),
+                    "repoll": int(knobs.get("SP_REPOLL"))}
 
     def key(self):
         pr = self.prog
@@ -646,8 +649,8 @@ def choose_rows(M, Ks, stage_floats, cu_count=256, itemsize=4):
     when the rows fit, else one workgroup per CU, else fewer; rows go to LDS first and spill into
     VGPRs (K % 256 == 0, REG_BUDGET per lane) — that is what lets H = 2048 (48 MiB of weights)
     stay on chip.  ``AESARA_HIP_SCAN_ROWS`` / ``AESARA_HIP_SCAN_WAVES`` override."""
-    env = os.environ.get("AESARA_HIP_SCAN_ROWS")
-    nw = int(os.environ.get("AESARA_HIP_SCAN_WAVES", "4"))
+    env = knobs.get("SCAN_ROWS")
+    nw = int(knobs.get("SCAN_WAVES"))
     half = max(cu_count // 2, 1)
     cands = [int(env)] if env else [-(-M // half), -(-M // cu_count), -(-M // (half // 2 or 1)),
                                     -(-M // (half // 4 or 1))]

@@ -45,6 +45,7 @@ import hashlib
 import json
 import os
 
+from . import knobs
 from . import codegen as cg
 from .scan_persist import SPIN_LIMIT
 
@@ -109,7 +110,7 @@ class SpecMat:
         self.NB = -(-B // 16)
         self.NJ = N // 16
         # granule loads a thread keeps in flight per polling pass (2 VGPRs each)
-        self.chunk = int(os.environ.get("AESARA_HIP_SM_CHUNK", "32"))
+        self.chunk = int(knobs.get("SM_CHUNK"))
         # exchange form: "flag" = untagged 8-byte float pairs + ONE tag word per producing
         # workgroup (half the bytes, one polling pass); "granule" = {tag, value} per element
         #   "frag" (default when the registers allow it) = the flag form with the payload laid out
@@ -139,30 +140,30 @@ class SpecMat:
         if xfold:
             self.xmode = "frag"
         else:
-            self.xmode = os.environ.get("AESARA_HIP_SM_XMODE", "frag" if regs <= 320 else "flag")
+            self.xmode = knobs.get("SM_XMODE") or ("frag" if regs <= 320 else "flag")
         if dtype == "float64" and not xfold:
             self.xmode = "frag" if regs <= 384 else "none"     # float64 exists in the fragment form only
         # products on operands that are already in registers run BEFORE the wait for the new
         # operand's tags (r03 timeline, config 4 B = 64: 6.7 us per step; issuing them after the
         # loads — to cover the load latency instead of the tag latency — measured 8.5)
-        self.early_first = os.environ.get("AESARA_HIP_SM_EARLY", "first") == "first"
+        self.early_first = knobs.get("SM_EARLY") == "first"
         # fragment form: the weight columns pinned to ARCHITECTURAL registers (the fragments the
         # loads deliver then live in accumulation registers).  Left to the allocator, products
         # end up with A and B both in AGPRs and get a v_accvgpr_read through ONE temporary in
         # front of every MFMA (r03 timeline: 64 such MFMAs 1.2 us, 64 plain ones 0.93)
-        self.pin = (self.xmode == "frag" and os.environ.get("AESARA_HIP_SM_PIN", "1") != "0" and
+        self.pin = (self.xmode == "frag" and int(knobs.get("SM_PIN")) != 0 and
                     wpr * sum(K // 16 for K in Ks.values()) <= 192)
         # per-phase timeline (tools/sm_trace.py): thread 0 of workgroups 0 and NB*NJ/2 stamps
         # s_memtime at every mark of steps TRACE_T0 .. TRACE_T0+TRACE_NT-1 into ctl[16..]
-        self.trace = bool(int(os.environ.get("AESARA_HIP_SM_TRACE", "0")))
+        self.trace = bool(int(knobs.get("SM_TRACE")))
 
     def key(self):
         pr = self.prog
-        blob = json.dumps(["sm9" + ("t" if self.trace else "") + ("/f5p%d%s" % (self.pin, os.environ.get("AESARA_HIP_SM_FENCE", "1")) if self.xmode == "frag" else ""), self.xfold and [self.xfold, "w15", os.environ.get("AESARA_HIP_SM_XTAIL", "10")], self.dtype, self.chunk, self.xmode, self.early_first, self.B, self.N, self.Nt, sorted(self.Ks.items()), sorted(pr.seq.items()),
+        blob = json.dumps(["sm9" + ("t" if self.trace else "") + ("/f5p%d%s" % (self.pin, str(knobs.get("SM_FENCE"))) if self.xmode == "frag" else ""), self.xfold and [self.xfold, "w15", str(knobs.get("SM_XTAIL"))], self.dtype, self.chunk, self.xmode, self.early_first, self.B, self.N, self.Nt, sorted(self.Ks.items()), sorted(pr.seq.items()),
                            sorted(pr.state.items()), sorted(pr.nsq.items()), sorted(pr.mats.items()),
                            [[ph["dots"], ph["ins"], ph["outs"], ph["scalar"], ph["out_refs"]]
                             for ph in pr.phases], pr.outs, pr.exchanged, sorted(pr.tap_seq.items())] +
-                          ([["nblk", self.nblk, os.environ.get("AESARA_HIP_SM_INTERLEAVE", "1")]] if self.nblk != 1 else []),
+                          ([["nblk", self.nblk, str(knobs.get("SM_INTERLEAVE"))]] if self.nblk != 1 else []),
                           sort_keys=True)
         return hashlib.sha256(blob.encode()).hexdigest()[:24]
 
@@ -750,7 +751,7 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
              % (Q, K // 16, PV, K // 16))
     L.append("  const unsigned ld_off = (unsigned)(((wave * %d) * 64 + lane) * 16);" % Q)
     marks = []
-    FENCE = os.environ.get("AESARA_HIP_SM_FENCE", "1") != "0"
+    FENCE = int(knobs.get("SM_FENCE")) != 0
 
     def stamp(label):
         if not spec.trace:
@@ -787,7 +788,7 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
         L.append("    *(f4*)(Wl + %d + 4 * f) = wv;" % (gi * K * 16))
         L.append("  }")
     XW = None
-    XTAIL = max(1, int(os.environ.get("AESARA_HIP_SM_XTAIL", "10")))  # fragments (4 MFMAs each) behind the payload loads
+    XTAIL = max(1, int(knobs.get("SM_XTAIL")))  # fragments (4 MFMAs each) behind the payload loads
 
     def emit_xload(step_expr, ind):
         """x of step ``step_expr`` -> xfr: one buffer over that step's x (uniform base, the
@@ -875,7 +876,7 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
     # gains 11 % on the training step interleaved; the forward kernel (h feeds two phases: 64 more
     # registers per block, and its early product already covered the wait) loses 5 % -> interleave
     # only when no operand needs registers per block ("2" forces it, "0" turns it off)
-    ilv_env = os.environ.get("AESARA_HIP_SM_INTERLEAVE", "1")
+    ilv_env = str(knobs.get("SM_INTERLEAVE"))
     ILV = NBLK > 1 and (ilv_env == "2" or (ilv_env == "1" and all(len(v_) == 1 for v_ in ph_of.values())))
     frs = ["fr%d%s" % (ki, "§" if (ILV and len(ph_of[keys[ki]]) > 1) else "") for ki in range(len(keys))]
     for ki in range(len(keys)):

@@ -183,8 +183,6 @@ def main():
     ex = PlanExecutor(plan_of("cfg2_gauss_sum"), use_graph=G, borrow=True)
 
     ref_warm = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        ref_warm = start_reference_warm()        # compiles the reference's C modules meanwhile
 
     # synthetic input of the named shape, generated on device (rank-specific row block);
     # NROT distinct buffers: consecutive evals never find their matrix in the 256 MiB MALL
@@ -284,6 +282,12 @@ def main():
     t1 = time.perf_counter()
     ms = C.c_float()
     check(lib.ahip_event_elapsed_ms(ev0, ev1, C.byref(ms)))
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # compiles the reference's C modules in the background while the secondary rows run — started
+        # only now: a few hundred gcc processes next to the headline's 0.6 ms timed region cost it
+        # 4 us per eval (r04: 32.8 vs 28.5 us on the same box)
+        ref_warm = start_reference_warm()
 
     elapsed = torch.tensor([t1 - t0], dtype=f64, device="cuda")
     if world > 1:
@@ -425,6 +429,7 @@ def main():
             "value": args.steps * world / elapsed,
             "unit": "evals/s",
             "n_gpus": world,
+            "ranks_seen": dist.get_world_size() if world > 1 else 1,   # what the process group reports
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -676,9 +681,20 @@ def sec_cfg5(c):
     b = torch.tensor(0.1, dtype=f32, device="cuda")
     yv = (torch.rand(n_loc, device="cuda", generator=g) < 0.5).to(f32)
 
-    from aesara_amd.dist import ShardedPlan
+    from aesara_amd.dist import HipComm, ShardedPlan
+    # the exchange: torch.distributed (backend nccl = RCCL; one Python call per round) by default;
+    # AESARA_BENCH_COMM=abi: the C-ABI communicator (ahip_comm_*: RCCL on the launch stream, the
+    # whole sharded evaluation — round 0, all-reduce, round 1 — ONE recorded launch list)
+    comm_kind = os.environ.get("AESARA_BENCH_COMM", "torch")
+    if world == 1:
+        group = None
+    elif comm_kind == "abi":
+        group = c.setdefault("hipcomm", None) or HipComm(bootstrap_group=dist.group.WORLD)
+        c["hipcomm"] = group
+    else:
+        group = dist.group.WORLD
     sp = ShardedPlan(c["plan_of"]("cfg5_logistic"), split_inputs={0: 0, 3: 0}, use_graph=c["G"], borrow=True,
-                     group=None if world == 1 else dist.group.WORLD)
+                     group=group)
     outs = sp(X, wv, b, yv)
     torch.cuda.synchronize()
     logp, gw, gb = [o.clone() for o in outs]
@@ -717,6 +733,10 @@ def sec_cfg5(c):
             "dtype": "f32", "n_gpus": world, "scaling": "strong",
             "evals_per_s": 1e3 / ms_job, "ms_per_eval": ms_job,
             "collective": None if world == 1 else "1 all-reduce(sum) of 258 fp64 per eval",
+            "transport": None if world == 1 else (
+                "C-ABI communicator (RCCL on the launch stream), %d of %d evals were single-list replays"
+                % (sp.replays, iters + 4) if comm_kind == "abi" else "torch.distributed (%s)" % dist.get_backend()),
+            "ranks_seen": world if world == 1 else (group.world if comm_kind == "abi" else dist.get_world_size()),
             "aggregate_GBs": world * local_bytes / (ms_job * 1e-3) / 1e9,
             "roofline": roof("hbm", local_bytes, d, HBM_PEAK_GBS,
                              note="per-rank: local X once + y; kernel_ms includes the collective for N>1"),

@@ -89,3 +89,37 @@ def test_two_rank_bench_control_flow_on_one_device():
         assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["evals_per_s"] > 0
     assert rows["placed"]["placement"] == [[0, 2, 4, 6], [1, 3, 5, 7]]
     assert rows["cfg5"]["check"]["logp_rel_err"] <= 1e-6
+
+
+@pytest.mark.gpu
+def test_eight_rank_bench_control_flow_on_one_device():
+    """The driver's 8-GPU launch line with all 8 ranks on cuda:0 over gloo: the headline's rotating
+    inputs / ring slots / bucketed asynchronous all-reduce, config 5 row-sharded 8 ways with its
+    packed fp64 all-reduce, the placed-outputs row (one tower per rank); max-over-ranks timing; ONE
+    JSON line from rank 0 that says how many ranks the process group saw.  (The batch-sharded
+    config-4 row is left to the 2-rank test: eight persistent kernels of eight processes cannot be
+    co-resident on one device.)"""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, AESARA_BENCH_BACKEND="gloo", AESARA_BENCH_ONE_DEVICE="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "24", "--warmup", "8",
+                          "--cfg5-log2n", "20", "--only-secondary", "cfg5,placed", "--rotate", "2"],
+                         capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["ranks_seen"] == 8 and line["steps"] == 24
+    assert abs(line["value"] - 8 * 1e3 / line["ms_per_step"]) / line["value"] < 1e-6     # whole-job evals/s
+    rows = {r["config"].split(":")[0].split(" ")[0]: r for r in line["secondary"]}
+    assert {"cfg5", "placed"} <= set(rows), list(rows)
+    for r in line["secondary"]:
+        assert "error" not in r, r
+        assert r["n_gpus"] == 8 and r["scaling"] == "strong" and r["evals_per_s"] > 0
+    assert rows["placed"]["placement"] == [[k] for k in range(8)]
+    assert rows["cfg5"]["ranks_seen"] == 8 and rows["cfg5"]["check"]["logp_rel_err"] <= 1e-6

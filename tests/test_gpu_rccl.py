@@ -89,9 +89,20 @@ def test_sharded_cfg5_and_two_round_softmax_over_the_abi_communicator(comm, use_
     e = np.exp(x - x.max(axis=0, keepdims=True))
     sp2 = ShardedPlan(colsoftmax_plan(), {0: 0}, group=comm, use_graph=use_graph, force_collectives=True)
     assert sp2.spec.n_exchange_rounds == 2
-    for _ in range(3):
-        (o,) = sp2(torch.from_numpy(x).cuda())
+    xd = torch.from_numpy(x).cuda()
+    for _ in range(4):
+        (o,) = sp2(xd)
         np.testing.assert_allclose(o.cpu().numpy(), e / e.sum(axis=0, keepdims=True), rtol=1e-12)
+    if use_graph:
+        # ONE launch list per sharded evaluation: the first evaluation of a signature builds the
+        # packed buffers, the second records rounds + all-reduces into a single list, the rest
+        # replay it (no Python between the rounds)
+        assert sp.single_list and sp.replays >= 1, sp.replays
+        assert sp2.single_list and sp2.replays >= 2, sp2.replays
+        (lst, _final, _keep) = next(iter(sp2._lists.values()))
+        from aesara_amd._lib import lib
+        assert lib.ahip_list_length(lst) >= 4        # >= 2 kernels + 2 all-reduces in ONE list
+        assert comm.recorded >= 2
 
 
 def test_torch_distributed_nccl_backend_world1():

@@ -1,0 +1,18 @@
+#!/bin/bash
+# round-4 sweep 4: software pipeline (next group's loads in flight during the ALU phase) x waves per CU,
+# on the XCD-contiguous walk; executor level, driver flags
+fmt='import sys, json, os
+for l in sys.stdin:
+    if l.startswith("{"):
+        r=json.loads(l); c=r["config"]; ce=c["read_only_ceiling"]
+        print("%-70s cold %.2f us (%.3f) | line %.2f us | sum-only %.2f us (%.3f)" % (os.environ.get("TAG",""), c["sustained"]["kernel_ms"]*1e3, c["sustained"]["frac"], r["roofline"]["kernel_ms"]*1e3, ce["kernel_ms"]*1e3, ce["frac"]))'
+run() { TAG="$*" env "$@" timeout 240 python bench.py --no-secondary --no-cpu-baseline --no-warm --executor-level --steps 20 --warmup 5 2>&1 | grep -v amdgpu | TAG="$*" python -c "$fmt"; }
+run A=default
+run AESARA_HIP_PIPE=1
+run AESARA_HIP_PIPE=1 AESARA_HIP_UNROLL=1
+run AESARA_HIP_RED_BPC=4
+run AESARA_HIP_RED_BPC=4 AESARA_HIP_PIPE=1
+run AESARA_HIP_RED_BPC=4 AESARA_HIP_PIPE=1 AESARA_HIP_UNROLL=1
+run AESARA_HIP_RED_BPC=4 AESARA_HIP_PIPE=1 AESARA_HIP_UNROLL=4
+run AESARA_HIP_RED_BPC=6 AESARA_HIP_RED_BLOCK=768
+run A=default
