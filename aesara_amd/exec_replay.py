@@ -168,9 +168,13 @@ class ReplayMixin:
             if rc:
                 check(rc)
             # index kernels (and the persistent Scan kernel) flag errors in device words: a
-            # replayed call never skips the check, but it does not stall the pipeline for it —
+            # replayed call never skips the check.  check_indices=True (default): one blocking
+            # read per call of a plan that has such kernels — the error is raised by the call
+            # that met it, like the reference; "deferred" (HipLinker(check_indices="deferred")):
             # the words are copied to pinned memory behind the launches and examined when they
-            # have landed (next call at the latest; ``check()`` waits)
+            # have landed (next call at the latest; ``check()`` waits) — no stall.  Plans without
+            # index kernels / persistent Scans never wait; the full-reduction finalize reports
+            # through a pinned host flag (``_check_reduce_flag``), no device read at all
             if (self._bad_index is not None or self._sp_ws) and self.check_indices:
                 if self.check_indices == "deferred":
                     self._deferred_check()

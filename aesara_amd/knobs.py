@@ -65,6 +65,8 @@ _def("SM_FENCE", 1, int, "scheduler fences at the phase marks")
 _def("SM_XTAIL", 10, int, "fragments of the sequence product behind the payload loads")
 _def("SM_XFOLD", 1, int, "sequence products x_t @ W inside the loop")
 _def("SM_INTERLEAVE", 1, int, "interleave the phases of the batch blocks of one workgroup")
+_def("SPIN_LOG2", 21, int, "log2 of the poll limit of the persistent Scan kernels before they raise their error word "
+     "(tools/profile_scan_r04.sh raises it: under the counter passes a kernel runs many times slower)")
 _def("SM_DEPTH", 8, int, "16-byte payload loads in flight per lane of the fragment fetch")
 
 

@@ -49,9 +49,16 @@ class HipLinker(JITLinker):
     """A ``Linker`` that runs a whole ``FunctionGraph`` as HIP kernels on an MI355X."""
 
     def __init__(self, *args, return_numpy=False, use_graph=True, executor_factory=None,
-                 fast_call=True, **kwargs):
+                 fast_call=True, check_indices=True, **kwargs):
         super().__init__(*args, **kwargs)
         self.return_numpy = return_numpy
+        # check_indices: True (default) — an out-of-range index / a persistent-Scan time-out is
+        # raised by the call that met it, as the reference does (one blocking read of the error
+        # words per call of a plan that HAS index kernels or a persistent Scan; plans without
+        # them never wait); "deferred" — the words are copied behind the launches and examined
+        # when they have landed (next call at the latest, ``executor.check()`` waits): no stall in
+        # a training loop, the error surfaces one call late; False — unchecked.
+        self.check_indices = check_indices
         # use_graph (default): the first call per input signature runs the host logic and records
         # the launches; later calls of that signature replay them with one host call (new device
         # buffers are rebound, host arrays staged) into a lifetime-packed arena and return fresh
@@ -110,7 +117,7 @@ class HipLinker(JITLinker):
             return self.executor_factory(plan)
         from .executor import PlanExecutor  # imports the C-ABI; fails loudly if missing
 
-        ex = PlanExecutor(plan, use_graph=self.use_graph)
+        ex = PlanExecutor(plan, use_graph=self.use_graph, check_indices=self.check_indices)
         if self.profile:
             ex.enable_profile()
         self.executor = ex
@@ -170,7 +177,8 @@ class HipLinker(JITLinker):
         # cells the reference's ``streamline`` clears before every run (link/utils.py:196-197):
         # outputs that are not borrowed must never be recycled — the executor hands out fresh
         # tensors for them anyway; the cells are dropped so no stale reference outlives a failure
-        clear = [c for c in self._no_recycling_cells(slow_fn) if c in out_cells]
+        out_ids = {id(c) for c in out_cells}        # identity, not list equality ([None] == [None])
+        clear = [c for c in self._no_recycling_cells(slow_fn) if id(c) in out_ids]
 
         if plain and len(out_cells) == 1:
             oc = out_cells[0]

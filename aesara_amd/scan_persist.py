@@ -43,7 +43,7 @@ SP_MAXMAT = 12
 SP_MAXSEQ = 28
 SP_MAXNSQ = 12
 SP_MAXOUT = 16
-SPIN_LIMIT = 1 << 21
+SPIN_LIMIT = 1 << int(knobs.get("SPIN_LOG2"))
 LDS_BUDGET = 156 * 1024
 
 

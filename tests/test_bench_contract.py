@@ -37,7 +37,7 @@ def _check(line, need_cpu):
 
 
 def test_committed_bench_line_meets_the_contract():
-    with open(os.path.join(ROOT, "profiles", "r03_bench_line.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r04_bench_line.json")) as f:
         line = json.loads(f.read())
     _check(line, need_cpu=True)
     names = " ".join(s["config"] for s in line["secondary"])
