@@ -616,6 +616,9 @@ class KernelSpec:
         self.early = bool(knobs.get("EARLY") if early is None else early) and flat_all and not pipe
         # one contiguous chunk of the stream per workgroup instead of a grid-stride walk
         self.blocked = int(knobs.get("RED_BLOCKED") if blocked is None else blocked) if flat_all else 0
+        # plain flat Elemwise streams (no reduction): the same walks, off unless measured better
+        if reduce is None and tile_dim is None and nd == 1 and vec > 1 and not pipe:
+            self.blocked = int(knobs.get("STREAM_BLOCKED") if blocked is None else blocked)
         # the second workgroup a CU receives loses every issue arbitration to the older one
         # (oldest first): static priority for the second half of the grid evens their progress
         self.prio = int(knobs.get("RED_PRIO")) if flat_all else 0

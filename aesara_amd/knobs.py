@@ -35,6 +35,7 @@ _def("FASTEXP", 1, int, "float64 exp through the 64-entry table in LDS (0: ocml'
 _def("EARLY", 1, int, "flat full reductions issue their first loads before the invariant prologue")
 _def("RED_BLOCKED", 2, int, "flat full reductions: 0 grid-stride walk, 1 one contiguous chunk per workgroup, "
      "2 (default) chunks ordered so that every XCD streams one contiguous eighth (r04 sweeps: 27.1 vs 27.7 us)")
+_def("STREAM_BLOCKED", 0, int, "flat Elemwise streams: 0 grid-stride, 1 contiguous chunk per workgroup, 2 XCD-contiguous")
 _def("RED_PRIO", 0, int, "flat full reductions: s_setprio for the second half of the grid (the younger workgroup of a CU)")
 _def("EW_TRACE", 0, int, "full reductions stamp s_memrealtime per workgroup into the workspace (tools/ew_trace.py)")
 _def("HFUSE", 1, int, "horizontal fusion of independent same-shape Elemwise/CAReduce steps into one launch")
