@@ -565,6 +565,127 @@ class ScanMixin:
             return why
         return None
 
+    def _scan_persist_ew(self, node, p, inner, n_steps, seqs, outs, store, pos, shared, non_seqs,
+                         pre_rows, n_rec, n_nit):
+        """Run a Scan whose step is purely element-wise as ONE kernel launch
+        (aesara_amd/scan_persist_ew.py: thread e runs the whole recurrence of element e).  Returns
+        (None, shared outputs, steps run) when it ran — the output buffers hold rows
+        pos .. pos + steps - 1 modulo store — else (reason, None, 0)."""
+        from . import scan_persist_ew as se
+        ent = getattr(inner, "_se_prog", None)
+        if ent is None:
+            ent = inner._se_prog = se.analyze(inner, p, getattr(inner, "_n_pre", 0))
+        prog, why = ent
+        if prog is None:
+            return why, None, 0
+        lp = inner.plan
+        n_seqs, n_sh = p["n_seqs"], p.get("n_shared_outs", 0)
+        n_fixed = len(lp.inputs) - len(pre_rows)
+        n_tapin = len(prog.tap)
+        inv_vars = lp.inputs[n_seqs + n_tapin + n_sh:n_fixed]
+        if len(inv_vars) != len(non_seqs):
+            return "invariant operand count", None, 0
+        inv_val = dict(zip(inv_vars, non_seqs))
+        # the ONE shape every loop-varying value has
+        if n_rec:
+            S = tuple(outs[0].shape[1:])
+        elif shared:
+            S = tuple(inner.to_device(shared[0]).shape)
+        elif seqs:
+            S = tuple(seqs[0].shape[1:])
+        else:
+            return "no loop-varying operand to take the shape from", None, 0
+        n = _prod(S) if S else 1
+        if n < 1:
+            return "empty state", None, 0
+        if prog.as_while and n != 1:
+            return "do-while over more than one element (the condition would be a reduction)", None, 0
+        cs = contiguous_strides(S)
+
+        def rows_ok(a):
+            return tuple(a.shape[1:]) == S and (n == 1 or tuple(a.strides[1:]) == tuple(cs))
+        g = se.EwScanArgs()
+        g.T, g.n = n_steps, n
+        for v, s_ in prog.seq.items():
+            a_ = seqs[s_] if s_ < n_seqs else pre_rows[s_ - n_seqs]
+            if a_ is None or a_.dtype != lp.vars[v].dtype or tuple(a_.shape[1:]) != S or a_.shape[0] < n_steps:
+                return "sequence operand layout", None, 0
+            if not rows_ok(a_):
+                a_ = inner.contiguous(a_)
+            g.seq[s_], g.seq_ts[s_] = a_.ptr, a_.strides[0]
+        bc = set()
+        for v, j in prog.nsq.items():
+            x = inner.to_device(inv_val[v])
+            if x.dtype != lp.vars[v].dtype:
+                return "invariant operand dtype", None, 0
+            if _prod(x.shape) == 1:
+                bc.add(j)
+                g.nsq[j], g.nsq_es[j] = x.ptr, 0
+            else:
+                if tuple(x.shape) != S:
+                    return "invariant operand shape", None, 0
+                x = inner.contiguous(x)
+                g.nsq[j], g.nsq_es[j] = x.ptr, 1
+        for k in range(n_rec):
+            b = outs[k]
+            if tuple(b.shape[1:]) != S or (n != 1 and tuple(b.strides[1:]) != tuple(cs)) or \
+                    store[k] < prog.depth[k] or b.dtype != lp.vars[lp.outputs[k]].dtype:
+                return "recurrent output layout", None, 0
+        out_dt = [outs[k].dtype for k in range(n_rec)]
+        for j in range(n_nit):
+            ov = lp.vars[lp.outputs[n_rec + j]]
+            if ov.ndim != len(S):
+                return "nit-sot output of another rank", None, 0
+            out_dt.append(ov.dtype)
+        sh_vals, sh_dt = [], []
+        for m in range(n_sh):
+            x = inner.to_device(shared[m])
+            if tuple(x.shape) != S:
+                return "shared value shape", None, 0
+            sh_vals.append(inner.contiguous(x))
+            sh_dt.append(x.dtype)
+        spec = se.SpecEw(prog, lp, out_dt, sh_dt, bc)
+        key = spec.key()
+        ent = _Kernels.cache.get(key) if not self.dry_run else \
+            ([None] if key in _Kernels.compiled else None)
+        if ent is None:
+            src, names = se.generate(spec)
+            if self.dry_run:
+                from .device import compile_cached
+                compile_cached(src)
+                _Kernels.compiled[key] = 1
+                ent = [None]
+            else:
+                ent = load_kernels(src, names)
+                _Kernels.cache[key] = ent
+        for j in range(n_nit):
+            outs[n_rec + j] = inner.alloc((store[n_rec + j],) + S, out_dt[n_rec + j])
+        for k in range(n_rec + n_nit):
+            b = outs[k]
+            g.out[k], g.out_rs[k], g.out_store[k], g.out_pos0[k] = b.ptr, b.strides[0], store[k], pos[k]
+        sh_out = []
+        for m in range(n_sh):
+            o = inner.alloc(S, sh_dt[m])
+            sh_out.append(o)
+            g.sh_in[m], g.sh_out[m] = sh_vals[m].ptr, o.ptr
+        ctl = None
+        if prog.as_while and not self.dry_run:
+            ctl = self._sp_ws.get(("se_ctl", id(inner)))
+            if ctl is None:
+                ctl = (None, torch.zeros(16, dtype=torch.int32, device=self.device))
+                self._sp_ws[("se_ctl", id(inner))] = ctl
+            g.ctl = ctl[1].data_ptr() + 16          # (word 1 of a persistent-Scan workspace is its error word)
+        offs, nptr = ptr_offsets(type(g))
+        self._launch("ahip_launch_p", (ent[0], (n + 255) // 256, 1, 1, 256, 1, 1, 0, C.byref(g), C.sizeof(g),
+                                       offs, nptr, 0, self._stream()))
+        done = n_steps
+        if prog.as_while:
+            if self._capturing:
+                raise HostReadInReplay("do-while Scan: the trip count is read on the host")
+            if not self.dry_run:
+                done = int(ctl[1][4].item())        # ONE host read per Scan (the launch list: one per step)
+        return None, sh_out, done
+
     def _launch_persistent(self, fn, grid, block, g):
         """Launch a persistent Scan kernel whose workgroups WAIT FOR EACH OTHER: only when the
         whole grid can be co-resident (occupancy query of THIS kernel x CU count; cached per
@@ -752,7 +873,21 @@ class ScanMixin:
 
         i, go = 0, True
         mm_inplace = None
-        if TUNE["scan_persist"] and self.fuse and n_steps >= 2:
+        ew_ran = False
+        if TUNE["scan_persist"] and self.fuse and n_steps >= 1 and not n_mm:
+            # a purely element-wise step: the whole recurrence as one launch, no exchange at all
+            why_ew, sh_out, done = self._scan_persist_ew(node, p, inner, n_steps, seqs, outs, store, pos,
+                                                         shared, non_seqs, pre_rows, n_rec, n_nit)
+            if why_ew is None:
+                ew_ran = True
+                self.scan_modes[node.outputs[0]] = "persistent"
+                self.scan_notes[node.outputs[0]] = "element-wise recurrence: one thread per element"
+                i, go = done, False
+                pos = [(pp + done) % st for pp, st in zip(pos, store)]
+                shared = sh_out
+        if ew_ran:
+            pass
+        elif TUNE["scan_persist"] and self.fuse and n_steps >= 2:
             why = self._scan_persist(node, p, inner, n_steps, seqs, outs, store, pos, non_seqs,
                                      pre_rows, n_rec, n_nit, xfold=xfold)
             if why is None and xfold is not None:

@@ -1,0 +1,291 @@
+"""K10e — a Scan whose step is purely ELEMENT-WISE as ONE kernel launch (round 4).
+
+Replaces, for this class, what ``Scan.perform`` drives from the host (scan/op.py:1673) through
+``scan_perform.pyx:309-541``: per step, slice the sequences and the taps (:321-340), run the inner
+function, store the outputs into the (circular) output buffers (:430-520), evaluate the ``until``
+condition of a do-while Scan (:424-426).  When every fused step of the inner graph is an Elemwise
+over values of ONE shape (cumulative sums / products, filters with taps, running statistics,
+counters, a scalar recurrence with a stop condition ...) element e of every value depends only on
+element e of the others, so no value ever has to cross between threads: thread e runs the whole
+recurrence for its element — ``T`` steps in one launch, the taps in registers (a shift per step),
+the sequences read eight steps ahead of their use, every step's outputs stored as they are made.
+No exchange, no polling, no co-residency requirement (any grid size runs).
+
+Covered: sequences (incl. hoisted sequence-only rows), sit-sot / mit-sot outputs with taps down to
+-8, nit-sot outputs, shared outputs (``n_shared_outs``: a recurrent value without a history),
+non-sequences (per element or one broadcast scalar), any dtype the Elemwise generator covers
+(float32/64, (u)int8-64, bool), and **do-while** (``as_while``) for recurrences of ONE element (the
+condition is a 0-d value: with more elements it would be a reduction): the thread stops at the
+first step whose condition is true and stores the number of steps it ran in a device word the
+executor reads once after the launch (the trip count sizes the outputs, scan/op.py:2139-2159).
+Not covered (launch-list path, ``PlanExecutor.scan_modes`` says why): mit-mot outputs, steps with
+dots / reductions / indexing, values of different shapes inside one step.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import hashlib
+import json
+
+from . import codegen as cg
+
+EW_MAXSEQ, EW_MAXNSQ, EW_MAXOUT, EW_MAXSH = 16, 16, 16, 8
+AHEAD = 8                 # steps whose sequence rows are loaded before the first of them is used
+
+
+class EwScanArgs(C.Structure):
+    _fields_ = [
+        ("T", C.c_int64), ("n", C.c_int64),
+        ("seq", C.c_void_p * EW_MAXSEQ), ("seq_ts", C.c_int64 * EW_MAXSEQ),
+        ("nsq", C.c_void_p * EW_MAXNSQ), ("nsq_es", C.c_int64 * EW_MAXNSQ),
+        ("out", C.c_void_p * EW_MAXOUT), ("out_rs", C.c_int64 * EW_MAXOUT),
+        ("out_store", C.c_int64 * EW_MAXOUT), ("out_pos0", C.c_int64 * EW_MAXOUT),
+        ("sh_in", C.c_void_p * EW_MAXSH), ("sh_out", C.c_void_p * EW_MAXSH),
+        ("ctl", C.c_void_p),
+    ]
+
+
+EW_STRUCT = r"""
+#define EW_MAXSEQ %d
+#define EW_MAXNSQ %d
+#define EW_MAXOUT %d
+#define EW_MAXSH %d
+struct EwScanArgs {
+  i64 T; i64 n;
+  const void* seq[EW_MAXSEQ]; i64 seq_ts[EW_MAXSEQ];
+  const void* nsq[EW_MAXNSQ]; i64 nsq_es[EW_MAXNSQ];
+  void* out[EW_MAXOUT]; i64 out_rs[EW_MAXOUT]; i64 out_store[EW_MAXOUT]; i64 out_pos0[EW_MAXOUT];
+  const void* sh_in[EW_MAXSH]; void* sh_out[EW_MAXSH];
+  unsigned* ctl;
+};
+""" % (EW_MAXSEQ, EW_MAXNSQ, EW_MAXOUT, EW_MAXSH)
+
+_ALIAS_OPS = ("SpecifyShape", "ViewOp", "ScalarFromTensor", "TensorFromScalar", "DeepCopyOp")
+
+
+class ProgramEw:
+    """The loop in terms of inner-plan variable ids.
+
+    ``seq``: var -> sequence slot; ``tap``: var -> (recurrent output k, depth d >= 1);
+    ``shared``: var -> shared slot; ``nsq``: var -> invariant slot; ``steps``: the Elemwise steps
+    in order; ``rec_new`` / ``nit_new`` / ``sh_new``: the variables holding each output's new
+    value; ``cond``: the do-while condition variable or None; ``depth``: k -> deepest tap."""
+
+    def __init__(self):
+        self.seq, self.tap, self.shared, self.nsq = {}, {}, {}, {}
+        self.steps, self.rec_new, self.nit_new, self.sh_new = [], [], [], []
+        self.cond, self.depth, self.dtype_of = None, {}, {}
+        self.as_while = False
+
+
+def analyze(inner, p, n_pre):
+    """(ProgramEw, None) or (None, reason)."""
+    plan = inner.plan
+    if p.get("mit_mot_in_slices"):
+        return None, "mit-mot outputs"
+    n_seqs, n_sh, n_nit = p["n_seqs"], p.get("n_shared_outs", 0), p["n_nit_sot"]
+    taps = [list(t) for t in p["mit_sot_in_slices"]] + [list(t) for t in p["sit_sot_in_slices"]]
+    if any(any(x >= 0 for x in t) or len(set(t)) != len(t) or min(t) < -8 for t in taps):
+        return None, "taps non-negative / deeper than 8"
+    pr = ProgramEw()
+    pr.as_while = bool(p.get("as_while", False))
+    ins = list(plan.inputs)
+    n_fixed = len(ins) - n_pre
+    if n_seqs + n_pre > EW_MAXSEQ or n_sh > EW_MAXSH:
+        return None, "too many sequences / shared outputs"
+    for s, v in enumerate(ins[:n_seqs]):
+        pr.seq[v] = s
+    idx = n_seqs
+    for k, tk in enumerate(taps):
+        for tap in tk:
+            pr.tap[ins[idx]] = (k, -tap)
+            idx += 1
+        pr.depth[k] = -min(tk)
+    for m in range(n_sh):
+        pr.shared[ins[idx]] = m
+        idx += 1
+    inv = ins[idx:n_fixed]
+    for j, v in enumerate(ins[n_fixed:]):
+        pr.seq[v] = n_seqs + j
+    inv_set = set(inv)
+    alias, produced = {}, set()
+
+    def res(v):
+        while v in alias:
+            v = alias[v]
+        return v
+    for st in inner.steps:
+        if st.kind == "node" and st.node.op in _ALIAS_OPS:
+            alias[st.outputs[0]] = st.inputs[0]
+            continue
+        if st.kind == "node" and st.node.op == "DimShuffle" and \
+                plan.vars[st.outputs[0]].ndim == plan.vars[st.inputs[0]].ndim == 0:
+            alias[st.outputs[0]] = st.inputs[0]
+            continue
+        if st.kind != "elemwise" or st.reduce is not None or st.post or st.fallback or st.extra.get("xprog"):
+            return None, f"step kind {st.kind} ({st.node.op if st.node else ''})"
+        st_in = [res(v) for v in st.inputs]
+        for v in st_in:
+            if plan.vars[v].const is not None:
+                return None, "array constant inside the step"
+            if v in inv_set:
+                if v not in pr.nsq:
+                    if len(pr.nsq) >= EW_MAXNSQ:
+                        return None, "too many invariant operands"
+                    pr.nsq[v] = len(pr.nsq)
+            elif not (v in pr.seq or v in pr.tap or v in pr.shared or v in produced):
+                return None, "operand of unknown origin"
+        pr.steps.append({"ins": st_in, "outs": list(st.outputs), "scalar": st.scalar,
+                         "out_refs": list(st.out_refs)})
+        produced.update(st.outputs)
+    n_rec = len(taps)
+    want = n_rec + n_nit + n_sh + (1 if pr.as_while else 0)
+    if len(plan.outputs) != want or n_rec + n_nit > EW_MAXOUT or n_rec + n_nit + n_sh == 0:
+        return None, "output count"
+    outs = [res(o) for o in plan.outputs]
+
+    def legal_src(v):
+        return v in produced or v in pr.seq or v in pr.tap or v in pr.shared or v in pr.nsq or v in inv_set
+    for v in outs:
+        if not legal_src(v):
+            return None, "a step output is not computed by a fused step"
+        if v in inv_set and v not in pr.nsq:
+            pr.nsq[v] = len(pr.nsq)
+    pr.rec_new = outs[:n_rec]
+    pr.nit_new = outs[n_rec:n_rec + n_nit]
+    pr.sh_new = outs[n_rec + n_nit:n_rec + n_nit + n_sh]
+    pr.cond = outs[-1] if pr.as_while else None
+    pr.dtype_of = {v: plan.vars[v].dtype for v in plan.vars}
+    if any(dt not in cg.CTYPE for dt in pr.dtype_of.values() if dt):
+        return None, "a dtype without kernels"
+    return pr, None
+
+
+class SpecEw:
+    def __init__(self, prog: ProgramEw, plan, out_dtypes, sh_dtypes, broadcast_nsq):
+        self.prog, self.plan = prog, plan
+        self.out_dtypes, self.sh_dtypes = list(out_dtypes), list(sh_dtypes)
+        self.bc = tuple(sorted(broadcast_nsq))       # invariant slots read as one scalar
+
+    def key(self):
+        pr = self.prog
+        blob = json.dumps(["se2", [[s["ins"], s["outs"], s["scalar"], s["out_refs"]] for s in pr.steps],
+                           sorted(pr.seq.items()), sorted((k, list(v)) for k, v in pr.tap.items()),
+                           sorted(pr.shared.items()), sorted(pr.nsq.items()), pr.rec_new, pr.nit_new,
+                           pr.sh_new, pr.cond, sorted(pr.depth.items()), self.out_dtypes, self.sh_dtypes,
+                           self.bc, sorted((k, v) for k, v in pr.dtype_of.items())], sort_keys=True)
+        return hashlib.sha256(blob.encode()).hexdigest()[:24]
+
+
+def generate(spec: SpecEw):
+    """Return (source, (kernel name,))."""
+    pr = spec.prog
+    name = "se_" + spec.key()
+    dt = pr.dtype_of
+    CT, RT = cg.CTYPE, cg.RTYPE
+    L = [cg.PRELUDE, EW_STRUCT]
+    L.append('extern "C" __global__ __launch_bounds__(256) void %s(EwScanArgs a) {' % name)
+    L.append("  const i64 e = (i64)blockIdx.x * 256 + threadIdx.x;")
+    L.append("  if (e >= a.n) return;")
+    used_seq = sorted({v for s in pr.steps for v in s["ins"] if v in pr.seq} |
+                      {v for v in pr.rec_new + pr.nit_new + pr.sh_new + ([pr.cond] if pr.cond is not None else [])
+                       if v in pr.seq}, key=lambda v: pr.seq[v])
+
+    def rd(expr, d):                       # a stored element -> register value
+        return "(%s != 0)" % expr if d == "bool" else expr
+    # invariants
+    for v, j in sorted(pr.nsq.items(), key=lambda kv: kv[1]):
+        off = "0" if j in spec.bc else "e * a.nsq_es[%d]" % j
+        L.append("  const %s nv%d = %s;" % (RT[dt[v]], j, rd("((const %s*)a.nsq[%d])[%s]" % (CT[dt[v]], j, off), dt[v])))
+    # recurrent state registers (tap -1 .. -depth) from the output buffers, shared values
+    n_rec, n_nit = len(pr.rec_new), len(pr.nit_new)
+    for k in range(n_rec):
+        odt = spec.out_dtypes[k]
+        L.append("  %s* const ob%d = (%s*)a.out[%d];" % (CT[odt], k, CT[odt], k))
+        L.append("  i64 op%d = a.out_pos0[%d];" % (k, k))
+        for d in range(1, pr.depth[k] + 1):
+            L.append("  %s r%d_%d = %s;" % (RT[odt], k, d, rd(
+                "ob%d[((op%d - %d + a.out_store[%d]) %% a.out_store[%d]) * a.out_rs[%d] + e]" % (k, k, d, k, k, k), odt)))
+    for j in range(n_nit):
+        k = n_rec + j
+        odt = spec.out_dtypes[k]
+        L.append("  %s* const ob%d = (%s*)a.out[%d];" % (CT[odt], k, CT[odt], k))
+        L.append("  i64 op%d = a.out_pos0[%d];" % (k, k))
+    for v, m in sorted(pr.shared.items(), key=lambda kv: kv[1]):
+        sdt = spec.sh_dtypes[m]
+        L.append("  %s s%d = %s;" % (RT[sdt], m, rd("((const %s*)a.sh_in[%d])[e]" % (CT[sdt], m), sdt)))
+    for v in used_seq:
+        L.append("  const %s* const sq%d = (const %s*)a.seq[%d];" % (CT[dt[v]], pr.seq[v], CT[dt[v]], pr.seq[v]))
+    L.append("  i64 t = 0;")
+    L.append("  for (i64 t0 = 0; t0 < a.T; t0 += %d) {" % AHEAD)
+    # the sequence rows of the next AHEAD steps, loaded before any of them is used (clamped rows:
+    # no branch between the loads)
+    for u in range(AHEAD):
+        L.append("    const i64 tt%d = t0 + %d < a.T ? t0 + %d : a.T - 1;" % (u, u, u))
+        for v in used_seq:
+            s = pr.seq[v]
+            L.append("    const %s x%d_%d = %s;" % (RT[dt[v]], s, u, rd("sq%d[tt%d * a.seq_ts[%d] + e]" % (s, u, s), dt[v])))
+    for u in range(AHEAD):
+        L.append("    if (t0 + %d < a.T) {" % u)
+        env = {}
+        for v in used_seq:
+            env[v] = "x%d_%d" % (pr.seq[v], u)
+        for v, (k, d) in pr.tap.items():
+            env[v] = "r%d_%d" % (k, d)
+        for v, m in pr.shared.items():
+            env[v] = "s%d" % m
+        for v, j in pr.nsq.items():
+            env[v] = "nv%d" % j
+        for si, st in enumerate(pr.steps):
+            in_exprs = [env[v] for v in st["ins"]]
+            in_dts = [dt[v] for v in st["ins"]]
+            lines, outs, odts = cg.emit_scalar_body(st["scalar"], in_exprs, in_dts, indent="      ",
+                                                    suffix="_s%d_u%d" % (si, u))
+            L.extend(lines)
+            for o, ri in zip(st["outs"], st["out_refs"]):
+                nm = "v%d_u%d" % (o, u)
+                L.append("      const %s %s = %s;" % (RT[dt[o]], nm, cg._cast(outs[ri], odts[ri], dt[o])))
+                env[o] = nm
+
+        def st_val(v, odt):
+            e_ = cg._cast(env[v], dt[v], odt)
+            return "(unsigned char)(%s)" % e_ if odt == "bool" else e_
+        for k in range(n_rec):
+            odt = spec.out_dtypes[k]
+            L.append("      const %s n%d = %s;" % (RT[odt], k, cg._cast(env[pr.rec_new[k]], dt[pr.rec_new[k]], odt)))
+        for k in range(n_rec):
+            odt = spec.out_dtypes[k]
+            L.append("      ob%d[op%d * a.out_rs[%d] + e] = %s;" % (
+                k, k, k, "(unsigned char)n%d" % k if odt == "bool" else "n%d" % k))
+        for j in range(n_nit):
+            k = n_rec + j
+            L.append("      ob%d[op%d * a.out_rs[%d] + e] = %s;" % (k, k, k, st_val(pr.nit_new[j], spec.out_dtypes[k])))
+        sh_tmp = []
+        for m, v in enumerate(pr.sh_new):
+            L.append("      const %s ns%d = %s;" % (RT[spec.sh_dtypes[m]], m, cg._cast(env[v], dt[v], spec.sh_dtypes[m])))
+            sh_tmp.append(m)
+        if pr.cond is not None:
+            L.append("      const bool stop_ = (bool)(%s);" % cg._cast(env[pr.cond], dt[pr.cond], "bool"))
+        # shift the taps, advance the circular positions
+        for k in range(n_rec):
+            for d in range(pr.depth[k], 1, -1):
+                L.append("      r%d_%d = r%d_%d;" % (k, d, k, d - 1))
+            L.append("      r%d_1 = n%d;" % (k, k))
+        for m in sh_tmp:
+            L.append("      s%d = ns%d;" % (m, m))
+        for k in range(n_rec + n_nit):
+            L.append("      if (++op%d == a.out_store[%d]) op%d = 0;" % (k, k, k))
+        L.append("      ++t;")
+        if pr.cond is not None:
+            L.append("      if (stop_) goto done_;")
+        L.append("    }")
+    L.append("  }")
+    if pr.cond is not None:
+        L.append("done_:")
+    for m in range(len(pr.sh_new)):
+        sdt = spec.sh_dtypes[m]
+        L.append("  ((%s*)a.sh_out[%d])[e] = %s;" % (CT[sdt], m, "(unsigned char)s%d" % m if sdt == "bool" else "s%d" % m))
+    if pr.as_while:
+        L.append("  if (e == 0) a.ctl[0] = (unsigned)t;      // steps this do-while ran")
+    L.append("}")
+    return "\n".join(L) + "\n", (name,)

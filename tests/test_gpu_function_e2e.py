@@ -317,3 +317,43 @@ def test_profile_is_filled_per_apply_node(ae, gg):
     assert sum(prof.apply_time.values()) > 0
     topo = f.maker.fgraph.toposort()          # fused steps are booked on their result's node
     assert len(prof.apply_time) >= 2 and all(n in topo for (_fg, n) in prof.apply_time)
+
+
+def test_scan_with_shared_outputs_and_do_while_runs_as_one_launch(ae, gg):
+    """Scan classes the element-wise kernel added in round 4 (aesara_amd/scan_persist_ew.py), through
+    the real front end: a recurrence that also updates SHARED variables every step
+    (``n_shared_outs``, scan/op.py:1673; tests/scan/test_basic.py:841
+    test_shared_arguments_with_updates) and a do-while — both one launch, values equal to the
+    reference's own linker run live on the host."""
+    import aesara.tensor as at
+    from aesara.scan.utils import until
+    from aesara_amd.sharedvar import hip_shared
+    rng = np.random.default_rng(21)
+    xv = rng.uniform(0.1, 0.9, 40)
+
+    def build(shared_ctor, mode):
+        x = at.dvector("x")
+        cnt = shared_ctor(np.asarray(2.0), name="cnt")
+        tot = shared_ctor(np.asarray(0.0), name="tot")
+
+        def step(x_t, acc):
+            return acc * 0.9 + x_t * cnt, {cnt: cnt + 0.5, tot: tot + x_t * x_t}
+        res, upd = ae.scan(step, sequences=[x], outputs_info=[at.as_tensor_variable(np.float64(0.0))])
+        f = ae.function([x], res, updates=upd, mode=mode)
+        w, _ = ae.scan(lambda x_t, s: (s + x_t, until(s + x_t > 3.0)), sequences=[x],
+                       outputs_info=[at.as_tensor_variable(np.float64(0.0))])
+        g = ae.function([x], [w, w.shape[0]], mode=mode)
+        return f, g, cnt, tot
+    f_h, g_h, cnt_h, tot_h = build(hip_shared, "HIP")
+    f_r, g_r, cnt_r, tot_r = build(ae.shared, None)
+    for call in range(3):
+        np.testing.assert_allclose(_host(f_h(xv))[0], f_r(xv), rtol=1e-13)
+        np.testing.assert_allclose(cnt_h.get_value(), cnt_r.get_value(), rtol=1e-13)
+        np.testing.assert_allclose(tot_h.get_value(), tot_r.get_value(), rtol=1e-13)
+    wh, nh = _host(g_h(xv))
+    wr, nr = g_r(xv)
+    assert int(nh) == int(nr) and 1 < int(nr) < 40
+    np.testing.assert_allclose(wh, wr, rtol=1e-13)
+    for fn in (f_h, g_h):
+        modes = fn.maker.linker.executor.scan_modes
+        assert list(modes.values()) == ["persistent"], modes

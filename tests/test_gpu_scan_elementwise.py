@@ -1,0 +1,101 @@
+"""A Scan whose step is purely element-wise as ONE kernel launch (aesara_amd/scan_persist_ew.py:
+thread e runs the whole recurrence of element e; taps in registers, sequences read ahead, a
+do-while's stop decided on the device): parity with the reference's outputs (goldens), with the
+launch-list path, and with NumPy restatements at sizes far beyond the goldens'."""
+import numpy as np
+import pytest
+
+from golden_util import CASES, assert_matches, case_expected, case_inputs, case_plan
+
+pytestmark = pytest.mark.gpu
+
+ELEMENTWISE = ["scan_cumsum", "scan_taps", "scan_two_outputs", "scan_nitsot_map", "scan_while_cumsum",
+               "scan_while_never_stops"]
+
+
+def _case(name):
+    return next(c for c in CASES if c["name"] == name)
+
+
+def _np(outs):
+    return [o.cpu().numpy() if hasattr(o, "cpu") else np.asarray(o) for o in outs]
+
+
+@pytest.mark.parametrize("name", ELEMENTWISE)
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_elementwise_scans_run_as_one_launch_and_match(name, use_graph):
+    from aesara_amd import executor as E
+    c = _case(name)
+    ex = E.PlanExecutor(case_plan(c), use_graph=use_graph)
+    ins = case_inputs(c)
+    for it in range(3):
+        got = _np(ex(*ins))
+        assert_matches(c, got, case_expected(c), f"call {it}")
+    assert list(ex.scan_modes.values()) == ["persistent"], ex.scan_modes
+    assert "element-wise" in list(ex.scan_notes.values())[0]
+    E.TUNE["scan_persist"] = 0
+    try:
+        ex2 = E.PlanExecutor(case_plan(c), use_graph=use_graph)
+        ref = _np(ex2(*ins))
+        assert all(v.startswith("launch-list") for v in ex2.scan_modes.values())
+    finally:
+        E.TUNE["scan_persist"] = 1
+    for g, r in zip(got, ref):
+        np.testing.assert_array_equal(g, r)          # the same arithmetic, element by element
+    ex.check()
+
+
+@pytest.mark.parametrize("T,n", [(700, 3000), (1, 5), (9, 1), (257, 70001)])
+def test_cumsum_recurrence_large(T, n):
+    """s_t = s_{t-1} + x_t over [T, n]: every row against np.cumsum (fp64, same order: exact)."""
+    import torch
+    from aesara_amd.executor import PlanExecutor
+    rng = np.random.default_rng(T + n)
+    x, s0 = rng.standard_normal((T, n)), rng.standard_normal(n)
+    ex = PlanExecutor(case_plan(_case("scan_cumsum")))
+    outs = _np(ex(torch.from_numpy(x).cuda(), torch.from_numpy(s0).cuda()))
+    want = np.cumsum(np.vstack([s0[None], x]), axis=0)[1:]        # ((s0 + x_0) + x_1) + ...: the same order
+    got = outs[0]
+    assert got.shape[0] >= T
+    np.testing.assert_array_equal(got[-T:], want)
+    assert list(ex.scan_modes.values()) == ["persistent"]
+
+
+def test_two_tap_recurrence_long():
+    """y_t = w * y_{t-2} + 0.5 * y_{t-1} + x_t (golden scan_taps' step) for 5000 steps."""
+    import torch
+    from aesara_amd.executor import PlanExecutor
+    rng = np.random.default_rng(7)
+    T = 5000
+    x, init, w = rng.standard_normal(T) * 0.1, rng.standard_normal(2), np.float64(0.3)
+    ex = PlanExecutor(case_plan(_case("scan_taps")))
+    (res,) = _np(ex(torch.from_numpy(x).cuda(), torch.from_numpy(init).cuda(), w))
+    a, b = init
+    want = []
+    for t in range(T):
+        y = w * a + 0.5 * b + x[t]
+        want.append(y)
+        a, b = b, y
+    np.testing.assert_allclose(res[-T:], np.array(want), rtol=1e-13, atol=1e-13)
+    assert list(ex.scan_modes.values()) == ["persistent"]
+
+
+@pytest.mark.parametrize("stop_at", [1, 37, 999, None])
+def test_do_while_stops_on_the_device(stop_at):
+    """s_t = s_{t-1} + x_t until s_t > 3 (golden scan_while_cumsum's step) over 1000 steps: the
+    trip count, the truncated output and the last value against a NumPy loop; one launch, one
+    host read (eager: a do-while plan is never replayed)."""
+    import torch
+    from aesara_amd.executor import PlanExecutor
+    T = 1000
+    x = np.full(T, 1e-3)
+    if stop_at is not None:
+        x[stop_at - 1] = 5.0                 # the step whose sum first exceeds 3
+    ex = PlanExecutor(case_plan(_case("scan_while_cumsum")), use_graph=True)
+    for call in range(2):
+        res, last, count = _np(ex(torch.from_numpy(x).cuda()))
+        k = T if stop_at is None else stop_at
+        assert int(count) == k and res.shape == (k,)
+        np.testing.assert_allclose(res, np.cumsum(x)[:k], rtol=1e-13)
+        np.testing.assert_allclose(last, np.cumsum(x)[k - 1], rtol=1e-13)
+    assert list(ex.scan_modes.values()) == ["persistent"]
