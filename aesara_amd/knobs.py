@@ -60,10 +60,30 @@ _def("SP_REPOLL", 0, int, "re-poll only the granules that were missing")
 _def("SM_CHUNK", 32, int, "k-chunk of the matrix-state kernel's exchange")
 _def("SM_XMODE", None, str, "exchange form of the matrix-state kernel: frag | flag (default by registers)")
 _def("SM_EARLY", "first", str, "which product of a step starts before the hand-off: first | none")
-_def("SM_PIN", 1, int, "pin the recurrent weights to architectural registers (fragment form)")
+_def("SM_PIN", None, int, "fragment form: pin the recurrent weights to architectural (1) or accumulation (2) "
+     "registers, 0 = leave them to the allocator (default: 2 with in-loop sequence products, else 1)")
 _def("SM_TRACE", 0, int, "stamp s_memtime at the phase marks (tools/sm_trace.py)")
 _def("SM_FENCE", 1, int, "scheduler fences at the phase marks")
-_def("SM_XTAIL", 10, int, "fragments of the sequence product behind the payload loads")
+_def("SM_INIT", "publish", str, "fragment form, initial state: branch (step 0 reads the output buffer) | publish "
+     "(every workgroup publishes its tile before the loop: no step-0 code in the loop)")
+_def("SM_XRELOAD", "late", str, "in-loop sequence products: the next x is requested behind the MFMAs of the first "
+     "product on the fetched operand (late) | of the next phase's product on staged operands (early)")
+_def("SM_ACKFILL", 1, int, "the next phase's products on staged operands are issued before the wait for the "
+     "acknowledgement of this phase's payload stores")
+_def("SM_EPRE", 6, int, "with SM_ACKFILL: fragments (of 16) of the staged-operand product issued before the "
+     "acknowledgement wait, the rest behind the tag (0 = all of them before)")
+_def("SM_ELOOK", 6, int, "fragments of the rest of that product issued before the first look at the next tags "
+     "(0 = the look belongs to the window, SM_LOOK)")
+_def("SM_XSPLIT", 4, int, "fragments of a wrapped sequence product that stay in the last window of the step; the "
+     "others move to the first window of the next step (0 = all stay)")
+_def("SM_XPRE", 6, int, "fragments of the next step's first sequence-product window issued before the wait for "
+     "the acknowledgement of the last phase's payload stores")
+_def("SM_NXT", "fetch", str, "per-step sequence operands of the epilogue: requested at the top of the step (top) | "
+     "behind the first fetch of the step (fetch: an HBM-cold load in front of the fetch delays every "
+     "in-order wait behind it)")
+_def("SM_LOOK", 8, int, "fragments of a window's head issued before the first look at the tags")
+_def("SM_ASM_MARKS", 0, int, "label the phase marks in the ISA (asm comments; for reading disassembly)")
+_def("SM_XTAIL", 8, int, "fragments of the sequence product behind the payload loads")
 _def("SM_XFOLD", 1, int, "sequence products x_t @ W inside the loop")
 _def("SM_INTERLEAVE", 1, int, "interleave the phases of the batch blocks of one workgroup")
 _def("SPIN_LOG2", 21, int, "log2 of the poll limit of the persistent Scan kernels before they raise their error word "

@@ -53,7 +53,7 @@ SM_MAXMAT = 8
 SM_MAXSEQ = 28
 SM_MAXNSQ = 8
 SM_MAXOUT = 16
-TRACE_T0, TRACE_NT, TRACE_MARKS = 200, 32, 24      # steps traced, stamps per step (u64 each)
+TRACE_T0, TRACE_NT, TRACE_MARKS = 200, 32, 32      # steps traced, stamps per step (u64 each)
 
 
 class SmArgs(C.Structure):
@@ -151,15 +151,37 @@ class SpecMat:
         # loads deliver then live in accumulation registers).  Left to the allocator, products
         # end up with A and B both in AGPRs and get a v_accvgpr_read through ONE temporary in
         # front of every MFMA (r03 timeline: 64 such MFMAs 1.2 us, 64 plain ones 0.93)
-        self.pin = (self.xmode == "frag" and int(knobs.get("SM_PIN")) != 0 and
-                    wpr * sum(K // 16 for K in Ks.values()) <= 192)
+        #   2 = pinned to ACCUMULATION registers instead (MFMA reads B from either file): the
+        #   fragments and x then stay in the architectural file the loads deliver into
+        pin_k = knobs.get("SM_PIN")
+        pin_k = (2 if xfold else 1) if pin_k is None else int(pin_k)
+        self.pin = pin_k if (self.xmode == "frag" and wpr * sum(K // 16 for K in Ks.values()) <= 192) else 0
         # per-phase timeline (tools/sm_trace.py): thread 0 of workgroups 0 and NB*NJ/2 stamps
         # s_memtime at every mark of steps TRACE_T0 .. TRACE_T0+TRACE_NT-1 into ctl[16..]
         self.trace = bool(int(knobs.get("SM_TRACE")))
+        # fragment form schedule:
+        #   init     "publish": every workgroup publishes its tile of the initial state through the
+        #            exchange before the loop — the loop body has no step-0 path (the merge of the two
+        #            paths cost 84 register copies per step and conservative s_waitcnt vmcnt(0))
+        #   xreload  where the next x is requested (16 loads per lane): behind the MFMAs of a product
+        #            that waits for payload ("late": each load finds the queue full of the 16 payload
+        #            loads and stalls the instruction stream) or of one that waits for nothing ("early")
+        #   ackfill / xpre   MFMAs that need nothing from the hand-off, issued between the payload
+        #            stores and the wait for their acknowledgement (0.35 us per hand-off otherwise idle)
+        self.init = str(knobs.get("SM_INIT")) if self.xmode == "frag" else "branch"
+        sched = self.xmode == "frag" and bool(xfold) and nblk == 1 and self.init == "publish"
+        self.xreload = str(knobs.get("SM_XRELOAD")) if sched else "late"
+        self.ackfill = int(knobs.get("SM_ACKFILL")) if sched else 0
+        self.xpre = int(knobs.get("SM_XPRE")) if sched else 0
+        self.look = int(knobs.get("SM_LOOK")) if sched else 0
+        self.epre = int(knobs.get("SM_EPRE")) if (sched and self.ackfill) else 0
+        self.elook = int(knobs.get("SM_ELOOK")) if (sched and self.ackfill) else 0
+        self.xsplit = int(knobs.get("SM_XSPLIT")) if sched else 0
+        self.nxt = str(knobs.get("SM_NXT")) if self.xmode == "frag" else "top"
 
     def key(self):
         pr = self.prog
-        blob = json.dumps(["sm9" + ("t" if self.trace else "") + ("/f5p%d%s" % (self.pin, str(knobs.get("SM_FENCE"))) if self.xmode == "frag" else ""), self.xfold and [self.xfold, "w15", str(knobs.get("SM_XTAIL"))], self.dtype, self.chunk, self.xmode, self.early_first, self.B, self.N, self.Nt, sorted(self.Ks.items()), sorted(pr.seq.items()),
+        blob = json.dumps(["sm9" + ("t" if self.trace else "") + ("/f5p%d%s" % (self.pin, str(knobs.get("SM_FENCE"))) if self.xmode == "frag" else ""), self.xfold and [self.xfold, "w15", str(knobs.get("SM_XTAIL"))], [self.init, self.xreload, self.ackfill, self.xpre, self.look, self.nxt, self.epre, self.elook, self.xsplit], self.dtype, self.chunk, self.xmode, self.early_first, self.B, self.N, self.Nt, sorted(self.Ks.items()), sorted(pr.seq.items()),
                            sorted(pr.state.items()), sorted(pr.nsq.items()), sorted(pr.mats.items()),
                            [[ph["dots"], ph["ins"], ph["outs"], ph["scalar"], ph["out_refs"]]
                             for ph in pr.phases], pr.outs, pr.exchanged, sorted(pr.tap_seq.items())] +
@@ -753,10 +775,15 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
     marks = []
     FENCE = int(knobs.get("SM_FENCE")) != 0
 
+    ASM_MARKS = int(knobs.get("SM_ASM_MARKS")) != 0
+
     def stamp(label):
         if not spec.trace:
             if FENCE:
                 L.append("    __builtin_amdgcn_sched_barrier(0);")
+                if ASM_MARKS:
+                    L.append('    asm volatile("; @@ %s");' % label)
+                    L.append("    __builtin_amdgcn_sched_barrier(0);")
             return
         k = len(marks)
         marks.append(label)
@@ -834,7 +861,9 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
         L.append("  __syncthreads();")
         # the products the first fetching phase of step 0 needs (later steps get theirs from the
         # last window of the step before)
+        i_wrap0 = len(L)
         emit_xunits([(gi, q) for gi in sorted(XW["wrapped"]) for q in range(Q)], "  ")
+        i_wrap1 = len(L)
         if XW["ahead"] == 2:
             L.append("  if (a.T > 1) {")
             emit_xload("1", "    ")
@@ -862,6 +891,34 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
     for ph in pr.phases:
         for o in ph["outs"]:
             L.append("  %s own_%d§ = %s;" % (T, o, ZERO))
+    PUBLISH = spec.init == "publish"
+    # the wait for the acknowledgement of the payload stores.  "publish" form: as an s_waitcnt the
+    # compiler's wait-count pass sees (after an inline-asm wait it still believes the x loads of the
+    # step before are pending and puts a vmcnt(0) in front of the first MFMA that reads x — where
+    # only the tag store of wavefront 0 is pending: 0.3 us of skew between the wavefronts)
+    WAIT_ACK = ('    __builtin_amdgcn_s_waitcnt(0x0F70); asm volatile("" ::: "memory");' if PUBLISH else
+                '    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");')
+    INIT_TAG = "(1ull << 32)"          # tags of the initial state: bit 32 set (step tags are 32-bit counts)
+    prev_ops = [x for (x, kind) in keys if kind == "prev"]
+    if PUBLISH and prev_ops:
+        # the initial state goes through the exchange like every later one: slot (0 - 1) & 3 = 3
+        L.append("  if (a.T > 0) {")
+        for x in prev_ops:
+            po_, lpp, fo_, lpf = xoff[pr.new_of_state.get(x, x)]
+            L.append("    { const %s v0_ = owner§ ? own_%d§ : %s;" % (T, x, ZERO))
+            L.append("      " + " ".join("const %s v%d_ = shfl_down_<%s>(v0_, %d);" % (T, e, T, e) for e in range(1, PV)))
+            L.append("      if ((ecol & %d) == 0 && eb§ < %d) {" % (PV - 1, B))
+            L.append("        const %s pv = {%s};" % (VT, ", ".join("v%d_" % e for e in range(PV))))
+            L.append("        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, pv), xr, pub_off, "
+                     "(unsigned)((%d + 3 * %d + (i64)bi§ * %d) * 8), 16);" % (po_, lpp, 16 * K * ISZ // 8))
+            L.append("      } }")
+        L.append(WAIT_ACK)
+        L.append("    __syncthreads();")
+        for x in prev_ops:
+            po_, lpp, fo_, lpf = xoff[pr.new_of_state.get(x, x)]
+            L.append("    if (tid == 0) __hip_atomic_store(a.xch + %d + 3 * %d + (i64)bi§ * %d + nj, "
+                     "%s | (unsigned long long)base, %s);" % (fo_, lpf, NJ, INIT_TAG, AG))
+        L.append("  }")
     L[i_tpl:] = per_block(L[i_tpl:])
     L.append("  for (i64 t = 0; t < a.T; ++t) {")
     # the operand fragments are per-step values: declared here, one whose last product lies
@@ -887,46 +944,75 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
     if spec.pin:
         for av, slot in sorted(pr.mats.items(), key=lambda t: t[1]):
             for s0 in range(0, spec.Ks[av] // 16, 16):
-                ops = ", ".join('"+v"(w%d_%d)' % (slot, s_) for s_ in range(s0, min(s0 + 16, spec.Ks[av] // 16)))
+                ops = ", ".join('"+%s"(w%d_%d)' % ("a" if spec.pin == 2 else "v", slot, s_)
+                                for s_ in range(s0, min(s0 + 16, spec.Ks[av] // 16)))
                 L.append('    asm volatile("" : %s);' % ops)
     i_body = len(L)              # the step body: a template, instantiated per batch block below
+    nxt_loads = []
     for v in pw_seq:
         s_ = pr.seq[v]
         L.append("    own_%d§ = nxt_%d§;" % (v, v))
-        L.append("    if (owner§ && t + 1 < a.T) nxt_%d§ = ((const %s*)a.seq[%d])[(t + 1) * a.seq_ts[%d] + "
-                 "eb§ * a.seq_rs[%d] + en * a.seq_cs[%d]];" % (v, T, s_, s_, s_, s_))
+        nxt_loads.append("    if (owner§ && t + 1 < a.T) nxt_%d§ = ((const %s*)a.seq[%d])[(t + 1) * a.seq_ts[%d] + "
+                         "eb§ * a.seq_rs[%d] + en * a.seq_cs[%d]];" % (v, T, s_, s_, s_, s_))
+    i_top = len(L)
+    if spec.nxt == "top":
+        L.extend(nxt_loads)
+        nxt_loads = []
     staged_this_step = set()
 
-    def emit_mfma(pi, d, a_, x, after_q=None):
-        """one product on this wavefront's K quarter: two independent accumulator chains (a chain
-        of dependent 16x16x4 MFMAs issues every 40 cycles, two interleaved ones every 32)"""
-        slot = pr.mats[a_]
-        ki = keys.index((x, "prev" if x in pr.state else "cur"))
-        L.append("    {")
+    def want_expr(step_expr, kind):
+        """the tag a consumer of step ``step_expr``'s value waits for (initial state: INIT_TAG | base)"""
+        e = "(unsigned long long)(base + (unsigned)%s + 1u)" % step_expr
+        if kind == "prev" and PUBLISH:
+            e = "(%s | ((unsigned long long)(t == 0) << 32))" % e
+        return e
+
+    def acc_init(pi, d):
+        """what the two accumulator chains of product (pi, d) start from"""
         if (pi, d) in xf_of:        # continue the accumulation the sequence product started
             gi_ = xf_of[(pi, d)][0]
             nm = "accs" if gi_ in snap else "accx"
-            L.append("      %s acc0 = %s%d_0, acc1 = %s%d_1;" % (AT, nm, gi_, nm, gi_))
+            return "%s%d_0" % (nm, gi_), "%s%d_1" % (nm, gi_)
+        z = "{%s}" % ", ".join([ZERO] * 4)
+        return z, z
+
+    def emit_mfma(pi, d, a_, x, after_q=None, q0=0, q1=None, acc=None):
+        """one product on this wavefront's K quarter: two independent accumulator chains (a chain
+        of dependent 16x16x4 MFMAs issues every 40 cycles, two interleaved ones every 32).
+        ``q0 .. q1``: a part of the quarter — ``acc``: the accumulators' name prefix, declared by
+        the caller (a product issued in two parts, around a hand-off)"""
+        slot = pr.mats[a_]
+        ki = keys.index((x, "prev" if x in pr.state else "cur"))
+        q1 = Q if q1 is None else q1
+        if acc is None:
+            L.append("    {")
+            L.append("      %s acc0 = %s, acc1 = %s;" % ((AT,) + acc_init(pi, d)))
+            n0, n1 = "acc0", "acc1"
         else:
-            L.append("      %s acc0 = {%s, %s, %s, %s}, acc1 = {%s, %s, %s, %s};" % ((AT,) + (ZERO,) * 8))
-        for q in range(Q):
+            n0, n1 = acc + "_0", acc + "_1"
+        for q in range(q0, q1):
             for e, c in enumerate("xyzw"[:PV]):
-                acc = "acc%d" % ((PV * q + e) & 1)
+                nm = (n0, n1)[(PV * q + e) & 1]
                 L.append("      %s = %s(%s[%d].%s, w%d_%d, %s, 0, 0, 0);"
-                         % (acc, MFMA, frs[ki], q, c, slot, PV * q + e, acc))
+                         % (nm, MFMA, frs[ki], q, c, slot, PV * q + e, nm))
             if after_q is not None:
                 after_q(q)
-        # C/D rows of a lane: f32 16x16x4 -> 4 * grp + i ; f64 16x16x4 -> grp + 4 * i
-        L.append("      for (int i = 0; i < 4; ++i) part[pp%d][%d][wave][(%s) * 16 + r16] = acc0[i] + acc1[i];"
-                 % (pi, d, "grp + 4 * i" if F64 else "4 * grp + i"))
-        L.append("    }")
+        if q1 == Q:
+            # C/D rows of a lane: f32 16x16x4 -> 4 * grp + i ; f64 16x16x4 -> grp + 4 * i
+            L.append("      for (int i = 0; i < 4; ++i) part[pp%d][%d][wave][(%s) * 16 + r16] = %s[i] + %s[i];"
+                     % (pi, d, "grp + 4 * i" if F64 else "4 * grp + i", n0, n1))
+        if acc is None:
+            L.append("    }")
 
     def emit_fetch(pi, x, kind):
         """wait for the tags of this wavefront's producers, then pull its K quarter into fr"""
         ki = keys.index((x, kind))
         src = pr.new_of_state.get(x, x)
         po_, lpp, fo_, lpf = xoff[src]
-        if kind == "prev":
+        if kind == "prev" and PUBLISH:
+            L.append("    {")
+            step_expr = "(t - 1)"
+        elif kind == "prev":
             k_out = pr.state[x]
             L.append("    if (t == 0) {")
             L.append("      const %s* ini = (const %s*)a.out[%d] + ((a.out_pos0[%d] + a.out_store[%d] - 1) %% "
@@ -947,7 +1033,7 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
             L.append("    {")
             step_expr = "t"
         ind = "      "
-        L.append(ind + "const unsigned long long want64 = (unsigned long long)(base + (unsigned)%s + 1u);" % step_expr)
+        L.append(ind + "const unsigned long long want64 = %s;" % want_expr(step_expr, kind))
         L.append(ind + "const u64* fl = a.xch + %d + (%s & 3) * %d + (i64)bi§ * %d + wave * %d;"
                  % (fo_, step_expr, lpf, NJ, PW))
         L.append(ind + "for (int spin = 0;; ++spin) {")
@@ -997,6 +1083,17 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
                          " %s[%d] = __builtin_bit_cast(%s, g); }" % (q * 64 * 16, n, frs[ki], q, VT))
         L.append("    }")
 
+    def emit_look(pi, ind, assign=False):
+        """the first look at the tags of phase pi's operand (examined after the head of the window);
+        every lane loads (a clamped address): no branch, no copy the compiler would wait for"""
+        decl = "" if assign else ("const unsigned long long " if PUBLISH else "const unsigned ")
+        if PUBLISH:     # 64-bit: the low word of an initial-state tag is a step count of the launch before
+            L.append(ind + "%stg0_w%d = __hip_atomic_load(fl_w%d + (lane < %d ? lane : 0), %s);"
+                     % (decl, pi, pi, PW, AG))
+        else:
+            L.append(ind + "%stg0_w%d = __hip_atomic_load((const unsigned*)(fl_w%d + (lane < %d ? lane : 0)), %s);"
+                     % (decl, pi, pi, PW, AG))
+
     def window_begin(pi, x, kind):
         """(sequence products in the loop) the first look at the tags of this phase's operand:
         started here — in front of the products on operands already in registers — and examined
@@ -1005,26 +1102,31 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
         po_, lpp, fo_, lpf = xoff[src]
         step_expr = "(t - 1)" if kind == "prev" else "t"
         ind = "    "
-        L.append(ind + "const unsigned want32_w%d = base + (unsigned)%s + 1u;" % (pi, step_expr))
+        if PUBLISH:
+            L.append(ind + "const unsigned long long want64_w%d = %s;" % (pi, want_expr(step_expr, kind)))
+        else:
+            L.append(ind + "const unsigned want32_w%d = base + (unsigned)%s + 1u;" % (pi, step_expr))
         L.append(ind + "const u64* fl_w%d = a.xch + %d + (%s & 3) * %d + (i64)bi * %d + wave * %d;"
                  % (pi, fo_, step_expr, lpf, NJ, PW))
         L.append(ind + "const unsigned so_w%d = (unsigned)((%d + (%s & 3) * %d + (i64)bi * %d) * 8);"
                  % (pi, po_, step_expr, lpp, 16 * K * ISZ // 8))
-        # every lane loads (a clamped address): no branch, no copy the compiler would wait for
-        L.append(ind + "const unsigned tg0_w%d = __hip_atomic_load((const unsigned*)(fl_w%d + (lane < %d ? lane : 0)), %s);"
-                 % (pi, pi, PW, AG))
+        if pi in look_in_product:       # issued among the MFMAs of the product in front of the window
+            L.append(ind + "unsigned long long tg0_w%d = 0ull;" % pi)
+        elif not spec.look:
+            emit_look(pi, ind)
 
-    def emit_window(pi, x, kind, xunits):
+    def emit_window(pi, x, kind, xunits, done=0):
         """The fetch of a phase with sequence products to run (r03 timelines of this kernel): a
         wavefront has two idle stretches here — until its producers' tags are visible (~1 us
         after its own tag) and while the payload is in flight (16 KiB per wavefront: ~0.4 us of
         load issue, which stalls the instruction stream when issued back to back, + ~0.7 us).
         HEAD: the fragments beyond the last XTAIL, issued while the first look at the tags is in
         flight; then the usual spin if that look did not find every tag.  TAIL: one payload load
-        in front of each of the remaining fragments' four MFMAs."""
+        in front of each of the remaining fragments' four MFMAs.  ``done``: fragments of this
+        window already issued in front of the previous hand-off's acknowledgement wait."""
         assert PW <= 64
         ki = keys.index((x, kind))
-        xunits = list(xunits)
+        xunits = list(xunits)[done:]
         n_head = max(0, len(xunits) - XTAIL)
         tail = xunits[n_head:]
         per = -(-Q // max(len(tail), 1))       # payload loads in front of each tail fragment
@@ -1032,7 +1134,7 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
         def load(q, ind2):
             L.append(ind2 + "{ const u4v g = __builtin_amdgcn_raw_buffer_load_b128(xr, ld_off, so_w%d + %du, 16);"
                      " fr%d[%d] = __builtin_bit_cast(%s, g); }" % (pi, q * 64 * 16, ki, q, VT))
-        if kind == "prev":
+        if kind == "prev" and not PUBLISH:
             k_out = pr.state[x]
             L.append("    if (t == 0) {")
             L.append("      const %s* ini = (const %s*)a.out[%d] + ((a.out_pos0[%d] + a.out_store[%d] - 1) %% "
@@ -1052,12 +1154,28 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
         else:
             L.append("    {")
         ind = "      "
-        emit_xunits(xunits[:n_head], ind)
+        if pi in look_in_product:
+            if pi not in look_emitted:      # the product that was to carry it was not split after all
+                emit_look(pi, ind, assign=True)
+            emit_xunits(xunits[:n_head], ind)
+        elif spec.look:
+            n_before = min(spec.look, n_head)
+            emit_xunits(xunits[:n_before], ind)
+            L.append(ind + "__builtin_amdgcn_sched_barrier(0);")
+            emit_look(pi, ind)
+            L.append(ind + "__builtin_amdgcn_sched_barrier(0);")
+            emit_xunits(xunits[n_before:n_head], ind)
+        else:
+            emit_xunits(xunits[:n_head], ind)
         L.append(ind + "__builtin_amdgcn_sched_barrier(0);")
-        if n_head:
+        if n_head or done:
             stamp("p%d window head issued" % pi)
-        L.append(ind + "if (!__all(tg0_w%d == want32_w%d)) {" % (pi, pi))
-        L.append(ind + "  const unsigned long long want64 = (unsigned long long)want32_w%d;" % pi)
+        if PUBLISH:
+            L.append(ind + "if (!__all(tg0_w%d == want64_w%d)) {" % (pi, pi))
+            L.append(ind + "  const unsigned long long want64 = want64_w%d;" % pi)
+        else:
+            L.append(ind + "if (!__all(tg0_w%d == want32_w%d)) {" % (pi, pi))
+            L.append(ind + "  const unsigned long long want64 = (unsigned long long)want32_w%d;" % pi)
         L.append(ind + "  for (int spin = 0;; ++spin) {")
         L.append(ind + "    bool ok = true;")
         L.append(ind + "    for (int j = lane; j < %d; j += 64) ok = ok && (__hip_atomic_load(fl_w%d + j, %s) == want64);" % (PW, pi, AG))
@@ -1092,13 +1210,85 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
     # epilogue reads never meet the next product phase's writes, and the barrier of the phase in
     # between orders everything two phases apart — no barrier between hand-off and products
     dot_phases = [pi for pi, ph in enumerate(pr.phases) if ph["dots"]]
+    nph = len(pr.phases)
+    SCHED = bool(XW) and NBLK == 1 and PUBLISH
+    done_early = set()          # (phase, dot) issued ahead, in front of the previous acknowledgement wait
+    reload_early = None         # the phase whose first staged-operand product carries the x loads
+    if SCHED and spec.xreload == "early" and spec.early_first:
+        nx_ = XW["reload"] + 1
+        if nx_ < nph and fetches[nx_][0] and fetches[XW["reload"]][1]:
+            reload_early = nx_
+    f0 = min((f for f in XW["win"] if XW["win"][f] and fetches[f][2]), default=None) if XW else None
+    # a wrapped product (computed at the end of step t for step t + 1) may leave its last fragments
+    # to the first window of step t + 1: the same x, more MFMAs in front of THAT hand-off
+    moved = set()
+    if SCHED and spec.xsplit and f0 is not None and f0 != last_f:
+        moved = {gi_ for gi_ in XW["win"][last_f] if gi_ in XW["wrapped"] and gi_ not in snap}
+    KEEP = min(max(spec.xsplit, 1), Q) if moved else Q
+
+    def units_of(pi):
+        u = []
+        if pi == f0:
+            u += [(gi_, q) for gi_ in sorted(moved) for q in range(KEEP, Q)]
+        for gi_ in XW["win"][pi]:
+            u += [(gi_, q) for q in range(KEEP if (gi_ in moved and pi == last_f) else Q)]
+        return u
+    # the staged-operand product of a phase issued in two parts around the hand-off in front of it
+    split_early = {}            # (phase, dot) -> fragments already issued
+    look_in_product = set()     # phases whose first look is issued among that product's MFMAs
+    look_emitted = set()
+    if SCHED and spec.ackfill and spec.early_first and 0 < spec.epre < Q:
+        for pi_ in range(1, nph):
+            if fetches[pi_][0] and XW["win"].get(pi_) and fetches[pi_][2] and 0 < spec.elook <= Q - spec.epre:
+                look_in_product.add(pi_)
+    if moved:                   # step 0's share of the moved products: the fragments that stay
+        i_ins = len(L)
+        emit_xunits([(gi_, q) for gi_ in sorted(XW["wrapped"]) for q in range(KEEP if gi_ in moved else Q)], "  ")
+        repl = L[i_ins:]
+        del L[i_ins:]
+        shift = len(repl) - (i_wrap1 - i_wrap0)
+        L[i_wrap0:i_wrap1] = repl
+        i_body += shift
+        i_top += shift
+    pre_n = 0                   # fragments of phase f0's window issued at the end of the step before
+    if SCHED and spec.xpre and f0 is not None:
+        pre_n = min(spec.xpre, len(units_of(f0)))
+        pre_units = units_of(f0)[:pre_n]
+        if any(gi_ in snap for gi_, _q in pre_units):
+            pre_n = 0           # that window's products start from what the fragments would overwrite
+    if pre_n:
+        i_ins = len(L)
+        emit_xunits(pre_units, "    ")           # step 0's: in front of the loop (moved there below)
+        pre0_lines = [l[2:] for l in L[i_ins:]]
+        del L[i_ins:]
+    if NBLK == 1:
+        for pi in dot_phases:
+            L.append("    const int pp%d = (int)((t * %d + %d) & 1);" % (pi, len(dot_phases), dot_phases.index(pi)))
+    XLPG = 2                    # x loads behind each fragment's MFMAs of the product that carries them
+
+    def declare_xs():
+        L.append("    const i64 xt_ = (t + %d < a.T) ? t + %d : a.T - 1;" % (XW["ahead"], XW["ahead"]))
+        L.append("    const __amdgpu_buffer_rsrc_t xs_ = __builtin_amdgcn_make_buffer_rsrc("
+                 "(void*)((const float*)a.seq[%d] + xt_ * a.seq_ts[%d]), 0, %du, 0x00020000);"
+                 % (spec.xfold["sx"], spec.xfold["sx"], NB * 16 * K * 4))
+
+    def xl_early(q):
+        # nothing else is in flight here: the loads issue without waiting for queue slots; all of
+        # them in the first half of the product (the rest of it covers their latency)
+        qs = range(q * XLPG, min(Q, (q + 1) * XLPG))
+        if qs:
+            L.append("      __builtin_amdgcn_sched_barrier(0);")
+            for q2 in qs:
+                L.append("      xfr[%d] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(xs_, xl_off, %du, 0));"
+                         % (q2, q2 * 64 * 16))
+            L.append("      __builtin_amdgcn_sched_barrier(0);")
     i_phase = []
     for pi, ph in enumerate(pr.phases):
         i_phase.append(len(L))
         L.append("    // ---- phase %d" % pi)
         if ph["dots"]:
             if NBLK == 1:
-                L.append("    const int pp%d = (int)((t * %d + %d) & 1);" % (pi, len(dot_phases), dot_phases.index(pi)))
+                pass
             elif ILV:   # product events in program order: phase by phase, block by block
                 L.append("    const int pp%d = (int)((t * %d + %d + ¤) & 1);"
                          % (pi, NBLK * len(dot_phases), NBLK * dot_phases.index(pi)))
@@ -1110,25 +1300,43 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
         if XW and pi == max(XW["win"]):
             for gi_ in sorted(snap):     # this window overwrites what this phase's products start from
                 L.append("    const f4 accs%d_0 = accx%d_0, accs%d_1 = accx%d_1;" % (gi_, gi_, gi_, gi_))
-        win_units = [(gi_, q) for gi_ in XW["win"][pi] for q in range(Q)] if (XW and fresh) else []
+        win_units = units_of(pi) if (XW and fresh) else []
         if win_units:
             window_begin(pi, *fresh[0])
+        early_all = early
+        early = [e_ for e_ in early if (pi, e_[0]) not in done_early]
+        if pi == reload_early and len(early) == len(early_all):
+            declare_xs()
         if spec.early_first:
-            for d, a_, x in early:
-                emit_mfma(pi, d, a_, x)
+            for li, (d, a_, x) in enumerate(early):
+                if (pi, d) in split_early:          # the rest of a product begun before the hand-off
+                    def look_hook(q, pi=pi):
+                        if pi in look_in_product and q == split_early_q0 + spec.elook - 1:
+                            look_emitted.add(pi)
+                            L.append("      __builtin_amdgcn_sched_barrier(0);")
+                            emit_look(pi, "      ", assign=True)
+                            L.append("      __builtin_amdgcn_sched_barrier(0);")
+                    split_early_q0 = split_early[(pi, d)]
+                    emit_mfma(pi, d, a_, x, look_hook, q0=split_early_q0, acc="eacc%d_%d" % (pi, d))
+                    continue
+                emit_mfma(pi, d, a_, x, xl_early if (pi == reload_early and li == 0 and
+                                                     len(early) == len(early_all)) else None)
         if not win_units and len(fresh) >= 2 and all(kind == "cur" for _x, kind in fresh):
             emit_fetch_joint(pi, fresh)
             staged_this_step.update(fresh)
         else:
             for fi, (x, kind) in enumerate(fresh):
                 if win_units and fi == 0:
-                    emit_window(pi, x, kind, win_units)
+                    emit_window(pi, x, kind, win_units, pre_n if pi == f0 else 0)
                 else:
                     emit_fetch(pi, x, kind)
                 staged_this_step.add((x, kind))
         if fresh:
             stamp("p%d tags seen, loads issued" % pi)
-        reload_here = bool(XW) and pi == XW["reload"] and bool(late)
+            if spec.nxt == "fetch":      # behind the payload loads in the in-order queue
+                L.extend(nxt_loads)
+                nxt_loads = []
+        reload_here = bool(XW) and pi == XW["reload"] and bool(late) and reload_early is None
         if reload_here:
             # the next x: same registers; the step index clamped (no branch); one load behind
             # each fragment's MFMAs of the first product below (issued back to back, 16 loads of
@@ -1198,8 +1406,34 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
                 L.append("      ((%s*)a.out[%d])[((a.out_pos0[%d] + t) %% a.out_store[%d]) * a.out_ts[%d] + "
                          "eb§ * a.out_rs[%d] + en] = own_%d§;" % (T, j, j, j, j, j, o))
         L.append("    }")
+        if SCHED and pub and spec.ackfill and pi + 1 < nph and spec.early_first and fetches[pi + 1][0]:
+            # products of the next phase that need nothing from this hand-off: issued while the
+            # payload stores travel (the wait below costs 0.35 us with nothing in front of it) —
+            # and in THEIR shadow the loads nobody waits for yet: the next step's epilogue operands
+            # and the next x (in front of any other wait of the step an HBM-cold load holds up the
+            # in-order queue; here it has the whole product to arrive)
+            if spec.nxt == "ack":
+                L.extend(nxt_loads)
+                nxt_loads = []
+            if pi + 1 == reload_early:
+                declare_xs()
+            for li, (d, a_, x) in enumerate(fetches[pi + 1][0]):
+                if 0 < spec.epre < Q:
+                    if li == 0:     # only its first fragments here: the tag goes out sooner
+                        L.append("    %s eacc%d_%d_0 = %s, eacc%d_%d_1 = %s;"
+                                 % ((AT, pi + 1, d, acc_init(pi + 1, d)[0], pi + 1, d, acc_init(pi + 1, d)[1])))
+                        emit_mfma(pi + 1, d, a_, x, xl_early if pi + 1 == reload_early else None,
+                                  q0=0, q1=spec.epre, acc="eacc%d_%d" % (pi + 1, d))
+                        split_early[(pi + 1, d)] = spec.epre
+                    continue
+                emit_mfma(pi + 1, d, a_, x, xl_early if (pi + 1 == reload_early and li == 0) else None)
+                done_early.add((pi + 1, d))
+            stamp("p%d products of p%d issued" % (pi, pi + 1))
+        if pre_n and pi == nph - 1:
+            emit_xunits(pre_units, "    ")
+            stamp("p%d fragments of the next window issued" % pi)
         if pub:
-            L.append('    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");')
+            L.append(WAIT_ACK)
             stamp("p%d own stores acknowledged" % pi)
             L.append("    __syncthreads();")
             for o in pub:
@@ -1212,11 +1446,20 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
             # two phases on: the products-done barrier of the next phase orders them
             pass
     i_phase.append(len(L))
+    if nxt_loads:               # no place found further down: at the top of the step after all
+        L[i_top:i_top] = nxt_loads
+        i_phase = [i + len(nxt_loads) if i >= i_top else i for i in i_phase]
+        nxt_loads = []
     stamp("step end")
     for v, nv in pr.new_of_state.items():
         L.append("    own_%d§ = own_%d§;" % (v, nv))
     body = L[i_body:]
     del L[i_body:]
+    i_for = max(i for i, l in enumerate(L) if l.startswith("  for (i64 t = 0;"))
+    if PUBLISH:     # nothing pending where the prologue meets the back edge (see WAIT_ACK)
+        L[i_for:i_for] = ["  __builtin_amdgcn_s_waitcnt(0x0F70);"]
+    if pre_n:
+        L[i_for:i_for] = pre0_lines
     if ILV:
         # phase by phase over the blocks: while block b's hand-off is in flight the workgroup works
         # on block b + 1 — by the time it comes back to b the tags are there (what the round-2
