@@ -397,12 +397,18 @@ class ScanMixin:
             # columns in registers spilled, r03) — spread over the windows of the step; the others
             # are computed up front after all
             n_lds = min(len(xfold["W"]), max(0, (158 * 1024 - 2 * ndm * 4096) // (N * 64)))
+            # ... and, with the recurrent weights in the accumulation file (SpecMat.pin == 2), further
+            # products with their columns in what is left of its 256 registers
+            n_reg = 0
+            if int(knobs.get("SM_XREG")) and knobs.get("SM_PIN") in (None, 2) and n_lds and \
+                    str(knobs.get("SM_INIT")) == "publish":
+                n_reg = min(len(xfold["W"]) - n_lds, max(0, (256 - sum(K // 16 for K in Ks.values())) // (N // 16)))
             wins = sm.xfold_windows(prog, xfold["pairs"])
             if not n_lds or wins is None:
                 return "sequence products: no room for their weight columns in LDS"
             where = {gi: f for f, gis in wins["win"].items() for gi in gis}
             fold, load = [], {}
-            while len(fold) < n_lds:
+            while len(fold) < n_lds + n_reg:
                 gi = min((g for g in range(len(xfold["pairs"])) if g not in fold),
                          key=lambda g: (load.get(where[g], 0), g))
                 fold.append(gi)
@@ -421,10 +427,13 @@ class ScanMixin:
                 xf_w.append(W)
                 folded.add(v)
             xf_spec = {"sx": prog.seq[items[0][0]], "items": items}
+            if n_reg:           # the last ones: weight columns in registers
+                xf_spec["reg"] = list(range(len(items) - n_reg, len(items)))
         spec = sm.SpecMat(prog, Bn, N, Ks, Nt, dtype=f32, xfold=xf_spec, nblk=nblk)
         if nblk > 1 and (spec.xmode != "frag" or spec.trace):
             return "more 16x16 tiles than CUs"
-        if xf_spec is not None and sum(K // 16 for K in Ks.values()) + (spec.nstaged + 1) * (N // 16) > 384:
+        if xf_spec is not None and sum(K // 16 for K in Ks.values()) + \
+                (spec.nstaged + 1 + len(xf_spec.get("reg", ()))) * (N // 16) > (448 if xf_spec.get("reg") else 384):
             # recurrent weight columns + the operand fragments alive together + one more fragment
             # for x: beyond this the allocator spills (r03: 442 -> 512 registers + scratch reloads
             # in front of the MFMAs made the folded form slower than the products up front)

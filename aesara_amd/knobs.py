@@ -81,10 +81,17 @@ _def("SM_XPRE", 6, int, "fragments of the next step's first sequence-product win
 _def("SM_NXT", "fetch", str, "per-step sequence operands of the epilogue: requested at the top of the step (top) | "
      "behind the first fetch of the step (fetch: an HBM-cold load in front of the fetch delays every "
      "in-order wait behind it)")
+_def("SM_POLLS", 1, int, "fragment form: tag polls a wavefront keeps in flight while it waits for a hand-off "
+     "(1 = one at a time.  More find the tags sooner after they arrive but 64 workgroups poll each tag line: "
+     "measured r04, GRU training step 17.7 ms with 1, 18.6 with 4; forward kernel unchanged)")
 _def("SM_LOOK", 8, int, "fragments of a window's head issued before the first look at the tags")
 _def("SM_ASM_MARKS", 0, int, "label the phase marks in the ISA (asm comments; for reading disassembly)")
 _def("SM_XTAIL", 8, int, "fragments of the sequence product behind the payload loads")
 _def("SM_XFOLD", 1, int, "sequence products x_t @ W inside the loop")
+_def("SM_XREG", 0, int, "1 = in-loop sequence products beyond the LDS capacity keep their weight columns in "
+     "accumulation registers (as many as fit next to the recurrent weights); 0 = those are computed up front "
+     "(config 4, B = 64: the third product in the loop costs 0.6 ms of exposed MFMA time, the GEMM it replaces 0.69 — "
+     "4.30 vs 4.12 ms)")
 _def("SM_INTERLEAVE", 1, int, "interleave the phases of the batch blocks of one workgroup")
 _def("SPIN_LOG2", 21, int, "log2 of the poll limit of the persistent Scan kernels before they raise their error word "
      "(tools/profile_scan_r04.sh raises it: under the counter passes a kernel runs many times slower)")

@@ -178,10 +178,11 @@ class SpecMat:
         self.elook = int(knobs.get("SM_ELOOK")) if (sched and self.ackfill) else 0
         self.xsplit = int(knobs.get("SM_XSPLIT")) if sched else 0
         self.nxt = str(knobs.get("SM_NXT")) if self.xmode == "frag" else "top"
+        self.polls = int(knobs.get("SM_POLLS")) if self.xmode == "frag" else 1
 
     def key(self):
         pr = self.prog
-        blob = json.dumps(["sm9" + ("t" if self.trace else "") + ("/f5p%d%s" % (self.pin, str(knobs.get("SM_FENCE"))) if self.xmode == "frag" else ""), self.xfold and [self.xfold, "w15", str(knobs.get("SM_XTAIL"))], [self.init, self.xreload, self.ackfill, self.xpre, self.look, self.nxt, self.epre, self.elook, self.xsplit], self.dtype, self.chunk, self.xmode, self.early_first, self.B, self.N, self.Nt, sorted(self.Ks.items()), sorted(pr.seq.items()),
+        blob = json.dumps(["sm9" + ("t" if self.trace else "") + ("/f5p%d%s" % (self.pin, str(knobs.get("SM_FENCE"))) if self.xmode == "frag" else ""), self.xfold and [self.xfold, "w15", str(knobs.get("SM_XTAIL"))], [self.init, self.xreload, self.ackfill, self.xpre, self.look, self.nxt, self.epre, self.elook, self.xsplit, self.polls], self.dtype, self.chunk, self.xmode, self.early_first, self.B, self.N, self.Nt, sorted(self.Ks.items()), sorted(pr.seq.items()),
                            sorted(pr.state.items()), sorted(pr.nsq.items()), sorted(pr.mats.items()),
                            [[ph["dots"], ph["ins"], ph["outs"], ph["scalar"], ph["out_refs"]]
                             for ph in pr.phases], pr.outs, pr.exchanged, sorted(pr.tap_seq.items())] +
@@ -732,8 +733,10 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
     folded = {v for v, _pi, _d, _s in XF}
     L.append('extern "C" __global__ __launch_bounds__(256) void %s(SmArgs a) {' % name)
     L.append("  __shared__ %s part[2][%d][4][256];" % (T, max(ndots_max, 1)))
-    if XF:
-        L.append("  __shared__ __attribute__((aligned(16))) float Wl[%d];" % (len(XF) * K * 16))
+    XREG = set(spec.xfold.get("reg", ())) if spec.xfold else set()     # weight columns in registers
+    lds_of = {gi: n for n, gi in enumerate(gi for gi in range(len(XF)) if gi not in XREG)}
+    if lds_of:
+        L.append("  __shared__ __attribute__((aligned(16))) float Wl[%d];" % (len(lds_of) * K * 16))
     L.append("  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;")
     L.append("  const int r16 = lane & 15, grp = lane >> 4;")
     NBLK = spec.nblk
@@ -807,12 +810,18 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
     # ---- in-kernel sequence products (xfold): the weight columns of x_t @ W_g in LDS, in MFMA
     #      B-fragment order: float4 (w*Q + q)*64 + lane = W_g[w*K/4 + grp*K/16 + 4q .. +3][nj*16 + r16]
     for gi, (_v, _pi, _d, slot) in enumerate(XF):
+        if gi in XREG:          # MFMA B layout in registers, like the recurrent weights
+            L.append("  const i64 wxk%d = (i64)wave * %d + grp * %d;" % (gi, K // 4, K // 16))
+            for s_ in range(K // 16):
+                L.append("  float wx%d_%d = ((const float*)a.mat[%d])[(wxk%d + %d) * a.mat_rs[%d] + nj * 16 + r16];"
+                         % (gi, s_, slot, gi, s_, slot))
+            continue
         L.append("  for (int f = tid; f < %d; f += 256) {" % (K * 16 // 4))
         L.append("    const int ln = f & 63, qq = (f >> 6) %% %d, ww = (f >> 6) / %d;" % (Q, Q))
         L.append("    const i64 k0 = (i64)ww * %d + (ln >> 4) * %d + 4 * qq;" % (K // 4, K // 16))
         L.append("    const float* wp = (const float*)a.mat[%d] + k0 * a.mat_rs[%d] + nj * 16 + (ln & 15);" % (slot, slot))
         L.append("    const f4 wv = {wp[0], wp[a.mat_rs[%d]], wp[2 * a.mat_rs[%d]], wp[3 * a.mat_rs[%d]]};" % (slot, slot, slot))
-        L.append("    *(f4*)(Wl + %d + 4 * f) = wv;" % (gi * K * 16))
+        L.append("    *(f4*)(Wl + %d + 4 * f) = wv;" % (lds_of[gi] * K * 16))
         L.append("  }")
     XW = None
     XTAIL = max(1, int(knobs.get("SM_XTAIL")))  # fragments (4 MFMAs each) behind the payload loads
@@ -833,18 +842,26 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
         for every (gi, q) of ``units``.  Weight columns in LDS are read one unit AHEAD into the
         other of two registers quads (an LDS read in front of each group of four MFMAs, waited for
         at once, costs as much as the MFMAs).  ``between(i)``: code emitted in front of unit i."""
-        if units:
-            L.append(ind + "bw0 = wl%d[%d];" % (units[0][0], units[0][1] * 64))
+        ldsu = [i for i, (gi, _q) in enumerate(units) if gi not in XREG]    # units that read LDS
+        nxt_lds = {ldsu[n]: ldsu[n + 1] for n in range(len(ldsu) - 1)}
+        slot_of = {i: n & 1 for n, i in enumerate(ldsu)}
+        if ldsu:
+            L.append(ind + "bw0 = wl%d[%d];" % (units[ldsu[0]][0], units[ldsu[0]][1] * 64))
         for i, (gi, q) in enumerate(units):
             if between is not None:
                 between(i)
             if q == 0:
                 L.append(ind + "accx%d_0 = zero4; accx%d_1 = zero4;" % (gi, gi))
-            if i + 1 < len(units):
-                gj, qj = units[i + 1]
-                L.append(ind + "bw%d = wl%d[%d];" % ((i + 1) & 1, gj, qj * 64))
+            if gi in XREG:
+                for e, c in enumerate("xyzw"):
+                    L.append(ind + "accx%d_%d = __builtin_amdgcn_mfma_f32_16x16x4f32(xfr[%d].%s, wx%d_%d, accx%d_%d, 0, 0, 0);"
+                             % (gi, e & 1, q, c, gi, 4 * q + e, gi, e & 1))
+                continue
+            if i in nxt_lds:
+                gj, qj = units[nxt_lds[i]]
+                L.append(ind + "bw%d = wl%d[%d];" % (slot_of[nxt_lds[i]], gj, qj * 64))
                 L.append(ind + "__builtin_amdgcn_sched_barrier(0);     // (the scheduler sinks the read to its use)")
-            bs = ["bw%d.%s" % (i & 1, c) for c in "xyzw"]
+            bs = ["bw%d.%s" % (slot_of[i], c) for c in "xyzw"]
             for e, c in enumerate("xyzw"):
                 L.append(ind + "accx%d_%d = __builtin_amdgcn_mfma_f32_16x16x4f32(xfr[%d].%s, %s, accx%d_%d, 0, 0, 0);"
                          % (gi, e & 1, q, c, bs[e], gi, e & 1))
@@ -857,7 +874,8 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
         emit_xload("0", "  ")
         for gi in range(len(XF)):
             L.append("  f4 accx%d_0 = zero4, accx%d_1 = zero4;" % (gi, gi))
-            L.append("  const f4* wl%d = (const f4*)(Wl + %d) + (wave * %d) * 64 + lane;" % (gi, gi * K * 16, Q))
+            if gi in lds_of:
+                L.append("  const f4* wl%d = (const f4*)(Wl + %d) + (wave * %d) * 64 + lane;" % (gi, lds_of[gi] * K * 16, Q))
         L.append("  __syncthreads();")
         # the products the first fetching phase of step 0 needs (later steps get theirs from the
         # last window of the step before)
@@ -947,6 +965,12 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
                 ops = ", ".join('"+%s"(w%d_%d)' % ("a" if spec.pin == 2 else "v", slot, s_)
                                 for s_ in range(s0, min(s0 + 16, spec.Ks[av] // 16)))
                 L.append('    asm volatile("" : %s);' % ops)
+    if spec.pin:
+        for gi in sorted(XREG):
+            for s0 in range(0, K // 16, 16):
+                ops = ", ".join('"+%s"(wx%d_%d)' % ("a" if spec.pin == 2 else "v", gi, s_)
+                                for s_ in range(s0, min(s0 + 16, K // 16)))
+                L.append('    asm volatile("" : %s);' % ops)
     i_body = len(L)              # the step body: a template, instantiated per batch block below
     nxt_loads = []
     for v in pw_seq:
@@ -1004,6 +1028,45 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
         if acc is None:
             L.append("    }")
 
+    POLLS = max(1, int(spec.polls)) if PW <= 64 else 1
+
+    def emit_spin(ind, fls, want="want64"):
+        """wait until every tag of this wavefront's producers (``fls``: one tag array per operand)
+        reads ``want``.  POLLS looks in flight: the oldest is examined while the others travel, a
+        new one replaces it — the tags are found a quarter of a round trip after they arrive, not
+        up to a whole one (r04 timeline of the gradient kernel: 2.0-2.7 us from a workgroup's own
+        tag to its loads, of which ~1.1 are the tag's way there and one look's way back)."""
+        if POLLS == 1:
+            L.append(ind + "for (int spin = 0;; ++spin) {")
+            L.append(ind + "  bool ok = true;")
+            for f in fls:
+                L.append(ind + "  for (int j = lane; j < %d; j += 64) ok = ok && (__hip_atomic_load(%s + j, %s) == %s);"
+                         % (PW, f, AG, want))
+            L.append(ind + "  if (__all(ok)) break;")
+            L.append(ind + "  if (spin > %d || ((spin & 255) == 255 && __hip_atomic_load(errp, %s) != 0u)) "
+                     "{ __hip_atomic_store(errp, 1u, %s); break; }" % (SPIN_LIMIT, AG, AG))
+            L.append(ind + "  __builtin_amdgcn_s_sleep(1);")
+            L.append(ind + "}")
+            return
+        L.append(ind + "{")
+        for n, f in enumerate(fls):
+            L.append(ind + "  const u64* fp%d_ = %s + (lane < %d ? lane : 0);" % (n, f, PW))
+        for d_ in range(POLLS):
+            for n in range(len(fls)):
+                L.append(ind + "  unsigned long long pl%d_%d = __hip_atomic_load(fp%d_, %s);" % (n, d_, n, AG))
+            if d_ + 1 < POLLS:
+                L.append(ind + "  __builtin_amdgcn_s_sleep(3);")
+        L.append(ind + "  for (int spin = 0;; ++spin) {")
+        L.append(ind + "    if (__all(%s)) break;" % " && ".join("pl%d_0 == %s" % (n, want) for n in range(len(fls))))
+        L.append(ind + "    if (spin > %d || ((spin & 255) == 255 && __hip_atomic_load(errp, %s) != 0u)) "
+                 "{ __hip_atomic_store(errp, 1u, %s); break; }" % (SPIN_LIMIT, AG, AG))
+        for n in range(len(fls)):
+            for d_ in range(POLLS - 1):
+                L.append(ind + "    pl%d_%d = pl%d_%d;" % (n, d_, n, d_ + 1))
+            L.append(ind + "    pl%d_%d = __hip_atomic_load(fp%d_, %s);" % (n, POLLS - 1, n, AG))
+        L.append(ind + "  }")
+        L.append(ind + "}")
+
     def emit_fetch(pi, x, kind):
         """wait for the tags of this wavefront's producers, then pull its K quarter into fr"""
         ki = keys.index((x, kind))
@@ -1036,14 +1099,7 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
         L.append(ind + "const unsigned long long want64 = %s;" % want_expr(step_expr, kind))
         L.append(ind + "const u64* fl = a.xch + %d + (%s & 3) * %d + (i64)bi§ * %d + wave * %d;"
                  % (fo_, step_expr, lpf, NJ, PW))
-        L.append(ind + "for (int spin = 0;; ++spin) {")
-        L.append(ind + "  bool ok = true;")
-        L.append(ind + "  for (int j = lane; j < %d; j += 64) ok = ok && (__hip_atomic_load(fl + j, %s) == want64);" % (PW, AG))
-        L.append(ind + "  if (__all(ok)) break;")
-        L.append(ind + "  if (spin > %d || ((spin & 255) == 255 && __hip_atomic_load(errp, %s) != 0u)) "
-                 "{ __hip_atomic_store(errp, 1u, %s); break; }" % (SPIN_LIMIT, AG, AG))
-        L.append(ind + "  __builtin_amdgcn_s_sleep(1);")
-        L.append(ind + "}")
+        emit_spin(ind, ["fl"])
         L.append(ind + "const unsigned so_ = (unsigned)((%d + (%s & 3) * %d + (i64)bi§ * %d) * 8);"
                  % (po_, step_expr, lpp, 16 * K * ISZ // 8))
         for q in range(Q):
@@ -1063,16 +1119,7 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
             po_, lpp, fo_, lpf = xoff[pr.new_of_state.get(x, x)]
             L.append(ind + "const u64* fl%d = a.xch + %d + (t & 3) * %d + (i64)bi§ * %d + wave * %d;"
                      % (n, fo_, lpf, NJ, PW))
-        L.append(ind + "for (int spin = 0;; ++spin) {")
-        L.append(ind + "  bool ok = true;")
-        for n in range(len(ops)):
-            L.append(ind + "  for (int j = lane; j < %d; j += 64) ok = ok && (__hip_atomic_load(fl%d + j, %s) == want64);"
-                     % (PW, n, AG))
-        L.append(ind + "  if (__all(ok)) break;")
-        L.append(ind + "  if (spin > %d || ((spin & 255) == 255 && __hip_atomic_load(errp, %s) != 0u)) "
-                 "{ __hip_atomic_store(errp, 1u, %s); break; }" % (SPIN_LIMIT, AG, AG))
-        L.append(ind + "  __builtin_amdgcn_s_sleep(1);")
-        L.append(ind + "}")
+        emit_spin(ind, ["fl%d" % n for n in range(len(ops))])
         for n, (x, kind) in enumerate(ops):
             ki = keys.index((x, kind))
             po_, lpp, fo_, lpf = xoff[pr.new_of_state.get(x, x)]
@@ -1176,14 +1223,7 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
         else:
             L.append(ind + "if (!__all(tg0_w%d == want32_w%d)) {" % (pi, pi))
             L.append(ind + "  const unsigned long long want64 = (unsigned long long)want32_w%d;" % pi)
-        L.append(ind + "  for (int spin = 0;; ++spin) {")
-        L.append(ind + "    bool ok = true;")
-        L.append(ind + "    for (int j = lane; j < %d; j += 64) ok = ok && (__hip_atomic_load(fl_w%d + j, %s) == want64);" % (PW, pi, AG))
-        L.append(ind + "    if (__all(ok)) break;")
-        L.append(ind + "    if (spin > %d || ((spin & 255) == 255 && __hip_atomic_load(errp, %s) != 0u)) "
-                 "{ __hip_atomic_store(errp, 1u, %s); break; }" % (SPIN_LIMIT, AG, AG))
-        L.append(ind + "    __builtin_amdgcn_s_sleep(1);")
-        L.append(ind + "  }")
+        emit_spin(ind + "  ", ["fl_w%d" % pi])
         L.append(ind + "}")
         L.append(ind + "__builtin_amdgcn_sched_barrier(0);")
         stamp("p%d tags seen" % pi)
