@@ -45,7 +45,18 @@ for k, cs in ctr.items():
     if "SQ_VALU_MFMA_BUSY_CYCLES" in cs and "GRBM_GUI_ACTIVE" in cs:
         # MFMA busy cycles are summed over the SIMDs' matrix pipes (256 CUs x 4): fraction of the
         # kernel's active cycles during which a pipe was busy
-        cs["mfma_busy_fraction"] = cs["SQ_VALU_MFMA_BUSY_CYCLES"]["avg"] / (cs["GRBM_GUI_ACTIVE"]["avg"] * 256 * 4)
+        cs["mfma_busy_fraction_under_the_counter_pass"] = cs["SQ_VALU_MFMA_BUSY_CYCLES"]["avg"] / (cs["GRBM_GUI_ACTIVE"]["avg"] * 256 * 4)
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in cs:
+        # the counter passes slow a persistent kernel several times (GRBM_GUI_ACTIVE above is THEIR
+        # duration); the busy cycles are the same work, so price them against the duration of the
+        # kernel-trace pass: cycles one SIMD's matrix pipe was busy / cycles the kernel took at the
+        # 2.35 GHz the in-kernel clock calibration reads (profiles/r04_cfg4_b64_timeline_after.json)
+        per_simd = cs["SQ_VALU_MFMA_BUSY_CYCLES"]["avg"] / (256 * 4)
+        dur = next((r["avg_us"] for r in out.get("kernel_stats", []) if r["name"].startswith(k[:20])), None)
+        cs["mfma_busy_cycles_per_simd"] = per_simd
+        if dur:
+            cs["kernel_trace_avg_us"] = dur
+            cs["mfma_busy_fraction"] = per_simd / (dur * 2350.0)
 json.dump(out, open(os.path.join(O, "r04_cfg4_b64_counters.json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])
 PY
