@@ -84,6 +84,9 @@ _def("SM_NXT", "fetch", str, "per-step sequence operands of the epilogue: reques
 _def("SM_POLLS", 1, int, "fragment form: tag polls a wavefront keeps in flight while it waits for a hand-off "
      "(1 = one at a time.  More find the tags sooner after they arrive but 64 workgroups poll each tag line: "
      "measured r04, GRU training step 17.7 ms with 1, 18.6 with 4; forward kernel unchanged)")
+_def("SM_SPIN_DELAY", 15, int, "fragment form, fetches with nothing in front of them: s_sleep units (64 cycles) "
+     "before the first poll of the tags (a poll that comes back empty costs a whole further round trip AND "
+     "slows the tag stores it polls for: GRU training step B = 64 17.7 -> 15.6 ms with 15)")
 _def("SM_LOOK", 8, int, "fragments of a window's head issued before the first look at the tags")
 _def("SM_ASM_MARKS", 0, int, "label the phase marks in the ISA (asm comments; for reading disassembly)")
 _def("SM_XTAIL", 8, int, "fragments of the sequence product behind the payload loads")

@@ -179,10 +179,11 @@ class SpecMat:
         self.xsplit = int(knobs.get("SM_XSPLIT")) if sched else 0
         self.nxt = str(knobs.get("SM_NXT")) if self.xmode == "frag" else "top"
         self.polls = int(knobs.get("SM_POLLS")) if self.xmode == "frag" else 1
+        self.spin_delay = int(knobs.get("SM_SPIN_DELAY")) if self.xmode == "frag" else 0
 
     def key(self):
         pr = self.prog
-        blob = json.dumps(["sm9" + ("t" if self.trace else "") + ("/f5p%d%s" % (self.pin, str(knobs.get("SM_FENCE"))) if self.xmode == "frag" else ""), self.xfold and [self.xfold, "w15", str(knobs.get("SM_XTAIL"))], [self.init, self.xreload, self.ackfill, self.xpre, self.look, self.nxt, self.epre, self.elook, self.xsplit, self.polls], self.dtype, self.chunk, self.xmode, self.early_first, self.B, self.N, self.Nt, sorted(self.Ks.items()), sorted(pr.seq.items()),
+        blob = json.dumps(["sm9" + ("t" if self.trace else "") + ("/f5p%d%s" % (self.pin, str(knobs.get("SM_FENCE"))) if self.xmode == "frag" else ""), self.xfold and [self.xfold, "w15", str(knobs.get("SM_XTAIL"))], [self.init, self.xreload, self.ackfill, self.xpre, self.look, self.nxt, self.epre, self.elook, self.xsplit, self.polls, self.spin_delay], self.dtype, self.chunk, self.xmode, self.early_first, self.B, self.N, self.Nt, sorted(self.Ks.items()), sorted(pr.seq.items()),
                            sorted(pr.state.items()), sorted(pr.nsq.items()), sorted(pr.mats.items()),
                            [[ph["dots"], ph["ins"], ph["outs"], ph["scalar"], ph["out_refs"]]
                             for ph in pr.phases], pr.outs, pr.exchanged, sorted(pr.tap_seq.items())] +
@@ -1030,12 +1031,17 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
 
     POLLS = max(1, int(spec.polls)) if PW <= 64 else 1
 
-    def emit_spin(ind, fls, want="want64"):
+    def emit_spin(ind, fls, want="want64", delay=False):
         """wait until every tag of this wavefront's producers (``fls``: one tag array per operand)
         reads ``want``.  POLLS looks in flight: the oldest is examined while the others travel, a
         new one replaces it — the tags are found a quarter of a round trip after they arrive, not
         up to a whole one (r04 timeline of the gradient kernel: 2.0-2.7 us from a workgroup's own
         tag to its loads, of which ~1.1 are the tag's way there and one look's way back)."""
+        if delay and spec.spin_delay > 0:
+            for _ in range(spec.spin_delay // 15):
+                L.append(ind + "__builtin_amdgcn_s_sleep(15);")
+            if spec.spin_delay % 15:
+                L.append(ind + "__builtin_amdgcn_s_sleep(%d);" % (spec.spin_delay % 15))
         if POLLS == 1:
             L.append(ind + "for (int spin = 0;; ++spin) {")
             L.append(ind + "  bool ok = true;")
@@ -1067,8 +1073,10 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
         L.append(ind + "  }")
         L.append(ind + "}")
 
-    def emit_fetch(pi, x, kind):
-        """wait for the tags of this wavefront's producers, then pull its K quarter into fr"""
+    def emit_fetch(pi, x, kind, bare=False):
+        """wait for the tags of this wavefront's producers, then pull its K quarter into fr.
+        ``bare``: nothing was issued between this workgroup's own tag and this wait — the first
+        poll is held back (SM_SPIN_DELAY) until it can find the tags"""
         ki = keys.index((x, kind))
         src = pr.new_of_state.get(x, x)
         po_, lpp, fo_, lpf = xoff[src]
@@ -1099,7 +1107,7 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
         L.append(ind + "const unsigned long long want64 = %s;" % want_expr(step_expr, kind))
         L.append(ind + "const u64* fl = a.xch + %d + (%s & 3) * %d + (i64)bi§ * %d + wave * %d;"
                  % (fo_, step_expr, lpf, NJ, PW))
-        emit_spin(ind, ["fl"])
+        emit_spin(ind, ["fl"], delay=bare)
         L.append(ind + "const unsigned so_ = (unsigned)((%d + (%s & 3) * %d + (i64)bi§ * %d) * 8);"
                  % (po_, step_expr, lpp, 16 * K * ISZ // 8))
         for q in range(Q):
@@ -1107,7 +1115,7 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
                      " %s[%d] = __builtin_bit_cast(%s, g); }" % (q * 64 * 16, frs[ki], q, VT))
         L.append("    }")
 
-    def emit_fetch_joint(pi, ops):
+    def emit_fetch_joint(pi, ops, bare=False):
         """Several operands of the current step published by the same epilogue (the two
         last-phase products of a gradient step): ONE polling pass over all their tags — fetched
         one after the other, the second wait costs a tag round trip (0.6 us) although its tags
@@ -1119,7 +1127,7 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
             po_, lpp, fo_, lpf = xoff[pr.new_of_state.get(x, x)]
             L.append(ind + "const u64* fl%d = a.xch + %d + (t & 3) * %d + (i64)bi§ * %d + wave * %d;"
                      % (n, fo_, lpf, NJ, PW))
-        emit_spin(ind, ["fl%d" % n for n in range(len(ops))])
+        emit_spin(ind, ["fl%d" % n for n in range(len(ops))], delay=bare)
         for n, (x, kind) in enumerate(ops):
             ki = keys.index((x, kind))
             po_, lpp, fo_, lpf = xoff[pr.new_of_state.get(x, x)]
@@ -1361,15 +1369,18 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
                     continue
                 emit_mfma(pi, d, a_, x, xl_early if (pi == reload_early and li == 0 and
                                                      len(early) == len(early_all)) else None)
+        # a fetch with nothing in front of it: one block per workgroup (other blocks' phases are
+        # work in between), no product on staged operands issued first, no window
+        bare = NBLK == 1 and not (spec.early_first and early_all)
         if not win_units and len(fresh) >= 2 and all(kind == "cur" for _x, kind in fresh):
-            emit_fetch_joint(pi, fresh)
+            emit_fetch_joint(pi, fresh, bare)
             staged_this_step.update(fresh)
         else:
             for fi, (x, kind) in enumerate(fresh):
                 if win_units and fi == 0:
                     emit_window(pi, x, kind, win_units, pre_n if pi == f0 else 0)
                 else:
-                    emit_fetch(pi, x, kind)
+                    emit_fetch(pi, x, kind, bare and fi == 0)
                 staged_this_step.add((x, kind))
         if fresh:
             stamp("p%d tags seen, loads issued" % pi)
