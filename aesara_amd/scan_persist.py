@@ -318,6 +318,7 @@ class Spec:
         # polling shape (measured defaults; environment overrides for sweeps)
         self.var = {"pollw": min(nw, int(knobs.get("SP_POLLW"))),
                     "sleep": int(knobs.get("SP_SLEEP")),
+                    "delay": int(knobs.get("SP_DELAY")),
                     "repoll": int(knobs.get("SP_REPOLL"))}
 
     def key(self):
@@ -475,6 +476,7 @@ def generate(spec: Spec):
         L.append("    // ---- phase %d" % pi)
         # -- gather the dot vectors that are not staged yet
         need_sync = False
+        delayed = False     # the first exchanged operand of a phase waits before its first poll
         for a_, x in ph["dots"]:
             if x in pr.nsq:
                 continue
@@ -520,6 +522,15 @@ def generate(spec: Spec):
                 for q in range(NGp):
                     L.append(ind + "have[%d] = %s;" % (q, "false" if (q + 1) * PT <= KG else
                                                       "!(threadIdx.x + %d < %d)" % (q * PT, KG)))
+            # a poll that comes back without the tags costs a whole further round trip (~0.7 us)
+            # and its traffic slows the very stores it waits for: hold the first one back until it
+            # can succeed (r04: config 4 B = 1 4.59 -> 4.05 us per step with 12 x 64 cycles)
+            if not delayed:
+                for _ in range(spec.var["delay"] // 15):
+                    L.append(ind + "__builtin_amdgcn_s_sleep(15);")
+                if spec.var["delay"] % 15:
+                    L.append(ind + "__builtin_amdgcn_s_sleep(%d);" % (spec.var["delay"] % 15))
+                delayed = True
             L.append(ind + "for (int spin = 0;; ++spin) {")
             L.append(ind + "  bool ok = true;")
             for q in range(NGp):

@@ -96,7 +96,10 @@ def roof(bound, work, dev_ms, peak, **extra):
 
 HANDOFF_FLOOR_US = 2.2   # one all-to-all vector hand-off between ~128 workgroups through L2
 #                          (MI355X_MICROARCH.md "allgather" row: 2.4-3.0 us at 256 pollers, -1.9 us
-#                          per halving of the readers; measured 2.2 us at 128)
+#                          per halving of the readers; measured 2.2 us at 128) — the
+#                          price with polls issued back to back.  Since round 4 the first poll of a
+#                          hand-off is held back until it can find the tags (AESARA_HIP_SP_DELAY):
+#                          ~2.0 us per hand-off, so the ratio below can read < 1
 
 
 def latency_row(dev_ms, T, restreamed_bytes, handoffs_per_step, resident_bound_bytes):
@@ -112,7 +115,8 @@ def latency_row(dev_ms, T, restreamed_bytes, handoffs_per_step, resident_bound_b
             "vs_restreamed_bound": restreamed_bytes / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "restreamed_bytes": restreamed_bytes, "resident_bound_bytes": resident_bound_bytes,
             "note": "latency-bound by construction: weights stay on chip, each step is "
-                    "`handoffs_per_step` dependent vector exchanges; no HBM/MFMA fraction applies"}
+                    "`handoffs_per_step` dependent vector exchanges; no HBM/MFMA fraction applies "
+                    "(floor = the guide's price of a hand-off polled back to back)"}
 
 
 def main():
