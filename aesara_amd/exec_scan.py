@@ -340,7 +340,7 @@ class ScanMixin:
         n_seqs = p["n_seqs"]
         n_fixed = len(lp.inputs) - len(pre_rows)
         n_mm = len(prog.tap_seq)                      # mit-mot groups ([0, 1] -> [1]): two taps each
-        inv_vars = lp.inputs[n_seqs + n_rec + n_mm:n_fixed]
+        inv_vars = lp.inputs[n_seqs + (prog.n_rec_inputs or n_rec + n_mm):n_fixed]
         if len(inv_vars) != len(non_seqs):
             return "invariant operand count"
         inv_val = dict(zip(inv_vars, non_seqs))
@@ -432,6 +432,13 @@ class ScanMixin:
         spec = sm.SpecMat(prog, Bn, N, Ks, Nt, dtype=f32, xfold=xf_spec, nblk=nblk)
         if nblk > 1 and (spec.xmode != "frag" or spec.trace):
             return "more 16x16 tiles than CUs"
+        if prog.older:
+            # taps older than -1: values the tile element's owner made itself (registers, a shift
+            # per step) — fragment form only; the rows they start from must be in the buffer
+            if spec.xmode != "frag":
+                return "taps other than [-1] on a matrix state (LDS exchange form)"
+            if any(store[k] < D for k, D in prog.depth.items()):
+                return "output buffer shorter than the deepest tap"
         if xf_spec is not None and sum(K // 16 for K in Ks.values()) + \
                 (spec.nstaged + 1 + len(xf_spec.get("reg", ()))) * (N // 16) > (448 if xf_spec.get("reg") else 384):
             # recurrent weight columns + the operand fragments alive together + one more fragment
@@ -489,7 +496,7 @@ class ScanMixin:
             nsq[v] = (x, st2)
         for ph in prog.phases:
             for v in ph["ins"]:
-                if v in prog.state or any(v in q["outs"] for q in prog.phases):
+                if v in prog.state or v in prog.older or any(v in q["outs"] for q in prog.phases):
                     continue
                 if v not in seq_arr and v not in nsq and v not in folded:
                     return "operand of unknown layout"
@@ -590,13 +597,14 @@ class ScanMixin:
         lp = inner.plan
         n_seqs, n_sh = p["n_seqs"], p.get("n_shared_outs", 0)
         n_fixed = len(lp.inputs) - len(pre_rows)
-        n_tapin = len(prog.tap)
-        inv_vars = lp.inputs[n_seqs + n_tapin + n_sh:n_fixed]
+        n_mm = len(prog.mm)
+        n_rec -= n_mm                         # here: the mit-sot / sit-sot outputs (slots n_mm ..)
+        inv_vars = lp.inputs[n_seqs + prog.n_rec_inputs + n_sh:n_fixed]
         if len(inv_vars) != len(non_seqs):
             return "invariant operand count", None, 0
         inv_val = dict(zip(inv_vars, non_seqs))
         # the ONE shape every loop-varying value has
-        if n_rec:
+        if n_mm + n_rec:
             S = tuple(outs[0].shape[1:])
         elif shared:
             S = tuple(inner.to_device(shared[0]).shape)
@@ -635,14 +643,23 @@ class ScanMixin:
                     return "invariant operand shape", None, 0
                 x = inner.contiguous(x)
                 g.nsq[j], g.nsq_es[j] = x.ptr, 1
-        for k in range(n_rec):
-            b = outs[k]
+        n_mmo = sum(len(to) for _ti, to in prog.mm)   # inner outputs of the mit-mot groups come first
+        for g_, (ti, to) in enumerate(prog.mm):
+            b = outs[g_]
+            # (not circular) rows pos .. pos + n_steps - 1 + the deepest tap must exist; one dtype
+            # for the buffer and everything the step reads from / writes to it
             if tuple(b.shape[1:]) != S or (n != 1 and tuple(b.strides[1:]) != tuple(cs)) or \
-                    store[k] < prog.depth[k] or b.dtype != lp.vars[lp.outputs[k]].dtype:
+                    pos[g_] + n_steps + max(ti + to) > store[g_] or \
+                    any(lp.vars[v].dtype != b.dtype for v, (gg, _t) in prog.mm_in.items() if gg == g_):
+                return "mit-mot buffer layout", None, 0
+        for k in range(n_rec):
+            b = outs[n_mm + k]
+            if tuple(b.shape[1:]) != S or (n != 1 and tuple(b.strides[1:]) != tuple(cs)) or \
+                    store[n_mm + k] < prog.depth[k] or b.dtype != lp.vars[lp.outputs[n_mmo + k]].dtype:
                 return "recurrent output layout", None, 0
-        out_dt = [outs[k].dtype for k in range(n_rec)]
+        out_dt = [outs[k].dtype for k in range(n_mm + n_rec)]
         for j in range(n_nit):
-            ov = lp.vars[lp.outputs[n_rec + j]]
+            ov = lp.vars[lp.outputs[n_mmo + n_rec + j]]
             if ov.ndim != len(S):
                 return "nit-sot output of another rank", None, 0
             out_dt.append(ov.dtype)
@@ -668,8 +685,9 @@ class ScanMixin:
                 ent = load_kernels(src, names)
                 _Kernels.cache[key] = ent
         for j in range(n_nit):
-            outs[n_rec + j] = inner.alloc((store[n_rec + j],) + S, out_dt[n_rec + j])
-        for k in range(n_rec + n_nit):
+            sl = n_mm + n_rec + j
+            outs[sl] = inner.alloc((store[sl],) + S, out_dt[sl])
+        for k in range(n_mm + n_rec + n_nit):
             b = outs[k]
             g.out[k], g.out_rs[k], g.out_store[k], g.out_pos0[k] = b.ptr, b.strides[0], store[k], pos[k]
         sh_out = []
@@ -883,7 +901,7 @@ class ScanMixin:
         i, go = 0, True
         mm_inplace = None
         ew_ran = False
-        if TUNE["scan_persist"] and self.fuse and n_steps >= 1 and not n_mm:
+        if TUNE["scan_persist"] and self.fuse and n_steps >= 1:
             # a purely element-wise step: the whole recurrence as one launch, no exchange at all
             why_ew, sh_out, done = self._scan_persist_ew(node, p, inner, n_steps, seqs, outs, store, pos,
                                                          shared, non_seqs, pre_rows, n_rec, n_nit)

@@ -275,8 +275,6 @@ def analyze(inner, p, n_seqdots):
                           "scalar": st.scalar, "out_refs": list(st.out_refs)})
     if len(pr.mats) > SP_MAXMAT or len(pr.nsq) > SP_MAXNSQ or not pr.mats:
         return None, "no / too many matrices"
-    if pr.older and pr.mode == "mat":
-        return None, "taps other than [-1] on a matrix state"
     if len(plan.outputs) != n_rec + n_nit or len(plan.outputs) > SP_MAXOUT:
         return None, "output count"
     for j, o in enumerate(plan.outputs):

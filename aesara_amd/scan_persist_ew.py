@@ -18,8 +18,14 @@ non-sequences (per element or one broadcast scalar), any dtype the Elemwise gene
 condition is a 0-d value: with more elements it would be a reduction): the thread stops at the
 first step whose condition is true and stores the number of steps it ran in a device word the
 executor reads once after the launch (the trip count sizes the outputs, scan/op.py:2139-2159).
-Not covered (launch-list path, ``PlanExecutor.scan_modes`` says why): mit-mot outputs, steps with
-dots / reductions / indexing, values of different shapes inside one step.
+**mit-mot** outputs with any non-negative taps (what ``Scan.L_op`` builds to propagate gradients,
+scan/op.py:2379 — [0, 1] -> [1] for a one-tap recurrence, [0, 1, 2] -> [1, 2] for taps [-1, -2], ...):
+step t reads rows t + tap of the buffer and overwrites rows t + out-tap (scan_perform.pyx:343-352,
+:437-452); the thread keeps the window of rows t .. t + max tap of its element in registers, the row
+that enters the window is read ahead like a sequence row (no earlier step writes it), every out-tap
+is stored as it is made.
+Not covered (launch-list path, ``PlanExecutor.scan_modes`` says why): steps with dots / reductions /
+indexing, values of different shapes inside one step.
 """
 from __future__ import annotations
 
@@ -73,6 +79,9 @@ class ProgramEw:
 
     def __init__(self):
         self.seq, self.tap, self.shared, self.nsq = {}, {}, {}, {}
+        # mit-mot groups: ``mm`` = [(in taps, out taps)], ``mm_in``: var -> (group, tap),
+        # ``mm_new``: per group [(out tap, var)] in the order of the inner outputs
+        self.mm, self.mm_in, self.mm_new = [], {}, []
         self.steps, self.rec_new, self.nit_new, self.sh_new = [], [], [], []
         self.cond, self.depth, self.dtype_of = None, {}, {}
         self.as_while = False
@@ -81,8 +90,12 @@ class ProgramEw:
 def analyze(inner, p, n_pre):
     """(ProgramEw, None) or (None, reason)."""
     plan = inner.plan
-    if p.get("mit_mot_in_slices"):
-        return None, "mit-mot outputs"
+    mm_in = [list(t) for t in p.get("mit_mot_in_slices", [])]
+    mm_out = [list(t) for t in p.get("mit_mot_out_slices", [])]
+    if len(mm_in) != len(mm_out) or any(
+            any(x < 0 or x > 8 for x in ti + to) or len(set(ti)) != len(ti) or len(set(to)) != len(to)
+            for ti, to in zip(mm_in, mm_out)):
+        return None, "mit-mot taps negative / deeper than 8 / repeated"
     n_seqs, n_sh, n_nit = p["n_seqs"], p.get("n_shared_outs", 0), p["n_nit_sot"]
     taps = [list(t) for t in p["mit_sot_in_slices"]] + [list(t) for t in p["sit_sot_in_slices"]]
     if any(any(x >= 0 for x in t) or len(set(t)) != len(t) or min(t) < -8 for t in taps):
@@ -96,11 +109,17 @@ def analyze(inner, p, n_pre):
     for s, v in enumerate(ins[:n_seqs]):
         pr.seq[v] = s
     idx = n_seqs
+    for g_, (ti, to) in enumerate(zip(mm_in, mm_out)):
+        pr.mm.append((ti, to))
+        for tap in ti:
+            pr.mm_in[ins[idx]] = (g_, tap)
+            idx += 1
     for k, tk in enumerate(taps):
         for tap in tk:
             pr.tap[ins[idx]] = (k, -tap)
             idx += 1
         pr.depth[k] = -min(tk)
+    pr.n_rec_inputs = idx - n_seqs
     for m in range(n_sh):
         pr.shared[ins[idx]] = m
         idx += 1
@@ -133,24 +152,31 @@ def analyze(inner, p, n_pre):
                     if len(pr.nsq) >= EW_MAXNSQ:
                         return None, "too many invariant operands"
                     pr.nsq[v] = len(pr.nsq)
-            elif not (v in pr.seq or v in pr.tap or v in pr.shared or v in produced):
+            elif not (v in pr.seq or v in pr.tap or v in pr.mm_in or v in pr.shared or v in produced):
                 return None, "operand of unknown origin"
         pr.steps.append({"ins": st_in, "outs": list(st.outputs), "scalar": st.scalar,
                          "out_refs": list(st.out_refs)})
         produced.update(st.outputs)
     n_rec = len(taps)
-    want = n_rec + n_nit + n_sh + (1 if pr.as_while else 0)
-    if len(plan.outputs) != want or n_rec + n_nit > EW_MAXOUT or n_rec + n_nit + n_sh == 0:
+    n_mmo = sum(len(to) for _ti, to in pr.mm)
+    want = n_mmo + n_rec + n_nit + n_sh + (1 if pr.as_while else 0)
+    if len(plan.outputs) != want or len(pr.mm) + n_rec + n_nit > EW_MAXOUT or n_mmo + n_rec + n_nit + n_sh == 0:
         return None, "output count"
     outs = [res(o) for o in plan.outputs]
 
     def legal_src(v):
-        return v in produced or v in pr.seq or v in pr.tap or v in pr.shared or v in pr.nsq or v in inv_set
+        return v in produced or v in pr.seq or v in pr.tap or v in pr.mm_in or v in pr.shared or \
+            v in pr.nsq or v in inv_set
     for v in outs:
         if not legal_src(v):
             return None, "a step output is not computed by a fused step"
         if v in inv_set and v not in pr.nsq:
             pr.nsq[v] = len(pr.nsq)
+    o_ = 0
+    for _ti, to in pr.mm:
+        pr.mm_new.append([(tap, outs[o_ + j]) for j, tap in enumerate(to)])
+        o_ += len(to)
+    outs = outs[n_mmo:]
     pr.rec_new = outs[:n_rec]
     pr.nit_new = outs[n_rec:n_rec + n_nit]
     pr.sh_new = outs[n_rec + n_nit:n_rec + n_nit + n_sh]
@@ -169,7 +195,8 @@ class SpecEw:
 
     def key(self):
         pr = self.prog
-        blob = json.dumps(["se2", [[s["ins"], s["outs"], s["scalar"], s["out_refs"]] for s in pr.steps],
+        blob = json.dumps(["se3", pr.mm, sorted((k, list(v)) for k, v in pr.mm_in.items()), pr.mm_new,
+                           [[s["ins"], s["outs"], s["scalar"], s["out_refs"]] for s in pr.steps],
                            sorted(pr.seq.items()), sorted((k, list(v)) for k, v in pr.tap.items()),
                            sorted(pr.shared.items()), sorted(pr.nsq.items()), pr.rec_new, pr.nit_new,
                            pr.sh_new, pr.cond, sorted(pr.depth.items()), self.out_dtypes, self.sh_dtypes,
@@ -187,9 +214,13 @@ def generate(spec: SpecEw):
     L.append('extern "C" __global__ __launch_bounds__(256) void %s(EwScanArgs a) {' % name)
     L.append("  const i64 e = (i64)blockIdx.x * 256 + threadIdx.x;")
     L.append("  if (e >= a.n) return;")
+    mm_vals = [v for grp in pr.mm_new for _tap, v in grp]
     used_seq = sorted({v for s in pr.steps for v in s["ins"] if v in pr.seq} |
-                      {v for v in pr.rec_new + pr.nit_new + pr.sh_new + ([pr.cond] if pr.cond is not None else [])
-                       if v in pr.seq}, key=lambda v: pr.seq[v])
+                      {v for v in mm_vals + pr.rec_new + pr.nit_new + pr.sh_new +
+                       ([pr.cond] if pr.cond is not None else []) if v in pr.seq}, key=lambda v: pr.seq[v])
+    # output slots (the order of the Scan's outer outputs): mit-mot groups, recurrent outputs, nit-sot
+    n_mm = len(pr.mm)
+    mm_top = [max(ti + to) for ti, to in pr.mm]         # the window of group g: rows t .. t + mm_top[g]
 
     def rd(expr, d):                       # a stored element -> register value
         return "(%s != 0)" % expr if d == "bool" else expr
@@ -199,18 +230,27 @@ def generate(spec: SpecEw):
         L.append("  const %s nv%d = %s;" % (RT[dt[v]], j, rd("((const %s*)a.nsq[%d])[%s]" % (CT[dt[v]], j, off), dt[v])))
     # recurrent state registers (tap -1 .. -depth) from the output buffers, shared values
     n_rec, n_nit = len(pr.rec_new), len(pr.nit_new)
+    for g_ in range(n_mm):
+        # a mit-mot buffer is not circular: row of step t, tap j = pos0 + t + j; the rows below the
+        # top of the window start in registers, the top row enters per step (read ahead below)
+        odt = spec.out_dtypes[g_]
+        L.append("  %s* const mb%d = (%s*)a.out[%d] + a.out_pos0[%d] * a.out_rs[%d] + e;" % (CT[odt], g_, CT[odt], g_, g_, g_))
+        for j in range(mm_top[g_]):
+            L.append("  %s w%d_%d = %s;" % (RT[odt], g_, j, rd("mb%d[%d * a.out_rs[%d]]" % (g_, j, g_), odt)))
+        L.append("  %s w%d_%d;" % (RT[odt], g_, mm_top[g_]))
     for k in range(n_rec):
-        odt = spec.out_dtypes[k]
-        L.append("  %s* const ob%d = (%s*)a.out[%d];" % (CT[odt], k, CT[odt], k))
-        L.append("  i64 op%d = a.out_pos0[%d];" % (k, k))
+        sl = n_mm + k
+        odt = spec.out_dtypes[sl]
+        L.append("  %s* const ob%d = (%s*)a.out[%d];" % (CT[odt], sl, CT[odt], sl))
+        L.append("  i64 op%d = a.out_pos0[%d];" % (sl, sl))
         for d in range(1, pr.depth[k] + 1):
             L.append("  %s r%d_%d = %s;" % (RT[odt], k, d, rd(
-                "ob%d[((op%d - %d + a.out_store[%d]) %% a.out_store[%d]) * a.out_rs[%d] + e]" % (k, k, d, k, k, k), odt)))
+                "ob%d[((op%d - %d + a.out_store[%d]) %% a.out_store[%d]) * a.out_rs[%d] + e]" % (sl, sl, d, sl, sl, sl), odt)))
     for j in range(n_nit):
-        k = n_rec + j
-        odt = spec.out_dtypes[k]
-        L.append("  %s* const ob%d = (%s*)a.out[%d];" % (CT[odt], k, CT[odt], k))
-        L.append("  i64 op%d = a.out_pos0[%d];" % (k, k))
+        sl = n_mm + n_rec + j
+        odt = spec.out_dtypes[sl]
+        L.append("  %s* const ob%d = (%s*)a.out[%d];" % (CT[odt], sl, CT[odt], sl))
+        L.append("  i64 op%d = a.out_pos0[%d];" % (sl, sl))
     for v, m in sorted(pr.shared.items(), key=lambda kv: kv[1]):
         sdt = spec.sh_dtypes[m]
         L.append("  %s s%d = %s;" % (RT[sdt], m, rd("((const %s*)a.sh_in[%d])[e]" % (CT[sdt], m), sdt)))
@@ -225,9 +265,19 @@ def generate(spec: SpecEw):
         for v in used_seq:
             s = pr.seq[v]
             L.append("    const %s x%d_%d = %s;" % (RT[dt[v]], s, u, rd("sq%d[tt%d * a.seq_ts[%d] + e]" % (s, u, s), dt[v])))
+        for g_ in range(n_mm):
+            # the row that enters the window at that step: written by no earlier step (an out-tap j
+            # of step t' lands on it when t' + j = t + top, i.e. t' >= t)
+            odt = spec.out_dtypes[g_]
+            L.append("    const %s mx%d_%d = %s;" % (RT[odt], g_, u, rd(
+                "mb%d[(tt%d + %d) * a.out_rs[%d]]" % (g_, u, mm_top[g_], g_), odt)))
     for u in range(AHEAD):
         L.append("    if (t0 + %d < a.T) {" % u)
         env = {}
+        for g_ in range(n_mm):
+            L.append("      w%d_%d = mx%d_%d;" % (g_, mm_top[g_], g_, u))
+        for v, (g_, tap) in pr.mm_in.items():
+            env[v] = "w%d_%d" % (g_, tap)
         for v in used_seq:
             env[v] = "x%d_%d" % (pr.seq[v], u)
         for v, (k, d) in pr.tap.items():
@@ -250,16 +300,28 @@ def generate(spec: SpecEw):
         def st_val(v, odt):
             e_ = cg._cast(env[v], dt[v], odt)
             return "(unsigned char)(%s)" % e_ if odt == "bool" else e_
+        # every new value is taken before any register of the step's inputs is overwritten
+        for g_ in range(n_mm):
+            odt = spec.out_dtypes[g_]
+            for tap, v in pr.mm_new[g_]:
+                L.append("      const %s nm%d_%d = %s;" % (RT[odt], g_, tap, cg._cast(env[v], dt[v], odt)))
         for k in range(n_rec):
-            odt = spec.out_dtypes[k]
+            odt = spec.out_dtypes[n_mm + k]
             L.append("      const %s n%d = %s;" % (RT[odt], k, cg._cast(env[pr.rec_new[k]], dt[pr.rec_new[k]], odt)))
+        for g_ in range(n_mm):
+            odt = spec.out_dtypes[g_]
+            for tap, v in pr.mm_new[g_]:
+                L.append("      w%d_%d = nm%d_%d;" % (g_, tap, g_, tap))
+                L.append("      mb%d[(t + %d) * a.out_rs[%d]] = %s;" % (
+                    g_, tap, g_, "(unsigned char)nm%d_%d" % (g_, tap) if odt == "bool" else "nm%d_%d" % (g_, tap)))
         for k in range(n_rec):
-            odt = spec.out_dtypes[k]
+            sl = n_mm + k
+            odt = spec.out_dtypes[sl]
             L.append("      ob%d[op%d * a.out_rs[%d] + e] = %s;" % (
-                k, k, k, "(unsigned char)n%d" % k if odt == "bool" else "n%d" % k))
+                sl, sl, sl, "(unsigned char)n%d" % k if odt == "bool" else "n%d" % k))
         for j in range(n_nit):
-            k = n_rec + j
-            L.append("      ob%d[op%d * a.out_rs[%d] + e] = %s;" % (k, k, k, st_val(pr.nit_new[j], spec.out_dtypes[k])))
+            sl = n_mm + n_rec + j
+            L.append("      ob%d[op%d * a.out_rs[%d] + e] = %s;" % (sl, sl, sl, st_val(pr.nit_new[j], spec.out_dtypes[sl])))
         sh_tmp = []
         for m, v in enumerate(pr.sh_new):
             L.append("      const %s ns%d = %s;" % (RT[spec.sh_dtypes[m]], m, cg._cast(env[v], dt[v], spec.sh_dtypes[m])))
@@ -273,8 +335,11 @@ def generate(spec: SpecEw):
             L.append("      r%d_1 = n%d;" % (k, k))
         for m in sh_tmp:
             L.append("      s%d = ns%d;" % (m, m))
-        for k in range(n_rec + n_nit):
-            L.append("      if (++op%d == a.out_store[%d]) op%d = 0;" % (k, k, k))
+        for g_ in range(n_mm):          # the window moves on one row
+            for j in range(mm_top[g_]):
+                L.append("      w%d_%d = w%d_%d;" % (g_, j, g_, j + 1))
+        for sl in range(n_mm, n_mm + n_rec + n_nit):
+            L.append("      if (++op%d == a.out_store[%d]) op%d = 0;" % (sl, sl, sl))
         L.append("      ++t;")
         if pr.cond is not None:
             L.append("      if (stop_) goto done_;")

@@ -184,7 +184,7 @@ class SpecMat:
     def key(self):
         pr = self.prog
         blob = json.dumps(["sm9" + ("t" if self.trace else "") + ("/f5p%d%s" % (self.pin, str(knobs.get("SM_FENCE"))) if self.xmode == "frag" else ""), self.xfold and [self.xfold, "w15", str(knobs.get("SM_XTAIL"))], [self.init, self.xreload, self.ackfill, self.xpre, self.look, self.nxt, self.epre, self.elook, self.xsplit, self.polls, self.spin_delay], self.dtype, self.chunk, self.xmode, self.early_first, self.B, self.N, self.Nt, sorted(self.Ks.items()), sorted(pr.seq.items()),
-                           sorted(pr.state.items()), sorted(pr.nsq.items()), sorted(pr.mats.items()),
+                           sorted(pr.state.items()), sorted(pr.older.items()), sorted(pr.depth.items()), sorted(pr.nsq.items()), sorted(pr.mats.items()),
                            [[ph["dots"], ph["ins"], ph["outs"], ph["scalar"], ph["out_refs"]]
                             for ph in pr.phases], pr.outs, pr.exchanged, sorted(pr.tap_seq.items())] +
                           ([["nblk", self.nblk, str(knobs.get("SM_INTERLEAVE"))]] if self.nblk != 1 else []),
@@ -895,6 +895,18 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
         L.append("  %s own_%d§ = %s;" % (T, v, ZERO))
         L.append("  if (owner§) own_%d§ = ((const %s*)a.out[%d])[((a.out_pos0[%d] + a.out_store[%d] - 1) %% "
                  "a.out_store[%d]) * a.out_ts[%d] + eb§ * a.out_rs[%d] + en];" % (v, T, k, k, k, k, k, k))
+    # older taps (-2, -3, ...: scan_perform.pyx:321-340): the tile element's own values of 2 ..
+    # depth steps ago — registers of its owner, a shift per step (buffer row pos0 - d holds the
+    # initial one; a depth no tap names still needs its register: taps [-1, -3] pass through -2)
+    hist = {}
+    by_kd = {kd: v for v, kd in pr.older.items()}
+    for k, D_ in sorted(pr.depth.items()):
+        for d in range(2, D_ + 1):
+            nm = ("own_%d§" % by_kd[(k, d)]) if (k, d) in by_kd else "hist_%d_%d§" % (k, d)
+            hist[(k, d)] = nm
+            L.append("  %s %s = %s;" % (T, nm, ZERO))
+            L.append("  if (owner§) %s = ((const %s*)a.out[%d])[((a.out_pos0[%d] + a.out_store[%d] * 8 - %d) %% "
+                     "a.out_store[%d]) * a.out_ts[%d] + eb§ * a.out_rs[%d] + en];" % (nm, T, k, k, k, d, k, k, k))
     pw_nsq = sorted({v for ph in pr.phases for v in ph["ins"] if v in pr.nsq})
     for v in pw_nsq:
         s_ = pr.nsq[v]
@@ -1503,6 +1515,9 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
         nxt_loads = []
     stamp("step end")
     for v, nv in pr.new_of_state.items():
+        k = pr.state[v]
+        for d in range(pr.depth.get(k, 1), 1, -1):      # shift the owner's history, oldest first
+            L.append("    %s = %s;" % (hist[(k, d)], hist[(k, d - 1)] if d > 2 else "own_%d§" % v))
         L.append("    own_%d§ = own_%d§;" % (v, nv))
     body = L[i_body:]
     del L[i_body:]

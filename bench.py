@@ -263,17 +263,20 @@ def main():
     # clocks yet.  ~60 ms of the same step first; the timed region itself is unchanged
     # (barrier + synchronize, exactly K steps, barrier + synchronize).
     CLOCK_WARMUP = 0 if args.no_clock_warmup else 2048
+    # (no garbage-collector pause inside or IN FRONT OF a 0.6 ms region: collected and switched off
+    # before the clock warm-up, as ``timeit`` does — a full collection between the warm-up and the
+    # timed region walks every object the golden plans loaded, tens of ms in which the chip idles
+    # and drops its clocks again: r04, 28 -> 37-42 us per eval once the golden set had grown)
+    import gc
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     for _ in range(CLOCK_WARMUP):
         h = step()
         if h is not None:
             h.wait()
     state["i"] = ((state["i"] + BUCKET - 1) // BUCKET) * BUCKET if world > 1 else state["i"]
 
-    # (no garbage-collector pause inside a 0.6 ms region: collected before, switched off during,
-    # as ``timeit`` does)
-    import gc
-    gc.collect()
-    gc.disable()
     barrier()
     t0 = time.perf_counter()
     check(lib.ahip_event_record(ev0, stream))
@@ -292,12 +295,6 @@ def main():
     gc.enable()
     ms = C.c_float()
     check(lib.ahip_event_elapsed_ms(ev0, ev1, C.byref(ms)))
-
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # compiles the reference's C modules in the background while the secondary rows run — started
-        # only now: a few hundred gcc processes next to the headline's 0.6 ms timed region cost it
-        # 4 us per eval (r04: 32.8 vs 28.5 us on the same box)
-        ref_warm = start_reference_warm()
 
     elapsed = torch.tensor([t1 - t0], dtype=f64, device="cuda")
     if world > 1:
@@ -364,6 +361,14 @@ def main():
                    "note": "x.sum() of the same matrices, same rotation, same launch shape: loads + "
                            "adds only (no ALU work to hide), in-kernel finalize included"}
         del exs
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # compiles the reference's C modules in the background while the secondary rows run — started
+        # only now, behind every leg that is paced by host calls of a few microseconds: a few hundred
+        # gcc processes next to the headline's 0.6 ms timed region cost it 4 us per eval (r04: 32.8 vs
+        # 28.5 us on the same box), next to the executor-level and read-only-ceiling legs half their
+        # rate (0.27 / 0.29 instead of 0.62 / 0.67)
+        ref_warm = start_reference_warm()
 
     secondary = []
     if not args.no_secondary:
@@ -827,8 +832,14 @@ def start_reference_warm():
         import subprocess
         env = dict(os.environ)
         env.pop("AESARA_FLAGS", None)
+        # the child only compiles (tiny shapes): one BLAS / OpenMP thread — at their defaults the
+        # tiny warm-up evaluations spin 256 threads next to the rows being measured (r04: Gemm rows
+        # 0.75 instead of 0.80 while it ran) — and the lowest scheduling priority
+        for k in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+            env[k] = "1"
         return subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "time_reference.py"), "--warm"],
-                                stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env)
+                                stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env,
+                                preexec_fn=lambda: os.nice(19))
     except Exception:                                   # noqa: BLE001
         return None
 

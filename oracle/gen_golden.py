@@ -1000,6 +1000,35 @@ def _():
         [N((11,), seed=1, scale=0.3), N((2,), seed=2), K(0.7, "float64")]
 
 
+@case("scan_grad_taps_wide", rtol=1e-10, atol=1e-10)
+def _():
+    """The gradient of a two-tap element-wise recurrence over vectors: Scan.L_op propagates it
+    through a mit-mot output with taps [0, 2, 1] -> [2, 1] (scan/op.py:2379) — 130 independent
+    elements, 37 steps (more than the kernel's read-ahead of 8)."""
+    x, init, w = at.dmatrix("x"), at.dmatrix("init"), at.dvector("w")
+    res, _ = ae.scan(lambda x_t, a, b, w: at.tanh(w * a + 0.5 * b) + x_t, sequences=[x],
+                     outputs_info=[dict(initial=init, taps=[-2, -1])], non_sequences=[w])
+    cost = (res * res).sum()
+    return [x, init, w], [cost] + list(ae.grad(cost, [x, init, w])), \
+        [N((37, 130), seed=1, scale=0.3), N((2, 130), seed=2), N((130,), seed=3, scale=0.5)]
+
+
+@case("scan_grad_taps13", rtol=1e-10, atol=1e-10)
+def _():
+    """Taps [-3, -1] and a second output with one tap: two mit-mot groups with different windows
+    in the gradient Scan."""
+    x, a0, b0 = at.dmatrix("x"), at.dmatrix("a0"), at.dvector("b0")
+
+    def step(x_t, a3, a1, b):
+        an = at.tanh(0.6 * a1 - 0.3 * a3 * b) + x_t
+        bn = at.sigmoid(b + 0.2 * an)
+        return an, bn
+    (as_, bs), _ = ae.scan(step, sequences=[x], outputs_info=[dict(initial=a0, taps=[-3, -1]), b0])
+    cost = (as_ * as_).sum() + (bs[-1] * bs[-1]).sum()
+    return [x, a0, b0], [cost] + list(ae.grad(cost, [x, a0, b0])), \
+        [N((19, 5), seed=1, scale=0.3), N((3, 5), seed=2), N((5,), seed=3, scale=0.5)]
+
+
 @case("scan_grad_last_state_f32", rtol=2e-5, atol=2e-5)
 def _():
     x, h0, W, U_ = at.fmatrix("x"), at.fvector("h0"), at.fmatrix("W"), at.fmatrix("U")
@@ -1118,6 +1147,39 @@ def _():
     return [x, h0, W, U], [hs, hs[-1]], \
         [N((9, 16, 64), "float32", 4, 0.5), N((16, 64), "float32", 3, 0.5),
          N((64, 64), "float32", 5, 0.125), N((64, 64), "float32", 6, 0.125)]
+
+
+
+@case("sm_taps_b16_f32", rtol=1e-5, atol=1e-5)
+def _():
+    """A batch of recurrences with taps [-1, -2] (scan_perform.pyx:321-340 hands the step one row
+    per tap): h_t = tanh(h_{t-1} @ U + 0.5 * h_{t-2} + x_t) — the older tap is element-wise, so it
+    stays in the registers of the tile element's owner (matrix-state persistent kernel)."""
+    x, h0, U = at.ftensor3("x"), at.ftensor3("h0"), at.fmatrix("U")
+
+    def step(x_t, h2, h1, U):
+        return at.tanh(at.dot(h1, U) + np.float32(0.5) * h2 + x_t)
+    hs, _ = ae.scan(step, sequences=[x], outputs_info=[dict(initial=h0, taps=[-2, -1])], non_sequences=[U])
+    return [x, h0, U], [hs, hs[-1]], \
+        [N((9, 16, 64), "float32", 4, 0.5), N((2, 16, 64), "float32", 3, 0.5), N((64, 64), "float32", 5, 0.125)]
+
+
+@case("sm_taps13_b32_f32", rtol=1e-5, atol=1e-5)
+def _():
+    """Taps [-1, -3] and a second state with the usual single tap, width 96 (not a multiple of
+    64: zero-padded weights), batch 32 (two batch blocks): the depth-2 value nobody names still
+    needs its register."""
+    x, h0, c0, U, V = at.ftensor3("x"), at.ftensor3("h0"), at.fmatrix("c0"), at.fmatrix("U"), at.fmatrix("V")
+
+    def step(x_t, h3, h1, c, U, V):
+        hn = at.tanh(at.dot(h1, U) + np.float32(0.25) * h3 * c + x_t)
+        cn = at.sigmoid(at.dot(c, V) + hn)
+        return hn, cn
+    (hs, cs), _ = ae.scan(step, sequences=[x], outputs_info=[dict(initial=h0, taps=[-3, -1]), c0],
+                          non_sequences=[U, V])
+    return [x, h0, c0, U, V], [hs, cs[-1]], \
+        [N((7, 32, 96), "float32", 4, 0.5), N((3, 32, 96), "float32", 3, 0.5), N((32, 96), "float32", 2, 0.5),
+         N((96, 96), "float32", 5, 0.1), N((96, 96), "float32", 6, 0.1)]
 
 
 

@@ -45,6 +45,33 @@ def test_elementwise_scans_run_as_one_launch_and_match(name, use_graph):
     ex.check()
 
 
+@pytest.mark.parametrize("name", ["scan_grad_taps", "scan_grad_taps_wide", "scan_grad_taps13"])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_gradient_scans_with_mit_mot_windows_run_as_one_launch(name, use_graph):
+    """Scan.L_op's gradient Scans of element-wise recurrences with several taps: mit-mot outputs
+    with taps [0, 2, 1] -> [2, 1] / [0, 3, 1] -> [3, 1] (scan/op.py:2379; scan_perform.pyx:343-352
+    reads rows t + tap, :437-452 writes rows t + out-tap).  Forward and gradient Scan both run as one
+    launch; results = the reference's outputs = the launch-list path bit for bit."""
+    from aesara_amd import executor as E
+    c = _case(name)
+    ex = E.PlanExecutor(case_plan(c), use_graph=use_graph)
+    ins = case_inputs(c)
+    for it in range(3):
+        got = _np(ex(*ins))
+        assert_matches(c, got, case_expected(c), f"call {it}")
+    assert list(ex.scan_modes.values()) == ["persistent", "persistent"], ex.scan_modes
+    E.TUNE["scan_persist"] = 0
+    try:
+        ex2 = E.PlanExecutor(case_plan(c), use_graph=use_graph)
+        ref = _np(ex2(*ins))
+        assert all(v.startswith("launch-list") for v in ex2.scan_modes.values())
+    finally:
+        E.TUNE["scan_persist"] = 1
+    for g, r in zip(got, ref):
+        np.testing.assert_array_equal(g, r)
+    ex.check()
+
+
 @pytest.mark.parametrize("T,n", [(700, 3000), (1, 5), (9, 1), (257, 70001)])
 def test_cumsum_recurrence_large(T, n):
     """s_t = s_{t-1} + x_t over [T, n]: every row against np.cumsum (fp64, same order: exact)."""
