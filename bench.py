@@ -275,6 +275,14 @@ def main():
         h = step()
         if h is not None:
             h.wait()
+    if CLOCK_WARMUP and world == 1:
+        # ... and the region's own shape a few times (drain, then K steps from an idle queue): the
+        # first K-step window behind the long warm-up read 0.5-1 us per eval slower than the ones
+        # after it (r04, AESARA_BENCH_REGIONS=8: 28.8-29.0 vs 27.5-28.6 us)
+        for _ in range(3):
+            barrier()
+            for _ in range(args.steps):
+                step()
     state["i"] = ((state["i"] + BUCKET - 1) // BUCKET) * BUCKET if world > 1 else state["i"]
 
     barrier()
@@ -295,6 +303,23 @@ def main():
     gc.enable()
     ms = C.c_float()
     check(lib.ahip_event_elapsed_ms(ev0, ev1, C.byref(ms)))
+    if os.environ.get("AESARA_BENCH_REGIONS"):
+        # (diagnostic) the same K-step region again, several times: spread of the short window
+        reg = []
+        for _r in range(int(os.environ["AESARA_BENCH_REGIONS"])):
+            barrier()
+            ta = time.perf_counter()
+            check(lib.ahip_event_record(ev0, stream))
+            for _ in range(args.steps):
+                step()
+            check(lib.ahip_event_record(ev1, stream))
+            barrier()
+            tb = time.perf_counter()
+            m2 = C.c_float()
+            check(lib.ahip_event_elapsed_ms(ev0, ev1, C.byref(m2)))
+            reg.append((round(m2.value / args.steps * 1e3, 2), round((tb - ta) / args.steps * 1e6, 2)))
+        print("regions (event us/eval, wall us/eval): first %.2f / %.2f, then %s"
+              % (ms.value / args.steps * 1e3, (t1 - t0) / args.steps * 1e6, reg), file=sys.stderr)
 
     elapsed = torch.tensor([t1 - t0], dtype=f64, device="cuda")
     if world > 1:
