@@ -1326,7 +1326,12 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
             L.append("    const int pp%d = (int)((t * %d + %d) & 1);" % (pi, len(dot_phases), dot_phases.index(pi)))
     XLPG = 2                    # x loads behind each fragment's MFMAs of the product that carries them
 
+    xs_declared = []
+
     def declare_xs():
+        if xs_declared:
+            return
+        xs_declared.append(1)
         L.append("    const i64 xt_ = (t + %d < a.T) ? t + %d : a.T - 1;" % (XW["ahead"], XW["ahead"]))
         L.append("    const __amdgpu_buffer_rsrc_t xs_ = __builtin_amdgcn_make_buffer_rsrc("
                  "(void*)((const float*)a.seq[%d] + xt_ * a.seq_ts[%d]), 0, %du, 0x00020000);"
@@ -1370,7 +1375,9 @@ def _generate_frag(spec: SpecMat, name, xoff, xtot):
         if spec.early_first:
             for li, (d, a_, x) in enumerate(early):
                 if (pi, d) in split_early:          # the rest of a product begun before the hand-off
-                    def look_hook(q, pi=pi):
+                    def look_hook(q, pi=pi, li=li):
+                        if pi == reload_early and li == 0:      # the x loads the first part did not get to
+                            xl_early(q)
                         if pi in look_in_product and q == split_early_q0 + spec.elook - 1:
                             look_emitted.add(pi)
                             L.append("      __builtin_amdgcn_sched_barrier(0);")

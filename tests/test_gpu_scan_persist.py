@@ -517,7 +517,11 @@ def test_persistent_scan_next_to_a_saturating_stream_and_occupancy_refusal():
         _Kernels.cache.update(saved)
 
 
-@pytest.mark.parametrize("T,H,B", [(7, 64, 16), (33, 128, 32), (12, 256, 48), (64, 1024, 64)])
+@pytest.mark.parametrize("T,H,B", [(7, 64, 16), (33, 128, 32), (12, 256, 48), (64, 1024, 64),
+                                   # round 4 (hand-offs re-scheduled): loops shorter than the schedule's
+                                   # look-ahead, 8 fragments per product (the staged-operand product
+                                   # split without a look inside it)
+                                   (2, 512, 32), (2, 1024, 16), (3, 1024, 64), (9, 512, 64)])
 def test_sequence_products_inside_the_persistent_loop(T, H, B, monkeypatch):
     """Round 3: the ``x_t @ W`` products of a batched recurrence are computed INSIDE the persistent
     matrix kernel (fragment-ordered x, weight columns in LDS — as many products as fit, the others
@@ -563,6 +567,43 @@ def test_sequence_products_inside_the_persistent_loop(T, H, B, monkeypatch):
     ex = PlanExecutor(plan)
     ex(x[:, :B - 3].contiguous(), h0[:B - 3].contiguous(), *Ws)             # ragged batch: up front
     assert list(ex.scan_modes.values()) == ["persistent"] and not ex.scan_notes
+
+
+@pytest.mark.parametrize("knobs_", [{"AESARA_HIP_SM_XREG": "1"}, {"AESARA_HIP_SM_POLLS": "4"},
+                                    {"AESARA_HIP_SM_INIT": "branch"}, {"AESARA_HIP_SM_XRELOAD": "early"},
+                                    {"AESARA_HIP_SM_EPRE": "0", "AESARA_HIP_SM_XSPLIT": "0", "AESARA_HIP_SM_XPRE": "0"},
+                                    {"AESARA_HIP_SM_ACKFILL": "0", "AESARA_HIP_SM_LOOK": "0", "AESARA_HIP_SM_PIN": "1"}])
+def test_opt_in_schedules_of_the_matrix_kernel_compute_the_same(knobs_, monkeypatch):
+    """The switches DESIGN §3.3b (round 4) measured and left off (third sequence product with its
+    weight columns in registers, several polls in flight, the step-0 path in the loop, the next x
+    requested early, no split products, the round-3 schedule) still compute the recurrence: every
+    step within 1e-5 of fp64 at the benchmark's width."""
+    import torch
+    from aesara_amd.executor import PlanExecutor
+    for k, v in knobs_.items():
+        monkeypatch.setenv(k, v)
+    T, H, B = 11, 1024, 64
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    x = torch.randn(T, B, H, dtype=torch.float32, device="cuda", generator=g) * 0.3
+    h0 = torch.randn(B, H, dtype=torch.float32, device="cuda", generator=g) * 0.5
+    Ws = [torch.randn(H, H, dtype=torch.float32, device="cuda", generator=g) / np.sqrt(H) for _ in range(6)]
+    Wz, Uz, Wr, Ur, Wh, Uh = [W.double() for W in Ws]
+    h, ref = h0.double(), []
+    for t in range(T):
+        xt = x[t].double()
+        z = torch.sigmoid(xt @ Wz + h @ Uz)
+        r = torch.sigmoid(xt @ Wr + h @ Ur)
+        h = (1 - z) * h + z * torch.tanh(xt @ Wh + (r * h) @ Uh)
+        ref.append(h)
+    ref = torch.stack(ref)
+    ex = PlanExecutor(case_plan(_case("cfg4_gru_b8_f32")))
+    for _ in range(2):
+        hs, hT = ex(x, h0, *Ws)
+    assert list(ex.scan_modes.values()) == ["persistent"], ex.scan_modes
+    err = ((hs.double() - ref).abs().max() / ref.abs().max()).item()
+    assert err <= 1e-5, (knobs_, err)
+    ex.check()
 
 
 @pytest.mark.parametrize("name", ["xfold_gru_b16_f32", "xfold_rnn_b16_f32"])
