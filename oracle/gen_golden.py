@@ -1164,6 +1164,37 @@ def _():
         [N((9, 16, 64), "float32", 4, 0.5), N((2, 16, 64), "float32", 3, 0.5), N((64, 64), "float32", 5, 0.125)]
 
 
+@case("sp_taps_bptt_f64", rtol=1e-9, atol=1e-10)
+def _():
+    """Two-tap recurrence on a vector state and its gradient: h_t = tanh(h_{t-1} @ U + 0.5 h_{t-2} + x_t).
+    Scan.L_op propagates through a mit-mot output with taps [0, 2, 1] -> [2, 1] (scan/op.py:2379)
+    AND accumulates the weight gradient inside the gradient Scan (a sit-sot output; PushOutDot1 does
+    not lift it for this tap set): the forward Scan runs persistent, the gradient Scan on the launch
+    list."""
+    x, h0, U = at.dmatrix("x"), at.dmatrix("h0"), at.dmatrix("U")
+
+    def step(x_t, h2, h1, U):
+        return at.tanh(at.dot(h1, U) + 0.5 * h2 + x_t)
+    hs, _ = ae.scan(step, sequences=[x], outputs_info=[dict(initial=h0, taps=[-2, -1])], non_sequences=[U])
+    cost = (hs * hs).sum()
+    return [x, h0, U], [cost] + list(ae.grad(cost, [x, h0, U])), \
+        [N((11, 64), seed=4, scale=0.5), N((2, 64), seed=3, scale=0.5), N((64, 64), seed=5, scale=0.125)]
+
+
+@case("sm_taps_bptt_b16_f32", rtol=2e-4, atol=2e-5)
+def _():
+    """The same with a batch (matrix state): forward = taps in the owner's registers (persistent),
+    gradient Scan (mit-mot [0, 2, 1] -> [2, 1] + the in-loop weight-gradient Gemm) on the launch list."""
+    x, h0, U = at.ftensor3("x"), at.ftensor3("h0"), at.fmatrix("U")
+
+    def step(x_t, h2, h1, U):
+        return at.tanh(at.dot(h1, U) + np.float32(0.5) * h2 + x_t)
+    hs, _ = ae.scan(step, sequences=[x], outputs_info=[dict(initial=h0, taps=[-2, -1])], non_sequences=[U])
+    cost = (hs * hs).sum()
+    return [x, h0, U], [cost] + list(ae.grad(cost, [x, h0, U])), \
+        [N((9, 16, 64), "float32", 4, 0.5), N((2, 16, 64), "float32", 3, 0.5), N((64, 64), "float32", 5, 0.125)]
+
+
 @case("sm_taps13_b32_f32", rtol=1e-5, atol=1e-5)
 def _():
     """Taps [-1, -3] and a second state with the usual single tap, width 96 (not a multiple of
