@@ -19,6 +19,37 @@ class ScanMixin:
         p = node.params
         inner_plan = p["inner"]
         key = id(inner_plan)
+        if self.fuse and p.get("sit_sot_in_slices") and not p.get("as_while"):
+            # a weight gradient summed inside the loop (sit-sot Gemm / Ger accumulator) whose
+            # buffer holds ONE row: the loop without it + one product over the stacked operands
+            # behind it (fusion.push_out_product_accumulators, applied to this node alone; the
+            # buffer length is known only now)
+            alt = self._inner.get(("sunk", key))
+            if alt is None:
+                need, same = [], []
+                wrap = Plan("scan_%d_sunk" % node.outputs[0], dict(self.plan.vars), list(node.inputs),
+                            list(node.outputs), [node])
+                wrap2 = push_out_product_accumulators(wrap, need, same)
+                alt = False
+                if wrap2 is not wrap and need:
+                    sub = PlanExecutor(wrap2, use_graph=False, dry_run=self.dry_run, fuse=self.fuse,
+                                       device=None if self.dry_run else self.device.index)
+                    alt = (sub, [node.inputs.index(v) for v in need],
+                           [(node.inputs.index(a_), node.inputs.index(b_)) for a_, b_ in same])
+                self._inner[("sunk", key)] = alt
+            if alt and all(getattr(args[i], "shape", (0,))[0] == 1 for i in alt[1]) and \
+                    all(self.host_int(args[i]) == self.host_int(args[j]) for i, j in alt[2]):
+                sub = alt[0]
+                sub._arena, sub._capturing = self._arena, self._capturing
+                sub._root = self._root or self
+                try:
+                    res = sub.run(list(args))
+                finally:
+                    sub._arena = None
+                    sub._capturing = False
+                self.scan_modes.update(sub.scan_modes)
+                self.scan_notes.update(sub.scan_notes)
+                return res
         ent = self._inner.get(key)
         if ent is None:
             # loop-invariant view/shape nodes of the inner graph (the W.T DimShuffles of every
@@ -158,6 +189,18 @@ class ScanMixin:
         prog, why = ent
         if prog is None:
             return why
+        if prog.mm_extra and len(outs) == n_rec + n_nit:
+            # out-taps 2 .. m of a mit-mot group write the group's buffer too: further output slots
+            # on the same buffer, each starting one row after the row its state is first read from
+            n_outer = len(outs)
+            outs.extend(outs[g_] for _sl, g_, _j in prog.mm_extra)
+            try:
+                return self._scan_persist(node, p, inner, n_steps, seqs, outs,
+                                          list(store) + [store[g_] for _sl, g_, _j in prog.mm_extra],
+                                          list(pos) + [pos[g_] + j_ for _sl, g_, j_ in prog.mm_extra],
+                                          non_seqs, pre_rows, n_rec, n_nit, xfold=xfold)
+            finally:
+                del outs[n_outer:]
         if prog.mode == "mat":
             return self._scan_persist_mat(prog, p, inner, n_steps, seqs, outs, store, pos,
                                           non_seqs, pre_rows, n_rec, n_nit, xfold=xfold)
@@ -192,12 +235,12 @@ class ScanMixin:
             if v in prog.tap_seq:
                 # rows pos + 1 .. pos + n_steps of the mit-mot buffer (what each step's tap 1 reads
                 # before it overwrites that very row)
-                g_ = prog.tap_seq[v]
+                g_, top = prog.tap_seq[v], prog.tap_top.get(v, 1)
                 b = outs[g_]
-                if pos[g_] + 1 + n_steps > store[g_]:
+                if pos[g_] + top + n_steps > store[g_]:
                     return "mit-mot buffer shorter than the loop"
                 seq_arr[v] = b.view((n_steps,) + tuple(b.shape[1:]), b.strides,
-                                    b.offset + (pos[g_] + 1) * b.strides[0])
+                                    b.offset + (pos[g_] + top) * b.strides[0])
             else:
                 seq_arr[v] = seqs[s] if s < n_seqs else pre_rows[s - n_seqs]
         f32 = prog.dtype                      # the one floating dtype of the loop (float32 / float64)
@@ -294,7 +337,8 @@ class ScanMixin:
             else:
                 outs[k] = inner.alloc((store[k], M), f32)
         g = sp.SpArgs()
-        nit_shapes = [tuple(1 if d == 1 else M for d in lp.vars[lp.outputs[n_rec + j]].shape)
+        n_mmo = n_mm + len(prog.mm_extra)      # inner outputs of the mit-mot groups (one per out-tap)
+        nit_shapes = [tuple(1 if d == 1 else M for d in lp.vars[lp.outputs[n_mmo + (n_rec - n_mm) + j]].shape)
                       for j in range(n_nit)]
         g.T = n_steps
         for av, slot in prog.mats.items():
@@ -473,12 +517,12 @@ class ScanMixin:
             if v in prog.tap_seq:
                 # rows pos + 1 .. pos + n_steps of the mit-mot buffer (tap 1: read by the element
                 # owner before it overwrites that very element)
-                g_ = prog.tap_seq[v]
+                g_, top = prog.tap_seq[v], prog.tap_top.get(v, 1)
                 b = outs[g_]
-                if pos[g_] + 1 + n_steps > store[g_]:
+                if pos[g_] + top + n_steps > store[g_]:
                     return "mit-mot buffer shorter than the loop"
                 a_ = b.view((n_steps,) + tuple(b.shape[1:]), b.strides,
-                            b.offset + (pos[g_] + 1) * b.strides[0])
+                            b.offset + (pos[g_] + top) * b.strides[0])
             else:
                 a_ = seqs[s_] if s_ < n_seqs else pre_rows[s_ - n_seqs]
             if a_.dtype != f32 or a_.shape[0] < n_steps:

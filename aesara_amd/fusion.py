@@ -606,6 +606,211 @@ def push_out_accumulators(plan: Plan) -> Plan:
     return plan
 
 
+def push_out_product_accumulators(plan: Plan, need_one_row: list = None, need_equal: list = None) -> Plan:
+    """The weight gradient a gradient Scan accumulates IN the loop — ``acc_t = acc_{t-1} + a_t^T @ g_t``
+    (``Gemm(acc, alpha, A_t, B_t, 1)``; for a vector state the outer product ``Ger(acc, alpha, x_t,
+    y_t)``) in a sit-sot output — is what the reference's ``PushOutDot1`` (scan/rewriting.py) turns
+    into ONE product over the stacked operands behind the loop.  That rewrite matches the gradient
+    of a one-tap recurrence; for taps [-1, -2] (mit-mot [0, 2, 1] -> [2, 1]) it leaves T small
+    products inside the step, which also keeps the step off the persistent kernels.  Done here for
+    every such accumulator whose buffer holds ONE row (only the final sum is kept: what Scan's
+    memory-saving rewrite leaves when the caller reads ``acc[-1]``):
+    ``acc_T = acc_0 + alpha * sum_t A_t @ B_t = acc_0 + alpha * [A_1 .. A_T] @ [B_1; ..; B_T]``,
+    the per-step operands taken from the sequences the Scan already receives or handed out as one
+    more nit-sot output.  Same sum in another association (one long-K GEMM): equal to the loop's up
+    to float reordering, like PushOutDot1's.
+
+    The buffer length is rarely static (``Alloc`` of a shape expression): with ``need_one_row`` (a
+    list) the static test is skipped and the variables that must turn out to hold one row are
+    appended to it — ``ScanMixin._op_Scan`` applies the rewrite to the single Scan node at hand
+    and runs the rewritten form when the buffers it is handed have one row.  ``need_equal``
+    collects pairs of host integers that must be equal then: a per-step operand that already IS a
+    nit-sot output is taken from there when that output keeps all ``n_steps`` rows."""
+    def cval(pl, vid):
+        v = pl.vars[vid]
+        if v.const is not None and len(v.const.get("data", ())) == 1:
+            return float(v.const["data"][0])
+        return None
+
+    orig = plan
+    plan = Plan(plan.name, dict(plan.vars), list(plan.inputs), list(plan.outputs), list(plan.nodes))
+    out_nodes, replaced, changed = [], {}, False
+    for node in plan.nodes:
+        if node.op != "Scan" or node.params.get("as_while") or not node.params.get("sit_sot_in_slices"):
+            out_nodes.append(node)
+            continue
+        p = dict(node.params)
+        inner = p["inner"]
+        n_seqs = p["n_seqs"]
+        mm_in = [list(t) for t in p.get("mit_mot_in_slices", [])]
+        mm_out = [list(t) for t in p.get("mit_mot_out_slices", [])]
+        ms = [list(t) for t in p["mit_sot_in_slices"]]
+        ss = [list(t) for t in p["sit_sot_in_slices"]]
+        n_mm, n_ms, n_ss, n_nit = len(mm_in), len(ms), len(ss), p["n_nit_sot"]
+        n_sh = p.get("n_shared_outs", 0)
+        tap0 = n_seqs + sum(len(t) for t in mm_in) + sum(len(t) for t in ms)      # first sit-sot tap
+        out0 = sum(len(t) for t in mm_out) + n_ms                                  # first sit-sot output
+        nit0 = out0 + n_ss
+        base_in = 1 + n_seqs + n_mm + n_ms            # position of the first sit-sot init in node.inputs
+        base_out = n_mm + n_ms
+        iprod = {o: n_ for n_ in inner.nodes for o in n_.outputs}
+        iclients = inner.clients()
+        V = plan.vars
+        found = []         # (q, alpha, "gemm" | "ger", a var, b var)
+        for q in range(n_ss):
+            if ss[q] != [-1]:
+                continue
+            tq, oq = inner.inputs[tap0 + q], inner.outputs[out0 + q]
+            upd = iprod.get(oq)
+            init_buf = node.inputs[base_in + q]
+            if upd is None or (need_one_row is None and V[init_buf].shape[0] != 1) or \
+                    len(iclients[tq]) != 1 or len(iclients[oq]) != 1 or \
+                    inner.vars[oq].dtype not in ("float32", "float64"):
+                continue
+            if upd.op == "Gemm" and upd.inputs[0] == tq and cval(inner, upd.inputs[1]) is not None and \
+                    cval(inner, upd.inputs[4]) == 1.0 and tq not in upd.inputs[1:]:
+                found.append((q, cval(inner, upd.inputs[1]), "gemm", upd.inputs[2], upd.inputs[3]))
+            elif upd.op == "Ger" and upd.inputs[0] == tq and cval(inner, upd.inputs[1]) is not None and \
+                    tq not in upd.inputs[1:]:
+                found.append((q, cval(inner, upd.inputs[1]), "ger", upd.inputs[2], upd.inputs[3]))
+        if not found:
+            out_nodes.append(node)
+            continue
+        # where the per-step operands come from: a sequence the Scan receives (rows 0 .. n_steps - 1
+        # of it), or a value of the step, handed out as one more nit-sot output of n_steps rows
+        n_steps_v = node.inputs[0]
+        new_nits = []                  # inner vars handed out additionally
+        post = []                      # nodes behind the Scan (appended after it)
+        new_nit_outs = {}              # inner var -> outer var of its rows
+
+        def rows_of(v):
+            """outer variable holding [T, ...] = the value of inner variable v at every step (None:
+            not a per-step value we can take out)"""
+            pn = iprod.get(v)
+            if pn is not None and pn.op == "DimShuffle":
+                r = rows_of(pn.inputs[0])
+                if r is None:
+                    return None
+                order = [0] + [(o if o == "x" else o + 1) for o in pn.params["new_order"]]
+                o_ = plan.new_var(inner.vars[v].dtype, [None] + list(inner.vars[v].shape))
+                post.append(Node("DimShuffle", [r], [o_], {"new_order": order}))
+                return o_
+            if v in inner.inputs:
+                k = inner.inputs.index(v)
+                if k >= n_seqs:
+                    return None        # a tap or an invariant: not a stack of per-step rows
+                o_ = plan.new_var(inner.vars[v].dtype, [None] + list(inner.vars[v].shape))
+                post.append(Node("Subtensor", [node.inputs[1 + k], n_steps_v], [o_],
+                                 {"idx_list": [{"slice": [None, "in", None]}]}))
+                return o_
+            if pn is None:
+                return None            # a constant
+            nits_ = inner.outputs[nit0:nit0 + n_nit]
+            if v in nits_ and need_equal is not None:
+                j_ = nits_.index(v)
+                len_v = node.inputs[1 + n_seqs + n_mm + n_ms + n_ss + n_sh + j_]
+                if len_v != n_steps_v:
+                    need_equal.append((len_v, n_steps_v))
+                return node.outputs[n_mm + n_ms + n_ss + j_]
+            if need_equal is not None:
+                # ... or handed out with broadcast axes added (a vector as a [1, n] row): the same rows
+                for j_, o in enumerate(nits_):
+                    on = iprod.get(o)
+                    if on is not None and on.op == "DimShuffle" and on.inputs[0] == v and \
+                            [d for d in on.params["new_order"] if d != "x"] == list(range(inner.vars[v].ndim)):
+                        len_v = node.inputs[1 + n_seqs + n_mm + n_ms + n_ss + n_sh + j_]
+                        if len_v != n_steps_v:
+                            need_equal.append((len_v, n_steps_v))
+                        o_ = plan.new_var(inner.vars[v].dtype, [None] + list(inner.vars[v].shape))
+                        keep = [0] + [1 + k for k, d in enumerate(on.params["new_order"]) if d != "x"]
+                        post.append(Node("DimShuffle", [node.outputs[n_mm + n_ms + n_ss + j_]], [o_],
+                                         {"new_order": keep}))
+                        return o_
+            if v not in new_nit_outs:
+                new_nits.append(v)
+                new_nit_outs[v] = plan.new_var(inner.vars[v].dtype, [None] + list(inner.vars[v].shape))
+            return new_nit_outs[v]
+
+        done = []
+        for q, alpha, kind, a, b in found:
+            mark = (len(post), len(new_nits), dict(new_nit_outs))
+            ra, rb = rows_of(a), rows_of(b)
+            if ra is None or rb is None:
+                del post[mark[0]:]
+                del new_nits[mark[1]:]
+                new_nit_outs.clear()
+                new_nit_outs.update(mark[2])
+                continue
+            old = node.outputs[base_out + q]
+            init_buf = node.inputs[base_in + q]
+            dt = V[old].dtype
+            if kind == "gemm":
+                # sum_t A_t[m, k] @ B_t[k, n] = [m, T*k] @ [T*k, n]
+                at_ = plan.new_var(dt, [None, None, None])
+                post.append(Node("DimShuffle", [ra], [at_], {"new_order": [1, 0, 2]}))
+                m_ = plan.new_var("int64", [])
+                post.append(Node("Shape_i", [init_buf], [m_], {"i": 1}))
+                n_ = plan.new_var("int64", [])
+                post.append(Node("Shape_i", [init_buf], [n_], {"i": 2}))
+                neg = plan.add_const(-1, "int64")
+                sa, sb = plan.new_var("int64", [2]), plan.new_var("int64", [2])
+                post.append(Node("MakeVector", [m_, neg], [sa], {"dtype": "int64"}))
+                post.append(Node("MakeVector", [neg, n_], [sb], {"dtype": "int64"}))
+                a2, b2 = plan.new_var(dt, [None, None]), plan.new_var(dt, [None, None])
+                post.append(Node("Reshape", [at_, sa], [a2], {"ndim": 2}))
+                post.append(Node("Reshape", [rb, sb], [b2], {"ndim": 2}))
+            else:
+                # sum_t outer(x_t, y_t) = X[T, m]^T @ Y[T, n]
+                a2 = plan.new_var(dt, [None, None])
+                post.append(Node("DimShuffle", [ra], [a2], {"new_order": [1, 0]}))
+                b2 = rb
+            prod = plan.new_var(dt, [None, None])
+            post.append(Node("Dot22", [a2, b2], [prod], {}))
+            prod3 = plan.new_var(dt, [1, None, None])
+            post.append(Node("DimShuffle", [prod], [prod3], {"new_order": ["x", 0, 1]}))
+            new = plan.new_var(dt, list(V[old].shape))
+            sc = {"n_in": 2, "nodes": [{"op": "mul", "in": [["c", alpha, dt], ["i", 1]], "dtype": dt},
+                                       {"op": "add", "in": [["i", 0], ["t", 0]], "dtype": dt}],
+                  "out": [["t", 1]]}
+            post.append(Node("Elemwise", [init_buf, prod3], [new], {"scalar": sc}))
+            replaced[old] = new
+            done.append(q)
+            if need_one_row is not None:
+                need_one_row.append(init_buf)
+        if not done:
+            out_nodes.append(node)
+            continue
+        changed = True
+        dq = set(done)
+        new_inputs = [v for k, v in enumerate(node.inputs) if not (base_in <= k < base_in + n_ss and k - base_in in dq)]
+        new_outputs = [v for k, v in enumerate(node.outputs) if not (base_out <= k < base_out + n_ss and k - base_out in dq)]
+        in_keep = [v for k, v in enumerate(inner.inputs) if not (tap0 <= k < tap0 + n_ss and k - tap0 in dq)]
+        out_keep = [v for k, v in enumerate(inner.outputs) if not (out0 <= k < out0 + n_ss and k - out0 in dq)]
+        # the additional nit-sot outputs: behind the existing ones (inner outputs, Scan outputs) and
+        # their lengths behind the existing lengths (Scan inputs: ..., shared, nit-sot lengths, non-seqs)
+        n_ss2 = n_ss - len(dq)
+        o_nit_end = sum(len(t) for t in mm_out) + n_ms + n_ss2 + n_nit
+        out_keep = out_keep[:o_nit_end] + new_nits + out_keep[o_nit_end:]
+        so_nit_end = n_mm + n_ms + n_ss2 + n_nit
+        new_outputs = new_outputs[:so_nit_end] + [new_nit_outs[v] for v in new_nits] + new_outputs[so_nit_end:]
+        si_nit_end = 1 + n_seqs + n_mm + n_ms + n_ss2 + n_sh + n_nit
+        new_inputs = new_inputs[:si_nit_end] + [n_steps_v] * len(new_nits) + new_inputs[si_nit_end:]
+        gone = {id(iprod[inner.outputs[out0 + q]]) for q in dq}        # the accumulating products themselves
+        new_inner = Plan(inner.name + "_noprod", inner.vars, in_keep, out_keep,
+                         [n_ for n_ in inner.nodes if id(n_) not in gone])
+        new_inner.nodes = _prune_dead(new_inner, list(new_inner.nodes))
+        p["inner"] = new_inner
+        p["sit_sot_in_slices"] = [t for q, t in enumerate(ss) if q not in dq]
+        p["n_nit_sot"] = n_nit + len(new_nits)
+        out_nodes.append(Node("Scan", new_inputs, new_outputs, p))
+        out_nodes.extend(post)
+    if not changed:
+        return orig
+    plan.nodes = [Node(n_.op, [replaced.get(i, i) for i in n_.inputs], list(n_.outputs), n_.params) for n_ in out_nodes]
+    plan.outputs = [replaced.get(o, o) for o in plan.outputs]
+    return plan
+
+
 def merge_shared_left_dots(plan: Plan) -> Plan:
     """Several ``Dot22(x, W_k)`` with the SAME left operand and plan-input right operands (the
     ``x_t @ W_gate`` products of every gate, lifted over a whole sequence: ``[T*B, K] @ [K, H]``

@@ -106,6 +106,9 @@ class Program:
         self.older = {}             # inner input var of a tap < -1 -> (recurrent output, depth)
         self.depth = {}             # recurrent output -> deepest tap (1 = the usual sit-sot)
         self.n_rec_inputs = 0       # inner inputs taken by the recurrent outputs' taps
+        self.tap_top = {}           # mit-mot sequence var -> the tap it is (the group's largest)
+        self.mm_extra = []          # [(slot, group, out tap)]: out-taps 2.. of a mit-mot group write the
+        #                             group's buffer too — further output slots on the same buffer
 
 
 class _DotPhase:
@@ -138,10 +141,17 @@ def analyze(inner, p, n_seqdots):
     # buffer and overwrites row i + 1.  Row i is what step i - 1 wrote (the running value: a
     # state with its initial value in row 0), row i + 1 still holds what the caller put there
     # (the incoming gradient of that step): a sequence that happens to live in the output buffer.
+    # The gradient of a recurrence with taps [-1 .. -m] gives taps [0 .. m] -> [1 .. m] (in any
+    # order): out-tap j of step i is what step i + 1 reads as tap j - 1 — m states, each with its
+    # own output slot on the SAME buffer (the slot of out-tap j starts one row after the row tap
+    # j - 1 reads first), and the largest tap is the buffer-resident sequence.  Other tap sets (a
+    # value read again two or more steps after it was written) stay on the launch list.
     mm_in = [list(t) for t in p.get("mit_mot_in_slices", [])]
     mm_out = [list(t) for t in p.get("mit_mot_out_slices", [])]
-    if any(t != [0, 1] for t in mm_in) or any(t != [1] for t in mm_out):
-        return None, "mit-mot taps other than [0, 1] -> [1]"
+    if len(mm_in) != len(mm_out) or any(
+            len(ti) < 2 or sorted(ti) != list(range(len(ti))) or sorted(to) != list(range(1, len(ti)))
+            for ti, to in zip(mm_in, mm_out)):
+        return None, "mit-mot taps other than [0 .. m] -> [1 .. m]"
     n_mm = len(mm_in)
     # sit-sot / mit-sot outputs: the tap -1 value is the recurrent state proper (may feed dots, is
     # exchanged); older taps (-2, -3, ...: scan_perform.pyx:321-340 hands the step one row per
@@ -159,11 +169,24 @@ def analyze(inner, p, n_seqdots):
     for s, v in enumerate(ins[:n_seqs]):
         pr.seq[v] = s
     idx = n_seqs
-    for g in range(n_mm):
-        pr.state[ins[idx]] = g
-        pr.seq[ins[idx + 1]] = n_seqs + n_seqdots + g     # slot of the buffer-resident sequence
-        pr.tap_seq[ins[idx + 1]] = g
-        idx += 2
+    n_outer = n_rec + n_nit
+    slot_of_mm = {}                                       # (group, out tap) -> output slot
+    for g, ti in enumerate(mm_in):
+        m = len(ti) - 1
+        for j in range(1, m + 1):
+            if j == 1:
+                slot_of_mm[(g, j)] = g
+            else:
+                slot_of_mm[(g, j)] = n_outer + len(pr.mm_extra)
+                pr.mm_extra.append((n_outer + len(pr.mm_extra), g, j))
+        for tap in ti:
+            if tap < m:
+                pr.state[ins[idx]] = slot_of_mm[(g, tap + 1)]
+            else:
+                pr.seq[ins[idx]] = n_seqs + n_seqdots + g     # slot of the buffer-resident sequence
+                pr.tap_seq[ins[idx]] = g
+                pr.tap_top[ins[idx]] = m
+            idx += 1
     for k, tk in enumerate(taps):
         for tap in tk:
             if tap == -1:
@@ -275,19 +298,25 @@ def analyze(inner, p, n_seqdots):
                           "scalar": st.scalar, "out_refs": list(st.out_refs)})
     if len(pr.mats) > SP_MAXMAT or len(pr.nsq) > SP_MAXNSQ or not pr.mats:
         return None, "no / too many matrices"
-    if len(plan.outputs) != n_rec + n_nit or len(plan.outputs) > SP_MAXOUT:
+    # inner outputs: every out-tap of every mit-mot group, the mit-sot / sit-sot outputs, the nit-sots
+    slot_of = [slot_of_mm[(g, j)] for g, to in enumerate(mm_out) for j in to] + \
+        list(range(n_mm, n_rec)) + list(range(n_rec, n_rec + n_nit))
+    if len(plan.outputs) != len(slot_of) or n_outer + len(pr.mm_extra) > SP_MAXOUT:
         return None, "output count"
-    for j, o in enumerate(plan.outputs):
+    inner_of_slot = {}
+    for ji, o in enumerate(plan.outputs):
+        j = slot_of[ji]
+        inner_of_slot[j] = ji
         if res(o) not in produced:
-            if j >= n_rec and res(o) in pr.seq and res(o) not in pr.tap_seq:
+            if n_rec <= j < n_outer and res(o) in pr.seq and res(o) not in pr.tap_seq:
                 pr.passthru[j] = res(o)      # a nit-sot output that is a row of a sequence
                 if o in pr.passthru_t:
                     pr.passthru_tj.add(j)
                 continue
             return None, "a step output is not computed by a fused step"
-        pr.outs.append((res(o), "rec" if j < n_rec else "nit", j))
+        pr.outs.append((res(o), "nit" if n_rec <= j < n_outer else "rec", j))
     for v, k in pr.state.items():
-        pr.new_of_state[v] = res(plan.outputs[k])
+        pr.new_of_state[v] = res(plan.outputs[inner_of_slot[k]])
     # which produced vectors have to be exchanged (some dot reads them in full)
     need = []
     for ph in pr.phases:

@@ -48,6 +48,39 @@ def test_persistent_path_is_taken_and_matches(name, use_graph):
         np.testing.assert_allclose(g, r, rtol=tol, atol=tol)
 
 
+@pytest.mark.parametrize("name", ["sp_taps_bptt_f64", "sm_taps_bptt_b16_f32", "scan_variant_1",
+                                  "scan_variant_4", "scan_variant_7", "scan_variant_10"])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_two_tap_bptt_runs_persistent(name, use_graph):
+    """Round 4: the gradient Scan of a recurrence with taps [-1, -2] WITH products.  Two things
+    kept it on the launch list: its mit-mot output has taps [0, 1, 2] -> [1, 2] (two states on one
+    buffer: out-tap j of step i is tap j - 1 of step i + 1; scan/op.py:2379) and it accumulates
+    the weight gradient inside the loop (a sit-sot Gemm / Ger per step that the reference's
+    PushOutDot1 lifts for one tap only) — now ONE product over the stacked operands behind the
+    loop (fusion.push_out_product_accumulators, decided per call: the buffer holds one row).
+    Forward and gradient Scan both persistent; results = the reference's, = the launch-list path
+    to summation order."""
+    from aesara_amd import executor as E
+    c = _case(name)
+    ex = E.PlanExecutor(case_plan(c), use_graph=use_graph)
+    ins = case_inputs(c)
+    for it in range(3):
+        got = _np(ex(*ins))
+        assert_matches(c, got, case_expected(c), f"persistent call {it}")
+    assert list(ex.scan_modes.values()) == ["persistent", "persistent"], ex.scan_modes
+    E.TUNE["scan_persist"] = 0
+    try:
+        ex2 = E.PlanExecutor(case_plan(c), use_graph=use_graph)
+        ref = _np(ex2(*ins))
+        assert all(v.startswith("launch-list") for v in ex2.scan_modes.values())
+    finally:
+        E.TUNE["scan_persist"] = 1
+    tol = 2e-4 if name.endswith("f32") else 1e-10
+    for g, r in zip(got, ref):
+        np.testing.assert_allclose(g, r, rtol=tol, atol=tol)
+    ex.check()
+
+
 def test_outside_the_class_falls_back():
     from aesara_amd.executor import PlanExecutor
     c = _case("sp_rnn_proj_narrow_f32")
