@@ -54,10 +54,12 @@ _def("SCAN_PERSIST", 1, int, "Scan loops as ONE persistent kernel where the clas
 _def("COOP", 0, int, "persistent kernels through hipLaunchCooperativeKernel (launch-time size check)")
 _def("SCAN_ROWS", None, str, "rows x waves geometry of the vector-state persistent kernel")
 _def("SCAN_WAVES", 4, int, "waves per workgroup of the vector-state persistent kernel")
-_def("SP_POLLW", 2, int, "polling waves of the vector-state kernel")
+_def("SP_POLLW", 4, int, "polling waves of the vector-state kernel (r04, with the first poll held back: 2 -> 4 "
+     "waves 4.05 -> 3.56 us per step at config 4 B = 1)")
 _def("SP_SLEEP", 1, int, "s_sleep between polls of the vector-state kernel")
-_def("SP_DELAY", 12, int, "vector-state kernel: s_sleep units (64 cycles) before the first poll of a hand-off "
-     "(config 4 B = 1: 4.59 us per step with 0, 4.05 with 12, 4.27 with 20)")
+_def("SP_DELAY", 15, int, "vector-state kernel: s_sleep units (64 cycles) before the first poll of a hand-off "
+     "(config 4 B = 1, 128 x 8 rows, 2 polling waves: 4.59 us per step with 0, 4.05 with 12, 4.27 with 20; "
+     "256 x 4 rows, 4 polling waves: 3.52 / 3.42 / 3.38 / 3.37 / 3.43 with 10 / 12 / 14 / 16 / 18)")
 _def("SP_REPOLL", 0, int, "re-poll only the granules that were missing")
 _def("SM_CHUNK", 32, int, "k-chunk of the matrix-state kernel's exchange")
 _def("SM_XMODE", None, str, "exchange form of the matrix-state kernel: frag | flag (default by registers)")
