@@ -591,3 +591,48 @@ def test_sequence_products_move_into_the_loop_at_eligible_shapes(name, folded, m
     ex = PlanExecutor(case_plan(c), dry_run=True)
     ex(*case_inputs(c))
     assert list(ex.scan_modes.values()) == ["persistent"] and not ex.scan_notes
+
+
+_PRODUCT_ACC = ["sp_taps_bptt_f64", "sm_taps_bptt_b16_f32", "scan_variant_1", "scan_variant_2", "scan_variant_4",
+                "scan_variant_5", "scan_variant_7", "scan_variant_8", "scan_variant_10", "scan_variant_11"]
+
+
+@pytest.mark.parametrize("name", _PRODUCT_ACC)
+def test_product_accumulators_leave_the_loop_as_one_product(name):
+    """fusion.push_out_product_accumulators (what PushOutDot1 of the reference, scan/rewriting.py,
+    does for the one-tap gradient only): the weight gradient a gradient Scan sums inside its loop —
+    a sit-sot ``Gemm(acc, 1, A_t, B_t, 1)`` / ``Ger(acc, 1, x_t, y_t)`` — becomes one product over
+    the stacked per-step operands behind the loop.  The rewritten plan, run by the NumPy oracle, must
+    reproduce the REFERENCE's outputs; the Scan must have lost the accumulator (and nothing else);
+    the runtime conditions (one-row buffer, nit-sot outputs that keep every row) are reported."""
+    import interp
+    from golden_util import assert_matches
+    from aesara_amd.fusion import push_out_accumulators, push_out_product_accumulators
+    c = next(c for c in CASES if c["name"] == name)
+    p1 = push_out_accumulators(case_plan(c))
+    # (without the lists only buffers whose length is STATICALLY one row are rewritten: an Alloc of
+    # a shape expression usually is not — the executor decides per call)
+    one_row, equal = [], []
+    p2 = push_out_product_accumulators(p1, one_row, equal)
+    assert p2 is not p1 and len(one_row) == 1
+    s1 = [n for n in p1.nodes if n.op == "Scan"]
+    s2 = [n for n in p2.nodes if n.op == "Scan"]
+    assert len(s1) == len(s2)
+    changed = [(a, b) for a, b in zip(s1, s2)
+               if len(a.params["sit_sot_in_slices"]) != len(b.params["sit_sot_in_slices"])]
+    assert len(changed) == 1
+    a, b = changed[0]
+    assert len(a.params["sit_sot_in_slices"]) - len(b.params["sit_sot_in_slices"]) == 1
+    assert len(b.inputs) <= len(a.inputs) and len(b.outputs) <= len(a.outputs)
+    assert not any(n.op in ("Gemm", "Ger") and b.params["inner"].inputs and
+                   n.inputs[0] in a.params["inner"].inputs and n.inputs[0] not in b.params["inner"].inputs
+                   for n in b.params["inner"].nodes)
+    got = interp.run_plan(p2, case_inputs(c))
+    assert_matches(c, got, case_expected(c), "accumulator behind the loop")
+    # and through the executor's own dispatch (dry run: kernels generated and compiled, no launch):
+    # the two-tap cases without reductions in the forward step run both Scans persistent
+    ex = PlanExecutor(case_plan(c), dry_run=True)
+    ex(*case_inputs(c))
+    if name in ("sp_taps_bptt_f64", "sm_taps_bptt_b16_f32", "scan_variant_1", "scan_variant_4",
+                "scan_variant_7", "scan_variant_10"):
+        assert list(ex.scan_modes.values()) == ["persistent", "persistent"], ex.scan_modes
