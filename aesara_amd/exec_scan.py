@@ -375,8 +375,63 @@ class ScanMixin:
                                          (b.strides[0],) + tuple(0 if d == 1 else 1 for d in shp))
         return None
 
+    def _scan_persist_mat_chunks(self, rows, prog, p, inner, n_steps, seqs, outs, store, pos, non_seqs,
+                                 pre_rows, n_rec, n_nit, xfold, inv_vars):
+        """A batch too large for one 16 x 16 tile per workgroup, run as consecutive launches of the
+        one-block-per-workgroup kernel over slices of ``rows`` batch rows: batch rows are
+        independent recurrences, every operand with a batch axis is sliced (views: no copies), the
+        weights are shared.  Each launch is the kernel the B = ``rows`` case runs (in-loop sequence
+        products and the schedule around the hand-offs included: config 4 at B = 128 two launches of
+        the B = 64 kernel, 0.66 of the MFMA peak, instead of one launch with two blocks per workgroup
+        at 0.53)."""
+        Bn = outs[0].shape[1]
+        lo_hi = [(b0, min(b0 + rows, Bn)) for b0 in range(0, Bn, rows)]
+
+        def cut(a, axis, b0, b1):
+            shape = list(a.shape)
+            shape[axis] = b1 - b0
+            return a.view(tuple(shape), a.strides, a.offset + b0 * a.strides[axis])
+        nsq_vars = set(prog.nsq)
+        full_nit = {}
+        full_front = {}
+        for b0, b1 in lo_hi:
+            seqs_c = [cut(a, 1, b0, b1) if a.ndim == 3 and a.shape[1] == Bn else a for a in seqs]
+            pre_c = [None if a is None else (cut(a, 1, b0, b1) if a.ndim == 3 and a.shape[1] == Bn else a)
+                     for a in pre_rows]
+            outs_c = [None if a is None else cut(a, 1, b0, b1) for a in outs]
+            non_c = []
+            for v, a in zip(inv_vars, non_seqs):
+                if v in nsq_vars and isinstance(a, DevArray) and a.ndim == 2 and a.shape[0] == Bn and Bn != 1:
+                    a = cut(a, 0, b0, b1)
+                non_c.append(a)
+            xf_c = None
+            if xfold is not None:
+                def front(k, b0=b0, b1=b1):
+                    if k not in full_front:
+                        full_front[k] = xfold["up_front"](k)        # the whole batch once
+                    return cut(full_front[k], 1, b0, b1)
+                xf_c = dict(xfold, x=cut(xfold["x"], 1, b0, b1), up_front=front)
+            why = self._scan_persist_mat(prog, p, inner, n_steps, seqs_c, outs_c, store, pos, non_c, pre_c,
+                                         n_rec, n_nit, xfold=xf_c, _chunk=True)
+            if why is not None and xf_c is not None:
+                # (a ragged last slice: its sequence products up front after all)
+                pre_c = [front(k) if a is None else a for k, a in enumerate(pre_c)]
+                why = self._scan_persist_mat(prog, p, inner, n_steps, seqs_c, outs_c, store, pos, non_c, pre_c,
+                                             n_rec, n_nit, xfold=None, _chunk=True)
+            if why is not None:
+                return why if b0 == 0 else "batch slice %d: %s" % (b0 // rows, why)
+            for j in range(n_nit):               # nit-sot outputs of the slice -> their rows of the whole
+                k = n_rec + j
+                o = outs_c[k]
+                if k not in full_nit:
+                    full_nit[k] = inner.alloc((o.shape[0], Bn) + tuple(o.shape[2:]), o.dtype)
+                inner.copy_into(cut(full_nit[k], 1, b0, b1), o)
+        for k, a in full_nit.items():
+            outs[k] = a
+        return None
+
     def _scan_persist_mat(self, prog, p, inner, n_steps, seqs, outs, store, pos, non_seqs,
-                          pre_rows, n_rec, n_nit, xfold=None):
+                          pre_rows, n_rec, n_nit, xfold=None, _chunk=False):
         """Matrix-state class (a batch of recurrences, small-M GEMM chains): one persistent
         kernel, weights in VGPRs in MFMA layout (aesara_amd/scan_persist_mat.py)."""
         from . import scan_persist_mat as sm
@@ -404,6 +459,12 @@ class ScanMixin:
         cus = 256 if self.dry_run else torch.cuda.get_device_properties(self.device).multi_processor_count
         NB, NJ = -(-Bn // 16), N // 16
         nblk = 1
+        mode_ = int(knobs.get("SM_BATCH_CHUNKS"))
+        if NB * NJ > cus and not _chunk and cus // NJ >= 1 and not prog.passthru and \
+                (mode_ == 2 or (mode_ == 1 and not prog.tap_seq)):
+            # consecutive launches over slices of the batch, one block per workgroup each
+            return self._scan_persist_mat_chunks((cus // NJ) * 16, prog, p, inner, n_steps, seqs, outs, store,
+                                                 pos, non_seqs, pre_rows, n_rec, n_nit, xfold, inv_vars)
         if NB * NJ > cus:
             # 2 / 4 / 8 batch blocks per workgroup (independent recurrences sharing the weight registers:
             # the step body runs once per block) — fragment form, products up front only
@@ -597,7 +658,17 @@ class ScanMixin:
                           (xs.strides[0], 16 * xs.strides[1], (K_ // 4) * xs.strides[2], 4 * xs.strides[2],
                            (K_ // 16) * xs.strides[2], xs.strides[1], xs.strides[2]))
             xp = inner.alloc((n_steps, NB, 4, Q_, 4, 16, 4), f32)
-            inner.copy_into(xp, src)
+            if xs.strides[0] == xs.shape[1] * xs.strides[1] or n_steps == 1 or NB == 1:
+                inner.copy_into(xp, src)        # (steps and batch blocks collapse: six dimensions)
+            else:
+                # a slice of a larger batch: seven dimensions that do not collapse — one copy per
+                # K quarter (the kernels take AHIP_MAXD = 6)
+                for w_ in range(4):
+                    inner.copy_into(
+                        xp.view((n_steps, NB, Q_, 4, 16, 4), xp.strides[:2] + xp.strides[3:],
+                                xp.offset + w_ * xp.strides[2]),
+                        src.view((n_steps, NB, Q_, 4, 16, 4), src.strides[:2] + src.strides[3:],
+                                 src.offset + w_ * src.strides[2]))
             sx = xf_spec["sx"]
             g.seq[sx], g.seq_ts[sx], g.seq_rs[sx], g.seq_cs[sx] = xp.ptr, NB * 16 * K_, 0, 0
             for (_v, _pi, _d, slot), W in zip(xf_spec["items"], xf_w):

@@ -94,6 +94,10 @@ _def("SM_SPIN_DELAY", 15, int, "fragment form, fetches with nothing in front of 
 _def("SM_LOOK", 8, int, "fragments of a window's head issued before the first look at the tags")
 _def("SM_ASM_MARKS", 0, int, "label the phase marks in the ISA (asm comments; for reading disassembly)")
 _def("SM_XTAIL", 8, int, "fragments of the sequence product behind the payload loads")
+_def("SM_BATCH_CHUNKS", 1, int, "a batch whose 16 x 16 tiles outnumber the CUs runs as several launches of the "
+     "one-block-per-workgroup kernel over slices of the batch (independent recurrences) instead of one launch with "
+     "2 / 4 / 8 blocks per workgroup: 1 = forward Scans (their in-loop sequence products need one block per "
+     "workgroup), 2 = every Scan, 0 = never")
 _def("SM_XFOLD", 1, int, "sequence products x_t @ W inside the loop")
 _def("SM_XREG", 0, int, "1 = in-loop sequence products beyond the LDS capacity keep their weight columns in "
      "accumulation registers (as many as fit next to the recurrent weights); 0 = those are computed up front "

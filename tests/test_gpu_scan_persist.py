@@ -554,7 +554,9 @@ def test_persistent_scan_next_to_a_saturating_stream_and_occupancy_refusal():
                                    # round 4 (hand-offs re-scheduled): loops shorter than the schedule's
                                    # look-ahead, 8 fragments per product (the staged-operand product
                                    # split without a look inside it)
-                                   (2, 512, 32), (2, 1024, 16), (3, 1024, 64), (9, 512, 64)])
+                                   (2, 512, 32), (2, 1024, 16), (3, 1024, 64), (9, 512, 64),
+                                   # more 16 x 16 tiles than CUs: consecutive launches over batch slices
+                                   (5, 1024, 128), (4, 1024, 256), (6, 512, 160)])
 def test_sequence_products_inside_the_persistent_loop(T, H, B, monkeypatch):
     """Round 3: the ``x_t @ W`` products of a batched recurrence are computed INSIDE the persistent
     matrix kernel (fragment-ordered x, weight columns in LDS — as many products as fit, the others
@@ -600,6 +602,41 @@ def test_sequence_products_inside_the_persistent_loop(T, H, B, monkeypatch):
     ex = PlanExecutor(plan)
     ex(x[:, :B - 3].contiguous(), h0[:B - 3].contiguous(), *Ws)             # ragged batch: up front
     assert list(ex.scan_modes.values()) == ["persistent"] and not ex.scan_notes
+
+
+@pytest.mark.parametrize("T,H,B,chunks", [(6, 1024, 200, "1"), (6, 1024, 128, "0"), (5, 512, 300, "1"),
+                                          (5, 1024, 136, "2")])
+def test_batches_beyond_one_tile_per_workgroup(T, H, B, chunks, monkeypatch):
+    """B * H / 256 tiles > CUs: consecutive launches of the one-block-per-workgroup kernel over slices
+    of the batch (SM_BATCH_CHUNKS, the default for forward Scans; a ragged last slice included) or
+    one launch with 2 / 4 / 8 blocks per workgroup (=0) — every step within 1e-5 of fp64 either way."""
+    import torch
+    from aesara_amd.executor import PlanExecutor
+    monkeypatch.setenv("AESARA_HIP_SM_BATCH_CHUNKS", chunks)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(13)
+    x = torch.randn(T, B, H, dtype=torch.float32, device="cuda", generator=g) * 0.3
+    h0 = torch.randn(B, H, dtype=torch.float32, device="cuda", generator=g) * 0.5
+    Ws = [torch.randn(H, H, dtype=torch.float32, device="cuda", generator=g) / np.sqrt(H) for _ in range(6)]
+    Wz, Uz, Wr, Ur, Wh, Uh = [W.double() for W in Ws]
+    h, ref = h0.double(), []
+    for t in range(T):
+        xt = x[t].double()
+        z = torch.sigmoid(xt @ Wz + h @ Uz)
+        r = torch.sigmoid(xt @ Wr + h @ Ur)
+        h = (1 - z) * h + z * torch.tanh(xt @ Wh + (r * h) @ Uh)
+        ref.append(h)
+    ref = torch.stack(ref)
+    for use_graph in (False, True):
+        ex = PlanExecutor(case_plan(_case("cfg4_gru_b8_f32")), use_graph=use_graph)
+        for _ in range(3):
+            hs, hT = ex(x, h0, *Ws)
+        if chunks != "0" or B % 32 == 0:
+            assert list(ex.scan_modes.values()) == ["persistent"], ex.scan_modes
+        err = ((hs.double() - ref).abs().max() / ref.abs().max()).item()
+        assert err <= 1e-5, (use_graph, err)
+        assert torch.equal(hT, hs[-1])
+        ex.check()
 
 
 @pytest.mark.parametrize("knobs_", [{"AESARA_HIP_SM_XREG": "1"}, {"AESARA_HIP_SM_POLLS": "4"},
