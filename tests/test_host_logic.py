@@ -636,3 +636,64 @@ def test_product_accumulators_leave_the_loop_as_one_product(name):
     if name in ("sp_taps_bptt_f64", "sm_taps_bptt_b16_f32", "scan_variant_1", "scan_variant_4",
                 "scan_variant_7", "scan_variant_10"):
         assert list(ex.scan_modes.values()) == ["persistent", "persistent"], ex.scan_modes
+
+
+def test_design_lists_every_switch_of_the_registry():
+    """DESIGN §3.5's table is generated from ``aesara_amd/knobs.py`` (``knobs.table()``): every
+    registered switch appears there with its current default, and nothing outside the registry
+    reads ``AESARA_HIP_*`` from the environment."""
+    import os
+    import re
+    from aesara_amd import knobs
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    design = open(os.path.join(root, "DESIGN.md")).read()
+    for name, default, _cur, _doc in knobs.table():
+        m = re.search(r"\| `%s` \| ([^|]*) \|" % re.escape(name), design)
+        assert m, f"{name} missing from DESIGN §3.5"
+        assert m.group(1).strip() == ("—" if default is None else str(default)), (name, m.group(1), default)
+    pkg = os.path.join(root, "aesara_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py") and fn != "knobs.py":
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"environ[^\n]*AESARA_HIP_", src), f"{fn} reads an AESARA_HIP_* switch directly"
+
+
+@pytest.mark.parametrize("B,launches,folded", [(64, 1, True), (128, 2, True), (200, 4, False), (256, 4, True)])
+def test_large_batches_run_as_slices_of_the_batch(B, launches, folded):
+    """A forward matrix-state Scan whose 16 x 16 tiles outnumber the CUs (dry run: 256) is handed to
+    the one-block-per-workgroup kernel slice by slice (exec_scan._scan_persist_mat_chunks): one
+    persistent launch per slice of 64 batch rows at H = 1024, the in-loop sequence products kept
+    when every slice is a multiple of 16 rows."""
+    plan = case_plan(next(c for c in CASES if c["name"] == "cfg4_gru_b8_f32"))
+    T, H = 6, 1024
+    Ws = [np.zeros((H, H), "float32") for _ in range(6)]
+    ex = PlanExecutor(plan, dry_run=True)
+    ex(np.zeros((T, B, H), "float32"), np.zeros((B, H), "float32"), *Ws)
+    assert list(ex.scan_modes.values()) == ["persistent"], ex.scan_modes
+    assert sum(1 for t in ex.trace if t == "ahip_launch_p") == launches
+    assert bool(ex.scan_notes) == folded, ex.scan_notes
+
+
+def test_two_tap_gradient_scan_maps_to_two_states_on_one_buffer():
+    """scan_persist.analyze on the gradient Scan of a two-tap recurrence (after the weight-gradient
+    product left the loop): mit-mot taps [0, 2, 1] -> [2, 1] = two states — tap 0 with the output
+    slot of out-tap 1 (the group's own slot), tap 1 with a further slot on the same buffer for
+    out-tap 2 — and tap 2 as the buffer-resident sequence."""
+    from aesara_amd import scan_persist as sp
+    from aesara_amd.fusion import push_out_product_accumulators
+    c = next(c for c in CASES if c["name"] == "sm_taps_bptt_b16_f32")
+    plan = push_out_product_accumulators(case_plan(c), [], [])
+    node = [n for n in plan.nodes if n.op == "Scan"][1]
+    p = node.params
+    assert p["mit_mot_in_slices"] == [[0, 2, 1]] and p["mit_mot_out_slices"] == [[2, 1]] and not p["sit_sot_in_slices"]
+    inner = PlanExecutor(p["inner"], dry_run=True)
+    prog, why = sp.analyze(inner, p, 0)
+    assert prog is not None, why
+    ins = p["inner"].inputs
+    t0, t2, t1 = ins[p["n_seqs"]:p["n_seqs"] + 3]
+    n_outer = 1 + p["n_nit_sot"]
+    assert prog.mm_extra == [(n_outer, 0, 2)]
+    assert prog.state[t0] == 0 and prog.state[t1] == n_outer          # slots of out-taps 1 and 2
+    assert prog.tap_seq == {t2: 0} and prog.tap_top == {t2: 2}
+    outs = p["inner"].outputs                                         # [out-tap 2, out-tap 1, nit-sots ...]
+    assert prog.new_of_state[t1] == outs[0] and prog.new_of_state[t0] == outs[1]
