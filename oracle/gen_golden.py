@@ -937,6 +937,35 @@ def _():
     return [x, W], [res], [N((12, 6), seed=1), N((6, 6), seed=2)]
 
 
+@case("scan_nitsot_value_and_its_view", rtol=1e-12, atol=1e-12)
+def _():
+    """Two nit-sot outputs that are the same value in two shapes (a vector and the [1, n] row view of
+    it, DimShuffle 'x', 0) next to the recurrent output — what a gradient Scan hands out when a
+    per-step vector is needed both ways; exercises the launch list's write-into-the-output-row
+    targets when one output is a view of another."""
+    x, W = at.dmatrix("x"), at.dmatrix("W")
+
+    def step(x_t, h, W):
+        u = at.tanh(at.dot(h, W) + x_t)
+        return u * 0.5 + h * 0.5, u, u.dimshuffle("x", 0)
+    (hs, us, urows), _ = ae.scan(step, sequences=[x], outputs_info=[at.zeros_like(x[0]), None, None],
+                                 non_sequences=[W])
+    return [x, W], [hs, us, urows, (urows * 2.0).sum(axis=1)], [N((7, 5), seed=1), N((5, 5), seed=2, scale=0.4)]
+
+
+@case("scan_nitsot_view_then_value", rtol=1e-12, atol=1e-12)
+def _():
+    """The same with the row view handed out BEFORE the value it is a view of, and the value twice."""
+    x, W = at.dmatrix("x"), at.dmatrix("W")
+
+    def step(x_t, h, W):
+        u = at.tanh(at.dot(h, W) + x_t)
+        return u * 0.5 + h * 0.5, u.dimshuffle("x", 0), u, u
+    (hs, urows, us, us2), _ = ae.scan(step, sequences=[x], outputs_info=[at.zeros_like(x[0]), None, None, None],
+                                      non_sequences=[W])
+    return [x, W], [hs, urows, us, us2 * 3.0], [N((7, 5), seed=1), N((5, 5), seed=2, scale=0.4)]
+
+
 @case("scan_two_outputs", rtol=1e-12, atol=1e-12)
 def _():
     x, a0, b0 = at.dvector("x"), at.dscalar("a0"), at.dscalar("b0")

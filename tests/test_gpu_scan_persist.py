@@ -81,6 +81,28 @@ def test_two_tap_bptt_runs_persistent(name, use_graph):
     ex.check()
 
 
+@pytest.mark.parametrize("name", ["scan_nitsot_value_and_its_view", "scan_nitsot_view_then_value"])
+@pytest.mark.parametrize("persist", [1, 0])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_nitsot_value_and_its_view_both_handed_out(name, persist, use_graph):
+    """A per-step vector handed out twice — as it is and as its [1, n] row view (DimShuffle 'x', 0) —
+    next to the recurrent output: on the persistent kernel (the row view is the same rows under
+    another shape) and on the launch list (each output row is a kernel's write target; one output
+    being a view of another must not make them share one)."""
+    from aesara_amd import executor as E
+    c = _case(name)
+    E.TUNE["scan_persist"] = persist
+    try:
+        ex = E.PlanExecutor(case_plan(c), use_graph=use_graph)
+        for it in range(3):
+            got = _np(ex(*case_inputs(c)))
+            assert_matches(c, got, case_expected(c), f"call {it}")
+        assert all(v.startswith("persistent" if persist else "launch-list") for v in ex.scan_modes.values())
+        ex.check()
+    finally:
+        E.TUNE["scan_persist"] = 1
+
+
 def test_outside_the_class_falls_back():
     from aesara_amd.executor import PlanExecutor
     c = _case("sp_rnn_proj_narrow_f32")
