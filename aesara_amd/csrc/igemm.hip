@@ -16,6 +16,7 @@ struct igemm_args {
   const void* A; const void* B; void* C;
   int64_t M, N, K;
   int64_t a_bs, a_rs, a_cs, b_bs, b_rs, b_cs, c_bs, c_rs, c_cs;
+  int64_t mt, nt;          // tiles along M / N: blockIdx.x = (batch * mt + my) * nt + nx
 };
 AHIP_PTRS_BEGIN(igemm_args) AHIP_PTR1(A) AHIP_PTR1(B) AHIP_PTR1(C) AHIP_PTRS_END
 
@@ -25,10 +26,13 @@ template <typename T, typename Acc, bool IS_BOOL>
 __global__ __launch_bounds__(256) void igemm_kernel(igemm_args a) {
   __shared__ Acc sA[TK][TM + 1];
   __shared__ Acc sB[TK][TN + 1];
-  const T* __restrict__ A = (const T*)a.A + (int64_t)blockIdx.z * a.a_bs;
-  const T* __restrict__ B = (const T*)a.B + (int64_t)blockIdx.z * a.b_bs;
-  T* __restrict__ C = (T*)a.C + (int64_t)blockIdx.z * a.c_bs;
-  const int64_t m0 = (int64_t)blockIdx.y * TM, n0 = (int64_t)blockIdx.x * TN;
+  // one linear grid axis (up to 2^31 - 1 workgroups): neither the batch (a 2-d BatchedDot with
+  // 100k rows is batch = 100k) nor the row tiles are held to gridDim.y/z's 65535
+  const int64_t lin = blockIdx.x, nx = lin % a.nt, rest = lin / a.nt, my = rest % a.mt, bz = rest / a.mt;
+  const T* __restrict__ A = (const T*)a.A + bz * a.a_bs;
+  const T* __restrict__ B = (const T*)a.B + bz * a.b_bs;
+  T* __restrict__ C = (T*)a.C + bz * a.c_bs;
+  const int64_t m0 = my * TM, n0 = nx * TN;
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;       // 16 x 16 threads, 4 x 4 outputs each
   Acc acc[4][4] = {};
   for (int64_t k0 = 0; k0 < a.K; k0 += TK) {
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(igemm_args a) {
 
 template <typename T, typename Acc, bool IS_BOOL = false>
 int run(const igemm_args& a, int64_t batch, hipStream_t s) {
-  dim3 grid((unsigned)((a.N + TN - 1) / TN), (unsigned)((a.M + TM - 1) / TM), (unsigned)batch);
+  dim3 grid((unsigned)(a.nt * a.mt * batch));
   AHIP_LAUNCH((igemm_kernel<T, Acc, IS_BOOL>), grid, dim3(256), 0, s, a);
   return AHIP_OK;
 }
@@ -90,10 +94,11 @@ extern "C" int ahip_igemm_batched(int dtype, int64_t batch, int64_t M, int64_t N
                                   const void* B, int64_t b_bs, int64_t b_rs, int64_t b_cs, void* C,
                                   int64_t c_bs, int64_t c_rs, int64_t c_cs, void* stream) {
   AHIP_REQUIRE(batch >= 0 && M >= 0 && N >= 0 && K >= 0, "negative extent");
-  AHIP_REQUIRE(batch <= 65535 && (M + TM - 1) / TM <= 65535, "igemm: batch / row-tile count above 65535");
   if (batch == 0 || M == 0 || N == 0) return AHIP_OK;
   AHIP_REQUIRE(A && B && C, "null operand");
-  igemm_args a{A, B, C, M, N, K, a_bs, a_rs, a_cs, b_bs, b_rs, b_cs, c_bs, c_rs, c_cs};
+  const int64_t mt = (M + TM - 1) / TM, nt = (N + TN - 1) / TN;
+  AHIP_REQUIRE((double)mt * (double)nt * (double)batch < 2147483647.0, "igemm: more than 2^31 - 1 output tiles");
+  igemm_args a{A, B, C, M, N, K, a_bs, a_rs, a_cs, b_bs, b_rs, b_cs, c_bs, c_rs, c_cs, mt, nt};
   hipStream_t s = as_stream(stream);
   switch (dtype) {
     case AHIP_BOOL: return run<unsigned char, unsigned, true>(a, batch, s);

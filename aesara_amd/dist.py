@@ -740,12 +740,17 @@ def _call_single_list(self, local_inputs, sig, world):
     from .executor import HostReadInReplay
     if not all(isinstance(x, torch.Tensor) and x.is_cuda for x in local_inputs):
         return None
-    key = (sig, tuple(x.data_ptr() for x in local_inputs))
+    # the recorded launches address these buffers with this layout: dtype, shape, strides AND
+    # base address are the signature (a transposed view / a reinterpretation of the same buffer
+    # is another signature), as PlanExecutor._layout_sig keys its own replays
+    key = (sig, tuple((x.dtype, tuple(x.shape), x.stride(), x.data_ptr()) for x in local_inputs))
     ent = self._lists.get(key)
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     if ent is not None:
+        self._lists[key] = self._lists.pop(key)               # most recently used last
         check(lib.ahip_list_run(ent[0], stream))
         self.replays += 1
+        self._check_after_list()
         final = ent[1]
         return final if self.borrow else [o.clone() if isinstance(o, torch.Tensor) else o for o in final]
     if key in self._no_list:
@@ -773,7 +778,11 @@ def _call_single_list(self, local_inputs, sig, world):
                     if not isinstance(o, torch.Tensor) or o.data_ptr() != views[pos].data_ptr():
                         raise _NoSingleList("round %d: partial %d is not produced in the packed buffer" % (k, pos))
                     outs[pos] = views[pos]
-                if world > 1 or self.force_collectives:
+                # pass 1 only learns the allocation trace (shapes never depend on the combined
+                # values): the collective is issued ONCE per evaluation, by the list run below —
+                # a rank that records and a rank that replays (or falls back to the per-round
+                # path) therefore issue the same number of all-reduces and can never mis-pair
+                if recording and (world > 1 or self.force_collectives):
                     for (rop, _xdt), buf in bufs.items():
                         self.group.all_reduce(buf, rop)       # while recording: a REC_ALLREDUCE entry
             results.append(outs)
@@ -794,10 +803,38 @@ def _call_single_list(self, local_inputs, sig, world):
         self._no_list.add(key)
         return None
     check(lib.ahip_list_run(lst, stream))                     # this call's results, from the list
-    self._lists[key] = (lst, final, list(local_inputs))       # inputs kept alive: their addresses are in the list
+    # what the list addresses must outlive it: the inputs, and EVERY round's planned arena with
+    # its bound values (an executor's ``_ext`` slot is overwritten by the next signature that is
+    # recorded — the entry owns them, not the executor)
+    exts = [ex.take_external() for ex in self.execs if hasattr(ex, "take_external")]
+    self._lists[key] = (lst, final, list(local_inputs), exts)
     self.group.recorded += 1                                  # the list holds the communicator's handle
+    while len(self._lists) > self.LISTS_MAX:                  # least recently used signature goes
+        self._drop_list(next(iter(self._lists)))
     self.replays += 1
+    self._check_after_list()
     return final if self.borrow else [o.clone() if isinstance(o, torch.Tensor) else o for o in final]
+
+
+def _drop_list(self, key):
+    from ._lib import lib
+    ent = self._lists.pop(key)
+    lib.ahip_list_destroy(ent[0])
+    self.group.recorded -= 1
+
+
+def _check_after_list(self):
+    """Error words (bad index, persistent-Scan time-out) of every round's executor, examined
+    after a single-list run as the per-round path does after each round (``check_indices``)."""
+    for ex in self.execs:
+        if getattr(ex, "check_indices", False) and hasattr(ex, "_raise_bad_index"):
+            ex._raise_bad_index()
+
+
+def _close_lists(self):
+    """Destroy every recorded list (they hold the communicator's handle: ``HipComm.close``)."""
+    for key in list(self._lists):
+        self._drop_list(key)
 
 
 class _NoSingleList(Exception):
@@ -805,6 +842,10 @@ class _NoSingleList(Exception):
 
 
 ShardedPlan._call_single_list = _call_single_list
+ShardedPlan._drop_list = _drop_list
+ShardedPlan._check_after_list = _check_after_list
+ShardedPlan.close = _close_lists
+ShardedPlan.LISTS_MAX = 16      # recorded signatures kept per sharded plan (LRU)
 
 
 def run_local_shards(plan: Plan, split_inputs: Dict[int, int], shard_inputs: Sequence[Sequence],

@@ -607,6 +607,19 @@ class OpsMixin:
                                            _VP(src_ptr), src_rs, 1 if accumulate else 0,
                                            _VP(self._bad_ptr()), self._stream()))
 
+    def _scatter_nodup(self, dst, nrows, row, lin, src):
+        """``x[idx] += y`` with NumPy's buffered semantics (AdvancedIncSubtensor
+        ``ignore_duplicates=True``, tensor/subtensor.py:2693): the indexed rows are READ first,
+        ``y`` is added to the copies, the sums are SET in index order (the last duplicate wins, its
+        sum started from the ORIGINAL row).  ``src``: contiguous [nidx, row] array, clobbered."""
+        nidx = lin.shape[0]
+        cur = self.alloc((nidx, row), dst.dtype)
+        self._launch("ahip_take_rows", (dtype_code(dst.dtype), _VP(dst.ptr), nrows, row, row,
+                                        _VP(lin.ptr), dtype_code("int64"), nidx, 1, _VP(cur.ptr), row,
+                                        _VP(self._bad_ptr()), self._stream()))
+        self.copy_into(cur, src.view((nidx, row), (row, 1)), accumulate=True)
+        self._scatter(dst, nrows, row, lin.ptr, "int64", nidx, 1, cur.ptr, row, False)
+
     def _op_AdvancedIncSubtensor(self, node, args):
         x0 = self.to_device(args[0])
         out = self._own_or_copy(node.inputs[0], x0)
@@ -629,7 +642,9 @@ class OpsMixin:
                 inv = [order.index(q) for q in range(nd)]
                 full = self.materialize(full.view([full.shape[q] for q in inv],
                                                   [full.strides[q] for q in inv]))
-            if lin.shape[0] and row:
+            if lin.shape[0] and row and node.params.get("ignore_duplicates"):
+                self._scatter_nodup(t, nrows, row, lin, full)
+            elif lin.shape[0] and row:
                 self._scatter(t, nrows, row, lin.ptr, "int64", lin.shape[0], 1, full.ptr, row,
                               not node.params["set_instead_of_inc"])
             if t is not v:
@@ -644,7 +659,9 @@ class OpsMixin:
             full = self.alloc(tgt, y.dtype)
             self.copy_into(full, y)
             y = full
-        if lin.shape[0] and row:
+        if lin.shape[0] and row and node.params.get("ignore_duplicates"):
+            self._scatter_nodup(out, nrows, row, lin, y)
+        elif lin.shape[0] and row:
             self._scatter(out, nrows, row, lin.ptr, "int64", lin.shape[0], 1, y.ptr, row,
                           not node.params["set_instead_of_inc"])
         return [out]

@@ -276,8 +276,8 @@ class ReplayMixin:
     def record_external(self):
         """Pass 2: the same steps again, every launch going into the launch list the caller has
         open (``ahip_list_begin`` .. ``ahip_list_end`` around SEVERAL executors and collectives).
-        The results live in this executor's planned arena, which ``self._ext`` keeps alive for as
-        long as the caller replays the list.  Raises ``HostReadInReplay`` for plans whose host
+        The results live in this executor's planned arena; the caller takes ownership of it with
+        :meth:`take_external` and keeps it for as long as it replays the list.  Raises ``HostReadInReplay`` for plans whose host
         control flow depends on device values (never replayable)."""
         arena, vals, targets = self._ext
         self._arena, self._capturing = arena, True
@@ -287,6 +287,13 @@ class ReplayMixin:
             self._arena = None
             self._capturing = False
         return [self._export(o) for o in outs]
+
+    def take_external(self):
+        """Hand the planned arena + bound values of the last ``trace_eager`` to the caller, who
+        keeps them alive for as long as it replays the list it recorded over them (the slot is
+        per executor and the next recorded signature overwrites it)."""
+        ext, self._ext = getattr(self, "_ext", None), None
+        return ext
 
     # -- zero-copy replay for rebound buffers ------------------------------------------------
     @staticmethod

@@ -419,7 +419,16 @@ class ScanMixin:
                 why = self._scan_persist_mat(prog, p, inner, n_steps, seqs_c, outs_c, store, pos, non_c, pre_c,
                                              n_rec, n_nit, xfold=None, _chunk=True)
             if why is not None:
-                return why if b0 == 0 else "batch slice %d: %s" % (b0 // rows, why)
+                if b0 == 0:
+                    return why
+                # earlier slices already ran INTO ``outs``: the launch-list fallback restarts from
+                # the initial-state rows, which a circular (memory-saved) buffer no longer holds
+                # for the finished slices -> only a buffer that keeps every step may fall back
+                if any(store[k] < n_steps + (pos[k] if k < n_rec else 0) for k in range(n_rec)):
+                    raise RuntimeError("persistent Scan: batch slice %d could not be launched (%s) after "
+                                       "earlier slices had overwritten the circular state buffers"
+                                       % (b0 // rows, why))
+                return "batch slice %d: %s" % (b0 // rows, why)
             for j in range(n_nit):               # nit-sot outputs of the slice -> their rows of the whole
                 k = n_rec + j
                 o = outs_c[k]

@@ -677,9 +677,10 @@ def _register_handlers():
     @hip_lower.register(AdvancedIncSubtensor)
     def _(op, node, ctx):
         # reference: tensor/subtensor.py:2647 AdvancedIncSubtensor (perform :2688: np.add.at / set)
-        if getattr(op, "ignore_duplicates", False):
-            raise UnsupportedOp("AdvancedIncSubtensor(ignore_duplicates=True)")
+        # ignore_duplicates (inc only; :2693): ``out[idx] += y`` = read, add, sequential set
         params = {"set_instead_of_inc": bool(op.set_instead_of_inc), "inplace": bool(op.inplace)}
+        if getattr(op, "ignore_duplicates", False) and not op.set_instead_of_inc:
+            params["ignore_duplicates"] = True
         if _only_arrays(node.inputs[2:]):
             _int_array_indices(op, node.inputs[2:])
             ctx.emit("AdvancedIncSubtensor", node, params)

@@ -13,7 +13,7 @@ with its own ``roofline`` timed by HIP events in this run and a correctness asse
 fp64 restatement on the same data:
 
 * cfg3b  Gemm fp32 4096^3 (the ``check_blas.py:54-57`` update ``C <- 0.4*C + 0.8*dot(A,B)``), MFMA-bound
-* cfg3a  Gemv fp64 4096^2 (``M.dot(v)*alpha + beta*y``), HBM-bound
+* cfg3a  Gemv fp64 4096^2 (``M.dot(v) + a``, BASELINE configs[2]'s graph), HBM-bound
 * cfg1b  matrix add fp64 4096^2, HBM-bound
 * cfg4   Scan GRU T=512 H=1024 fp32, B=1 (vector state) and B=64 (matrix state)
 * cfg5   logistic-regression logp + grad, N=2^24 x 256 fp32 (16 GiB of X) — row-sharded over the
@@ -119,6 +119,38 @@ def latency_row(dev_ms, T, restreamed_bytes, handoffs_per_step, resident_bound_b
                     "(floor = the guide's price of a hand-off polled back to back)"}
 
 
+def pick_transport(world, torch, dist):
+    """The exchange transport of an N > 1 run: the C-ABI communicator by default (ahip_comm_*:
+    RCCL enqueued by the shim on the launch stream — a sharded evaluation, rounds + all-reduces,
+    is ONE recorded launch list, no Python between the rounds); torch.distributed (backend nccl =
+    RCCL, one Python call per collective) when AESARA_BENCH_COMM=torch, when the process group is
+    not RCCL (the one-device gloo hooks: RCCL refuses two ranks on one device) or when
+    ahip_comm_init_rank fails on any rank.  Returns (group, kind, description)."""
+    if world == 1:
+        return None, "none", None
+    from aesara_amd.dist import HipComm
+    kind = os.environ.get("AESARA_BENCH_COMM", "abi")
+    if dist.get_backend() != "nccl":
+        kind = "torch"
+    err = None
+    if kind == "abi":
+        group, ok = None, torch.ones(1, device="cuda")
+        try:
+            group = HipComm(bootstrap_group=dist.group.WORLD)
+        except Exception as e:              # noqa: BLE001
+            err = "%s: %s" % (type(e).__name__, e)
+            ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)        # every rank takes the same transport
+        if ok.item() == 1.0:
+            return group, "abi", ("C-ABI communicator (ahip_comm_*: RCCL on the launch stream, "
+                                  "all-reduces recorded into the launch lists), %d ranks" % group.world)
+        if group is not None:
+            group.close(force=True)
+        err = err or "another rank failed"
+    return dist.group.WORLD, "torch", "torch.distributed (%s)%s" % (
+        dist.get_backend(), "; C-ABI communicator unavailable: " + err if err else "")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -151,8 +183,25 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain ``python bench.py --gpus N``: become the launcher the contract names (one rank per
+        # GPU of this node over RCCL), same arguments, loopback rendezvous on a free port
+        import socket
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+               "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        if os.environ.get("AESARA_BENCH_DRY_LAUNCH"):       # (tests: show the launch line, run nothing)
+            print(json.dumps({"launch": cmd}))
+            return
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run "
+                         "--nproc-per-node %d" % (args.gpus, world, args.gpus))
     # test hooks (single-GPU boxes): AESARA_BENCH_BACKEND=gloo + AESARA_BENCH_ONE_DEVICE=1 run
     # the N>1 control flow (ring slots, bucketed async all-reduce) with every rank on cuda:0
     backend = os.environ.get("AESARA_BENCH_BACKEND", "nccl")
@@ -172,6 +221,7 @@ def main():
     from aesara_amd.executor import PlanExecutor
 
     G = not args.eager
+    group, comm_kind, transport = pick_transport(world, torch, dist)
 
     def plan_of(name):
         return case_plan(next(c for c in CASES if c["name"] == name))
@@ -207,7 +257,7 @@ def main():
     ring = torch.zeros(R, dtype=f64, device="cuda")
     slots = [ring[i] for i in range(R)]
     state = {"i": 0}
-    reducer = ShardedFunction(lambda bucket: [bucket], kinds)
+    reducer = ShardedFunction(lambda bucket: [bucket], kinds, group=group if comm_kind == "abi" else None)
 
     # N = 1 with the reference front end present (the packed overlay travels to the GPU box): the
     # timed step is ``f(x, mu, sigma)`` of ``f = aesara.function([x, mu, sigma], expr, mode="HIP")``
@@ -399,7 +449,8 @@ def main():
     if not args.no_secondary:
         only = [s for s in args.only_secondary.split(",") if s]
         ctx = dict(torch=torch, np=np, dist=dist, timer=timer, plan_of=plan_of, randn=randn,
-                   PlanExecutor=PlanExecutor, G=G, rank=rank, world=world, args=args)
+                   PlanExecutor=PlanExecutor, G=G, rank=rank, world=world, args=args,
+                   group=group, comm_kind=comm_kind, transport=transport)
         for name, fn in SECONDARY:
             if only and name not in only:
                 continue
@@ -470,6 +521,7 @@ def main():
             "unit": "evals/s",
             "n_gpus": world,
             "ranks_seen": dist.get_world_size() if world > 1 else 1,   # what the process group reports
+            "transport": transport,                                    # which exchange path ran (N > 1)
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -512,6 +564,8 @@ def main():
                 res["vs_reference"] = vs        # top level: the driver's record keeps top-level keys
         print(json.dumps(res))
     if world > 1:
+        if comm_kind == "abi":
+            group.close(force=True)
         dist.destroy_process_group()
 
 
@@ -556,26 +610,29 @@ def sec_cfg3b(c):
 def sec_cfg3a(c):
     torch = c["torch"]
     f64 = torch.float64
-    plan = c["plan_of"]("gemv_beta_float64")        # beta*y + alpha*M.v (alpha, beta: plan constants)
+    # BASELINE configs[2]'s graph: ``M.dot(v) + a`` as the linker lowers it (golden cfg3a_gemv,
+    # second output: AllocEmpty -> Gemv(beta = 0) -> Elemwise add of the broadcast scalar) — the
+    # plan tests/refcheck.py checks against the reference is the plan that is timed
+    from aesara_amd.dist import subplan_for_outputs
+    plan = subplan_for_outputs(c["plan_of"]("cfg3a_gemv"), [1])
     ex = c["PlanExecutor"](plan, use_graph=c["G"], borrow=True)
-    alpha, beta = (float(plan.vars[k].const["data"][0]) for k in (3, 4))
     M = c["randn"]((4096, 4096), f64, 2)
-    v, y = c["randn"]((4096,), f64, 3), c["randn"]((4096,), f64, 4)
-    (out,) = ex(y, M, v)
-    ref = alpha * (M @ v) + beta * y
+    v, a = c["randn"]((4096,), f64, 3), torch.tensor(2.0, dtype=f64, device="cuda")
+    (out,) = ex(M, v, a)
+    ref = M @ v + a
     err = ((out - ref).abs().max() / ref.abs().max()).item()
     assert err <= 1e-10, f"cfg3a rel err {err}"
-    dw, _ = c["timer"].time(lambda: ex(y, M, v), 200)
+    dw, _ = c["timer"].time(lambda: ex(M, v, a), 200)
     # rotate over 8 distinct matrices (1 GiB > the 256 MiB MALL): the HBM figure
     Ms = [M] + [c["randn"]((4096, 4096), f64, 20 + k) for k in range(7)]
     st = {"i": 0}
 
     def step():
         st["i"] += 1
-        ex(y, Ms[st["i"] & 7], v)
+        ex(Ms[st["i"] & 7], v, a)
     d, w = c["timer"].time(step, 200, warmup=16)
     work = 4096 * 4096 * 8 + 2 * 4096 * 8
-    return {"config": "cfg3a Gemv fp64 4096^2 alpha*M.v + beta*y (rotating over 8 matrices: MALL-cold)",
+    return {"config": "cfg3a Gemv fp64 4096^2 M.dot(v) + a (rotating over 8 matrices: MALL-cold)",
             "dtype": "f64", "evals_per_s": 1e3 / max(d, w),
             "roofline": roof("hbm", work, d, HBM_PEAK_GBS,
                              warm={"kernel_ms": dw, "frac": work / (dw * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -722,17 +779,7 @@ def sec_cfg5(c):
     yv = (torch.rand(n_loc, device="cuda", generator=g) < 0.5).to(f32)
 
     from aesara_amd.dist import HipComm, ShardedPlan
-    # the exchange: torch.distributed (backend nccl = RCCL; one Python call per round) by default;
-    # AESARA_BENCH_COMM=abi: the C-ABI communicator (ahip_comm_*: RCCL on the launch stream, the
-    # whole sharded evaluation — round 0, all-reduce, round 1 — ONE recorded launch list)
-    comm_kind = os.environ.get("AESARA_BENCH_COMM", "torch")
-    if world == 1:
-        group = None
-    elif comm_kind == "abi":
-        group = c.setdefault("hipcomm", None) or HipComm(bootstrap_group=dist.group.WORLD)
-        c["hipcomm"] = group
-    else:
-        group = dist.group.WORLD
+    group, comm_kind = c["group"], c["comm_kind"]
     sp = ShardedPlan(c["plan_of"]("cfg5_logistic"), split_inputs={0: 0, 3: 0}, use_graph=c["G"], borrow=True,
                      group=group)
     outs = sp(X, wv, b, yv)
@@ -774,8 +821,8 @@ def sec_cfg5(c):
             "evals_per_s": 1e3 / ms_job, "ms_per_eval": ms_job,
             "collective": None if world == 1 else "1 all-reduce(sum) of 258 fp64 per eval",
             "transport": None if world == 1 else (
-                "C-ABI communicator (RCCL on the launch stream), %d of %d evals were single-list replays"
-                % (sp.replays, iters + 4) if comm_kind == "abi" else "torch.distributed (%s)" % dist.get_backend()),
+                c["transport"] + (", %d of %d evals were single-list replays" % (sp.replays, iters + 4)
+                                  if comm_kind == "abi" else "")),
             "ranks_seen": world if world == 1 else (group.world if comm_kind == "abi" else dist.get_world_size()),
             "aggregate_GBs": world * local_bytes / (ms_job * 1e-3) / 1e9,
             "roofline": roof("hbm", local_bytes, d, HBM_PEAK_GBS,
@@ -869,18 +916,50 @@ def start_reference_warm():
         return None
 
 
-def reference_rows(budget, configs, openmp=False, timeout=420, dump_dir=None):
+def reference_rows(budget, configs, openmp=False, timeout=420, dump_dir=None, full=False):
     import subprocess
     env = dict(os.environ)
     env.pop("AESARA_FLAGS", None)
     cmd = [sys.executable, os.path.join(ROOT, "oracle", "time_reference.py"), "--budget", str(budget),
            "--configs", ",".join(configs)] + (["--openmp"] if openmp else []) + \
-        (["--dump-dir", dump_dir] if dump_dir else [])
+        (["--dump-dir", dump_dir] if dump_dir else []) + (["--full"] if full else [])
     p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout)
     line = next((ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")), None)
     if line is None:
         raise RuntimeError("time_reference.py gave no result: " + (p.stderr or p.stdout)[-400:])
     return json.loads(line[7:])
+
+
+def full_shape_reference_check(refcheck):
+    """Configs 4 (B = 1 and B = 64, T = 512) and 5 (N = 2^24, 16 GiB of X) ONCE through the
+    reference's C linker on this host, then the HIP path on the same seeded inputs.  One child per
+    config (bounded: a slow host costs that config's check, not the line); config 5 needs ~40 GiB
+    of free host memory (X in the child and again here for the upload) and is skipped below that."""
+    import shutil
+    import tempfile
+    out = {}
+    for cfg, limit in (("cfg4_b1", 240), ("cfg4_b64", 420), ("cfg5", 600)):
+        if cfg == "cfg5":
+            try:
+                with open("/proc/meminfo") as f:
+                    avail = next(int(ln.split()[1]) for ln in f if ln.startswith("MemAvailable")) >> 20
+            except Exception:                           # noqa: BLE001
+                avail = 0
+            if avail < 40:
+                raise RuntimeError("cfg5 at N = 2^24 needs ~40 GiB of free host memory, %d GiB available"
+                                   % avail)
+        dump = tempfile.mkdtemp(prefix="aesara_ref_full_")
+        try:
+            r = reference_rows(0.0, [cfg], timeout=limit, dump_dir=dump, full=True)
+            row = r["rows"][cfg]
+            if "error" in row:
+                raise RuntimeError("%s: %s" % (cfg, row["error"]))
+            got = refcheck.hip_vs_reference(dump, [cfg], full=True)
+            got[cfg]["reference_ms_full_shape"] = row.get("ms_per_eval")
+            out.update(got)
+        finally:
+            shutil.rmtree(dump, ignore_errors=True)
+    return out
 
 
 def make_function(x0, torch, np):
@@ -961,12 +1040,30 @@ def cpu_baseline(np, ref_warm=None, secondary=None):
                 import refcheck
                 vs = refcheck.hip_vs_reference(dump)
                 shutil.rmtree(dump, ignore_errors=True)
+                sampled = {k: v["max"] for k, v in vs.items() if not v["full_shape"]}
+                # configs 4 and 5 are TIMED on samples (T = 64 of 512 steps, 2^20 of 2^24 rows);
+                # their RESULTS are checked at BASELINE's full shapes: the reference evaluates each
+                # once (SURVEY §8d "run it once"), the HIP path runs the same seeded inputs
+                full_note = None
+                if not os.environ.get("AESARA_BENCH_NO_FULL_REFERENCE"):
+                    try:
+                        vs.update(full_shape_reference_check(refcheck))
+                    except Exception as e:              # noqa: BLE001
+                        full_note = "%s: %s" % (type(e).__name__, str(e)[:300])
                 res["vs_reference"] = {"bar": refcheck.BAR, "rel_err": {k: v["max"] for k, v in vs.items()},
                                        "per_output": {k: v["rel_err"] for k, v in vs.items()},
+                                       "full_shape": bool(vs) and all(v["full_shape"] for v in vs.values()),
+                                       "full_shape_per_config": {k: v["full_shape"] for k, v in vs.items()},
+                                       "input_shapes": {k: v["input_shapes"] for k, v in vs.items()},
+                                       "sampled_rel_err": sampled,
                                        "ok": bool(vs) and all(v["max"] <= refcheck.BAR for v in vs.values()),
                                        "what": "||hip - ref||_2 / ||ref||_2 per output, same seeded inputs "
                                                "(oracle/time_reference.make_inputs); ref = the reference's "
-                                               "Mode('cvm','fast_run') on this host"}
+                                               "Mode('cvm','fast_run') on this host; every config at "
+                                               "BASELINE's full shape (cfg 4: T = 512, cfg 5: N = 2^24 — "
+                                               "one reference evaluation each)"}
+                if full_note:
+                    res["vs_reference"]["full_shape_error"] = full_note
             except Exception as e:                      # noqa: BLE001  (a check row must not cost the line)
                 res["vs_reference"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
             # next to every secondary row: the reference's time for the same config on this host

@@ -565,6 +565,8 @@ def run_plan(plan, inputs):
             idx = adv_index(p, a[2:])
             if p["set_instead_of_inc"]:
                 out[idx] = a[1]
+            elif p.get("ignore_duplicates"):
+                out[idx] += a[1]              # :2693 (buffered: read, add, sequential set)
             else:
                 np.add.at(out, idx, a[1])
             r = [out]

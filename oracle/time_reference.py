@@ -24,10 +24,30 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ALL = ["cfg2", "cfg1b", "cfg3a", "cfg3b", "cfg4_b1", "cfg4_b64", "cfg5"]
 
 
-def make_inputs(name, np, tiny=False):
+def _normal_f32_parallel(np, seed, rows, cols):
+    """(rows, cols) float32 standard normals, filled in 2^20-row chunks by a thread pool (NumPy's
+    generators release the GIL): chunk k comes from ``default_rng([seed, k])``, so the array is the
+    same whatever the number of threads — 16 GiB in seconds on the GPU box's host cores instead
+    of ~30 s single-threaded."""
+    from concurrent.futures import ThreadPoolExecutor
+    out = np.empty((rows, cols), dtype="float32")
+    blk = 1 << 20
+
+    def fill(k):
+        lo = k * blk
+        np.random.default_rng([seed, k]).standard_normal(out=out[lo:lo + blk], dtype="float32")
+    with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as pool:
+        list(pool.map(fill, range((rows + blk - 1) // blk)))
+    return out
+
+
+def make_inputs(name, np, tiny=False, full=False):
     """The seeded input arrays of one config — a dict; no front end needed, so ``bench.py`` and the
     GPU tests regenerate exactly what the reference child evaluated and compare results.
-    ``tiny``: small shapes (same graph and dtypes), used by --warm."""
+    ``tiny``: small shapes (same graph and dtypes), used by --warm.  ``full``: BASELINE's full
+    shapes for the two configs whose TIMED rows are samples — config 4 with all T = 512 steps,
+    config 5 with all N = 2^24 rows (16 GiB of X) — evaluated ONCE by the reference for the
+    full-shape result check (SURVEY §8d "run it once")."""
     n = 64 if tiny else 4096
     if name == "cfg2":
         return {"x": np.random.default_rng(1).standard_normal((n, n)), "mu": np.asarray(0.1),
@@ -43,7 +63,7 @@ def make_inputs(name, np, tiny=False):
                 "C": np.zeros((n, n), "float32")}
     if name in ("cfg4_b1", "cfg4_b64"):
         B_ = 1 if name == "cfg4_b1" else 64
-        T_, H = (8, 32) if tiny else (64, 1024)       # 1/8 of the config's 512 steps (bounded sample)
+        T_, H = (8, 32) if tiny else ((512, 1024) if full else (64, 1024))   # sample: 1/8 of the 512 steps
         if tiny and B_ > 1:
             B_ = 4
         xs = (T_, H) if B_ == 1 else (T_, B_, H)
@@ -54,6 +74,12 @@ def make_inputs(name, np, tiny=False):
         return d
     if name == "cfg5":
         N, D = (256, 16) if tiny else (1 << 20, 256)
+        if full and not tiny:
+            N = 1 << 24
+            return {"X": _normal_f32_parallel(np, 6, N, D),
+                    "w": (np.random.default_rng(7).standard_normal(D) / 16).astype("float32"),
+                    "b": np.asarray(0.1, "float32"),
+                    "y": (np.random.default_rng(8).random(N) < 0.5).astype("float32")}
         return {"X": np.random.default_rng(6).standard_normal((N, D), dtype="float32"),
                 "w": (np.random.default_rng(7).standard_normal(D) / 16).astype("float32"),
                 "b": np.asarray(0.1, "float32"),
@@ -61,7 +87,7 @@ def make_inputs(name, np, tiny=False):
     raise ValueError(name)
 
 
-def build(ae, name, np, tiny=False):
+def build(ae, name, np, tiny=False, full=False):
     """-> (function, args, sample description, cores used, result getter).  ``tiny``: small shapes
     (same graph and dtypes — the compiled modules are shape-independent), used by --warm."""
     import aesara.tensor as at
@@ -69,7 +95,7 @@ def build(ae, name, np, tiny=False):
     mode = Mode("cvm", "fast_run")
     nthreads = os.cpu_count()
     n = 64 if tiny else 4096
-    d = make_inputs(name, np, tiny)
+    d = make_inputs(name, np, tiny, full)
     if name == "cfg2":
         x, mu, sg = at.dmatrix("x"), at.dscalar("mu"), at.dscalar("sigma")
         f = ae.function([x, mu, sg], at.exp(-((x - mu) ** 2) / (2 * sg ** 2)).sum(), mode=mode)
@@ -109,8 +135,8 @@ def build(ae, name, np, tiny=False):
         hs, _ = ae.scan(step, sequences=[x], outputs_info=[h0], non_sequences=Ws)
         f = ae.function([x, h0], hs[-1], mode=mode)
         return f, (d["x"], d["h0"]), \
-            "fp32 Scan GRU T=%d of 512 steps (x8 for the config), H=%d B=%d (scan_perform.pyx loop, inner cvm " \
-            "function)" % (T_, H, B_), nthreads
+            "fp32 Scan GRU T=%d of 512 steps%s, H=%d B=%d (scan_perform.pyx loop, inner cvm " \
+            "function)" % (T_, "" if T_ == 512 else " (x8 for the config)", H, B_), nthreads
     if name == "cfg5":
         N, D = d["X"].shape
         X, w, b, y = at.fmatrix("X"), at.fvector("w"), at.fscalar("b"), at.fvector("y")
@@ -119,8 +145,9 @@ def build(ae, name, np, tiny=False):
         gw, gb = ae.grad(logp, [w, b])
         f = ae.function([X, w, b, y], [logp, gw, gb], mode=mode)
         return f, (d["X"], d["w"], d["b"], d["y"]), \
-            "fp32 logistic logp+grad N=2^%d D=%d (1/16 of the config's rows: x16 for the full batch)" % (
-                N.bit_length() - 1, D), nthreads
+            "fp32 logistic logp+grad N=2^%d D=%d%s" % (
+                N.bit_length() - 1, D, "" if N == 1 << 24 else
+                " (1/16 of the config's rows: x16 for the full batch)"), nthreads
     raise ValueError(name)
 
 
@@ -130,6 +157,9 @@ def main():
     ap.add_argument("--budget", type=float, default=5.0, help="seconds of timed evals per config")
     ap.add_argument("--warm", action="store_true")
     ap.add_argument("--openmp", action="store_true")
+    ap.add_argument("--full", action="store_true",
+                    help="BASELINE's full shapes for cfg4 (T = 512) and cfg5 (N = 2^24); with "
+                         "--budget 0 every config is evaluated exactly once (the result check)")
     ap.add_argument("--dump-dir", default="",
                     help="save what the FIRST evaluation of every config returned (npy files "
                          "<cfg>_out<i>.npy): the values bench.py / the GPU tests check the HIP path against")
@@ -148,7 +178,7 @@ def main():
     for name in [c for c in args.configs.split(",") if c]:
         t0 = time.perf_counter()
         try:
-            f, fargs, sample, cores = build(ae, name, np, tiny=args.warm)
+            f, fargs, sample, cores = build(ae, name, np, tiny=args.warm, full=args.full)
             f.trust_input = True
             row = {"cores": cores, "sample": sample}
             t = time.perf_counter()

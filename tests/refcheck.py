@@ -56,9 +56,14 @@ def max_err(got, ref):
     return float(np.abs(got - ref).max() / (den if den > 0 else 1.0))
 
 
-def hip_vs_reference(dump_dir, configs=None):
+FULL_SHAPE_ALWAYS = ("cfg2", "cfg1b", "cfg3a", "cfg3b")     # their timed rows ARE the BASELINE shapes
+FULL_SHAPE_ONCE = ("cfg4_b1", "cfg4_b64", "cfg5")           # timed as samples; ``full=True`` below
+
+
+def hip_vs_reference(dump_dir, configs=None, full=False):
     """{config: {"rel_err": [...], "max": worst, "outputs": n}} for every config whose dumped
-    reference outputs are in ``dump_dir`` (needs a HIP device)."""
+    reference outputs are in ``dump_dir`` (needs a HIP device).  ``full``: the dump came from
+    ``time_reference.py --full`` (config 4 with T = 512, config 5 with N = 2^24)."""
     import torch
     import time_reference
     from golden_util import CASES, case_plan
@@ -75,7 +80,7 @@ def hip_vs_reference(dump_dir, configs=None):
             refs.append(np.load(p))
         if len(refs) != len(outs):
             continue
-        d = time_reference.make_inputs(cfg, np)
+        d = time_reference.make_inputs(cfg, np, full=full)
         args = []
         for n in names:
             a = d[n]
@@ -86,7 +91,9 @@ def hip_vs_reference(dump_dir, configs=None):
         vals = [got[o].detach().cpu().numpy() for o in outs]
         errs = [rel_err(v, r) for v, r in zip(vals, refs)]
         out[cfg] = {"rel_err": errs, "max": max(errs), "outputs": len(errs),
-                    "max_abs_over_max_ref": [max_err(v, r) for v, r in zip(vals, refs)]}
-        del ex, got, args
+                    "max_abs_over_max_ref": [max_err(v, r) for v, r in zip(vals, refs)],
+                    "full_shape": bool(full or cfg in FULL_SHAPE_ALWAYS),
+                    "input_shapes": {n: list(d[n].shape) for n in names if d[n].ndim}}
+        del ex, got, args, d
         torch.cuda.empty_cache()
     return out

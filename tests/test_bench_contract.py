@@ -45,6 +45,40 @@ def test_committed_bench_line_meets_the_contract():
         assert cfg in names, cfg
 
 
+def test_plain_python_launch_with_gpus_n_becomes_the_contract_launcher():
+    """`python bench.py --gpus N` without WORLD_SIZE in the environment re-executes itself as
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py <the same arguments>` (shown, not run, under the dry-launch hook)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["AESARA_BENCH_DRY_LAUNCH"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20",
+                          "--warmup", "5"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    cmd = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])["launch"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 0 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    k = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[k + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+
+
+@pytest.mark.gpu
+def test_plain_python_two_rank_launch_runs_on_one_device():
+    """The same, for real: `python bench.py --gpus 2` (no launcher, no WORLD_SIZE) with the
+    one-device gloo hooks — rank 0 prints the one JSON line of a 2-rank run."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(AESARA_BENCH_BACKEND="gloo", AESARA_BENCH_ONE_DEVICE="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "16",
+                          "--warmup", "8", "--no-secondary"], capture_output=True, text=True, timeout=900,
+                         cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["steps"] == 16
+    assert line["transport"].startswith("torch.distributed (gloo)")       # RCCL needs one device per rank
+
+
 @pytest.mark.gpu
 def test_live_bench_line_meets_the_contract():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5",

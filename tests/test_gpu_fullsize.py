@@ -678,3 +678,41 @@ def test_baseline_configs_against_the_reference_c_linker(tmp_path):
     assert got["cfg1b"]["max"] == 0.0                          # an add is exact
     for k, v in got.items():
         assert v["max"] <= refcheck.BAR, (k, v)
+
+
+@pytest.mark.parametrize("cfg", ["cfg4_b1", "cfg4_b64", "cfg5"])
+def test_sampled_configs_at_full_shape_against_the_reference_c_linker(tmp_path, cfg):
+    """The two configs whose TIMED rows are samples, at BASELINE's full shape against the
+    reference itself: config 4 with all T = 512 steps (vector and B = 64 matrix state) and config
+    5 with all N = 2^24 rows (16 GiB of X) — ``oracle/time_reference.py --full --budget 0``
+    evaluates each exactly once with ``Mode("cvm","fast_run")``, the HIP path runs the same
+    seeded inputs (SURVEY §8d "run it once").  ``bench.py`` puts the same numbers on its line
+    (``vs_reference.full_shape``)."""
+    import os
+    import subprocess
+    import sys
+    import ref_overlay
+    if not ref_overlay.available():
+        pytest.skip("no reference front end (oracle/_ref overlay not packed)")
+    if cfg == "cfg5":
+        with open("/proc/meminfo") as f:
+            avail = next(int(ln.split()[1]) for ln in f if ln.startswith("MemAvailable")) >> 20
+        if avail < 40:
+            pytest.skip("config 5 at N = 2^24 needs ~40 GiB of free host memory (%d GiB here)" % avail)
+    import refcheck
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("AESARA_FLAGS", None)
+    p = subprocess.run([sys.executable, os.path.join(root, "oracle", "time_reference.py"), "--full",
+                        "--budget", "0", "--configs", cfg, "--dump-dir", str(tmp_path)],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert "RESULT " in p.stdout, (p.stdout + p.stderr)[-2000:]
+    got = refcheck.hip_vs_reference(str(tmp_path), [cfg], full=True)
+    assert list(got) == [cfg], (got, p.stdout[-1500:])
+    v = got[cfg]
+    assert v["full_shape"] and v["max"] <= refcheck.BAR, v
+    shapes = v["input_shapes"]
+    if cfg == "cfg5":
+        assert shapes["X"] == [1 << 24, 256]
+    else:
+        assert shapes["x"][0] == 512 and shapes["x"][-1] == 1024

@@ -99,10 +99,62 @@ def test_sharded_cfg5_and_two_round_softmax_over_the_abi_communicator(comm, use_
         # replay it (no Python between the rounds)
         assert sp.single_list and sp.replays >= 1, sp.replays
         assert sp2.single_list and sp2.replays >= 2, sp2.replays
-        (lst, _final, _keep) = next(iter(sp2._lists.values()))
+        (lst, _final, _keep, _exts) = next(iter(sp2._lists.values()))
         from aesara_amd._lib import lib
         assert lib.ahip_list_length(lst) >= 4        # >= 2 kernels + 2 all-reduces in ONE list
         assert comm.recorded >= 2
+
+
+def test_single_list_signatures_keep_their_arenas_and_are_evicted(comm):
+    """Two signatures replayed ALTERNATELY from their own recorded lists (another batch shape, a
+    second input buffer, a transposed view of the same buffer): every entry owns the arenas its
+    list addresses (the executors' one slot is overwritten by the next recording), allocations
+    made in between must not be written by a replay, and the cache is LRU-bounded with
+    ``ahip_list_destroy`` + the communicator's ``recorded`` count following."""
+    import torch
+    from dist_plans import colsoftmax_plan
+    from aesara_amd.dist import ShardedPlan
+
+    def want(x):
+        e = np.exp(x - x.max(axis=0, keepdims=True))
+        return e / e.sum(axis=0, keepdims=True)
+    rng = np.random.default_rng(11)
+    sp = ShardedPlan(colsoftmax_plan(), {0: 0}, group=comm, use_graph=True, force_collectives=True)
+    base = comm.recorded
+    xa, xb = rng.standard_normal((1037, 65)), rng.standard_normal((523, 65))
+    xs = rng.standard_normal((96, 96))
+    da, db, ds = (torch.from_numpy(v).cuda() for v in (xa, xb, xs))
+    for _ in range(3):                       # a: ordinary, record, replay / b: the same
+        for d, x in ((da, xa), (db, xb)):
+            (o,) = sp(d)
+            np.testing.assert_allclose(o.cpu().numpy(), want(x), rtol=1e-12)
+    assert len(sp._lists) == 2 and comm.recorded == base + 2
+    guard = []
+    for it in range(6):
+        # memory the allocator hands out now is where a freed arena would have been
+        guard.append(torch.full((1 << 16,), float(it), dtype=torch.float64, device="cuda"))
+        for d, x in ((da, xa), (db, xb)):
+            (o,) = sp(d)
+            np.testing.assert_allclose(o.cpu().numpy(), want(x), rtol=1e-12)
+        for i, g in enumerate(guard):
+            assert float(g.min()) == float(i) == float(g.max())
+    # same buffer, same shape, other strides: another signature, not the cached launches
+    for _ in range(3):
+        (o,) = sp(ds)
+        np.testing.assert_allclose(o.cpu().numpy(), want(xs), rtol=1e-12)
+        (o,) = sp(ds.t())
+        np.testing.assert_allclose(o.cpu().numpy(), want(xs.T), rtol=1e-12)
+    n = len(sp._lists)
+    assert 3 <= n <= sp.LISTS_MAX
+    sp.LISTS_MAX = 2
+    fresh = [torch.from_numpy(xb).cuda() for _ in range(4)]      # fresh batch tensors: new signatures
+    for d in fresh:
+        for _ in range(3):
+            (o,) = sp(d)
+            np.testing.assert_allclose(o.cpu().numpy(), want(xb), rtol=1e-12)
+    assert len(sp._lists) <= 2 and comm.recorded == base + len(sp._lists)
+    sp.close()
+    assert not sp._lists and comm.recorded == base
 
 
 def test_torch_distributed_nccl_backend_world1():
