@@ -157,6 +157,16 @@ __device__ __forceinline__ float fdiv_inv(float x, float c, float r, bool ok) {
   }
   return res;
 }
+// tolerance mode (AESARA_HIP_FASTDIV=1): x * (1/c) without the refinement — at most 1.5 ulp from
+// the quotient (north_star's bar is 1e-6 rel); the full division when c or 1/c is not a normal number
+template <typename T> __device__ __forceinline__ T fdiv_rcp(T x, T c, T r, bool ok) {
+  T res = x * r;
+  if (__builtin_expect(!ok, 0)) {
+    asm volatile("" ::: "memory");
+    res = x / c;
+  }
+  return res;
+}
 __device__ __forceinline__ float sigmoid_(float x) { return 1.0f / (1.0f + expf(-x)); }   // Sigmoid :1110
 __device__ __forceinline__ double sigmoid_(double x) { return 1.0 / (1.0 + exp(-x)); }
 __device__ __forceinline__ float softplus_(float x) {                                      // Softplus :1173
@@ -513,8 +523,9 @@ def emit_scalar_body(scalar, in_exprs, in_dts, indent="      ", suffix="", hoist
                 and hoisted[div[1]][1] and refs[1][1] == dt):
             # divisor is loop invariant: correctly-rounded division from its hoisted
             # reciprocal (q = x*r; q += r*fma(-q, c, x)) instead of the full v_div_* sequence
-            e = "fdiv_inv(%s, %s, %s)" % (_cast(refs[0][0], refs[0][1], dt), refs[1][0],
-                                          hoisted[div[1]][1])
+            # (AESARA_HIP_FASTDIV=1, tolerance mode: the rounded product x * r alone, <= 1.5 ulp)
+            e = "%s(%s, %s, %s)" % ("fdiv_rcp" if knobs.get("FASTDIV") else "fdiv_inv",
+                                    _cast(refs[0][0], refs[0][1], dt), refs[1][0], hoisted[div[1]][1])
         elif exp_tbl and n["op"] == "exp" and dt == "float64":
             e = "exp_tbl64(%s, %s)" % (_cast(refs[0][0], refs[0][1], dt), exp_tbl)
         else:
@@ -663,8 +674,8 @@ class KernelSpec:
         return _memo_key([self.scalar], fields, self._key)
 
     def _variant(self):
-        return "r4%d%d%d%d%d%s" % (self.early, self.blocked, self.trace, self.fast_exp, self.prio,
-                                   "H" if self.hjobs else "")
+        return "r4%d%d%d%d%d%s%s" % (self.early, self.blocked, self.trace, self.fast_exp, self.prio,
+                                     "H" if self.hjobs else "", "D" if knobs.get("FASTDIV") else "")
 
     def _key(self):
         import json

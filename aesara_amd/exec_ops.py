@@ -90,13 +90,23 @@ class OpsMixin:
     def _op_Reshape(self, node, args):
         x = args[0]
         shp = [int(s) for s in self.host_array(args[1]).reshape(-1)]
+        nd = node.params.get("ndim")
+        if nd is not None and len(shp) != nd:          # tensor/shape.py:649 Reshape.perform
+            raise ValueError(f"Shape argument to Reshape has incorrect length: {len(shp)}, should be {nd}")
         if not isinstance(x, DevArray):
             return [np.reshape(x, shp)]
+        want = tuple(shp)
+        if shp.count(-1) > 1:                          # np.reshape's own errors from here on
+            raise ValueError("can only specify one unknown dimension")
+        if any(s < -1 for s in shp):
+            raise ValueError("negative dimensions not allowed")
         if -1 in shp:
-            known = _prod(([s for s in shp if s != -1])) or 1
+            known = _prod(([s for s in shp if s != -1]))
+            if known == 0 or x.size % known:
+                raise ValueError(f"cannot reshape array of size {x.size} into shape {want}")
             shp[shp.index(-1)] = x.size // known
         if _prod((shp)) != x.size:
-            raise ValueError(f"cannot reshape array of size {x.size} into shape {tuple(shp)}")
+            raise ValueError(f"cannot reshape array of size {x.size} into shape {want}")
         x = self.contiguous(x)
         return [x.view(shp, contiguous_strides(shp))]
 

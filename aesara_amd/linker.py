@@ -159,7 +159,9 @@ class HipLinker(JITLinker):
         in_cells = list(thunk.inputs)
         out_cells = list(thunk.outputs)
         out_vars = list(self.fgraph.outputs)
-        plain = not self.return_numpy
+        # (a ScalarType output — ScalarFromTensor handed out — is a NumPy scalar in the reference,
+        # scalar/basic.py:302 ScalarType.filter: it goes through ``output_filter`` as well)
+        plain = not self.return_numpy and not any(_is_scalar_type(v) for v in out_vars)
         ofilter = self.output_filter
         n_in = len(in_cells)
         if n_in == 1:
@@ -274,10 +276,21 @@ class HipLinker(JITLinker):
         # return_numpy=True: results handed to the caller become ndarrays, ``updates=`` results stay
         # device tensors (they go back into shared-variable cells); "all": those too — for host
         # ``aesara.shared`` state, e.g. the reference's own test-suite (tests/reference_suites.py)
+        if _is_scalar_type(var):
+            # a host value of the reference's ScalarType: ``np.int8(56)``, not a 0-d array
+            if hasattr(out, "detach"):
+                out = out.detach().cpu().numpy()
+            import numpy as np
+            return np.asarray(out, dtype=var.type.dtype)[()]
         if self.return_numpy and hasattr(out, "detach") \
                 and (self.return_numpy == "all" or var not in getattr(self, "_update_outputs", ())):
             return out.detach().cpu().numpy()
         return out
+
+
+def _is_scalar_type(var):
+    from aesara.scalar.basic import ScalarType
+    return isinstance(var.type, ScalarType)
 
 
 class _ValueView:

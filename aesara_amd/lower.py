@@ -694,12 +694,12 @@ def _register_handlers():
     @hip_lower.register(Eye)
     def _(op, node, ctx):
         # reference: tensor/basic.py:1257 Eye(n, m, k) (perform :1278 np.eye)
-        ctx.emit("Eye", node, {"dtype": str(op.dtype)})
+        ctx.emit("Eye", node, {"dtype": np.dtype(op.dtype).name})
 
     @hip_lower.register(Tri)
     def _(op, node, ctx):
         # reference: tensor/basic.py:982 Tri(N, M, k) (perform :1000 np.tri)
-        ctx.emit("Tri", node, {"dtype": str(op.dtype)})
+        ctx.emit("Tri", node, {"dtype": np.dtype(op.dtype).name})    # (``dtype=bool`` the class)
 
     @hip_lower.register(ExtractDiag)
     def _(op, node, ctx):

@@ -455,7 +455,18 @@ def run_plan(plan, inputs):
             r = [np.asarray(a[0] + a[1] * np.outer(a[2], a[3]), dtype=ov[0].dtype)]
         elif op == "BatchedDot":
             # reference: tensor/blas.py:2224 BatchedDot.perform
-            r = [np.asarray(np.matmul(a[0], a[1]), dtype=ov[0].dtype)]
+            # (z[i] = np.dot(x[i], y[i]); a 2-d operand is a batch of vectors, :2196-2207)
+            x_, y_ = np.asarray(a[0]), np.asarray(a[1])
+            if x_.shape[0] != y_.shape[0]:
+                raise TypeError(f"Shape mismatch: x has {x_.shape[0]} rows but y has {y_.shape[0]} rows")
+            xs_ = x_[:, None, :] if x_.ndim == 2 else x_
+            ys_ = y_[:, :, None] if y_.ndim == 2 else y_
+            z_ = np.matmul(xs_, ys_)
+            if y_.ndim == 2:
+                z_ = z_[:, :, 0]
+            if x_.ndim == 2:
+                z_ = z_[:, 0]
+            r = [np.asarray(z_, dtype=ov[0].dtype)]
         elif op == "Alloc":
             # reference: tensor/basic.py:1427 Alloc.perform
             shape = tuple(int(np.asarray(s)) for s in a[1:])
@@ -579,7 +590,11 @@ def run_plan(plan, inputs):
         elif op == "Shape":
             r = [np.asarray(a[0].shape, dtype="int64")]
         elif op == "Reshape":
-            r = [np.reshape(a[0], tuple(int(s) for s in np.asarray(a[1])))]
+            shp = tuple(int(s) for s in np.asarray(a[1]).reshape(-1))
+            if p.get("ndim") is not None and len(shp) != p["ndim"]:     # tensor/shape.py:649
+                raise ValueError("Shape argument to Reshape has incorrect length: "
+                                 f"{len(shp)}, should be {p['ndim']}")
+            r = [np.reshape(a[0], shp)]
         elif op == "Subtensor":
             r = [a[0][_resolve_idx(p["idx_list"], a[1:])]]
         elif op == "IncSubtensor":

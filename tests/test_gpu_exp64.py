@@ -82,16 +82,18 @@ def _device_exp(x, nd=1):
 def test_exp_tbl64_is_the_kernel_under_test(monkeypatch):
     """The float64 ``exp`` kernels these tests launch really are generated with the table form."""
     import torch
-    from aesara_amd import exec_elemwise, knobs
+    from aesara_amd import exec_common, exec_elemwise, knobs
     from aesara_amd.executor import PlanExecutor
     assert int(knobs.get("FASTEXP")) == 1
     seen = []
-    real = exec_elemwise.load_kernels
+    real = exec_common.load_kernels
 
     def spy(src, names):
         seen.append(src)
         return real(src, names)
-    monkeypatch.setattr(exec_elemwise, "load_kernels", spy)
+    monkeypatch.setattr(exec_common, "load_kernels", spy)       # _Kernels.get (flat / n-d kernels)
+    monkeypatch.setattr(exec_elemwise, "load_kernels", spy)     # row chains, tiled forms
+    exec_common._Kernels.cache.clear()                          # (kernels other tests already loaded)
     for nd, shape in ((1, (4099,)), (2, (37, 1000))):
         PlanExecutor(_exp_plan(nd))(torch.zeros(shape, dtype=torch.float64, device="cuda"))
     PlanExecutor(_exp_plan(1, with_sum=True))(torch.zeros(4099, dtype=torch.float64, device="cuda"))

@@ -1,0 +1,34 @@
+"""The reference's own test FILES, unmodified, with the default mode = HIP on the MI355X
+(``tests/reference_files.py``: test_subtensor / test_basic / test_blas / test_special /
+test_extra_ops / test_elemwise / test_shape / test_math / scan/test_basic — every test of those
+files through ``aesara.function`` -> ``HipLinker`` -> ``PlanExecutor`` -> the C-ABI; a child
+``pytest`` per call, several workers sharing the device).  A test that does not pass must be
+explained (fails with the reference's own linker in this image / UnsupportedOp for an out-of-scope
+dtype or Op / listed not-applicable); anything else fails here.  The summary is written to
+``gpurun_out/r05_reference_files.log`` when that directory can be created (copied to ``profiles/``)."""
+import os
+
+import pytest
+
+import reference_files as rf
+
+import ref_overlay
+
+pytestmark = pytest.mark.gpu
+
+if not ref_overlay.available():
+    pytest.skip("no reference front end (oracle/_ref overlay not packed)", allow_module_level=True)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_reference_test_files_under_the_hip_mode_on_the_device():
+    import torch
+    assert torch.cuda.is_available()
+    workers = max(2, min(12, (os.cpu_count() or 4) // 4))
+    log = os.path.join(ROOT, "gpurun_out", "r05_reference_files.log")
+    s, bad, text = rf.check("device", rf.FILES, workers=workers, log_path=log, timeout=3300)
+    print(text)
+    assert not bad, text
+    c = s["counts"]
+    assert c["passed"] >= 3500, text
