@@ -94,9 +94,11 @@ int copy_typed(CopyArgs& a, int vec, int accumulate, hipStream_t s) {
   return accumulate ? launch_copy<T, true>(a, vec, s) : launch_copy<T, false>(a, vec, s);
 }
 
-// ---- ARange: out[i] = first + i * delta in the output dtype (np.arange's fill rule; the caller
-// passes first = dtype(start) and delta = dtype(start + step) - first) ----
-struct ArangeArgs { void* dst; int64_t n; double fstart, fdelta; int64_t istart, istep; };
+// ---- ARange: np.arange's fill rule (numpy/core/src/multiarray/arraytypes.c.src @TYPE@_fill):
+// out[0] = first = dtype(start), out[1] = next = dtype(start + step), out[i] = first + i * delta
+// with delta = next - first, the product and the sum each ROUNDED in the output dtype (no fused
+// multiply-add: NumPy's baseline build has none there) ----
+struct ArangeArgs { void* dst; int64_t n; double fstart, fdelta, fnext; int64_t istart, istep; };
 AHIP_PTRS_BEGIN(ArangeArgs) AHIP_PTR1(dst) AHIP_PTRS_END
 
 template <typename T, bool FLT>
@@ -104,8 +106,14 @@ __global__ __launch_bounds__(256) void arange_kernel(ArangeArgs a) {
   T* __restrict__ dst = static_cast<T*>(a.dst);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.n;
        i += (int64_t)gridDim.x * blockDim.x) {
-    if constexpr (FLT) dst[i] = (T)a.fstart + (T)i * (T)a.fdelta;
-    else dst[i] = (T)(a.istart + i * a.istep);
+    if constexpr (FLT) {
+      T v;
+      if (i == 0) v = (T)a.fstart;
+      else if (i == 1) v = (T)a.fnext;
+      else if constexpr (sizeof(T) == 4) v = __fadd_rn((T)a.fstart, __fmul_rn((T)i, (T)a.fdelta));
+      else v = __dadd_rn((T)a.fstart, __dmul_rn((T)i, (T)a.fdelta));
+      dst[i] = v;
+    } else dst[i] = (T)(a.istart + i * a.istep);
   }
 }
 
@@ -208,7 +216,7 @@ int ahip_arange(int dtype, const void* first, const void* delta, int64_t n, void
   AHIP_REQUIRE(dst != nullptr, "null dst");
   hipStream_t s = as_stream(stream);
   unsigned grid = stream_grid(n);
-  ArangeArgs a{dst, n, 0.0, 0.0, 0, 0};
+  ArangeArgs a{dst, n, 0.0, 0.0, 0.0, 0, 0};
   auto ival = [&](const void* p) -> int64_t {
     switch (dtype) {
       case AHIP_BOOL: case AHIP_U8: return *static_cast<const uint8_t*>(p);
@@ -222,11 +230,11 @@ int ahip_arange(int dtype, const void* first, const void* delta, int64_t n, void
   };
   if (dtype == AHIP_F32) {
     const float st = *static_cast<const float*>(start), sp = *static_cast<const float*>(step);
-    a.fstart = st; a.fdelta = sp;
+    a.fstart = st; a.fdelta = sp; a.fnext = static_cast<const float*>(start)[1];
     AHIP_LAUNCH((arange_kernel<float, true>), dim3(grid), dim3(256), 0, s, a);
   } else if (dtype == AHIP_F64) {
     const double st = *static_cast<const double*>(start), sp = *static_cast<const double*>(step);
-    a.fstart = st; a.fdelta = sp;
+    a.fstart = st; a.fdelta = sp; a.fnext = static_cast<const double*>(start)[1];
     AHIP_LAUNCH((arange_kernel<double, true>), dim3(grid), dim3(256), 0, s, a);
   } else {
     a.istart = ival(start); a.istep = ival(step);

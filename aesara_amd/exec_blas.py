@@ -243,7 +243,16 @@ class BlasMixin:
         if x.ndim != 2 or y.ndim != 2 or z.ndim != 2:
             raise ValueError("Gemm operands must be matrices")
         if z.shape != (x.shape[0], y.shape[1]):
-            raise ValueError("Gemm: z has the wrong shape")
+            # Gemm.perform (tensor/blas.py:995-1016): z is broadcast UP to dot(x, y)'s shape, and
+            # ``z += a * dot(x, y)`` broadcasts the product up to z's (infer_shape :1018: the
+            # maximum per dim) — extent-1 dims become zero strides of the operands, no copy
+            M, N, K = max(x.shape[0], z.shape[0]), max(y.shape[1], z.shape[1]), x.shape[1]
+
+            def up(t, shape, what):
+                if any(n != m and n != 1 for n, m in zip(t.shape, shape)):
+                    raise ValueError(f"Gemm: {what} of shape {tuple(t.shape)} does not broadcast to {shape}")
+                return t.view(shape, tuple(0 if n != m else s_ for n, m, s_ in zip(t.shape, shape, t.strides)))
+            z, x, y = up(z, (M, N), "z"), up(x, (M, K), "x"), up(y, (y.shape[0], N), "y")
         return [self._gemm(self.host_scalar(a), x, y, self.host_scalar(b), z)]
 
     def _op_Dot22(self, node, args):

@@ -646,6 +646,22 @@ class ElemwiseMixin:
         out_var = self.plan.vars[red["out"]]
         axis = list(range(nd)) if red["axis"] is None else list(red["axis"])
         kept = [d for d in range(nd) if d not in axis]
+        if nd > AHIP_MAXD and axis and not st.outputs:
+            # more non-mergeable dims than a kernel takes (a Sum over the 8-d DimShuffle view that
+            # ``tile``'s gradient builds): operands re-laid out contiguously in [kept | reduced]
+            # order first — each group then folds into one dim.  The reference's loop nest has no
+            # such limit (elemwise_cgen.py:305 make_reordered_loop)
+            ksh, _ = collapse_dims([shape[d] for d in kept] or [1], [[s[d] for d in kept] or [0] for s in in_strides])
+            rsh, _ = collapse_dims([shape[d] for d in axis], [[s[d] for d in axis] for s in in_strides])
+            if len(ksh) + len(rsh) > AHIP_MAXD or (not kept and len(collapse_dims(shape, in_strides)[0]) > AHIP_MAXD):
+                perm = kept + axis
+                relaid = []
+                for a, st_ in zip(arrs, in_strides):
+                    buf = self.alloc([shape[d] for d in perm], a.dtype)
+                    view = buf.view(tuple(shape), tuple(buf.strides[perm.index(d)] for d in range(nd)))
+                    self.copy_into(view, a.view(tuple(shape), tuple(st_)))
+                    relaid.append(view)
+                arrs, in_strides = relaid, [list(v.strides) for v in relaid]
         out_shape = [shape[d] for d in kept]
         mat_vars = [self.plan.vars[o] for o in st.outputs]
         mats = [self.alloc(shape, ov.dtype) for ov in mat_vars]
@@ -871,6 +887,16 @@ class ElemwiseMixin:
                 raise ValueError(f"cannot broadcast shape {src.shape} into {dst.shape}")
         if src.dtype != dst.dtype:
             raise TypeError("copy_into needs equal dtypes")
+        if nd > AHIP_MAXD and len(collapse_dims(list(dst.shape), [list(ss), list(dst.strides)])[0]) > AHIP_MAXD:
+            # more non-mergeable dims than the copy kernel takes (``tile``: an 8-d DimShuffle view
+            # made contiguous for a Reshape): one copy per index of the outermost non-unit dim
+            d0 = next(d for d in range(nd) if dst.shape[d] != 1)
+            rest = tuple(dst.shape[:d0]) + (1,) + tuple(dst.shape[d0 + 1:])
+            sv = src.view(tuple(dst.shape), tuple(ss))
+            for i in range(dst.shape[d0]):
+                self.copy_into(dst.view(rest, dst.strides, dst.offset + i * dst.strides[d0]),
+                               sv.view(rest, sv.strides, sv.offset + i * ss[d0]), accumulate)
+            return
         if not accumulate and nd >= 2 and dst.size >= 4096:
             # transposing copy: identity program through the LDS-tiled Elemwise kernel
             cshape, cstr = collapse_dims(list(dst.shape), [list(ss), list(dst.strides)])

@@ -189,7 +189,9 @@ class OpsMixin:
             idx = tuple(slice(pos, pos + p.shape[axis]) if d == axis else slice(None)
                         for d in range(nd))
             sh, st, off = hostops.view_from_index(out.shape, out.strides, out.offset, idx)
-            self.copy_into(out.view(sh, st, off), p)
+            # (Join.make_node upcasts to the common dtype; the arrays arrive in their own:
+            # tensor/basic.py:2214 — np.concatenate's own promotion in perform :2342)
+            self.copy_into(out.view(sh, st, off), p if p.dtype == out.dtype else self.cast(p, out.dtype))
             pos += p.shape[axis]
         return [out]
 
@@ -280,8 +282,8 @@ class OpsMixin:
         out = self.alloc((n,), dt)
         if n:
             npdt = np.dtype(dt)
-            first = np.array([start]).astype(npdt)
-            delta = (np.array([start + step]).astype(npdt) - first).astype(npdt)
+            first = np.array([start, start + step]).astype(npdt)          # [first, next]
+            delta = (first[1:] - first[:1]).astype(npdt)
             self._launch("ahip_arange", (dtype_code(dt), first.ctypes.data_as(_VP),
                                          delta.ctypes.data_as(_VP), n, _VP(out.ptr),
                                          self._stream()))

@@ -931,7 +931,10 @@ class ScanMixin:
                 rows = [r if r.ndim == 2 and r.strides[1] == 1 and stacked else inner.contiguous(r)
                         for r in rows]
                 if stacked:
-                    rows = [r.view((n_steps, nb, r.shape[1]), (nb * r.strides[0], r.strides[0], 1))
+                    # (sequences of one Scan may differ in their per-step row count — x_t [3, 4]
+                    # next to y_t [5, 6]: every result unfolds with ITS rows per step)
+                    rows = [r.view((n_steps, r.shape[0] // n_steps, r.shape[1]),
+                                   ((r.shape[0] // n_steps) * r.strides[0], r.strides[0], 1))
                             for r in rows]
             finally:
                 lx._arena = None

@@ -1056,7 +1056,8 @@ def cpu_baseline(np, ref_warm=None, secondary=None):
                                        "full_shape_per_config": {k: v["full_shape"] for k, v in vs.items()},
                                        "input_shapes": {k: v["input_shapes"] for k, v in vs.items()},
                                        "sampled_rel_err": sampled,
-                                       "ok": bool(vs) and all(v["max"] <= refcheck.BAR for v in vs.values()),
+                                       "bars": {k: v["bars"] for k, v in vs.items()},
+                                       "ok": bool(vs) and all(v["ok"] for v in vs.values()),
                                        "what": "||hip - ref||_2 / ||ref||_2 per output, same seeded inputs "
                                                "(oracle/time_reference.make_inputs); ref = the reference's "
                                                "Mode('cvm','fast_run') on this host; every config at "

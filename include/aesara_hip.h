@@ -356,11 +356,12 @@ int ahip_copy_strided(int dtype, int nd, const int64_t* shape, const void* src,
                       const int64_t* sstrides, void* dst, const int64_t* dstrides, int accumulate,
                       void* stream);
 int ahip_fill(int dtype, const void* value /* host scalar */, void* dst, int64_t n, void* stream);
-/* tensor/basic.py:2867 ARange (perform :2937, np.arange(start, stop, step, dtype)): dst[i] = first +
- * i*delta evaluated in the output dtype — NumPy's fill rule with first = dtype(start), delta =
- * dtype(start + step) - first, both host scalars of `dtype`; n = ceil((stop - start) / step) is the
- * caller's.                                                                                     */
-int ahip_arange(int dtype, const void* first, const void* delta, int64_t n, void* dst, void* stream);
+/* tensor/basic.py:2867 ARange (perform :2937, np.arange(start, stop, step, dtype)): NumPy's fill
+ * rule in the output dtype — dst[0] = first_next[0] = dtype(start), dst[1] = first_next[1] =
+ * dtype(start + step), dst[i] = first + i*delta with delta = next - first, product and sum each
+ * rounded (no fused multiply-add).  `first_next` (two values) and `delta` are host scalars of
+ * `dtype`; n = ceil((stop - start) / step) is the caller's.                                      */
+int ahip_arange(int dtype, const void* first_next, const void* delta, int64_t n, void* dst, void* stream);
 
 /* ---- K9: integer row gather / scatter (bit-exact) ------------------------------------------
  * replaces: tensor/subtensor.py:1925 AdvancedSubtensor1 (perform :1953, x.take(idx, axis=0)) and

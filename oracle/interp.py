@@ -259,7 +259,9 @@ def gemm(z, a, x, y, b):
         r = a * np.dot(x, y) if a != 1.0 else np.dot(x, y)
     else:
         r = b * z + a * np.dot(x, y)
-    return np.asarray(r, dtype=dt)
+    if np.ndim(z) == 2:          # :995 z broadcast up to the product, the product up to z
+        r = np.broadcast_to(r, (max(z.shape[0], x.shape[0]), max(z.shape[1], y.shape[1])))
+    return np.array(r, dtype=dt)
 
 
 def gemv(y, alpha, A, x, beta):

@@ -65,7 +65,8 @@ if KIND != "reference":
                     try:
                         dry(*a)
                     except Exception:                   # noqa: BLE001  (a dry run cannot follow
-                        pass                            # data-dependent control flow)
+                        if os.environ.get("AESARA_HIP_SUITE_DRY_STRICT"):   # data-dependent control flow)
+                            raise
                 return interp.run_plan(plan, a)
             return run
 

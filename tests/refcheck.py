@@ -19,6 +19,18 @@ for p in (HERE, ORACLE):
         sys.path.insert(0, p)
 
 BAR = 1e-6
+# per-output bars where north_star / SURVEY §8d state another one: config 5's weight gradient is
+# "<= max(1e-5, the reference's own error)" — at N = 2^24 the reference's float32 Gemv(X.T, r)
+# (OpenBLAS, thread count of the host) is itself ~1e-6 from the exact sum
+BARS = {"cfg5": [1e-6, 1e-5, 1e-6]}
+
+
+def bar_for(cfg, i):
+    return BARS.get(cfg, [BAR] * (i + 1))[i] if cfg in BARS else BAR
+
+
+def within_bars(cfg, errs):
+    return all(e <= bar_for(cfg, i) for i, e in enumerate(errs))
 # config of time_reference.py -> (golden plan, input names in plan order, plan outputs compared
 # with the dumped reference outputs in that order)
 CONFIGS = {
@@ -92,6 +104,7 @@ def hip_vs_reference(dump_dir, configs=None, full=False):
         errs = [rel_err(v, r) for v, r in zip(vals, refs)]
         out[cfg] = {"rel_err": errs, "max": max(errs), "outputs": len(errs),
                     "max_abs_over_max_ref": [max_err(v, r) for v, r in zip(vals, refs)],
+                    "ok": within_bars(cfg, errs), "bars": [bar_for(cfg, i) for i in range(len(errs))],
                     "full_shape": bool(full or cfg in FULL_SHAPE_ALWAYS),
                     "input_shapes": {n: list(d[n].shape) for n in names if d[n].ndim}}
         del ex, got, args, d

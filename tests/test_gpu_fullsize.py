@@ -677,7 +677,7 @@ def test_baseline_configs_against_the_reference_c_linker(tmp_path):
     assert sorted(got) == sorted(cfgs), (sorted(got), p.stdout[-1500:])
     assert got["cfg1b"]["max"] == 0.0                          # an add is exact
     for k, v in got.items():
-        assert v["max"] <= refcheck.BAR, (k, v)
+        assert v["ok"], (k, v)
 
 
 @pytest.mark.parametrize("cfg", ["cfg4_b1", "cfg4_b64", "cfg5"])
@@ -710,7 +710,7 @@ def test_sampled_configs_at_full_shape_against_the_reference_c_linker(tmp_path, 
     got = refcheck.hip_vs_reference(str(tmp_path), [cfg], full=True)
     assert list(got) == [cfg], (got, p.stdout[-1500:])
     v = got[cfg]
-    assert v["full_shape"] and v["max"] <= refcheck.BAR, v
+    assert v["full_shape"] and v["ok"], v
     shapes = v["input_shapes"]
     if cfg == "cfg5":
         assert shapes["X"] == [1 << 24, 256]
