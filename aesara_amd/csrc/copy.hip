@@ -107,11 +107,11 @@ __global__ __launch_bounds__(256) void arange_kernel(ArangeArgs a) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.n;
        i += (int64_t)gridDim.x * blockDim.x) {
     if constexpr (FLT) {
+#pragma clang fp contract(off)   // HIP's __fmul_rn / __fadd_rn are plain * and +: only this keeps the FMA out
       T v;
       if (i == 0) v = (T)a.fstart;
       else if (i == 1) v = (T)a.fnext;
-      else if constexpr (sizeof(T) == 4) v = __fadd_rn((T)a.fstart, __fmul_rn((T)i, (T)a.fdelta));
-      else v = __dadd_rn((T)a.fstart, __dmul_rn((T)i, (T)a.fdelta));
+      else { const T prod = (T)i * (T)a.fdelta; v = (T)a.fstart + prod; }
       dst[i] = v;
     } else dst[i] = (T)(a.istart + i * a.istep);
   }

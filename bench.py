@@ -94,12 +94,13 @@ def roof(bound, work, dev_ms, peak, **extra):
     return r
 
 
-HANDOFF_FLOOR_US = 2.2   # one all-to-all vector hand-off between ~128 workgroups through L2
-#                          (MI355X_MICROARCH.md "allgather" row: 2.4-3.0 us at 256 pollers, -1.9 us
-#                          per halving of the readers; measured 2.2 us at 128) — the
-#                          price with polls issued back to back.  Since round 4 the first poll of a
-#                          hand-off is held back until it can find the tags (AESARA_HIP_SP_DELAY):
-#                          ~2.0 us per hand-off, so the ratio below can read < 1
+HANDOFF_FLOOR_US = 0.89  # ONE all-to-all hand-off of a 1024-float vector between 256 co-resident workgroups,
+#                          measured in isolation with the kernel's own exchange (tagged 8-byte granules, 4 polling
+#                          wavefronts, first poll held back 15 x 64 cycles, s_sleep 1 between polls) and nothing
+#                          else in the step: tools/handoff_floor.py -> profiles/r05_handoff_floor.json (0.886 us;
+#                          0.857 with 8 polling wavefronts; 1.63 with the polls issued back to back, the form the
+#                          guide's "allgather" row prices at 2.4-3.0 us).  A step of config 4 B = 1 has two of
+#                          them plus the row dots and LDS staging between them, so the ratio below reads ~1.9
 
 
 def latency_row(dev_ms, T, restreamed_bytes, handoffs_per_step, resident_bound_bytes):
@@ -116,7 +117,7 @@ def latency_row(dev_ms, T, restreamed_bytes, handoffs_per_step, resident_bound_b
             "restreamed_bytes": restreamed_bytes, "resident_bound_bytes": resident_bound_bytes,
             "note": "latency-bound by construction: weights stay on chip, each step is "
                     "`handoffs_per_step` dependent vector exchanges; no HBM/MFMA fraction applies "
-                    "(floor = the guide's price of a hand-off polled back to back)"}
+                    "(floor = the same exchange measured in isolation, tools/handoff_floor.py)"}
 
 
 def pick_transport(world, torch, dist):
