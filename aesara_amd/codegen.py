@@ -159,6 +159,14 @@ __device__ __forceinline__ float fdiv_inv(float x, float c, float r, bool ok) {
 }
 // tolerance mode (AESARA_HIP_FASTDIV=1): x * (1/c) without the refinement — at most 1.5 ulp from
 // the quotient (north_star's bar is 1e-6 rel); the full division when c or 1/c is not a normal number
+template <typename T> __device__ __forceinline__ T fdiv_rcp_s(T y, T K, T c, T r, bool ok) {
+  T res = y * (K * r);            // (K * y) / c, K a power of two: K * r is exact and loop invariant
+  if (__builtin_expect(!ok, 0)) {
+    asm volatile("" ::: "memory");
+    res = (K * y) / c;
+  }
+  return res;
+}
 template <typename T> __device__ __forceinline__ T fdiv_rcp(T x, T c, T r, bool ok) {
   T res = x * r;
   if (__builtin_expect(!ok, 0)) {
@@ -493,6 +501,14 @@ def invariant_nodes(scalar, inv_inputs):
     return inv
 
 
+def _is_pow2(v):
+    try:
+        m, _e = np.frexp(float(v))
+        return abs(m) == 0.5 and np.isfinite(float(v))
+    except (TypeError, ValueError):
+        return False
+
+
 def emit_scalar_body(scalar, in_exprs, in_dts, indent="      ", suffix="", hoisted=None,
                      only=None, exp_tbl=None):
     """Lines computing the temporaries of a plan scalar expression; returns (lines, out_exprs,
@@ -513,6 +529,11 @@ def emit_scalar_body(scalar, in_exprs, in_dts, indent="      ", suffix="", hoist
             return "t%d%s" % (r[1], suffix), tdt[r[1]]
         return _lit(r[1], r[2]), r[2]
 
+    uses = {}
+    for n in scalar["nodes"]:
+        for r in n["in"]:
+            if r[0] == "t":
+                uses[r[1]] = uses.get(r[1], 0) + 1
     for k, n in enumerate(scalar["nodes"]):
         if k in hoisted or (only is not None and k not in only):
             continue
@@ -524,8 +545,24 @@ def emit_scalar_body(scalar, in_exprs, in_dts, indent="      ", suffix="", hoist
             # divisor is loop invariant: correctly-rounded division from its hoisted
             # reciprocal (q = x*r; q += r*fma(-q, c, x)) instead of the full v_div_* sequence
             # (AESARA_HIP_FASTDIV=1, tolerance mode: the rounded product x * r alone, <= 1.5 ulp)
-            e = "%s(%s, %s, %s)" % ("fdiv_rcp" if knobs.get("FASTDIV") else "fdiv_inv",
-                                    _cast(refs[0][0], refs[0][1], dt), refs[1][0], hoisted[div[1]][1])
+            e = None
+            num = n["in"][0]
+            if knobs.get("FASTDIV") and num[0] == "t" and num[1] not in hoisted \
+                    and uses.get(num[1], 0) == 1 and list(num) not in [list(o) for o in scalar["out"]]:
+                # (K * y) / c with K = +-2^k a literal: scaling by a power of two is exact, so the
+                # quotient is y * (K * r) — K * r is loop invariant (the compiler hoists it), the
+                # scaling multiply of every element goes away (config 2: -0.5 * sqr(x - mu))
+                m = scalar["nodes"][num[1]]
+                if m["op"] == "mul" and len(m["in"]) == 2 and m["dtype"] == dt:
+                    for ci in (0, 1):
+                        c_, y_ = m["in"][ci], m["in"][1 - ci]
+                        if c_[0] == "c" and _is_pow2(c_[1]) and ref(y_)[1] == dt:
+                            e = "fdiv_rcp_s(%s, %s, %s, %s)" % (ref(y_)[0], _lit(c_[1], dt), refs[1][0],
+                                                               hoisted[div[1]][1])
+                            break
+            if e is None:
+                e = "%s(%s, %s, %s)" % ("fdiv_rcp" if knobs.get("FASTDIV") else "fdiv_inv",
+                                        _cast(refs[0][0], refs[0][1], dt), refs[1][0], hoisted[div[1]][1])
         elif exp_tbl and n["op"] == "exp" and dt == "float64":
             e = "exp_tbl64(%s, %s)" % (_cast(refs[0][0], refs[0][1], dt), exp_tbl)
         else:

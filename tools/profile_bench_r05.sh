@@ -51,6 +51,10 @@ out["per_kernel"] = per
 # the row's own kernel: the matching kernel with the largest share of GPU time that is not the
 # headline kernel every bench process also runs (cfg2's own row excepted)
 cands = sorted(out.get("kernels", []), key=lambda k: -k["pct_of_gpu_time"])
+if algo:   # (other rows also run the headline kernel: take the match whose counter bytes fit this row)
+    fit = [k for k in cands if per.get(k["name"], {}).get("hbm_bytes_per_launch_corrected")]
+    if fit:
+        cands = sorted(fit, key=lambda k: abs(per[k["name"]]["hbm_bytes_per_launch_corrected"] / algo - 1.0))
 out["row_kernel"] = cands[0]["name"] if cands else None
 tot = per.get(out["row_kernel"], {}).get("hbm_bytes_per_launch_corrected") if cands else None
 out["hbm_bytes_per_launch_corrected"] = tot
