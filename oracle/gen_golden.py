@@ -836,6 +836,81 @@ def _():
         [N((50, 64), "float32", 1), N((300, 64), "float32", 2), I((300,), "int64", 3, 0, 50)]
 
 
+# ---- round 5: what the reference's own test files found on the device (tests/reference_files.py) ----
+@case("advinc_nodup_int", exact=True, ref_py=True)
+def _():
+    # AdvancedIncSubtensor(ignore_duplicates=True) (tensor/subtensor.py:2693): ``out[idx] += y`` —
+    # read, add, sequential set: the LAST duplicate wins, its sum started from the original value
+    from aesara.tensor.subtensor import advanced_inc_subtensor_nodup
+    x, y = at.lmatrix("x"), at.lvector("y")
+    i, j = at.lvector("i"), at.lvector("j")
+    return [x, y, i, j], [advanced_inc_subtensor_nodup(x, y, i, j)], \
+        [I((6, 5), "int64", 1), I((12,), "int64", 2), I((12,), "int64", 3, -6, 6), I((12,), "int64", 4, -5, 5)]
+
+
+@case("gemm_bcast_z_f64", rtol=1e-12)
+def _():
+    # Gemm.perform (tensor/blas.py:995): z broadcast UP to the product's shape
+    from aesara.tensor.blas import gemm_no_inplace
+    z, x, y = at.dmatrix("z"), at.dmatrix("x"), at.dmatrix("y")
+    a, b = at.dscalar("a"), at.dscalar("b")
+    return [z, a, x, y, b], [gemm_no_inplace(z, a, x, y, b)], \
+        [N((1, 40), seed=1), K(0.5, "float64"), N((33, 17), seed=2), N((17, 40), seed=3), K(0.25, "float64")]
+
+
+@case("gemm_bcast_dot_f64", rtol=1e-12)
+def _():
+    # ... and ``z += a * dot(x, y)`` broadcasts the product up to z's shape
+    from aesara.tensor.blas import gemm_no_inplace
+    z, x, y = at.dmatrix("z"), at.dmatrix("x"), at.dmatrix("y")
+    a, b = at.dscalar("a"), at.dscalar("b")
+    return [z, a, x, y, b], [gemm_no_inplace(z, a, x, y, b)], \
+        [N((35, 40), seed=1), K(0.5, "float64"), N((1, 17), seed=2), N((17, 40), seed=3), K(1.0, "float64")]
+
+
+@case("join_mixed_dtypes", exact=True)
+def _():
+    # Join upcasts to the common dtype (tensor/basic.py:2214); the parts arrive in their own
+    a, b, c = at.bmatrix("a"), at.imatrix("b"), at.matrix("c", dtype="int16")
+    return [a, b, c], [at.join(1, a, b, c), at.join(0, a, c)], \
+        [I((4, 3), "int8", 1), I((4, 5), "int32", 2, -1000, 1000), I((4, 3), "int16", 3, -300, 300)]
+
+
+@case("arange_float32_fill", exact=True)
+def _():
+    # np.arange's fill rule in float32 (first, next, first + i * delta; product and sum each rounded)
+    st, sp, se = at.fscalar("start"), at.fscalar("stop"), at.fscalar("step")
+    return [st, sp, se], [at.arange(st, sp, se)], \
+        [K(-5.0, "float32"), K(101.1, "float32"), K(1.2, "float32")]
+
+
+@case("tile_8d_views", exact=True)
+def _():
+    # ``tile`` of a 4-d array: an 8-d DimShuffle view made contiguous for a Reshape, and the Sum over
+    # such a view in its gradient — more non-mergeable dims than one kernel takes (6)
+    x = at.TensorType("int64", shape=(None,) * 4)("x")
+    t = at.tile(x, (2, 3, 2, 2))
+    y = at.TensorType("int64", shape=(None,) * 8)("y")
+    return [x, y], [t, y.dimshuffle(0, 2, 4, 6, 1, 3, 5, 7).sum(axis=(0, 1, 2, 3))], \
+        [I((2, 3, 4, 5), "int64", 1), I((2, 3, 2, 4, 3, 2, 5, 2), "int64", 2)]
+
+
+@case("scan_seq_products_two_row_counts", rtol=1e-12)
+def _():
+    # sequences of one Scan with DIFFERENT rows per step ([3, 4] next to [5, 6]): the hoisted
+    # sequence products are stacked over time and unfolded per result (tests/scan/test_rewriting.py:741)
+    s1, s2, s3 = at.dtensor3("s1"), at.dtensor3("s2"), at.dtensor3("s3")
+    W, U_ = at.dmatrix("W"), at.dmatrix("U")
+    init = at.dmatrix("init")
+
+    def step(a, b, c, prev, W, U_):
+        return prev + at.dot(at.dot(a, W) + c, at.dot(b, U_))
+    h, _ = ae.scan(step, sequences=[s1, s2, s3], outputs_info=init, non_sequences=[W, U_])
+    return [s1, s2, s3, W, U_, init], [h[-1], h], \
+        [N((6, 3, 4), seed=1), N((6, 5, 6), seed=2), N((6, 3, 5), seed=3), N((4, 5), seed=4),
+         N((6, 7), seed=5), N((3, 7), seed=6)]
+
+
 @case("alloc_join", exact=True)
 def _():
     v, m = at.dvector("v"), at.dmatrix("m")
