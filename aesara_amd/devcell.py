@@ -106,7 +106,7 @@ class DeviceFilterType:
     in-place Op would destroy; this linker's rewrite query excludes ``inplace`` and the executor
     only ever writes into buffers it allocated itself, so there is nothing for it to protect.
     """
-    __slots__ = ("_t", "_want", "_ndim", "_static")
+    __slots__ = ("_t", "_want", "_ndim", "_static", "_np")
 
     def __init__(self, t):
         t = t._t if isinstance(t, DeviceFilterType) else t
@@ -115,8 +115,24 @@ class DeviceFilterType:
         object.__setattr__(self, "_want", TORCH_DTYPES.get(getattr(t, "dtype", None)))
         object.__setattr__(self, "_ndim", getattr(t, "ndim", None))
         object.__setattr__(self, "_static", any(x is not None for x in getattr(t, "shape", ())))
+        # host fast path: an ndarray that IS what ``TensorType.filter`` (tensor/type.py:153-156, then
+        # the rank / alignment / static-shape checks :236-251) returns unchanged.  Built-in NumPy
+        # dtypes are singletons, so the dtype test is an identity test; ``None`` disables the path
+        # (a type that also checks finiteness, :253, or one without a NumPy dtype)
+        npdt = getattr(t, "numpy_dtype", None)
+        if getattr(t, "filter_checks_isfinite", False) or not isinstance(npdt, np.dtype) \
+                or np.dtype(npdt.name) is not npdt:
+            npdt = None
+        object.__setattr__(self, "_np", npdt)
 
     def filter(self, value, strict=False, allow_downcast=None):
+        if type(value) is np.ndarray:
+            # (the 0-d ``mu`` / ``sigma`` / learning-rate arguments of every call: 0.3 us instead of
+            # the 1.9 us of the general filter below, which reaches the same ``return data``)
+            if value.dtype is self._np and value.ndim == self._ndim and not self._static \
+                    and value.flags.aligned:
+                return value
+            return self._t.filter(value, strict=strict, allow_downcast=allow_downcast)
         if type(value) is torch.Tensor:
             if value.dtype is self._want and value.ndim == self._ndim and not self._static \
                     and value.device.type != "cpu":

@@ -113,6 +113,73 @@ class ReplayMixin:
             res[k] = t
         return inputs if res is None else res
 
+    def _memoize(self, ids, args, inputs, ent):
+        """Remember a replay entry under the identities of the call's argument objects (second
+        sighting of that tuple of ids: one-off arguments — Python floats filtered into new arrays
+        on every call — never get here twice).  Device tensors are validated by identity (weak
+        reference: an id can be reused) and data pointer, small host float arrays by identity and
+        value (``inputs``: the same list with those arrays replaced by their cached device tensors,
+        which the memo keeps alive — the entry's launches address them); anything else (index-like
+        host integers, staged host arrays) is not memoized.  The generation number drops every
+        memo when a launch list is released."""
+        if self._memo_seen.get(ids) is None:
+            if len(self._memo_seen) >= 256:
+                self._memo_seen.clear()
+            self._memo_seen[ids] = 1
+            return
+        chk, keep = [], []
+        for x, d in zip(args, inputs):
+            if type(x) is torch.Tensor:
+                if not x.is_cuda:
+                    return
+                chk.append((weakref.ref(x), x.data_ptr()))
+            elif type(x) is np.ndarray and x.dtype.char in self._SMALL_FLOAT and x.size <= 16 \
+                    and type(d) is torch.Tensor:
+                chk.append((weakref.ref(x), x.tobytes()))
+                keep.append(d)
+            else:
+                return
+        if len(self._memo) >= 64:
+            self._memo.pop(next(iter(self._memo)))
+        self._memo[ids] = (self._memo_gen, ent, chk, keep)
+
+    def _replay(self, ent, out):
+        """Issue a recorded entry (launch list, rebased launch list or hipGraph) on the current
+        stream and hand out its results."""
+        stream = torch._C._cuda_getCurrentRawStream(self.device.index)
+        fresh = None
+        if ent[7] is not None:
+            bases = ent[7]
+            if ent[8] and not self.borrow:
+                # fresh outputs WITHOUT a copy: the launches that produce them are re-pointed
+                # at newly allocated tensors (slot = position in the rebinding table)
+                fresh = {}
+                for k, slot, shape, dtype in ent[8]:
+                    t = torch.empty(shape, dtype=dtype, device=self.device)
+                    fresh[k] = t
+                    bases[slot] = t.data_ptr()
+            rc = lib.ahip_list_run_rebased(ent[0], bases, len(bases), stream)
+        else:
+            rc = (lib.ahip_list_run(ent[0], stream) if ent[1] is None
+                  else lib.ahip_graph_launch(ent[1], stream))
+        if rc:
+            check(rc)
+        # index kernels (and the persistent Scan kernel) flag errors in device words: a
+        # replayed call never skips the check.  check_indices=True (default): one blocking
+        # read per call of a plan that has such kernels — the error is raised by the call
+        # that met it, like the reference; "deferred" (HipLinker(check_indices="deferred")):
+        # the words are copied to pinned memory behind the launches and examined when they
+        # have landed (next call at the latest; ``check()`` waits) — no stall.  Plans without
+        # index kernels / persistent Scans never wait; the full-reduction finalize reports
+        # through a pinned host flag (``_check_reduce_flag``), no device read at all
+        if (self._bad_index is not None or self._sp_ws) and self.check_indices:
+            if self.check_indices == "deferred":
+                self._deferred_check()
+            else:
+                self._raise_bad_index()
+        self._check_reduce_flag()
+        return self._hand_out(ent[2], out, fresh)
+
     LIST_MAX = 48   # launches replayed as a plain launch list; longer lists become a hipGraph
 
     def _call_graph(self, inputs, vals=None, out=None):
@@ -121,8 +188,24 @@ class ReplayMixin:
         kernel launch appended to a C-side launch list instead of executed, (3) short lists are
         replayed as is (one host call, plain launches), long ones (Scan) are turned into a
         hipGraph by capturing one replay of the list."""
+        ids = None
+        if not out:
+            # the same argument OBJECTS as an earlier replayed call (a loop over a few batches with
+            # the same host scalars: BASELINE config 2's ``f(x, mu, sigma)``): one dictionary lookup
+            # and one identity / pointer / value test per argument instead of the keys below
+            ids = tuple(map(id, inputs))
+            m = self._memo.get(ids)
+            if m is not None:
+                if m[0] == self._memo_gen:
+                    for x, (r, p_) in zip(inputs, m[2]):
+                        if r() is not x or (x.data_ptr() if type(x) is torch.Tensor else x.tobytes()) != p_:
+                            break
+                    else:
+                        return self._replay(m[1], None)
+                del self._memo[ids]
         okey = tuple(-1 if t is None else t.data_ptr() for t in out) if out else ()
         ent = None
+        args = inputs
         if not all(type(x) is torch.Tensor for x in inputs):
             inputs = self._small_host_values(inputs)
         if all(type(x) is torch.Tensor for x in inputs):     # fast path: same tensors as before
@@ -142,6 +225,7 @@ class ReplayMixin:
             # launches to the new addresses instead of copying into staging buffers
             ent = self._rebind(inputs, out, okey)
         if ent is None:
+            ids = None               # (an entry reached through staging copies is never memoized)
             staged = self._stage_inputs(inputs)
             if staged is not None:
                 inputs, vals = staged, None
@@ -149,39 +233,9 @@ class ReplayMixin:
                          for x in inputs]) + okey
             ent = self._graphs.get(key)
         if ent is not None:
-            stream = torch._C._cuda_getCurrentRawStream(self.device.index)
-            fresh = None
-            if ent[7] is not None:
-                bases = ent[7]
-                if ent[8] and not self.borrow:
-                    # fresh outputs WITHOUT a copy: the launches that produce them are re-pointed
-                    # at newly allocated tensors (slot = position in the rebinding table)
-                    fresh = {}
-                    for k, slot, shape, dtype in ent[8]:
-                        t = torch.empty(shape, dtype=dtype, device=self.device)
-                        fresh[k] = t
-                        bases[slot] = t.data_ptr()
-                rc = lib.ahip_list_run_rebased(ent[0], bases, len(bases), stream)
-            else:
-                rc = (lib.ahip_list_run(ent[0], stream) if ent[1] is None
-                      else lib.ahip_graph_launch(ent[1], stream))
-            if rc:
-                check(rc)
-            # index kernels (and the persistent Scan kernel) flag errors in device words: a
-            # replayed call never skips the check.  check_indices=True (default): one blocking
-            # read per call of a plan that has such kernels — the error is raised by the call
-            # that met it, like the reference; "deferred" (HipLinker(check_indices="deferred")):
-            # the words are copied to pinned memory behind the launches and examined when they
-            # have landed (next call at the latest; ``check()`` waits) — no stall.  Plans without
-            # index kernels / persistent Scans never wait; the full-reduction finalize reports
-            # through a pinned host flag (``_check_reduce_flag``), no device read at all
-            if (self._bad_index is not None or self._sp_ws) and self.check_indices:
-                if self.check_indices == "deferred":
-                    self._deferred_check()
-                else:
-                    self._raise_bad_index()
-            self._check_reduce_flag()
-            return self._hand_out(ent[2], out, fresh)
+            if ids is not None:
+                self._memoize(ids, args, inputs, ent)
+            return self._replay(ent, out)
         if vals is None:
             vals = self._bind_inputs(inputs)
         # 1. eager pass
@@ -436,6 +490,7 @@ class ReplayMixin:
         """Free the C-side launch list / hipGraph of an evicted replay entry (a list rebound to
         several buffer sets is shared by their entries: freed with the last of them)."""
         lst, graph = ent[0], ent[1]
+        self._memo_gen += 1          # (memoized calls may point at this entry)
         if graph is not None:
             lib.ahip_graph_destroy(graph)
         if lst is not None:

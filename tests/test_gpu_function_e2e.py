@@ -279,6 +279,54 @@ def test_untrusted_function_filters_device_tensors(ae, gg):
     np.testing.assert_allclose(_host(f(x=xd, v=vd))[0], want, rtol=1e-12)
 
 
+def test_memoized_argument_objects_follow_their_values(ae, gg):
+    """Calls with the same argument OBJECTS take the executor's memo (``ReplayMixin._memoize``: one
+    lookup on the arguments' identities); the memo must notice everything a caller can do to
+    those objects between calls: a host scalar changed in place, a device matrix overwritten in
+    place (same pointer: the launches read what is there now), another tensor, a tensor that died
+    and whose id / pointer were re-used, a second shape — each against NumPy."""
+    import gc
+    import torch
+    import aesara.tensor as at
+    x, mu, sg = at.dmatrix("x"), at.dscalar("mu"), at.dscalar("sigma")
+    f = ae.function([x, mu, sg], at.exp(-(x - mu) ** 2 / (2 * sg ** 2)).sum(), mode="HIP")
+    assert f.trust_input is False
+    ex = f.vm.jit_fn
+    rng = np.random.default_rng(17)
+    xs = [rng.standard_normal((96, 80)) for _ in range(3)]
+    xd = [torch.from_numpy(a).cuda() for a in xs]
+    m, s = np.asarray(0.1), np.asarray(1.3)
+
+    def want(a, m_, s_):
+        return np.exp(-(a - m_) ** 2 / (2 * s_ ** 2)).sum()
+    for rep in range(4):                                  # rotation: three memo entries
+        for a, d in zip(xs, xd):
+            np.testing.assert_allclose(f(d, m, s).item(), want(a, 0.1, 1.3), rtol=1e-12)
+    assert len(ex._memo) == 3
+    m[...] = 0.4                                          # host scalar changed in place
+    np.testing.assert_allclose(f(xd[0], m, s).item(), want(xs[0], 0.4, 1.3), rtol=1e-12)
+    np.testing.assert_allclose(f(xd[0], m, s).item(), want(xs[0], 0.4, 1.3), rtol=1e-12)
+    np.testing.assert_allclose(f(xd[0], m, s).item(), want(xs[0], 0.4, 1.3), rtol=1e-12)
+    xd[1].copy_(xd[2])                                    # device matrix overwritten in place
+    np.testing.assert_allclose(f(xd[1], m, s).item(), want(xs[2], 0.4, 1.3), rtol=1e-12)
+    # a tensor dies, the next one may get its id and its pointer
+    for k in range(6):
+        a = rng.standard_normal((96, 80))
+        d = torch.from_numpy(a).cuda()
+        for _ in range(3):
+            np.testing.assert_allclose(f(d, m, s).item(), want(a, 0.4, 1.3), rtol=1e-12)
+        del d
+        gc.collect()
+    a = rng.standard_normal((50, 33))                     # another shape: a new signature
+    d = torch.from_numpy(a).cuda()
+    for _ in range(3):
+        np.testing.assert_allclose(f(d, m, s).item(), want(a, 0.4, 1.3), rtol=1e-12)
+    # results stay caller-owned on the memo path too
+    r1, r2 = f(xd[0], m, s), f(xd[0], m, s)
+    assert r1.data_ptr() != r2.data_ptr()
+    ex.check()
+
+
 def test_errors_name_the_apply_node(ae, gg):
     """A failure inside the thunk is re-raised by ``Function.__call__`` through
     ``raise_with_op`` (link/utils.py:270, types.py:974-991) with the Apply node that caused it —
