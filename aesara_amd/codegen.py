@@ -651,7 +651,7 @@ class KernelSpec:
     """
 
     def __init__(self, scalar, in_dtypes, out_dtypes, out_refs, inner, nd, vec, block=256,
-                 idx64=False, reduce=None, unroll=1, nt=False, invariant=None, tile_dim=None, pipe=0,
+                 idx64=False, reduce=None, unroll=1, nt=False, invariant=None, tile_dim=None,
                  early=None, blocked=None, trace=None, fast_exp=None, hjobs=False):
         self.scalar = scalar
         # horizontal fusion: the kernel takes an ArgsH block — several independent jobs of this
@@ -661,18 +661,15 @@ class KernelSpec:
                     and nd == 1 and vec > 1)
         # flat full reductions: the first group of loads is issued before the invariant prologue
         # (its dependent scalar loads and the reciprocal would otherwise delay them ~0.3 us)
-        self.early = bool(knobs.get("EARLY") if early is None else early) and flat_all and not pipe
+        self.early = bool(knobs.get("EARLY") if early is None else early) and flat_all
         # one contiguous chunk of the stream per workgroup instead of a grid-stride walk
         self.blocked = int(knobs.get("RED_BLOCKED") if blocked is None else blocked) if flat_all else 0
         # plain flat Elemwise streams (no reduction): the same walks, off unless measured better
-        if reduce is None and tile_dim is None and nd == 1 and vec > 1 and not pipe:
+        if reduce is None and tile_dim is None and nd == 1 and vec > 1:
             self.blocked = int(knobs.get("STREAM_BLOCKED") if blocked is None else blocked)
-        # the second workgroup a CU receives loses every issue arbitration to the older one
-        # (oldest first): static priority for the second half of the grid evens their progress
-        self.prio = int(knobs.get("RED_PRIO")) if flat_all else 0
         if self.hjobs:
             assert flat_all and len(in_dtypes) + len(out_dtypes) <= 6, "hjobs: flat full reductions only"
-            self.blocked, self.prio = 1, 0      # a contiguous chunk per workgroup inside its job
+            self.blocked = 1                    # a contiguous chunk per workgroup inside its job
         # per-workgroup s_memrealtime stamps into the reduce workspace (tools/ew_trace.py)
         self.trace = bool(knobs.get("EW_TRACE") if trace is None else trace) and \
             reduce is not None and reduce.get("kind") == "all" and tile_dim is None
@@ -680,10 +677,6 @@ class KernelSpec:
         self.fast_exp = bool(knobs.get("FASTEXP") if fast_exp is None else fast_exp) and \
             tile_dim is None and any(n["op"] == "exp" and n["dtype"] == "float64"
                                      for n in scalar["nodes"])
-        # flat 1-d streams only: ping-pong software pipeline — the loads of the NEXT group of
-        # `unroll` vectors are in flight while the current group is evaluated (every wave keeps
-        # loads outstanding through its ALU phase, which a load-all / compute-all body does not)
-        self.pipe = int(pipe)
         self.in_dtypes = list(in_dtypes)
         self.out_dtypes = list(out_dtypes)
         self.out_refs = list(out_refs)
@@ -706,12 +699,11 @@ class KernelSpec:
     def key(self):
         fields = [self.in_dtypes, self.out_dtypes, self.out_refs, self.inner, self.nd, self.vec,
                   self.block, self.idx64, self.reduce, self.unroll, self.nt, self.invariant,
-                  self.tile_dim, "v11" if self.tile_dim else "v10", self._variant()] + \
-            (["pipe"] if self.pipe else [])
+                  self.tile_dim, "v11" if self.tile_dim else "v10", self._variant()]
         return _memo_key([self.scalar], fields, self._key)
 
     def _variant(self):
-        return "r4%d%d%d%d%d%s%s" % (self.early, self.blocked, self.trace, self.fast_exp, self.prio,
+        return "r4%d%d%d%d%d%s%s" % (self.early, self.blocked, self.trace, self.fast_exp, 0,
                                      "H" if self.hjobs else "", "D" if knobs.get("FASTDIV") else "")
 
     def _key(self):
@@ -719,8 +711,7 @@ class KernelSpec:
         blob = json.dumps([self.scalar, self.in_dtypes, self.out_dtypes, self.out_refs,
                            self.inner, self.nd, self.vec, self.block, self.idx64, self.reduce,
                            self.unroll, self.nt, self.invariant, "v10", self._variant()] +
-                          ([["tile2", self.tile_dim]] if self.tile_dim is not None else []) +
-                          (["pipe"] if self.pipe else []),
+                          ([["tile2", self.tile_dim]] if self.tile_dim is not None else []),
                           sort_keys=True)
         return hashlib.sha256(blob.encode()).hexdigest()[:24]
 
@@ -805,8 +796,6 @@ def _kernel_prologue(spec, name, L, mid=None, pre=None):
     # ones first (exp-table entry, scalar operands, launch epoch: they come back from the
     # memory-side cache), then — ``mid`` — the first group of a flat reduction's stream, so the
     # invariant arithmetic below runs while the stream's first bytes are in flight
-    if getattr(spec, "prio", 0):
-        L.append("  if (blockIdx.x >= gridDim.x / 2) __builtin_amdgcn_s_setprio(%d);" % min(3, spec.prio))
     if pre is not None:
         pre(L)
     fast_exp = getattr(spec, "fast_exp", False)
@@ -1143,8 +1132,7 @@ def generate(spec: KernelSpec):
     name = "ew_" + spec.key()
     L = []
     etbl = "etbl_" if spec.fast_exp else None
-    flat_u = (red is None or red["kind"] == "all") and spec.nd == 1 and U > 1 and not (
-        spec.pipe and V > 1)
+    flat_u = (red is None or red["kind"] == "all") and spec.nd == 1 and U > 1
     early = spec.early and flat_u
     inv_set = {k for k in range(nin) if spec.invariant[k]}
 
@@ -1283,47 +1271,7 @@ def generate(spec: KernelSpec):
         nd = spec.nd
         if not early:
             index_setup(L)
-        if nd == 1 and spec.pipe and V > 1 and all(
-                spec.inner[k] == "c" or k in inv_in for k in range(nin)):
-            # ping-pong pipeline over groups of U vectors: A = [item, item + U) is loaded; per
-            # round: load B = next group, evaluate A, load A' = the group after, evaluate B
-            G = max(U, 1)
-            streamed = [k for k in range(nin) if k not in inv_in]
-            flatx = ["(i64)%%s * %d" % V if spec.inner[k] == "c" else "0" for k in range(nops)]
-
-            def ld(grp, base):
-                out = []
-                for u in range(G):
-                    it = "(item + %d * step)" % (base + u)
-                    for k in streamed:
-                        ct = CTYPE[spec.in_dtypes[k]]
-                        ptr = "(const Pack<%s, %d>*)(p%d + (i64)%s * %d)" % (ct, V, k, it, V)
-                        out.append("      x%d_%s%d = %s;" % (k, grp, u, ("nt_load(%s)" % ptr) if int(spec.nt) & 1
-                                                            else "*" + ptr))
-                return out
-
-            def ev(grp, base):
-                out = []
-                for u in range(G):
-                    it = "(item + %d * step)" % (base + u)
-                    out.extend(compute([f % it if "%s" in f else f for f in flatx], "_%s%d" % (grp, u)))
-                return out
-            for grp in "AB":
-                for u in range(G):
-                    for k in streamed:
-                        L.append("  Pack<%s, %d> x%d_%s%d;" % (CTYPE[spec.in_dtypes[k]], V, k, grp, u))
-            L.append("  if (item + %d * step < items) {" % (G - 1))
-            L.extend(ld("A", 0))
-            L.append("    for (; item + %d * step < items; item += %d * step) {" % (3 * G - 1, 2 * G))
-            L.extend(ld("B", G))
-            L.extend(ev("A", 0))
-            L.extend(ld("A", 2 * G))
-            L.extend(ev("B", G))
-            L.append("    }")
-            L.extend(ev("A", 0))
-            L.append("    item += %d * step;" % G)
-            L.append("  }")
-        elif nd == 1 and U > 1:
+        if nd == 1 and U > 1:
             # flat streaming shape: U independent vectors in flight per lane, loads first
             if early:
                 L.append("  if (first_) {")

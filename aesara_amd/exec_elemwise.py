@@ -731,16 +731,15 @@ class ElemwiseMixin:
                 (2 if n * max(ITEMSIZE[d] for d in dtypes[:len(arrs)]) <= (1 << 28) else 1)
             mk = ("all", id(st.scalar), tuple(st.out_refs), tuple(dtypes), tuple(classes),
                   len(cshape), vec, idx64, flat1, invariant, rspec["op"], rspec["acc"],
-                  rspec["out"], rspec["ref"], unroll_all, int(knobs.get("PIPE")))
-            pipe = int(knobs.get("PIPE")) if flat1 else 0
+                  rspec["out"], rspec["ref"], unroll_all)
 
             def mkspec(hjobs=False, st=st, dtypes=dtypes, classes=classes, nd_=len(cshape), vec=vec,
                        idx64=idx64, flat1=flat1, invariant=invariant, rspec=rspec, unroll_all=unroll_all,
-                       nin=len(arrs), pipe=pipe):
+                       nin=len(arrs)):
                 return cg.KernelSpec(st.scalar, dtypes[:nin], dtypes[nin:], st.out_refs,
                                      classes, nd_, vec, idx64=idx64,
                                      reduce=dict(rspec, kind="all"), block=TUNE["red_block"],
-                                     unroll=unroll_all if flat1 else 1, pipe=0 if hjobs else pipe,
+                                     unroll=unroll_all if flat1 else 1,
                                      nt=TUNE["nt"] and flat1, invariant=list(invariant), hjobs=hjobs)
 
             def single(mk=mk, mkspec=mkspec, st=st, cshape=cshape, cstrides=cstrides, ops=ops,
@@ -760,7 +759,7 @@ class ElemwiseMixin:
                     _i64arr(flat), vec, block, _VP(result.ptr), _VP(ws.data_ptr()),
                     ws.numel(), self._stream()))
 
-            if self._defer is not None and flat1 and not idx64 and len(ops) <= 6 and not pipe \
+            if self._defer is not None and flat1 and not idx64 and len(ops) <= 6 \
                     and all(c in ("c", "b") for c in classes):
                 # member of a horizontal group: hand the launch over (``_run_hgroup``)
                 self._defer.append({

@@ -727,31 +727,59 @@ class ScanMixin:
         if len(inv_vars) != len(non_seqs):
             return "invariant operand count", None, 0
         inv_val = dict(zip(inv_vars, non_seqs))
-        # the ONE shape every loop-varying value has
-        if n_mm + n_rec:
-            S = tuple(outs[0].shape[1:])
-        elif shared:
-            S = tuple(inner.to_device(shared[0]).shape)
-        elif seqs:
-            S = tuple(seqs[0].shape[1:])
-        else:
-            return "no loop-varying operand to take the shape from", None, 0
+        wg = prog.wg
+        rec_kind, nit_kind, sh_kind = se.slot_kinds(prog)
+
+        def kind(v):
+            return prog.cls.get(v, 0) if wg else 0
+        # the ONE shape every per-element value has (``wg``: 0-d values ride along, ProgramEw.cls)
+        S = None
+        for k in range(n_mm + n_rec):
+            if k < n_mm or not rec_kind[k - n_mm]:
+                S = tuple(outs[k].shape[1:])
+                break
+        if S is None:
+            for m in range(n_sh):
+                if not sh_kind[m]:
+                    S = tuple(inner.to_device(shared[m]).shape)
+                    break
+        if S is None:
+            for v, s_ in sorted(prog.seq.items(), key=lambda kv: kv[1]):
+                a_ = seqs[s_] if s_ < n_seqs else pre_rows[s_ - n_seqs]
+                if a_ is not None and not kind(v):
+                    S = tuple(a_.shape[1:])
+                    break
+        if S is None and wg:
+            for v in prog.nsq:
+                if not kind(v) and _prod(inner.to_device(inv_val[v]).shape) != 1:
+                    S = tuple(inner.to_device(inv_val[v]).shape)
+                    break
+        if S is None:
+            if not wg:
+                return "no loop-varying operand to take the shape from", None, 0
+            S = ()
         n = _prod(S) if S else 1
         if n < 1:
             return "empty state", None, 0
-        if prog.as_while and n != 1:
+        if prog.as_while and n != 1 and not (wg and kind(prog.cond)):
             return "do-while over more than one element (the condition would be a reduction)", None, 0
+        if wg and n > 1024:
+            return "a reduction / 0-d value in the step and more than 1024 elements (one workgroup)", None, 0
         cs = contiguous_strides(S)
 
         def rows_ok(a):
             return tuple(a.shape[1:]) == S and (n == 1 or tuple(a.strides[1:]) == tuple(cs))
+
+        def one(a):
+            return _prod(a.shape[1:]) == 1
         g = se.EwScanArgs()
         g.T, g.n = n_steps, n
         for v, s_ in prog.seq.items():
             a_ = seqs[s_] if s_ < n_seqs else pre_rows[s_ - n_seqs]
-            if a_ is None or a_.dtype != lp.vars[v].dtype or tuple(a_.shape[1:]) != S or a_.shape[0] < n_steps:
+            if a_ is None or a_.dtype != lp.vars[v].dtype or a_.shape[0] < n_steps or \
+                    (not one(a_) if kind(v) else tuple(a_.shape[1:]) != S):
                 return "sequence operand layout", None, 0
-            if not rows_ok(a_):
+            if not kind(v) and not rows_ok(a_):
                 a_ = inner.contiguous(a_)
             g.seq[s_], g.seq_ts[s_] = a_.ptr, a_.strides[0]
         bc = set()
@@ -763,7 +791,7 @@ class ScanMixin:
                 bc.add(j)
                 g.nsq[j], g.nsq_es[j] = x.ptr, 0
             else:
-                if tuple(x.shape) != S:
+                if tuple(x.shape) != S or kind(v):
                     return "invariant operand shape", None, 0
                 x = inner.contiguous(x)
                 g.nsq[j], g.nsq_es[j] = x.ptr, 1
@@ -778,19 +806,31 @@ class ScanMixin:
                 return "mit-mot buffer layout", None, 0
         for k in range(n_rec):
             b = outs[n_mm + k]
-            if tuple(b.shape[1:]) != S or (n != 1 and tuple(b.strides[1:]) != tuple(cs)) or \
+            if (not one(b) if rec_kind[k] else
+                    (tuple(b.shape[1:]) != S or (n != 1 and tuple(b.strides[1:]) != tuple(cs)))) or \
                     store[n_mm + k] < prog.depth[k] or b.dtype != lp.vars[lp.outputs[n_mmo + k]].dtype:
                 return "recurrent output layout", None, 0
+            if wg and not rec_kind[k] and kind(prog.rec_new[k]) and n != 1:
+                pass        # (a 0-d value written into every element of a vector state: fine)
+            if wg and rec_kind[k] and not kind(prog.rec_new[k]) and n != 1:
+                return "per-element value stored into a 0-d output", None, 0
         out_dt = [outs[k].dtype for k in range(n_mm + n_rec)]
+        nit_shape = []
         for j in range(n_nit):
             ov = lp.vars[lp.outputs[n_mmo + n_rec + j]]
-            if ov.ndim != len(S):
+            if nit_kind[j]:
+                if not kind(prog.nit_new[j]) and n != 1:
+                    return "per-element value stored into a 0-d output", None, 0
+                nit_shape.append((1,) * ov.ndim)
+            elif ov.ndim != len(S):
                 return "nit-sot output of another rank", None, 0
+            else:
+                nit_shape.append(S)
             out_dt.append(ov.dtype)
         sh_vals, sh_dt = [], []
         for m in range(n_sh):
             x = inner.to_device(shared[m])
-            if tuple(x.shape) != S:
+            if (_prod(x.shape) != 1) if sh_kind[m] else (tuple(x.shape) != S):
                 return "shared value shape", None, 0
             sh_vals.append(inner.contiguous(x))
             sh_dt.append(x.dtype)
@@ -810,13 +850,13 @@ class ScanMixin:
                 _Kernels.cache[key] = ent
         for j in range(n_nit):
             sl = n_mm + n_rec + j
-            outs[sl] = inner.alloc((store[sl],) + S, out_dt[sl])
+            outs[sl] = inner.alloc((store[sl],) + tuple(nit_shape[j]), out_dt[sl])
         for k in range(n_mm + n_rec + n_nit):
             b = outs[k]
             g.out[k], g.out_rs[k], g.out_store[k], g.out_pos0[k] = b.ptr, b.strides[0], store[k], pos[k]
         sh_out = []
         for m in range(n_sh):
-            o = inner.alloc(S, sh_dt[m])
+            o = inner.alloc(tuple(sh_vals[m].shape) if sh_kind[m] else S, sh_dt[m])
             sh_out.append(o)
             g.sh_in[m], g.sh_out[m] = sh_vals[m].ptr, o.ptr
         ctl = None
@@ -827,7 +867,9 @@ class ScanMixin:
                 self._sp_ws[("se_ctl", id(inner))] = ctl
             g.ctl = ctl[1].data_ptr() + 16          # (word 1 of a persistent-Scan workspace is its error word)
         offs, nptr = ptr_offsets(type(g))
-        self._launch("ahip_launch_p", (ent[0], (n + 255) // 256, 1, 1, 256, 1, 1, 0, C.byref(g), C.sizeof(g),
+        # (``wg``: ONE workgroup of whole wavefronts covering the n elements, see scan_persist_ew)
+        grid_, block_ = (1, max(64, (n + 63) // 64 * 64)) if wg else ((n + 255) // 256, 256)
+        self._launch("ahip_launch_p", (ent[0], grid_, 1, 1, block_, 1, 1, 0, C.byref(g), C.sizeof(g),
                                        offs, nptr, 0, self._stream()))
         done = n_steps
         if prog.as_while:

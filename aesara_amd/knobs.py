@@ -30,7 +30,6 @@ _def("RED_BLOCK", None, int, "threads per workgroup of full reductions (default 
 _def("RED_UNROLL", 1, int, "axis-reduce loop unroll (1 = the default 8)")
 _def("COL_LANES", 128, int, "column-reduce strip width in lanes")
 _def("TILED", 1, int, "LDS-tiled form for transposed operands")
-_def("PIPE", 0, int, "ping-pong software pipeline for flat streams (measured null, r03)")
 _def("FASTEXP", 1, int, "float64 exp through the 64-entry table in LDS (0: ocml's exp)")
 _def("FASTDIV", 1, int, "x / c for a loop-invariant c (a broadcast scalar divisor): 1 = x * (1/c), <= 1.5 ulp from the "
      "quotient (what the reference's own FAST_RUN canonicaliser does to constant divisors; north_star's bar is 1e-6 rel; "
@@ -39,7 +38,6 @@ _def("EARLY", 1, int, "flat full reductions issue their first loads before the i
 _def("RED_BLOCKED", 2, int, "flat full reductions: 0 grid-stride walk, 1 one contiguous chunk per workgroup, "
      "2 (default) chunks ordered so that every XCD streams one contiguous eighth (r04 sweeps: 27.1 vs 27.7 us)")
 _def("STREAM_BLOCKED", 0, int, "flat Elemwise streams: 0 grid-stride, 1 contiguous chunk per workgroup, 2 XCD-contiguous")
-_def("RED_PRIO", 0, int, "flat full reductions: s_setprio for the second half of the grid (the younger workgroup of a CU)")
 _def("EW_TRACE", 0, int, "full reductions stamp s_memrealtime per workgroup into the workspace (tools/ew_trace.py)")
 _def("HFUSE", 1, int, "horizontal fusion of independent same-shape Elemwise/CAReduce steps into one launch")
 # ---- launch shapes owned by the C side (ahip_set_param) ----------------------------------------
@@ -63,7 +61,6 @@ _def("SP_SLEEP", 1, int, "s_sleep between polls of the vector-state kernel")
 _def("SP_DELAY", 15, int, "vector-state kernel: s_sleep units (64 cycles) before the first poll of a hand-off "
      "(config 4 B = 1, 128 x 8 rows, 2 polling waves: 4.59 us per step with 0, 4.05 with 12, 4.27 with 20; "
      "256 x 4 rows, 4 polling waves: 3.52 / 3.42 / 3.38 / 3.37 / 3.43 with 10 / 12 / 14 / 16 / 18)")
-_def("SP_REPOLL", 0, int, "re-poll only the granules that were missing")
 _def("SM_CHUNK", 32, int, "k-chunk of the matrix-state kernel's exchange")
 _def("SM_XMODE", None, str, "exchange form of the matrix-state kernel: frag | flag (default by registers)")
 _def("SM_EARLY", "first", str, "which product of a step starts before the hand-off: first | none")

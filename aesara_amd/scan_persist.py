@@ -346,7 +346,7 @@ class Spec:
         self.var = {"pollw": min(nw, int(knobs.get("SP_POLLW"))),
                     "sleep": int(knobs.get("SP_SLEEP")),
                     "delay": int(knobs.get("SP_DELAY")),
-                    "repoll": int(knobs.get("SP_REPOLL"))}
+                    "repoll": 0}      # (re-polling only the missing granules: measured null r03, removed)
 
     def key(self):
         pr = self.prog
@@ -544,11 +544,6 @@ def generate(spec: Spec):
             L.append(ind + "const unsigned want = base + (unsigned)%s + 1u;" % step_expr)
             L.append(ind + pg + "{")
             L.append(ind + "u64 g[%d];" % NGp)
-            if spec.var["repoll"]:
-                L.append(ind + "bool have[%d];" % NGp)
-                for q in range(NGp):
-                    L.append(ind + "have[%d] = %s;" % (q, "false" if (q + 1) * PT <= KG else
-                                                      "!(threadIdx.x + %d < %d)" % (q * PT, KG)))
             # a poll that comes back without the tags costs a whole further round trip (~0.7 us)
             # and its traffic slows the very stores it waits for: hold the first one back until it
             # can succeed (r04: config 4 B = 1 4.59 -> 4.05 us per step with 12 x 64 cycles)
@@ -561,17 +556,9 @@ def generate(spec: Spec):
             L.append(ind + "for (int spin = 0;; ++spin) {")
             L.append(ind + "  bool ok = true;")
             for q in range(NGp):
-                if spec.var["repoll"]:
-                    L.append(ind + "  if (!have[%d]) { g[%d] = __hip_atomic_load(src + threadIdx.x + %d, %s); }"
-                             % (q, q, q * PT, AG))
-                else:
-                    guard = "" if (q + 1) * PT <= KG else "if (threadIdx.x + %d < %d) " % (q * PT, KG)
-                    L.append(ind + "  %s{ g[%d] = __hip_atomic_load(src + threadIdx.x + %d, %s); "
-                             "ok = ok && ((unsigned)(g[%d] >> 32) == want); }" % (guard, q, q * PT, AG, q))
-            if spec.var["repoll"]:
-                for q in range(NGp):
-                    L.append(ind + "  if (!have[%d]) { have[%d] = ((unsigned)(g[%d] >> 32) == want); ok = ok && have[%d]; }"
-                             % (q, q, q, q))
+                guard = "" if (q + 1) * PT <= KG else "if (threadIdx.x + %d < %d) " % (q * PT, KG)
+                L.append(ind + "  %s{ g[%d] = __hip_atomic_load(src + threadIdx.x + %d, %s); "
+                         "ok = ok && ((unsigned)(g[%d] >> 32) == want); }" % (guard, q, q * PT, AG, q))
             L.append(ind + "  if (ok) break;")
             # bounded spin; once any workgroup has given up every later wait ends within 256 polls
             L.append(ind + "  if (spin > %d || ((spin & 255) == 255 && __hip_atomic_load(errp, %s) != 0u)) "

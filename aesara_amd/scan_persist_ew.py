@@ -24,8 +24,19 @@ step t reads rows t + tap of the buffer and overwrites rows t + out-tap (scan_pe
 :437-452); the thread keeps the window of rows t .. t + max tap of its element in registers, the row
 that enters the window is read ahead like a sequence row (no earlier step writes it), every out-tap
 is stored as it is made.
-Not covered (launch-list path, ``PlanExecutor.scan_modes`` says why): steps with dots / reductions /
-indexing, values of different shapes inside one step.
+**Full reductions inside the step** (round 5: ``x / abs(x).sum()``, ``until(at_all(x > u))``,
+``until(max(abs(x_new - x)) < tol)``, a per-step energy handed out as a nit-sot output — the
+reference runs them in the same loop, scan_perform.pyx:309-541, condition :424-426): the loop then has
+values of TWO kinds, per-element ones (shape S) and ones every element sees alike (0-d results of the
+reductions and whatever is computed from them, ``ProgramEw.cls``).  Such a loop runs as ONE workgroup
+of up to 1024 threads, thread e still owning element e: a reduction folds inside the wavefronts by
+DPP (fixed tree), the wavefronts' partials cross through LDS (two parities: one barrier per
+reduction) and every thread folds them in wave order — all threads hold the identical value, so a
+do-while condition computed from it is uniform (the vector-state do-while).  0-d recurrent states /
+outputs next to the vectors are kept by every thread and stored by thread 0.
+Not covered (launch-list path, ``PlanExecutor.scan_modes`` says why): steps with dots / partial
+reductions / indexing, reductions over more than 1024 elements or in gradient (mit-mot) loops, values
+of different non-scalar shapes inside one step.
 """
 from __future__ import annotations
 
@@ -85,6 +96,10 @@ class ProgramEw:
         self.steps, self.rec_new, self.nit_new, self.sh_new = [], [], [], []
         self.cond, self.depth, self.dtype_of = None, {}, {}
         self.as_while = False
+        # ``cls``: var -> 1 for a value every element sees alike (0-d / all dims broadcastable:
+        # reduction results and what follows from them), 0 (or absent) for a per-element value of
+        # shape S; only filled when the loop mixes the two (``wg``: it then runs as ONE workgroup)
+        self.cls, self.nred, self.wg = {}, 0, False
 
 
 def analyze(inner, p, n_pre):
@@ -133,6 +148,24 @@ def analyze(inner, p, n_pre):
         while v in alias:
             v = alias[v]
         return v
+    def scalar_like(v):
+        sh = plan.vars[v].shape
+        return plan.vars[v].ndim == 0 or all(x == 1 for x in sh)
+    # values of two kinds (see the module docstring) only when the loop holds a reduction or mixes
+    # 0-d values with arrays; a loop of one rank keeps the plain one-thread-per-element form
+    ranks = {plan.vars[v].ndim for v in ins[:n_fixed - len(inv)] + ins[n_fixed:]}
+    for st in inner.steps:
+        if st.kind == "reduce":
+            pr.nred += 1
+        ranks.update(plan.vars[o].ndim for o in st.outputs)
+    pr.wg = pr.nred > 0 or (len(ranks) > 1 and 0 in ranks)
+    if pr.wg and pr.mm:
+        return None, "reductions / 0-d values in a gradient (mit-mot) loop"
+    if pr.wg:
+        for v in ins[:n_fixed - len(inv)] + ins[n_fixed:]:
+            pr.cls[v] = 1 if scalar_like(v) else 0
+        for v in inv:
+            pr.cls[v] = 1 if plan.vars[v].ndim == 0 else 0       # (one element at run time: ``bc``)
     for st in inner.steps:
         if st.kind == "node" and st.node.op in _ALIAS_OPS:
             alias[st.outputs[0]] = st.inputs[0]
@@ -141,7 +174,25 @@ def analyze(inner, p, n_pre):
                 plan.vars[st.outputs[0]].ndim == plan.vars[st.inputs[0]].ndim == 0:
             alias[st.outputs[0]] = st.inputs[0]
             continue
-        if st.kind != "elemwise" or st.reduce is not None or st.post or st.fallback or st.extra.get("xprog"):
+        if st.kind == "node" and st.node.op == "DimShuffle" and pr.wg and \
+                pr.cls.get(res(st.inputs[0])) == 1 and scalar_like(st.outputs[0]):
+            alias[st.outputs[0]] = st.inputs[0]      # a 0-d value made broadcastable against S
+            continue
+        red = None
+        if st.kind == "reduce" and st.reduce is not None and not (st.post or st.fallback or st.dots
+                                                                  or st.extra.get("xprog")):
+            nd_in = max([plan.vars[res(v)].ndim for v in st.inputs] or [0])
+            ax = st.reduce["axis"]
+            if st.reduce["scalar_op"] not in ("add", "mul", "maximum", "minimum", "and", "or", "xor"):
+                return None, "reduction with %s" % st.reduce["scalar_op"]
+            if nd_in == 0 or (ax is not None and sorted(ax) != list(range(nd_in))) or \
+                    plan.vars[st.reduce["out"]].ndim != 0:
+                return None, "partial reduction inside the step"
+            red = {"op": st.reduce["scalar_op"], "acc": st.reduce["acc_dtype"], "ref": st.reduce["ref"],
+                   "out": st.reduce["out"]}
+            if red["acc"] not in cg.CTYPE:
+                return None, "a dtype without kernels"
+        elif st.kind != "elemwise" or st.reduce is not None or st.post or st.fallback or st.extra.get("xprog"):
             return None, f"step kind {st.kind} ({st.node.op if st.node else ''})"
         st_in = [res(v) for v in st.inputs]
         for v in st_in:
@@ -154,8 +205,22 @@ def analyze(inner, p, n_pre):
                     pr.nsq[v] = len(pr.nsq)
             elif not (v in pr.seq or v in pr.tap or v in pr.mm_in or v in pr.shared or v in produced):
                 return None, "operand of unknown origin"
-        pr.steps.append({"ins": st_in, "outs": list(st.outputs), "scalar": st.scalar,
-                         "out_refs": list(st.out_refs)})
+        step = {"ins": st_in, "outs": list(st.outputs), "scalar": st.scalar,
+                "out_refs": list(st.out_refs)}
+        if pr.wg:
+            kinds = [pr.cls.get(v, 0) for v in st_in]
+            oc = 1 if (kinds and all(kinds)) else 0
+            if not kinds:
+                oc = 1 if all(scalar_like(o) for o in st.outputs) else 0
+            for o in st.outputs:
+                pr.cls[o] = oc
+            if red is not None:
+                if oc == 1:
+                    return None, "reduction of a 0-d value"
+                step["reduce"] = red
+                pr.cls[red["out"]] = 1
+                produced.add(red["out"])
+        pr.steps.append(step)
         produced.update(st.outputs)
     n_rec = len(taps)
     n_mmo = sum(len(to) for _ti, to in pr.mm)
@@ -195,13 +260,29 @@ class SpecEw:
 
     def key(self):
         pr = self.prog
-        blob = json.dumps(["se3", pr.mm, sorted((k, list(v)) for k, v in pr.mm_in.items()), pr.mm_new,
-                           [[s["ins"], s["outs"], s["scalar"], s["out_refs"]] for s in pr.steps],
-                           sorted(pr.seq.items()), sorted((k, list(v)) for k, v in pr.tap.items()),
-                           sorted(pr.shared.items()), sorted(pr.nsq.items()), pr.rec_new, pr.nit_new,
-                           pr.sh_new, pr.cond, sorted(pr.depth.items()), self.out_dtypes, self.sh_dtypes,
-                           self.bc, sorted((k, v) for k, v in pr.dtype_of.items())], sort_keys=True)
-        return hashlib.sha256(blob.encode()).hexdigest()[:24]
+        blob = ["se3", pr.mm, sorted((k, list(v)) for k, v in pr.mm_in.items()), pr.mm_new,
+                [[s["ins"], s["outs"], s["scalar"], s["out_refs"]] for s in pr.steps],
+                sorted(pr.seq.items()), sorted((k, list(v)) for k, v in pr.tap.items()),
+                sorted(pr.shared.items()), sorted(pr.nsq.items()), pr.rec_new, pr.nit_new,
+                pr.sh_new, pr.cond, sorted(pr.depth.items()), self.out_dtypes, self.sh_dtypes,
+                self.bc, sorted((k, v) for k, v in pr.dtype_of.items())]
+        if pr.wg:       # (the one-workgroup form: value kinds and reductions are part of the kernel)
+            blob += ["wg1", sorted(pr.cls.items()), [s.get("reduce") for s in pr.steps]]
+        return hashlib.sha256(json.dumps(blob, sort_keys=True).encode()).hexdigest()[:24]
+
+
+def slot_kinds(pr: ProgramEw):
+    """(kinds of the recurrent outputs, of the nit-sot outputs, of the shared values): 1 = one
+    value for all elements (a 0-d output: stored by thread 0), 0 = per element."""
+    if not pr.wg:
+        return [0] * len(pr.rec_new), [0] * len(pr.nit_new), [0] * len(pr.sh_new)
+    rec = [0] * len(pr.rec_new)
+    for v, (k, _d) in pr.tap.items():
+        rec[k] = pr.cls.get(v, 0)
+    sh = [0] * len(pr.sh_new)
+    for v, m in pr.shared.items():
+        sh[m] = pr.cls.get(v, 0)
+    return rec, [pr.cls.get(v, 0) for v in pr.nit_new], sh
 
 
 def generate(spec: SpecEw):
@@ -210,10 +291,37 @@ def generate(spec: SpecEw):
     name = "se_" + spec.key()
     dt = pr.dtype_of
     CT, RT = cg.CTYPE, cg.RTYPE
+    wg = pr.wg
+    rec_kind, nit_kind, sh_kind = slot_kinds(pr)
+    E = "el" if wg else "e"                # element a thread LOADS (clamped in the one-workgroup form)
+
+    def kind(v):
+        return pr.cls.get(v, 0) if wg else 0
+
+    def at(c):                             # "+ element" of an address
+        return "" if c else " + " + E
+
+    def guard(c):                          # who stores a value of kind c
+        return ("if (e == 0) " if c else "if (live) ") if wg else ""
     L = [cg.PRELUDE, EW_STRUCT]
-    L.append('extern "C" __global__ __launch_bounds__(256) void %s(EwScanArgs a) {' % name)
-    L.append("  const i64 e = (i64)blockIdx.x * 256 + threadIdx.x;")
-    L.append("  if (e >= a.n) return;")
+    L.append('extern "C" __global__ __launch_bounds__(%d) void %s(EwScanArgs a) {' % (1024 if wg else 256, name))
+    if wg:
+        # ONE workgroup, thread e = element e; threads past the state stay (barriers), load the
+        # last element and never store
+        L.append("  const i64 e = threadIdx.x;")
+        L.append("  const bool live = e < a.n;")
+        L.append("  const i64 el = live ? e : a.n - 1;")
+        L.append("  const unsigned nw_ = blockDim.x >> 6, wv_ = threadIdx.x >> 6, ln_ = threadIdx.x & 63u;")
+        ri = 0
+        for st in pr.steps:
+            red = st.get("reduce")
+            if red is not None:
+                acc_t = RT[red["acc"]]
+                L.append("  __shared__ %s smr%d[2][16];" % (acc_t if acc_t != "bool" else "unsigned char", ri))
+                ri += 1
+    else:
+        L.append("  const i64 e = (i64)blockIdx.x * 256 + threadIdx.x;")
+        L.append("  if (e >= a.n) return;")
     mm_vals = [v for grp in pr.mm_new for _tap, v in grp]
     used_seq = sorted({v for s in pr.steps for v in s["ins"] if v in pr.seq} |
                       {v for v in mm_vals + pr.rec_new + pr.nit_new + pr.sh_new +
@@ -226,7 +334,7 @@ def generate(spec: SpecEw):
         return "(%s != 0)" % expr if d == "bool" else expr
     # invariants
     for v, j in sorted(pr.nsq.items(), key=lambda kv: kv[1]):
-        off = "0" if j in spec.bc else "e * a.nsq_es[%d]" % j
+        off = "0" if (j in spec.bc or kind(v)) else "%s * a.nsq_es[%d]" % (E, j)
         L.append("  const %s nv%d = %s;" % (RT[dt[v]], j, rd("((const %s*)a.nsq[%d])[%s]" % (CT[dt[v]], j, off), dt[v])))
     # recurrent state registers (tap -1 .. -depth) from the output buffers, shared values
     n_rec, n_nit = len(pr.rec_new), len(pr.nit_new)
@@ -245,7 +353,8 @@ def generate(spec: SpecEw):
         L.append("  i64 op%d = a.out_pos0[%d];" % (sl, sl))
         for d in range(1, pr.depth[k] + 1):
             L.append("  %s r%d_%d = %s;" % (RT[odt], k, d, rd(
-                "ob%d[((op%d - %d + a.out_store[%d]) %% a.out_store[%d]) * a.out_rs[%d] + e]" % (sl, sl, d, sl, sl, sl), odt)))
+                "ob%d[((op%d - %d + a.out_store[%d]) %% a.out_store[%d]) * a.out_rs[%d]%s]" % (
+                    sl, sl, d, sl, sl, sl, at(rec_kind[k])), odt)))
     for j in range(n_nit):
         sl = n_mm + n_rec + j
         odt = spec.out_dtypes[sl]
@@ -253,9 +362,14 @@ def generate(spec: SpecEw):
         L.append("  i64 op%d = a.out_pos0[%d];" % (sl, sl))
     for v, m in sorted(pr.shared.items(), key=lambda kv: kv[1]):
         sdt = spec.sh_dtypes[m]
-        L.append("  %s s%d = %s;" % (RT[sdt], m, rd("((const %s*)a.sh_in[%d])[e]" % (CT[sdt], m), sdt)))
+        L.append("  %s s%d = %s;" % (RT[sdt], m, rd("((const %s*)a.sh_in[%d])[%s]" % (
+            CT[sdt], m, "0" if sh_kind[m] else E), sdt)))
     for v in used_seq:
         L.append("  const %s* const sq%d = (const %s*)a.seq[%d];" % (CT[dt[v]], pr.seq[v], CT[dt[v]], pr.seq[v]))
+    if wg and (any(rec_kind) or any(sh_kind)):
+        # every thread has read the 0-d initial values before thread 0 may overwrite their rows
+        # (a circular buffer of two rows: step 1 lands on the row of the initial value)
+        L.append("  __syncthreads();")
     L.append("  i64 t = 0;")
     L.append("  for (i64 t0 = 0; t0 < a.T; t0 += %d) {" % AHEAD)
     # the sequence rows of the next AHEAD steps, loaded before any of them is used (clamped rows:
@@ -264,7 +378,8 @@ def generate(spec: SpecEw):
         L.append("    const i64 tt%d = t0 + %d < a.T ? t0 + %d : a.T - 1;" % (u, u, u))
         for v in used_seq:
             s = pr.seq[v]
-            L.append("    const %s x%d_%d = %s;" % (RT[dt[v]], s, u, rd("sq%d[tt%d * a.seq_ts[%d] + e]" % (s, u, s), dt[v])))
+            L.append("    const %s x%d_%d = %s;" % (RT[dt[v]], s, u, rd("sq%d[tt%d * a.seq_ts[%d]%s]" % (
+                s, u, s, at(kind(v))), dt[v])))
         for g_ in range(n_mm):
             # the row that enters the window at that step: written by no earlier step (an out-tap j
             # of step t' lands on it when t' + j = t + top, i.e. t' >= t)
@@ -286,16 +401,40 @@ def generate(spec: SpecEw):
             env[v] = "s%d" % m
         for v, j in pr.nsq.items():
             env[v] = "nv%d" % j
+        ri = 0
         for si, st in enumerate(pr.steps):
             in_exprs = [env[v] for v in st["ins"]]
             in_dts = [dt[v] for v in st["ins"]]
             lines, outs, odts = cg.emit_scalar_body(st["scalar"], in_exprs, in_dts, indent="      ",
                                                     suffix="_s%d_u%d" % (si, u))
             L.extend(lines)
-            for o, ri in zip(st["outs"], st["out_refs"]):
+            for o, ri_ in zip(st["outs"], st["out_refs"]):
                 nm = "v%d_u%d" % (o, u)
-                L.append("      const %s %s = %s;" % (RT[dt[o]], nm, cg._cast(outs[ri], odts[ri], dt[o])))
+                L.append("      const %s %s = %s;" % (RT[dt[o]], nm, cg._cast(outs[ri_], odts[ri_], dt[o])))
                 env[o] = nm
+            red = st.get("reduce")
+            if red is not None:
+                # the step's full reduction: dead threads contribute the identity; wavefront fold
+                # (DPP, fixed tree: every lane ends with it), the wavefronts' folds through LDS
+                # (parity of t: one barrier), every thread folds them in wave order
+                acc_t = RT[red["acc"]]
+                comb = lambda a_, b_, _r=red: cg.red_combine(_r["op"], _r["acc"], a_, b_)  # noqa: E731
+                rv = "rd%d_u%d" % (si, u)
+                L.append("      %s %s = live ? %s : %s;" % (
+                    acc_t, rv, cg._cast(outs[red["ref"]], odts[red["ref"]], red["acc"]),
+                    "(%s)%s" % (acc_t, cg.red_identity(red["op"], red["acc"]))))
+                L.extend(cg.wave_fold_lines(acc_t, comb, var=rv, indent="      "))
+                L.append("      if (nw_ > 1u) {")
+                L.append("        if (ln_ == 0) smr%d[t & 1][wv_] = %s;" % (ri, rv))
+                L.append("        __syncthreads();")
+                L.append("        %s = (%s)smr%d[t & 1][0];" % (rv, acc_t, ri))
+                L.append("        for (unsigned w_ = 1; w_ < nw_; ++w_) %s = %s;" % (
+                    rv, comb(rv, "(%s)smr%d[t & 1][w_]" % (acc_t, ri))))
+                L.append("      }")
+                nm = "v%d_u%d" % (red["out"], u)
+                L.append("      const %s %s = %s;" % (RT[dt[red["out"]]], nm, cg._cast(rv, red["acc"], dt[red["out"]])))
+                env[red["out"]] = nm
+                ri += 1
 
         def st_val(v, odt):
             e_ = cg._cast(env[v], dt[v], odt)
@@ -317,11 +456,14 @@ def generate(spec: SpecEw):
         for k in range(n_rec):
             sl = n_mm + k
             odt = spec.out_dtypes[sl]
-            L.append("      ob%d[op%d * a.out_rs[%d] + e] = %s;" % (
-                sl, sl, sl, "(unsigned char)n%d" % k if odt == "bool" else "n%d" % k))
+            L.append("      %sob%d[op%d * a.out_rs[%d]%s] = %s;" % (
+                guard(rec_kind[k]), sl, sl, sl, " + e" if not rec_kind[k] else "",
+                "(unsigned char)n%d" % k if odt == "bool" else "n%d" % k))
         for j in range(n_nit):
             sl = n_mm + n_rec + j
-            L.append("      ob%d[op%d * a.out_rs[%d] + e] = %s;" % (sl, sl, sl, st_val(pr.nit_new[j], spec.out_dtypes[sl])))
+            L.append("      %sob%d[op%d * a.out_rs[%d]%s] = %s;" % (
+                guard(nit_kind[j]), sl, sl, sl, " + e" if not nit_kind[j] else "",
+                st_val(pr.nit_new[j], spec.out_dtypes[sl])))
         sh_tmp = []
         for m, v in enumerate(pr.sh_new):
             L.append("      const %s ns%d = %s;" % (RT[spec.sh_dtypes[m]], m, cg._cast(env[v], dt[v], spec.sh_dtypes[m])))
@@ -349,7 +491,9 @@ def generate(spec: SpecEw):
         L.append("done_:")
     for m in range(len(pr.sh_new)):
         sdt = spec.sh_dtypes[m]
-        L.append("  ((%s*)a.sh_out[%d])[e] = %s;" % (CT[sdt], m, "(unsigned char)s%d" % m if sdt == "bool" else "s%d" % m))
+        L.append("  %s((%s*)a.sh_out[%d])[%s] = %s;" % (
+            guard(sh_kind[m]), CT[sdt], m, "0" if sh_kind[m] else "e",
+            "(unsigned char)s%d" % m if sdt == "bool" else "s%d" % m))
     if pr.as_while:
         L.append("  if (e == 0) a.ctl[0] = (unsigned)t;      // steps this do-while ran")
     L.append("}")

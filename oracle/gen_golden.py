@@ -1082,6 +1082,82 @@ def _():
         [N((30, 6), seed=1), N((6, 6), seed=2, scale=0.5), K(0.0, "float64", (6,))]
 
 
+# full reductions inside the step (scan_perform.pyx:309-541 runs them in the same loop; the do-while
+# condition of a VECTOR state is a reduction, :424-426): tests/scan/test_basic.py TestGradUntil
+# test_grad_until_ndim_greater_one :2391 (``until(at_all(x > u))``), power-iteration-like
+# normalisation, a convergence loop, a per-step energy next to a vector state, a 0-d running total
+@case("scan_red_normalise", rtol=1e-12, atol=1e-12)
+def _():
+    x0, a = at.dvector("x0"), at.dvector("a")
+    res, _ = ae.scan(lambda x, a: x * a / at.abs(x * a).sum(), outputs_info=[x0], non_sequences=[a],
+                     n_steps=7)
+    return [x0, a], [res, res[-1]], [U((40,), seed=1, low=0.5, high=1.5), U((40,), seed=2, low=0.5, high=1.5)]
+
+
+@case("scan_red_normalise_wide_f32", rtol=2e-5, atol=1e-6)
+def _():
+    # 300 elements: five wavefronts, the partials cross through LDS
+    x0, a = at.fvector("x0"), at.fvector("a")
+    res, _ = ae.scan(lambda x, a: x * a / at.sqrt((x * a * x * a).sum()), outputs_info=[x0],
+                     non_sequences=[a], n_steps=9)
+    return [x0, a], [res], [U((300,), "float32", seed=1, low=0.5, high=1.5),
+                            U((300,), "float32", seed=2, low=0.5, high=1.5)]
+
+
+@case("scan_red_until_all", rtol=1e-12, atol=1e-12)
+def _():
+    from aesara.scan.utils import until
+    X, thr = at.dmatrix("X"), at.dscalar("thr")
+    r, _ = ae.scan(lambda x, u: (x * x, until(at.all(x > u))), sequences=X, non_sequences=[thr])
+    return [X, thr], [r, r.shape[0]], [
+        {"kind": "const_list", "shape": [15, 5], "dtype": "float64",
+         "values": [float(i) for i in range(15) for _ in range(5)]}, K(5.0, "float64")]
+
+
+@case("scan_red_newton_until", rtol=1e-12, atol=1e-12)
+def _():
+    from aesara.scan.utils import until
+    x0, a = at.dvector("x0"), at.dvector("a")
+
+    def step(x, a):
+        xn = 0.5 * (x + a / x)
+        return xn, until(at.max(at.abs(xn - x)) < 1e-9)
+    r, _ = ae.scan(step, outputs_info=[x0], non_sequences=[a], n_steps=50)
+    return [x0, a], [r, r[-1], r.shape[0]], [U((33,), seed=3, low=1.0, high=2.0), U((33,), seed=4, low=1.0, high=9.0)]
+
+
+@case("scan_red_energy", rtol=1e-12, atol=1e-12)
+def _():
+    s, h0 = at.dmatrix("s"), at.dvector("h0")
+    (hs, en), _ = ae.scan(lambda s_t, h: (0.9 * h + s_t, ((0.9 * h + s_t) ** 2).sum()), sequences=[s],
+                          outputs_info=[h0, None])
+    return [s, h0], [hs, en], [N((20, 70), seed=1), N((70,), seed=2)]
+
+
+@case("scan_red_running_total", rtol=1e-12, atol=1e-12)
+def _():
+    # a 0-d recurrent state fed by a reduction of the step's vector, next to a vector state; only
+    # the last total is used (scan_save_mem: a circular buffer of the 0-d state)
+    s, h0 = at.dmatrix("s"), at.dvector("h0")
+    (hs, tot), _ = ae.scan(lambda s_t, h, tot: (at.tanh(h + s_t), tot + (h * s_t).sum()), sequences=[s],
+                           outputs_info=[h0, at.as_tensor_variable(np.float64(0.0))])
+    return [s, h0], [hs[-1], tot[-1], tot], [N((25, 130), seed=5), N((130,), seed=6)]
+
+
+@case("scan_red_int_minmax", exact=True)
+def _():
+    # integer reductions (exact): per-step minimum and maximum of a running integer vector, and a
+    # bool ``any`` deciding a scale factor
+    x, v0 = at.lmatrix("x"), at.lvector("v0")
+
+    def step(x_t, v):
+        vn = v + x_t
+        big = at.any(vn > 40)
+        return [at.switch(big, vn // 2, vn), vn.min(), vn.max()]
+    (vs, lo, hi), _ = ae.scan(step, sequences=[x], outputs_info=[v0, None, None])
+    return [x, v0], [vs, lo, hi], [I((18, 77), "int64", seed=1, low=-5, high=12), I((77,), "int64", seed=2)]
+
+
 # gradients through Scan: Scan.L_op (scan/op.py:2379) builds a reversed Scan with mit-mot
 # accumulators (tests/scan/test_basic.py test_grad_one_output / test_grad_multiple_outs_taps)
 @case("scan_grad_rnn", rtol=1e-11, atol=1e-11)

@@ -126,3 +126,78 @@ def test_do_while_stops_on_the_device(stop_at):
         np.testing.assert_allclose(res, np.cumsum(x)[:k], rtol=1e-13)
         np.testing.assert_allclose(last, np.cumsum(x)[k - 1], rtol=1e-13)
     assert list(ex.scan_modes.values()) == ["persistent"]
+
+
+# ---- full reductions inside the step: ONE workgroup, thread e = element e (round 5) ------------
+REDUCTIONS = ["scan_red_normalise", "scan_red_normalise_wide_f32", "scan_red_until_all",
+              "scan_red_newton_until", "scan_red_energy", "scan_red_running_total", "scan_red_int_minmax"]
+
+
+@pytest.mark.parametrize("name", REDUCTIONS)
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_steps_with_full_reductions_run_as_one_launch(name, use_graph):
+    """Steps holding full reductions (scan_perform.pyx:309-541 runs them in the same loop; a
+    do-while over a VECTOR state is one, :424-426): one launch, results = the reference's outputs
+    (integer case: exact) and = the launch-list path (reductions fold in another order there:
+    compared at the case's tolerance, integers bit for bit)."""
+    from aesara_amd import executor as E
+    c = _case(name)
+    ex = E.PlanExecutor(case_plan(c), use_graph=use_graph)
+    ins = case_inputs(c)
+    for it in range(3):
+        got = _np(ex(*ins))
+        assert_matches(c, got, case_expected(c), f"call {it}")
+    assert list(ex.scan_modes.values()) == ["persistent"], ex.scan_modes
+    assert "element-wise" in list(ex.scan_notes.values())[0]
+    E.TUNE["scan_persist"] = 0
+    try:
+        ex2 = E.PlanExecutor(case_plan(c), use_graph=use_graph)
+        ref = _np(ex2(*ins))
+        assert all(v.startswith("launch-list") for v in ex2.scan_modes.values())
+    finally:
+        E.TUNE["scan_persist"] = 1
+    assert_matches(c, got, ref, "against the launch-list path")
+    ex.check()
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 128, 700, 1024, 1025, 5000])
+def test_normalising_recurrence_over_sizes(n):
+    """x <- x * a / sum|x * a| for 12 steps at sizes around the wavefront / workgroup limits (one
+    partial wavefront, exactly one, several, the full 1024-thread workgroup) against NumPy; beyond
+    1024 elements the loop runs on the launch list (same results)."""
+    import torch
+    from aesara_amd.executor import PlanExecutor
+    rng = np.random.default_rng(n)
+    x0, a = rng.uniform(0.5, 1.5, n), rng.uniform(0.5, 1.5, n)
+    ex = PlanExecutor(case_plan(_case("scan_red_normalise")), use_graph=True)
+    for call in range(2):
+        res, last = _np(ex(torch.from_numpy(x0).cuda(), torch.from_numpy(a).cuda()))
+        x, want = x0, []
+        for _ in range(7):
+            x = x * a / np.abs(x * a).sum()
+            want.append(x)
+        np.testing.assert_allclose(res[-7:], np.array(want), rtol=1e-12)
+        np.testing.assert_allclose(last, want[-1], rtol=1e-12)
+    mode = list(ex.scan_modes.values())[0]
+    assert (mode == "persistent") == (n <= 1024), mode
+    ex.check()
+
+
+@pytest.mark.parametrize("rows,cols,thr", [(15, 5, 5.0), (40, 257, 11.0), (9, 1000, 100.0), (30, 64, -1.0)])
+def test_vector_do_while_stops_on_the_device(rows, cols, thr):
+    """``until(at_all(x > u))`` over matrix rows (tests/scan/test_basic.py:2391
+    test_grad_until_ndim_greater_one): the condition is a reduction of a vector, every thread of
+    the workgroup reaches the same decision; trip count and truncated output against NumPy
+    (a threshold no row passes: the loop runs to the end; one the first row passes: one step)."""
+    import torch
+    from aesara_amd.executor import PlanExecutor
+    X = np.tile(np.arange(rows, dtype="float64").reshape(-1, 1), (1, cols))
+    X[:, -1] -= 0.5                                   # the last column passes the threshold one row later
+    ex = PlanExecutor(case_plan(_case("scan_red_until_all")), use_graph=True)
+    stop = next((i for i in range(rows) if np.all(X[i] > thr)), rows - 1)
+    for call in range(2):
+        res, count = _np(ex(torch.from_numpy(X).cuda(), np.float64(thr)))
+        assert int(count) == stop + 1 and res.shape == (stop + 1, cols)
+        np.testing.assert_array_equal(res, (X * X)[:stop + 1])
+    assert list(ex.scan_modes.values()) == ["persistent"]
+    ex.check()

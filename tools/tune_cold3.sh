@@ -1,4 +1,5 @@
 #!/bin/bash
+# (historical sweep: AESARA_HIP_PIPE / AESARA_HIP_RED_PRIO measured null — profiles/r03_*, r04_cfg2_cold_sweep* — and were removed from the generator in round 5; those rows are no-ops now)
 # third MALL-cold sweep of config 2: ping-pong software pipeline (AESARA_HIP_PIPE) x vectors per group
 fmt='import sys, json, os
 for l in sys.stdin:

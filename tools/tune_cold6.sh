@@ -1,4 +1,5 @@
 #!/bin/bash
+# (historical sweep: AESARA_HIP_PIPE / AESARA_HIP_RED_PRIO measured null — profiles/r03_*, r04_cfg2_cold_sweep* — and were removed from the generator in round 5; those rows are no-ops now)
 # round-4 sweep 3: waves per CU x vectors in flight x walk x priority of the younger workgroup
 fmt='import sys, json, os
 for l in sys.stdin:

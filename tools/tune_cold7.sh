@@ -1,4 +1,5 @@
 #!/bin/bash
+# (historical sweep: AESARA_HIP_PIPE / AESARA_HIP_RED_PRIO measured null — profiles/r03_*, r04_cfg2_cold_sweep* — and were removed from the generator in round 5; those rows are no-ops now)
 # round-4 sweep 4: software pipeline (next group's loads in flight during the ALU phase) x waves per CU,
 # on the XCD-contiguous walk; executor level, driver flags
 fmt='import sys, json, os
