@@ -288,6 +288,10 @@ class ScanMixin:
         for ph in prog.phases:
             for o in ph["outs"]:
                 lens[o] = M
+            if ph.get("reduce"):
+                lens[ph["reduce"]["u"]] = M          # the vector the reduction folds (exchanged)
+        for v in prog.zero_d:
+            lens[v] = 1
         for ph in prog.phases:
             for av, x in ph["dots"]:
                 if lens.get(x) is None or -(-lens[x] // vecw) * vecw != Ks[av]:
@@ -299,6 +303,8 @@ class ScanMixin:
         for ph in prog.phases:
             for av, x in ph["dots"]:
                 staged[x] = Ks[av]
+            if ph.get("reduce"):
+                staged[ph["reduce"]["u"]] = -(-M // vecw) * vecw
         stage = 2 * sum(staged.values()) + 64      # LDS floats for the staged dot vectors
         cus = 256 if self.dry_run else torch.cuda.get_device_properties(self.device).multi_processor_count
         geo = sp.choose_rows(M, Ks, stage, cus, isz)
@@ -334,6 +340,8 @@ class ScanMixin:
                 src = seqs[s_] if s_ < n_seqs else pre_rows[s_ - n_seqs]
                 src = src.view((n_steps, M), src.strides)
                 outs[k] = inner.materialize(src) if s_ < n_seqs else inner.contiguous(src)
+            elif any(j_ == k and o_ in prog.zero_d for o_, _kd, j_ in prog.outs):
+                outs[k] = inner.alloc((store[k],), f32)       # a 0-d value per step
             else:
                 outs[k] = inner.alloc((store[k], M), f32)
         g = sp.SpArgs()
@@ -368,6 +376,13 @@ class ScanMixin:
         why = self._launch_persistent(ent[0], G, 64 * nw, g)
         if why:
             return why
+        self._sp_done = None
+        if prog.cond is not None:
+            # do-while: every workgroup left the loop after the same step; ONE host read per Scan
+            # (the launch list: one per step) — the trip count sizes the outputs (scan/op.py:2139-2159)
+            if self._capturing:
+                raise HostReadInReplay("do-while Scan: the trip count is read on the host")
+            self._sp_done = n_steps if self.dry_run else int(ws[1][4].item())
         for j, shp in enumerate(nit_shapes):
             if len(shp) != 1:      # the step hands the vector out as a row / column (DimShuffle 'x')
                 b = outs[n_rec + j]
@@ -1084,6 +1099,7 @@ class ScanMixin:
         if ew_ran:
             pass
         elif TUNE["scan_persist"] and self.fuse and n_steps >= 2:
+            self._sp_done = None
             why = self._scan_persist(node, p, inner, n_steps, seqs, outs, store, pos, non_seqs,
                                      pre_rows, n_rec, n_nit, xfold=xfold)
             if why is None and xfold is not None:
@@ -1098,8 +1114,11 @@ class ScanMixin:
                                          pre_rows, n_rec, n_nit)
             self.scan_modes[node.outputs[0]] = "persistent" if why is None else "launch-list: " + why
             if why is None:
-                i = n_steps
-                pos = [(pp + n_steps) % st for pp, st in zip(pos, store)]
+                done = getattr(self, "_sp_done", None)
+                i = n_steps if done is None else done
+                if done is not None:
+                    go = False                # (a do-while that stopped on the device)
+                pos = [(pp + i) % st for pp, st in zip(pos, store)]
         elif n_steps >= 1:
             self.scan_modes[node.outputs[0]] = "launch-list: disabled or fewer than 2 steps"
         while i < n_steps and go:

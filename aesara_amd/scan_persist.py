@@ -20,8 +20,18 @@ weight matrix from L2 / HBM on every step; here one launch runs all T steps:
 * everything a row owner needs again (its previous state rows, the rows of sequence operands of
   the next step) stays in registers: lane i of a wavefront owns one output row.
 
+**Full reductions inside the step** (round 5; the reference runs them in the same loop,
+scan_perform.pyx:309-541): ``(h ** 2).sum()``, ``x_t.max()`` ... of a vector of the state's length.
+The row owners evaluate the reduced expression for their rows and publish it like any exchanged
+vector; every workgroup gathers the whole vector and folds it in ONE fixed order (lanes stride over
+it, butterfly across the wavefront: the same tree everywhere), so all threads of all workgroups hold
+the identical 0-d result with no second protocol.  0-d values computed from such results run on every
+lane; a 0-d nit-sot output is stored by one lane of workgroup 0.  That also gives the **do-while** of
+a vector state (condition :424-426): every workgroup sees the same condition value, leaves the loop
+after the same step, workgroup 0 stores the trip count for the one host read after the launch.
+
 Eligibility (anything else runs the launch-list path, and ``PlanExecutor.scan_modes`` says which
-was taken): no shared outputs / do-while, sit- / mit-sot outputs with taps down to -8 (tap -1 is
+was taken): no shared outputs, do-while only on a condition behind a reduction, sit- / mit-sot outputs with taps down to -8 (tap -1 is
 the exchanged state; older taps are values the row owner produced itself and stay in its
 registers, usable element-wise), mit-mot groups only of the gradient form ([0, 1] -> [1], see
 ``analyze``), the fused inner steps are Gemv
@@ -109,6 +119,8 @@ class Program:
         self.tap_top = {}           # mit-mot sequence var -> the tap it is (the group's largest)
         self.mm_extra = []          # [(slot, group, out tap)]: out-taps 2.. of a mit-mot group write the
         #                             group's buffer too — further output slots on the same buffer
+        self.zero_d = set()         # 0-d values (reduction results and what is computed from them)
+        self.cond = None            # do-while: the 0-d condition variable (as_while)
 
 
 class _DotPhase:
@@ -125,16 +137,33 @@ class _DotPhase:
         self.node = None
 
 
+class _RowDot:
+    """Stand-in step for a bare ``rowdot(A, x)`` of a vector-state loop (a Gemv whose epilogue went
+    into another fused step, e.g. a reduction with Elemwise outputs): a product phase that hands
+    the dot through."""
+    kind, reduce, post, fallback, extra, node = "gemv_epi", None, (), (), {}, None
+
+    def __init__(self, A, x, out):
+        self.dots = [[A, x]]
+        self.inputs, self.outputs = [], [out]
+        self.scalar = {"n_in": 1, "nodes": [], "out": [["i", 0]]}
+        self.out_refs = [0]
+
+
 def _const1(plan, vid):
     v = plan.vars[vid]
     return v.const is not None and len(v.const.get("data", ())) == 1 and float(v.const["data"][0]) == 1.0
+
+
+RED_BASE = 1 << 20          # id of the vector a reduction folds: RED_BASE + its 0-d result's id
 
 
 def analyze(inner, p, n_seqdots):
     """Returns (Program, None) or (None, reason)."""
     plan = inner.plan
     n_seqs = p["n_seqs"]
-    if p.get("n_shared_outs", 0) or p.get("as_while", False):
+    as_while = bool(p.get("as_while", False))
+    if p.get("n_shared_outs", 0):
         return None, "shared outputs / do-while"
     # mit-mot groups of the form a gradient Scan uses for the state it propagates (Scan.L_op,
     # scan/op.py:2379): input taps [0, 1], output tap [1] — step i reads rows i and i + 1 of the
@@ -231,9 +260,15 @@ def analyze(inner, p, n_seqdots):
     for st in steps:
         for v in list(st.inputs) + [x for d in st.dots for x in d]:
             readers[v] = readers.get(v, 0) + 1
+    if as_while and pr.mode != "vec":
+        return None, "shared outputs / do-while"
     for st in steps:
         if st.kind == "node" and st.node.op in ("SpecifyShape", "ViewOp"):
             alias[st.outputs[0]] = st.inputs[0]      # value-preserving views: same vector / matrix
+            continue
+        if st.kind == "node" and st.node.op == "DimShuffle" and pr.mode == "vec" and \
+                res(st.inputs[0]) in pr.zero_d and all(d == "x" for d in st.node.params["new_order"]):
+            alias[st.outputs[0]] = st.inputs[0]      # a 0-d value made broadcastable against the vectors
             continue
         if st.kind == "node" and st.node.op == "DimShuffle" and pr.mode == "mat" and \
                 st.node.params["new_order"] == [1, 0] and st.inputs[0] in pr.seq and \
@@ -258,7 +293,25 @@ def analyze(inner, p, n_seqdots):
                 st.outputs[0] in plan.outputs:
             alias[st.outputs[0]] = st.inputs[0]      # a step output handed out as a row / column
             continue
-        if st.kind not in ok_kinds or st.reduce is not None or st.post or \
+        if st.kind == "rowdot" and pr.mode == "vec" and len(st.inputs) == 2:
+            st = _RowDot(st.inputs[0], st.inputs[1], st.outputs[0])
+        red = None
+        if st.kind == "reduce" and pr.mode == "vec" and st.reduce is not None and not st.dots and \
+                not st.post and not st.fallback and not st.extra.get("xprog"):
+            r_ = st.reduce
+            nd_in = max([plan.vars[res(v)].ndim for v in st.inputs] or [0])
+            if r_["scalar_op"] not in ("add", "mul", "maximum", "minimum"):
+                return None, "reduction with %s" % r_["scalar_op"]
+            if nd_in != 1 or (r_["axis"] is not None and list(r_["axis"]) != [0]) or \
+                    plan.vars[r_["out"]].ndim != 0:
+                return None, "partial reduction inside the step"
+            # (float32 values fold in float64 when the reference's accumulator is — CAReduce's
+            # acc_dtype rule, tensor/elemwise.py:1495 — and are rounded to the state's dtype once)
+            if r_["acc_dtype"] not in (pr.dtype, "float64") or plan.vars[r_["out"]].dtype != pr.dtype:
+                return None, "reduction accumulates in another dtype"
+            red = {"op": r_["scalar_op"], "ref": r_["ref"], "out": r_["out"], "u": RED_BASE + r_["out"],
+                   "acc": r_["acc_dtype"]}
+        elif st.kind not in ok_kinds or st.reduce is not None or st.post or \
                 (st.fallback and st.kind != "gemm_epi"):
             return None, f"step kind {st.kind} ({st.node.op if st.node else ''})"
         dots = []
@@ -290,21 +343,47 @@ def analyze(inner, p, n_seqdots):
                 return None, "operand of unknown origin"
             if plan.vars[v].dtype != pr.dtype:
                 return None, "operand dtype differs from the state's"
+        # a phase whose operands are all 0-d (results of reductions, scalars): its outputs are 0-d,
+        # every lane evaluates it (the do-while condition must be uniform)
+        scalar_phase = pr.mode == "vec" and not dots and red is None and bool(st_inputs) and \
+            all(v in pr.zero_d or (v in inv_set and plan.vars[v].ndim == 0) for v in st_inputs)
         for o in st.outputs:
-            if plan.vars[o].ndim != nd or plan.vars[o].dtype != pr.dtype:
+            if scalar_phase and plan.vars[o].ndim == 0 and \
+                    (plan.vars[o].dtype == pr.dtype or (as_while and plan.vars[o].dtype == "bool")):
+                pr.zero_d.add(o)            # (bool: only ever the condition, kept as 0 / 1 in a register)
+            elif plan.vars[o].ndim != nd or plan.vars[o].dtype != pr.dtype:
                 return None, "step output is not a %s %s" % (pr.dtype, "matrix" if nd == 2 else "vector")
             produced[o] = len(pr.phases)
-        pr.phases.append({"dots": dots, "ins": list(st_inputs), "outs": list(st.outputs),
-                          "scalar": st.scalar, "out_refs": list(st.out_refs)})
+        ph = {"dots": dots, "ins": list(st_inputs), "outs": list(st.outputs),
+              "scalar": st.scalar, "out_refs": list(st.out_refs)}
+        if red is not None:
+            if any(v in pr.zero_d for v in st_inputs) and all(
+                    v in pr.zero_d or v in inv_set and plan.vars[v].ndim == 0 for v in st_inputs):
+                return None, "reduction of a 0-d value"
+            ph["reduce"] = red
+            pr.zero_d.add(red["out"])
+            produced[red["out"]] = len(pr.phases)
+        if scalar_phase:
+            ph["scalar_phase"] = True
+        pr.phases.append(ph)
     if len(pr.mats) > SP_MAXMAT or len(pr.nsq) > SP_MAXNSQ or not pr.mats:
         return None, "no / too many matrices"
     # inner outputs: every out-tap of every mit-mot group, the mit-sot / sit-sot outputs, the nit-sots
     slot_of = [slot_of_mm[(g, j)] for g, to in enumerate(mm_out) for j in to] + \
         list(range(n_mm, n_rec)) + list(range(n_rec, n_rec + n_nit))
-    if len(plan.outputs) != len(slot_of) or n_outer + len(pr.mm_extra) > SP_MAXOUT:
+    if len(plan.outputs) != len(slot_of) + (1 if as_while else 0) or n_outer + len(pr.mm_extra) > SP_MAXOUT:
         return None, "output count"
+    if as_while:
+        # the condition must come behind a reduction of the same step: every workgroup has then
+        # gathered a vector all the others published after reading the launch's tag base, so
+        # none can leave the loop (and workgroup 0 advance the base) before all have started
+        c = res(plan.outputs[-1])
+        first_red = [pi for pi, ph in enumerate(pr.phases) if ph.get("reduce")]
+        if c not in pr.zero_d or c not in produced or not first_red or produced[c] < first_red[0]:
+            return None, "do-while condition not behind a reduction of the step"
+        pr.cond = c
     inner_of_slot = {}
-    for ji, o in enumerate(plan.outputs):
+    for ji, o in enumerate(plan.outputs[:len(slot_of)]):
         j = slot_of[ji]
         inner_of_slot[j] = ji
         if res(o) not in produced:
@@ -314,6 +393,8 @@ def analyze(inner, p, n_seqdots):
                     pr.passthru_tj.add(j)
                 continue
             return None, "a step output is not computed by a fused step"
+        if res(o) in pr.zero_d and not (n_rec <= j < n_outer):
+            return None, "0-d recurrent output"
         pr.outs.append((res(o), "nit" if n_rec <= j < n_outer else "rec", j))
     for v, k in pr.state.items():
         pr.new_of_state[v] = res(plan.outputs[inner_of_slot[k]])
@@ -326,7 +407,9 @@ def analyze(inner, p, n_seqdots):
                 need.append(src)
     if not need:
         return None, "no recurrent dot product"
-    pr.exchanged = need
+    if any(v in pr.zero_d for v in need):
+        return None, "dot with a 0-d value"
+    pr.exchanged = need + [ph["reduce"]["u"] for ph in pr.phases if ph.get("reduce")]
     return pr, None
 
 
@@ -354,7 +437,9 @@ class Spec:
                            self.R, self.nw, sorted(pr.seq.items()), sorted(pr.state.items()),
                            sorted(pr.nsq.items()), sorted(pr.mats.items()),
                            [[ph["dots"], ph["ins"], ph["outs"], ph["scalar"], ph["out_refs"]]
-                            for ph in pr.phases], pr.outs, pr.exchanged, sorted(pr.tap_seq.items())],
+                            for ph in pr.phases], pr.outs, pr.exchanged, sorted(pr.tap_seq.items())] +
+                          ([["red1", [ph.get("reduce") for ph in pr.phases], sorted(pr.zero_d), pr.cond]]
+                           if pr.zero_d else []),
                           sort_keys=True)
         return hashlib.sha256(blob.encode()).hexdigest()[:24]
 
@@ -409,6 +494,10 @@ def generate(spec: Spec):
                 if (x, kind) not in stage:
                     stage[(x, kind)] = stot
                     stot += K
+    for ph in pr.phases:
+        if ph.get("reduce"):         # the vector a reduction folds is gathered like a dot operand
+            stage[(ph["reduce"]["u"], "cur")] = stot
+            stot += -(-M // VEC) * VEC
     xoff, _xtot = xch_layout(pr, spec.lens, GPV)
     L.append('extern "C" __global__ __launch_bounds__(%d) void %s(SpArgs a) {' % (BLOCK, name))
     L.append("  __shared__ __attribute__((aligned(16))) %s Wl[%d];" % (T, max(wtot, 4)))
@@ -478,8 +567,9 @@ def generate(spec: Spec):
     for v in pw_nsq:
         es_one = spec.lens[v] == 1
         L.append("  %s own_%d = 0;" % (T, v))
-        L.append("  if (owner) own_%d = ((const %s*)a.nsq[%d])[%s];"
-                 % (v, T, pr.nsq[v], "0" if es_one else "myrow * a.nsq_es[%d]" % pr.nsq[v]))
+        L.append("  if (%s) own_%d = ((const %s*)a.nsq[%d])[%s];"
+                 % ("true" if es_one and pr.zero_d else "owner", v, T, pr.nsq[v],
+                    "0" if es_one else "myrow * a.nsq_es[%d]" % pr.nsq[v]))
     pw_seq = sorted({v for ph in pr.phases for v in ph["ins"] if v in pr.seq})
     for v in pw_seq:
         s = pr.seq[v]
@@ -489,6 +579,10 @@ def generate(spec: Spec):
     for ph in pr.phases:
         for o in ph["outs"]:
             L.append("  %s own_%d = 0;" % (T, o))
+        if ph.get("reduce"):
+            L.append("  %s own_%d = 0, own_%d = 0;" % (T, ph["reduce"]["u"], ph["reduce"]["out"]))
+    if pr.cond is not None:
+        L.append("  i64 steps_ = a.T;           // do-while: steps run (every workgroup stops alike)")
     L.append("  __syncthreads();")
     L.append("  for (i64 t = 0; t < a.T; ++t) {")
     L.append("    const int par = (int)(t & 1);")
@@ -498,6 +592,52 @@ def generate(spec: Spec):
         L.append("    own_%d = nxt_%d;" % (v, v))
         L.append("    if (owner && t + 1 < a.T) nxt_%d = ((const %s*)a.seq[%d])[(t + 1) * a.seq_ts[%d] + %s];"
                  % (v, T, s, s, idx))
+    def gather(xo, lp, so, K, step_expr, ind, delayed):
+        """Poll the granules of an exchanged vector until they carry the producing step's tag and
+        stage the values in Vl[par][so ..]; returns the new ``delayed`` (the first poll of a phase
+        is held back)."""
+        PT = 64 * spec.var["pollw"]
+        KG = GPV * K                   # granules of this vector (float64: hi / lo halves)
+        NGp = (KG + PT - 1) // PT
+        pg = "" if PT == BLOCK else "if (threadIdx.x < %d) " % PT
+        L.append(ind + "const u64* src = a.xch + %d + (%s & 3) * %d;" % (xo, step_expr, lp))
+        L.append(ind + "const unsigned want = base + (unsigned)%s + 1u;" % step_expr)
+        L.append(ind + pg + "{")
+        L.append(ind + "u64 g[%d];" % NGp)
+        # a poll that comes back without the tags costs a whole further round trip (~0.7 us)
+        # and its traffic slows the very stores it waits for: hold the first one back until it
+        # can succeed (r04: config 4 B = 1 4.59 -> 4.05 us per step with 12 x 64 cycles)
+        if not delayed:
+            for _ in range(spec.var["delay"] // 15):
+                L.append(ind + "__builtin_amdgcn_s_sleep(15);")
+            if spec.var["delay"] % 15:
+                L.append(ind + "__builtin_amdgcn_s_sleep(%d);" % (spec.var["delay"] % 15))
+            delayed = True
+        L.append(ind + "for (int spin = 0;; ++spin) {")
+        L.append(ind + "  bool ok = true;")
+        for q in range(NGp):
+            guard = "" if (q + 1) * PT <= KG else "if (threadIdx.x + %d < %d) " % (q * PT, KG)
+            L.append(ind + "  %s{ g[%d] = __hip_atomic_load(src + threadIdx.x + %d, %s); "
+                     "ok = ok && ((unsigned)(g[%d] >> 32) == want); }" % (guard, q, q * PT, AG, q))
+        L.append(ind + "  if (ok) break;")
+        # bounded spin; once any workgroup has given up every later wait ends within 256 polls
+        L.append(ind + "  if (spin > %d || ((spin & 255) == 255 && __hip_atomic_load(errp, %s) != 0u)) "
+                 "{ __hip_atomic_store(errp, 1u, %s); break; }" % (SPIN_LIMIT, AG, AG))
+        if spec.var["sleep"]:
+            L.append(ind + "  __builtin_amdgcn_s_sleep(%d);" % spec.var["sleep"])
+        L.append(ind + "}")
+        for q in range(NGp):
+            guard = "" if (q + 1) * PT <= KG else "if (threadIdx.x + %d < %d) " % (q * PT, KG)
+            if F64:
+                # granule 2k = {tag, high word}, 2k + 1 = {tag, low word}: two 4-byte LDS stores
+                # rebuild the double in place (little endian: low word first)
+                L.append(ind + "%s((unsigned*)(Vl[par] + %d))[(threadIdx.x + %d) ^ 1] = (unsigned)g[%d];"
+                         % (guard, so, q * PT, q))
+            else:
+                L.append(ind + "%sVl[par][%d + threadIdx.x + %d] = __uint_as_float((unsigned)g[%d]);"
+                         % (guard, so, q * PT, q))
+        return delayed
+
     staged_this_step = set()
     for pi, ph in enumerate(pr.phases):
         L.append("    // ---- phase %d" % pi)
@@ -536,46 +676,7 @@ def generate(spec: Spec):
             else:
                 L.append("    {")
                 step_expr, ind = "t", "      "
-            PT = 64 * spec.var["pollw"]
-            KG = GPV * K                   # granules of this vector (float64: hi / lo halves)
-            NGp = (KG + PT - 1) // PT
-            pg = "" if PT == BLOCK else "if (threadIdx.x < %d) " % PT
-            L.append(ind + "const u64* src = a.xch + %d + (%s & 3) * %d;" % (xo, step_expr, lp))
-            L.append(ind + "const unsigned want = base + (unsigned)%s + 1u;" % step_expr)
-            L.append(ind + pg + "{")
-            L.append(ind + "u64 g[%d];" % NGp)
-            # a poll that comes back without the tags costs a whole further round trip (~0.7 us)
-            # and its traffic slows the very stores it waits for: hold the first one back until it
-            # can succeed (r04: config 4 B = 1 4.59 -> 4.05 us per step with 12 x 64 cycles)
-            if not delayed:
-                for _ in range(spec.var["delay"] // 15):
-                    L.append(ind + "__builtin_amdgcn_s_sleep(15);")
-                if spec.var["delay"] % 15:
-                    L.append(ind + "__builtin_amdgcn_s_sleep(%d);" % (spec.var["delay"] % 15))
-                delayed = True
-            L.append(ind + "for (int spin = 0;; ++spin) {")
-            L.append(ind + "  bool ok = true;")
-            for q in range(NGp):
-                guard = "" if (q + 1) * PT <= KG else "if (threadIdx.x + %d < %d) " % (q * PT, KG)
-                L.append(ind + "  %s{ g[%d] = __hip_atomic_load(src + threadIdx.x + %d, %s); "
-                         "ok = ok && ((unsigned)(g[%d] >> 32) == want); }" % (guard, q, q * PT, AG, q))
-            L.append(ind + "  if (ok) break;")
-            # bounded spin; once any workgroup has given up every later wait ends within 256 polls
-            L.append(ind + "  if (spin > %d || ((spin & 255) == 255 && __hip_atomic_load(errp, %s) != 0u)) "
-                     "{ __hip_atomic_store(errp, 1u, %s); break; }" % (SPIN_LIMIT, AG, AG))
-            if spec.var["sleep"]:
-                L.append(ind + "  __builtin_amdgcn_s_sleep(%d);" % spec.var["sleep"])
-            L.append(ind + "}")
-            for q in range(NGp):
-                guard = "" if (q + 1) * PT <= KG else "if (threadIdx.x + %d < %d) " % (q * PT, KG)
-                if F64:
-                    # granule 2k = {tag, high word}, 2k + 1 = {tag, low word}: two 4-byte LDS stores
-                    # rebuild the double in place (little endian: low word first)
-                    L.append(ind + "%s((unsigned*)(Vl[par] + %d))[(threadIdx.x + %d) ^ 1] = (unsigned)g[%d];"
-                             % (guard, so, q * PT, q))
-                else:
-                    L.append(ind + "%sVl[par][%d + threadIdx.x + %d] = __uint_as_float((unsigned)g[%d]);"
-                             % (guard, so, q * PT, q))
+            delayed = gather(xo, lp, so, K, step_expr, ind, delayed)
             L.append(ind + "}")
             L.append("    }")
         if need_sync:
@@ -625,14 +726,23 @@ def generate(spec: Spec):
             for i in range(RPW - 2, -1, -1):
                 sel = "(lane == %d ? acc%d_%d_%d : %s)" % (i, pi, d, i, sel)
             L.append("    const %s dot_%d_%d = %s;" % (T, pi, d, sel))
-        # -- epilogue on the row owners
-        L.append("    if (owner) {")
+        # -- epilogue on the row owners (a phase of 0-d values: on every lane — what follows from a
+        #    reduction, the do-while condition included, must be uniform)
+        red = ph.get("reduce")
+        L.append("    {" if ph.get("scalar_phase") else "    if (owner) {")
         ins = ["dot_%d_%d" % (pi, d) for d in range(D)] + ["own_%d" % v for v in ph["ins"]]
         lines, outs, odts = cg.emit_scalar_body(ph["scalar"], ins, [spec.dtype] * len(ins),
                                                 indent="      ", suffix="_p%d" % pi)
         L.extend(lines)
-        for k, (o, ri) in enumerate(zip(ph["outs"], ph["out_refs"])):
+        pub = list(zip(ph["outs"], ph["out_refs"])) + ([(red["u"], red["ref"])] if red else [])
+        for k, (o, ri) in enumerate(pub):
             L.append("      own_%d = %s;" % (o, cg._cast(outs[ri], odts[ri], spec.dtype)))
+            if o in pr.zero_d:
+                # a 0-d result (every lane holds it): one lane of workgroup 0 stores it
+                for kind, j in out_of.get(o, []):
+                    L.append("      if (blockIdx.x == 0 && threadIdx.x == 0) ((%s*)a.out[%d])[((a.out_pos0[%d] + t) "
+                             "%% a.out_store[%d]) * a.out_rs[%d]] = own_%d;" % (T, j, j, j, j, o))
+                continue
             if o in xoff:
                 xo, lp = xoff[o]
                 if F64:
@@ -647,15 +757,41 @@ def generate(spec: Spec):
                 L.append("      ((%s*)a.out[%d])[((a.out_pos0[%d] + t) %% a.out_store[%d]) * a.out_rs[%d] + myrow] = own_%d;"
                          % (T, j, j, j, j, o))
         L.append("    }")
+        if red:
+            # -- the reduction: gather the whole vector the owners just published, fold it in one
+            #    fixed order (lane l folds elements l, l + 64, ...; butterfly over the wavefront:
+            #    every lane of every wavefront of every workgroup ends with the same value)
+            xo, lp = xoff[red["u"]]
+            so = stage[(red["u"], "cur")]
+            AT = cg.RTYPE[red["acc"]]
+            comb = lambda a_, b_, _r=red: cg.red_combine(_r["op"], _r["acc"], a_, b_)   # noqa: E731
+            L.append("    {")
+            gather(xo, lp, so, M, "t", "      ", False)
+            L.append("      }")
+            L.append("    }")
+            L.append("    __syncthreads();")
+            L.append("    {")
+            L.append("      %s rr = (%s)%s;" % (AT, AT, cg.red_identity(red["op"], red["acc"])))
+            L.append("      for (int k = lane; k < %d; k += 64) rr = %s;" % (M, comb("rr", "(%s)Vl[par][%d + k]" % (AT, so))))
+            L.append("      for (int s = 32; s > 0; s >>= 1) rr = %s;" % comb("rr", "shfl_xor_<%s>(rr, s)" % AT))
+            L.append("      own_%d = (%s)rr;" % (red["out"], T))
+            L.append("    }")
+            for kind, j in out_of.get(red["out"], []):
+                L.append("    if (blockIdx.x == 0 && threadIdx.x == 0) ((%s*)a.out[%d])[((a.out_pos0[%d] + t) "
+                         "%% a.out_store[%d]) * a.out_rs[%d]] = own_%d;" % (T, j, j, j, j, red["out"]))
     for v, nv in pr.new_of_state.items():
         k = pr.state[v]
         for d in range(pr.depth.get(k, 1), 1, -1):      # shift the owner's history, oldest first
             L.append("    %s = %s;" % (hist[(k, d)], hist[(k, d - 1)] if d > 2 else "own_%d" % v))
         L.append("    own_%d = own_%d;" % (v, nv))
+    if pr.cond is not None:
+        L.append("    if (own_%d != 0) { steps_ = t + 1; break; }" % pr.cond)
     L.append("  }")
     # every workgroup read `base` before workgroup 0 can get here (it gathered, in its last
     # step, a vector that every workgroup published after reading `base`; T >= 2)
     L.append("  if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.ctl, base + (unsigned)a.T, %s);" % AG)
+    if pr.cond is not None:
+        L.append("  if (blockIdx.x == 0 && threadIdx.x == 0) a.ctl[4] = (unsigned)steps_;   // the one host read")
     L.append("}")
     return "\n".join(L) + "\n", (name,)
 

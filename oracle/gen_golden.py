@@ -1144,6 +1144,36 @@ def _():
     return [s, h0], [hs[-1], tot[-1], tot], [N((25, 130), seed=5), N((130,), seed=6)]
 
 
+@case("scan_red_rnn_normalised", rtol=1e-11, atol=1e-12)
+def _():
+    # power-iteration-like recurrence: the new state is divided by its own norm (a reduction whose
+    # result feeds the SAME step's state), the norm is handed out per step
+    x, W, h0 = at.dmatrix("x"), at.dmatrix("W"), at.dvector("h0")
+
+    def step(x_t, h, W):
+        z = at.tanh(at.dot(W, h) + x_t)
+        nrm = at.sqrt((z ** 2).sum())
+        return [z / nrm, nrm]
+    (hs, nr), _ = ae.scan(step, sequences=[x], outputs_info=[h0, None], non_sequences=[W])
+    return [x, W, h0], [hs, nr], [N((24, 70), seed=1), N((70, 70), seed=2, scale=0.3), N((70,), seed=3)]
+
+
+@case("scan_red_rnn_until_f32", rtol=2e-5, atol=1e-6)
+def _():
+    # do-while over a vector state with a dot in the step: stop when the state's largest element
+    # passes a threshold (scan_perform.pyx:424-426); trip count, truncated outputs
+    from aesara.scan.utils import until
+    x, W, h0 = at.fmatrix("x"), at.fmatrix("W"), at.fvector("h0")
+
+    def step(x_t, h, W):
+        hn = 0.9 * h + at.tanh(at.dot(W, h) + x_t) * 0.5
+        return [hn, hn.max()], until(hn.max() > 1.25)
+    (hs, mx), _ = ae.scan(step, sequences=[x], outputs_info=[h0, None], non_sequences=[W])
+    return [x, W, h0], [hs, mx, hs.shape[0]], [
+        N((40, 96), "float32", seed=4, scale=0.5), N((96, 96), "float32", seed=5, scale=0.1),
+        K(0.0, "float32", (96,))]
+
+
 @case("scan_red_int_minmax", exact=True)
 def _():
     # integer reductions (exact): per-step minimum and maximum of a running integer vector, and a

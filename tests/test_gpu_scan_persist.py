@@ -741,3 +741,71 @@ def test_elman_sequence_product_a_step_ahead(T, H, B):
     err = ((hs.double() - ref).abs().max() / ref.abs().max()).item()
     assert err <= 1e-5, err
     assert torch.equal(hT, hs[-1])
+
+
+# ---- full reductions inside the step of the vector-state kernel (round 5) ------------------------
+RED_BOTH = ["scan_variant_0", "scan_variant_3", "scan_variant_6", "scan_variant_9"]        # forward + gradient Scan
+RED_FWD = ["scan_variant_2", "scan_variant_5", "scan_variant_8", "scan_variant_11"]        # forward Scan only
+RED_ONE = ["scan_while_nitsot_matrix", "scan_red_rnn_normalised", "scan_red_rnn_until_f32"]
+
+
+@pytest.mark.parametrize("name", RED_BOTH + RED_FWD + RED_ONE)
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_steps_with_reductions_run_in_the_persistent_kernel(name, use_graph):
+    """Steps with full reductions next to the recurrent dot (``(h ** 2).sum()``, ``x_t.max()``, a state
+    divided by its own norm, a do-while on ``h.max()``; scan_perform.pyx:309-541, :424-426): the
+    reduced vector is exchanged like the state, every workgroup folds it in one fixed order.
+    Results = the reference's outputs = the launch-list path (at the case's tolerance: other
+    summation order)."""
+    from aesara_amd import executor as E
+    c = _case(name)
+    ex = E.PlanExecutor(case_plan(c), use_graph=use_graph)
+    ins = case_inputs(c)
+    for it in range(4):                       # later calls: advanced tag epochs (and replays)
+        got = _np(ex(*ins))
+        assert_matches(c, got, case_expected(c), f"persistent call {it}")
+    modes = list(ex.scan_modes.values())
+    if name in RED_FWD:
+        assert modes.count("persistent") >= 1, ex.scan_modes
+    else:
+        assert all(m == "persistent" for m in modes), ex.scan_modes
+    E.TUNE["scan_persist"] = 0
+    try:
+        ex2 = E.PlanExecutor(case_plan(c), use_graph=use_graph)
+        ref = _np(ex2(*ins))
+        assert all(v.startswith("launch-list") for v in ex2.scan_modes.values())
+    finally:
+        E.TUNE["scan_persist"] = 1
+    assert_matches(c, got, ref, "against the launch-list path")
+    ex.check()
+
+
+@pytest.mark.parametrize("scale", [0.01, 0.3, 0.5, 1.0, 8.0])
+def test_vector_state_do_while_trip_counts(scale):
+    """h <- 0.9 h + 0.5 tanh(W h + x_t) until max(h) > 1.25 (golden scan_red_rnn_until_f32's step):
+    inputs scaled so that the loop never stops, stops late, early, after one step — trip count and
+    truncated outputs against a NumPy loop in float64 (float32 tolerance)."""
+    import torch
+    from aesara_amd.executor import PlanExecutor
+    rng = np.random.default_rng(3)
+    T, H = 40, 96
+    x = (rng.standard_normal((T, H)) * scale).astype("float32")
+    W = (rng.standard_normal((H, H)) * 0.1).astype("float32")
+    h0 = np.zeros(H, dtype="float32")
+    h, rows, mx = h0.astype("float64"), [], []
+    for t in range(T):
+        h = 0.9 * h + 0.5 * np.tanh(W.astype("float64") @ h + x[t])
+        rows.append(h.copy())
+        mx.append(h.max())
+        if h.max() > 1.25:
+            break
+    if any(abs(m - 1.25) < 1e-3 for m in mx):
+        pytest.skip("a maximum within float32 noise of the threshold")
+    ex = PlanExecutor(case_plan(_case("scan_red_rnn_until_f32")), use_graph=True)
+    for call in range(2):
+        hs, ms, count = _np(ex(torch.from_numpy(x).cuda(), torch.from_numpy(W).cuda(), torch.from_numpy(h0).cuda()))
+        assert int(count) == len(rows) and hs.shape == (len(rows), H) and ms.shape == (len(rows),)
+        np.testing.assert_allclose(hs, np.array(rows), rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(ms, np.array(mx), rtol=2e-4, atol=2e-5)
+    assert list(ex.scan_modes.values()) == ["persistent"], ex.scan_modes
+    ex.check()

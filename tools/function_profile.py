@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Where the host time of one ``f(x, mu, sigma)`` goes (config 2 through aesara.function(mode="HIP"),
 untrusted Function.__call__): cProfile over N calls with the device kept busy.
-usage (GPU box): python tools/function_profile.py [--trust] > gpurun_out/function_profile.txt"""
+usage (GPU box): python tools/function_profile.py [--trust] [--small] > gpurun_out/function_profile.txt"""
 import cProfile
 import os
 import pstats
@@ -24,7 +24,9 @@ def main():
     x, mu, sg = at.dmatrix("x"), at.dscalar("mu"), at.dscalar("sigma")
     f = ae.function([x, mu, sg], at.exp(-(x - mu) ** 2 / (2 * sg ** 2)).sum(), mode="HIP")
     f.trust_input = "--trust" in sys.argv
-    xs = [torch.randn(4096, 4096, dtype=torch.float64, device="cuda") for _ in range(8)]
+    # --small: 256 x 256 matrices — the device is never the bottleneck, the loop measures the host alone
+    side = 256 if "--small" in sys.argv else 4096
+    xs = [torch.randn(side, side, dtype=torch.float64, device="cuda") for _ in range(8)]
     m, s = np.asarray(0.1), np.asarray(1.3)
     for k in range(64):
         f(xs[k % 8], m, s)
