@@ -194,12 +194,21 @@ def main():
             row["build_s"] = time.perf_counter() - t0 - first
             if not args.warm:
                 ts = []
+                # cfg3a streams ONE 128 MiB matrix per eval: the GPU leg rotates over 8 matrices so
+                # that none is cache-resident (MALL) — the host leg rotates over 16 copies (2 GiB,
+                # beyond the L3 of any EPYC) for the same reason (it used to
+                # re-read one L3-resident matrix)
+                alts = [fargs]
+                if name == "cfg3a":
+                    alts = [(np.array(fargs[0], copy=True),) + tuple(fargs[1:]) for _ in range(16)]
+                    row["sample"] = sample + ", rotating over 16 copies of M (cache-cold like the GPU leg)"
                 t_end = time.perf_counter() + args.budget
                 if first > args.budget / 2:             # slow config: the first eval IS the sample
                     ts = [first]
                 while not ts or (time.perf_counter() < t_end and len(ts) < 50):
+                    a_ = alts[len(ts) % len(alts)]
                     t = time.perf_counter()
-                    f(*fargs)
+                    f(*a_)
                     ts.append(time.perf_counter() - t)
                 ts.sort()
                 row.update(ms_per_eval=ts[len(ts) // 2] * 1e3, evals=len(ts),
