@@ -1474,7 +1474,10 @@ class GemvEpiSpec:
     """
 
     def __init__(self, dtype, dot_vec, scalar, in_dtypes, out_dtypes, out_refs, block=256,
-                 rpw=1, kvs=None, xprogs=None):
+                 rpw=1, kvs=None, xprogs=None, nt=False):
+        # nt: the matrix rows are read with non-temporal 16-byte loads (a matrix of half the
+        # memory-side cache or more is read once as far as the caches go, exec_elemwise.BIG_STREAM)
+        self.nt = bool(nt)
         # xprogs: per dot None or {"scalar", "cls": ["v" | "s", ...], "out_ref", "store"}: the
         # dot's vector is an Elemwise of <= 4 vectors / scalars, evaluated while it is loaded
         # (and stored by the first wavefront when something else reads it).  Needs kvs.
@@ -1500,7 +1503,7 @@ class GemvEpiSpec:
     def key(self):
         xp = [None if x is None else [x["cls"], x["out_ref"], x["store"]] for x in (self.xprogs or [])]
         fields = ["gv4", self.dtype, self.dot_vec, self.in_dtypes, self.out_dtypes, self.out_refs,
-                  self.block, self.rpw, self.kvs, xp]
+                  self.block, self.rpw, self.kvs, xp] + (["nt"] if self.nt else [])
         return _memo_key([self.scalar] + [x["scalar"] for x in (self.xprogs or []) if x],
                          fields, self._key)
 
@@ -1508,7 +1511,7 @@ class GemvEpiSpec:
         import json
         blob = json.dumps(["gv4", self.dtype, self.dot_vec, self.scalar, self.in_dtypes,
                            self.out_dtypes, self.out_refs, self.block, self.rpw, self.kvs,
-                           self.xprogs],
+                           self.xprogs] + (["nt"] if self.nt else []),
                           sort_keys=True)
         return hashlib.sha256(blob.encode()).hexdigest()[:24]
 
@@ -1522,6 +1525,7 @@ def generate_gemv_epilogue(spec: GemvEpiSpec):
     name = "gv_" + spec.key()
     waves = spec.block // 64
     L = [PRELUDE, GV_STRUCT]
+    LD = "nt_load(%s)" if spec.nt else "*%s"          # how a 16-byte piece of a matrix row is read
     L.append('extern "C" __global__ __launch_bounds__(%d) void %s(GvArgs a) {' % (spec.block, name))
     L.append("  const int lane = threadIdx.x & 63;")
     L.append("  const i64 nwaves = (i64)gridDim.x * %d;" % waves)
@@ -1541,8 +1545,8 @@ def generate_gemv_epilogue(spec: GemvEpiSpec):
             xp = spec.xprogs[d] if spec.xprogs else None
             for j in range(spec.kvs[d]):
                 for r in range(R):
-                    L.append("    const Pack<%s, %d> a%d_%d_%d = *(const Pack<%s, %d>*)"
-                             "(row%d_%d + (%d + lane) * %d);" % (T, V, d, r, j, T, V, d, r, j * 64, V))
+                    L.append("    const Pack<%s, %d> a%d_%d_%d = %s;" % (T, V, d, r, j, LD % (
+                        "(const Pack<%s, %d>*)(row%d_%d + (%d + lane) * %d)" % (T, V, d, r, j * 64, V))))
                 if xp is None:
                     L.append("    const Pack<%s, %d> x%d_%d = *(const Pack<%s, %d>*)(xv%d + (%d + lane) * %d);"
                              % (T, V, d, j, T, V, d, j * 64, V))
@@ -1600,15 +1604,15 @@ def generate_gemv_epilogue(spec: GemvEpiSpec):
                 L.append("      %s e0 = 0, e1 = 0;" % T)
                 L.append("      i64 v = lane;")
                 L.append("      for (; v + 64 < nv; v += 128) {")
-                L.append("        const Pack<%s, %d> a0 = *(const Pack<%s, %d>*)(row0 + v * %d);" % (T, V, T, V, V))
-                L.append("        const Pack<%s, %d> a1 = *(const Pack<%s, %d>*)(row0 + (v + 64) * %d);" % (T, V, T, V, V))
+                L.append("        const Pack<%s, %d> a0 = %s;" % (T, V, LD % ("(const Pack<%s, %d>*)(row0 + v * %d)" % (T, V, V))))
+                L.append("        const Pack<%s, %d> a1 = %s;" % (T, V, LD % ("(const Pack<%s, %d>*)(row0 + (v + 64) * %d)" % (T, V, V))))
                 L.append("        const Pack<%s, %d> x0 = *(const Pack<%s, %d>*)(xv + v * %d);" % (T, V, T, V, V))
                 L.append("        const Pack<%s, %d> x1 = *(const Pack<%s, %d>*)(xv + (v + 64) * %d);" % (T, V, T, V, V))
                 for e in range(V):
                     L.append("        e0 += a0.v[%d] * x0.v[%d]; e1 += a1.v[%d] * x1.v[%d];" % (e, e, e, e))
                 L.append("      }")
                 L.append("      for (; v < nv; v += 64) {")
-                L.append("        const Pack<%s, %d> a0 = *(const Pack<%s, %d>*)(row0 + v * %d);" % (T, V, T, V, V))
+                L.append("        const Pack<%s, %d> a0 = %s;" % (T, V, LD % ("(const Pack<%s, %d>*)(row0 + v * %d)" % (T, V, V))))
                 L.append("        const Pack<%s, %d> x0 = *(const Pack<%s, %d>*)(xv + v * %d);" % (T, V, T, V, V))
                 for e in range(V):
                     L.append("        e0 += a0.v[%d] * x0.v[%d];" % (e, e))
@@ -1618,8 +1622,8 @@ def generate_gemv_epilogue(spec: GemvEpiSpec):
                 L.append("      for (i64 v = lane; v < nv; v += 64) {")
                 L.append("        const Pack<%s, %d> x0 = *(const Pack<%s, %d>*)(xv + v * %d);" % (T, V, T, V, V))
                 for r in range(R):
-                    L.append("        const Pack<%s, %d> a%d = *(const Pack<%s, %d>*)(row%d + v * %d);"
-                             % (T, V, r, T, V, r, V))
+                    L.append("        const Pack<%s, %d> a%d = %s;" % (T, V, r, LD % (
+                        "(const Pack<%s, %d>*)(row%d + v * %d)" % (T, V, r, V))))
                 for r in range(R):
                     for e in range(V):
                         L.append("        d%d_%d += a%d.v[%d] * x0.v[%d];" % (d, r, r, e, e))
@@ -1694,7 +1698,8 @@ class RowPassSpec:
     """
 
     def __init__(self, dtype, kv, scalar, in_dtypes, out_dtypes, out_refs, reds, col_ref,
-                 rpw=2, block=256):
+                 rpw=2, block=256, nt=False):
+        self.nt = bool(nt)      # rows of X read with non-temporal loads (exec_elemwise.BIG_STREAM)
         self.dtype, self.kv, self.scalar = dtype, kv, scalar
         self.in_dtypes, self.out_dtypes, self.out_refs = list(in_dtypes), list(out_dtypes), list(out_refs)
         self.reds, self.col_ref, self.rpw, self.block = [list(r) for r in reds], col_ref, rpw, block
@@ -1702,14 +1707,14 @@ class RowPassSpec:
 
     def key(self):
         fields = ["rp2", self.dtype, self.kv, self.in_dtypes, self.out_dtypes, self.out_refs,
-                  self.reds, self.col_ref, self.rpw, self.block]
+                  self.reds, self.col_ref, self.rpw, self.block] + (["nt"] if self.nt else [])
         return _memo_key([self.scalar], fields, self._key)
 
     def _key(self):
         import json
         blob = json.dumps(["rp2", self.dtype, self.kv, self.scalar, self.in_dtypes, self.out_dtypes,
-                           self.out_refs, self.reds, self.col_ref, self.rpw, self.block],
-                          sort_keys=True)
+                           self.out_refs, self.reds, self.col_ref, self.rpw, self.block] +
+                          (["nt"] if self.nt else []), sort_keys=True)
         return hashlib.sha256(blob.encode()).hexdigest()[:24]
 
 
@@ -1751,8 +1756,8 @@ def generate_rowpass(spec: RowPassSpec):
         L.append("    const %s* __restrict__ row%d = X + ((m0 + %d < a.N) ? (m0 + %d) : (a.N - 1)) * a.x_rs;"
                  % (T, r, r, r))
         for v in range(KV):
-            L.append("    const Pack<%s, %d> x%d_%d = *(const Pack<%s, %d>*)(row%d + (%d * 64 + lane) * %d);"
-                     % (T, V, r, v, T, V, r, v, V))
+            L.append("    const Pack<%s, %d> x%d_%d = %s((const Pack<%s, %d>*)(row%d + (%d * 64 + lane) * %d));"
+                     % (T, V, r, v, "nt_load" if spec.nt else "*", T, V, r, v, V))
     for r in range(R):
         terms = " + ".join("x%d_%d.v[%d] * w%d.v[%d]" % (r, v, e, v, e)
                            for v in range(KV) for e in range(V))

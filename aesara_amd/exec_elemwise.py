@@ -276,8 +276,10 @@ class ElemwiseMixin:
         for o, arr in zip(st.outputs, outs):
             env[o] = arr
         rpw = {1: 16, 2: 8}.get(kv, 4 if kv <= 4 else 2)
+        big = not (knobs.is_set("VECBYTES") or knobs.is_set("NT")) and N * K * ITEMSIZE[dt] >= self.BIG_STREAM
         spec = cg.RowPassSpec(dt, kv, st.scalar, [o.dtype for o in ops], [o.dtype for o in outs],
-                              st.out_refs, ex["reds"], ex["col_ref"], rpw=rpw)
+                              st.out_refs, ex["reds"], ex["col_ref"], rpw=rpw,
+                              nt=big or bool(TUNE["nt"] & 1))
         grid = int(lib.ahip_rowpass_grid(N, spec.block, rpw))
         col_ws = self.alloc((grid, K), dt)
         nred = len(ex["reds"])
@@ -331,13 +333,29 @@ class ElemwiseMixin:
         strides = [[0 if a.shape[d] == 1 else a.strides[d] for d in range(nd)] for a in arrs]
         return shape, strides
 
-    def _pick_vec(self, shape, strides_list, ptrs, dtypes, classes):
+    # A flat stream with an operand of this many bytes or more is read ONCE per evaluation as far
+    # as the caches are concerned (half of the 256 MiB memory-side cache: it cannot still be there
+    # when it is read again): 16 bytes per lane and load, non-temporal loads and stores.  Measured
+    # MALL-cold on the MI355X (profiles/r05_cfg2_cold_sweep8.txt / 9.txt, r05_stream_probe.txt): config 2
+    # 26.5 -> 25.1 us per eval (0.63 -> 0.67 of the HBM peak), config 1b add 73.6 -> 61.8 us (0.68 ->
+    # 0.81), the read-only ceiling 0.68 -> 0.75; either switch alone does nothing (16 bytes) or loses
+    # (non-temporal 32-byte packs: 28.2 us).  Smaller operands keep 32 bytes per lane and the default
+    # cache policy: eight 32 MiB towers re-read every evaluation sit in the memory-side cache and lose
+    # with streaming loads (45 -> 51 us).  AESARA_HIP_VECBYTES / AESARA_HIP_NT override both.
+    BIG_STREAM = 96 << 20
+
+    def _big_stream(self, n, dtypes, classes):
+        if knobs.is_set("VECBYTES") or knobs.is_set("NT"):
+            return False
+        return any(c == "c" and n * ITEMSIZE[dt] >= self.BIG_STREAM for dt, c in zip(dtypes, classes))
+
+    def _pick_vec(self, shape, strides_list, ptrs, dtypes, classes, vecbytes=None):
         if any(c == "s" for c in classes):
             return 1
         csz = [ITEMSIZE[dt] for dt, c in zip(dtypes, classes) if c == "c"]
         if not csz:
             return 1
-        target = max(1, min(8, TUNE["vecbytes"] // max(csz)))
+        target = max(1, min(8, (vecbytes or TUNE["vecbytes"]) // max(csz)))
         v = target
         while v > 1:
             ok = shape[-1] % v == 0
@@ -535,9 +553,11 @@ class ElemwiseMixin:
                 for q, o in enumerate(ops_):
                     g.xin[d][q] = o.ptr
                 g.xout[d] = dots[d][1].ptr if xp["store"] else None
+        big = not (knobs.is_set("VECBYTES") or knobs.is_set("NT")) and all(dot_vec) and any(
+            A.shape[0] * A.shape[1] * ITEMSIZE[dt] >= self.BIG_STREAM for A, _ in dots)
         spec = cg.GemvEpiSpec(dt, dot_vec, st.scalar, [o.dtype for o in others],
                               [o.dtype for o in outs], st.out_refs, rpw=rpw, kvs=kvs,
-                              xprogs=xprogs)
+                              xprogs=xprogs, nt=big or bool(TUNE["nt"] & 1))
         key = spec.key()
         ent = _Kernels.cache.get(key) if not self.dry_run else \
             ([None] if key in _Kernels.compiled else None)
@@ -611,20 +631,22 @@ class ElemwiseMixin:
         classes = ["c" if s[-1] == 1 else ("b" if s[-1] == 0 else "s") for s in cstrides]
         if cshape[-1] == 1:
             classes = ["b"] * len(ops)
-        vec = self._pick_vec(cshape, cstrides, ptrs, dtypes, classes)
         n = _prod((cshape))
+        big = len(cshape) == 1 and self._big_stream(n, dtypes, classes)
+        vec = self._pick_vec(cshape, cstrides, ptrs, dtypes, classes, vecbytes=16 if big else None)
         flat = len(cshape) == 1 and vec > 1
         idx64 = n >= (1 << 31) - (1 << 24)
         invariant = tuple(not any(st_) for st_ in cstrides[:len(arrs)])
+        nt = (3 if big else TUNE["nt"]) if flat else 0
         # launch memo: (program identity, layout class) -> kernel; skips spec construction and
         # key hashing on the eager path (the program object is kept alive so its id stays unique)
         mk = (id(scalar), tuple(out_refs), tuple(dtypes), tuple(classes), len(cshape), vec, idx64,
-              flat, invariant)
+              flat, invariant, nt)
         hit = self._ew_memo.get(mk)
         if hit is None:
             spec = cg.KernelSpec(scalar, dtypes[:len(arrs)], dtypes[len(arrs):], out_refs, classes,
                                  len(cshape), vec, idx64=idx64,
-                                 unroll=TUNE["unroll"] if flat else 1, nt=TUNE["nt"] and flat,
+                                 unroll=TUNE["unroll"] if flat else 1, nt=nt,
                                  invariant=list(invariant))
             (fn,) = _Kernels.get(spec, load=not self.dry_run)
             if len(self._ew_memo) > 4096:
@@ -718,29 +740,33 @@ class ElemwiseMixin:
             classes = ["c" if s[-1] == 1 else ("b" if s[-1] == 0 else "s") for s in cstrides]
             if cshape[-1] == 1:
                 classes = ["b"] * len(ops)
-            vec = self._pick_vec(cshape, cstrides, ptrs, dtypes, classes)
             n = _prod((cshape))
+            big = len(cshape) == 1 and self._big_stream(n, dtypes, classes)
+            vec = self._pick_vec(cshape, cstrides, ptrs, dtypes, classes, vecbytes=16 if big else None)
             flat1 = len(cshape) == 1 and vec > 1
             idx64 = n >= (1 << 31) - (1 << 24)
             invariant = tuple(not any(st_) for st_ in cstrides[:len(arrs)])
+            nt = (3 if big else TUNE["nt"]) if flat1 else 0
             # short streams (a few sweeps of the grid per thread: BASELINE config 2 is 8) keep two
             # vectors in flight per lane: r03 MALL-cold sweep (tools/tune_cold*.sh) 128 MiB fp64
             # 33.6 -> 29.1 / 31.7 -> 29.3 us on two boxes; long streams (512 MiB: 96.9 vs 101.9 us)
             # are better off with one
+            # (16-byte streaming loads, see BIG_STREAM: two in flight at every size — the same bytes
+            # in flight per lane as one 32-byte pack)
             unroll_all = TUNE["unroll"] if knobs.is_set("UNROLL") else \
-                (2 if n * max(ITEMSIZE[d] for d in dtypes[:len(arrs)]) <= (1 << 28) else 1)
+                (2 if big or n * max(ITEMSIZE[d] for d in dtypes[:len(arrs)]) <= (1 << 28) else 1)
             mk = ("all", id(st.scalar), tuple(st.out_refs), tuple(dtypes), tuple(classes),
                   len(cshape), vec, idx64, flat1, invariant, rspec["op"], rspec["acc"],
-                  rspec["out"], rspec["ref"], unroll_all)
+                  rspec["out"], rspec["ref"], unroll_all, nt)
 
             def mkspec(hjobs=False, st=st, dtypes=dtypes, classes=classes, nd_=len(cshape), vec=vec,
                        idx64=idx64, flat1=flat1, invariant=invariant, rspec=rspec, unroll_all=unroll_all,
-                       nin=len(arrs)):
+                       nin=len(arrs), nt=nt):
                 return cg.KernelSpec(st.scalar, dtypes[:nin], dtypes[nin:], st.out_refs,
                                      classes, nd_, vec, idx64=idx64,
                                      reduce=dict(rspec, kind="all"), block=TUNE["red_block"],
                                      unroll=unroll_all if flat1 else 1,
-                                     nt=TUNE["nt"] and flat1, invariant=list(invariant), hjobs=hjobs)
+                                     nt=nt, invariant=list(invariant), hjobs=hjobs)
 
             def single(mk=mk, mkspec=mkspec, st=st, cshape=cshape, cstrides=cstrides, ops=ops,
                        ptrs=ptrs, vec=vec, result=result):
@@ -764,7 +790,7 @@ class ElemwiseMixin:
                 # member of a horizontal group: hand the launch over (``_run_hgroup``)
                 self._defer.append({
                     # (the members of a group share their scalar program: the layout decides)
-                    "sig": (tuple(dtypes), tuple(classes), vec, invariant, unroll_all),
+                    "sig": (tuple(dtypes), tuple(classes), vec, invariant, unroll_all, nt),
                     "mkspec": mkspec, "single": single, "ptrs": ptrs, "n": n, "vec": vec,
                     "result": result})
                 return
@@ -842,12 +868,16 @@ class ElemwiseMixin:
         nslices = max(nslices, 1)
         idx64 = max(nkept, nred) >= (1 << 31) - 1
         out_dt = rspec["out"] if nslices == 1 else rspec["acc"]
+        # (streaming loads for big operands, BIG_STREAM, are NOT the default here: on re-read 128-256 MiB
+        # inputs they won up to 6 % on five layouts and lost up to 24 % on four,
+        # profiles/r05_axisred_nt_ab.txt; AESARA_HIP_NT=1 switches them on)
+        nt = TUNE["nt"] & 1
         mk = ("axis", id(scalar), tuple(out_refs), tuple(dtypes), tuple(classes), nk, nr, vec,
-              idx64, mode, lanes, rspec["op"], rspec["acc"], out_dt, rspec["ref"])
+              idx64, mode, lanes, rspec["op"], rspec["acc"], out_dt, rspec["ref"], nt)
         hit = self._ew_memo.get(mk)
         if hit is None:
             spec = cg.KernelSpec(scalar, dtypes[:nin], dtypes[nin:], out_refs, classes,
-                                 nk + nr, vec, idx64=idx64, unroll=TUNE["red_unroll"],
+                                 nk + nr, vec, idx64=idx64, unroll=TUNE["red_unroll"], nt=nt,
                                  reduce=dict(rspec, kind="row" if mode == 0 else "col", nk=nk,
                                              nr=nr, lanes=lanes, out=out_dt))
             (fn,) = _Kernels.get(spec, load=not self.dry_run)

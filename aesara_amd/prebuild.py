@@ -62,6 +62,11 @@ def _prebuild_full_shapes(cases):
         ("cfg3b_gemm_update", [fake((512, 512), "float32")] * 3),
         ("cfg5_logistic", [fake((1 << 16, 256), "float32"), fake((256,), "float32"),
                            np.float32(0.1), fake((1 << 16,), "float32")]),
+        # (the bench shapes proper: operands of 96 MiB and more take the streaming variants,
+        # exec_elemwise.BIG_STREAM — 16-byte non-temporal loads)
+        ("cfg5_logistic", [fake((1 << 24, 256), "float32"), fake((256,), "float32"),
+                           np.float32(0.1), fake((1 << 24,), "float32")]),
+        ("cfg3a_gemv", [fake((4096, 4096), "float64"), fake((4096,), "float64"), np.float64(2.0)]),
         ("softmax_rows_f32", [fake((4096, 1024), "float32")]),
     ]
     # BASELINE config 4 and its training step at the bench shape: the persistent Scan kernels are
