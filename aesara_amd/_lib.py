@@ -127,6 +127,7 @@ SIGNATURES = {
                             i32, vp]),
     "ahip_occupancy": (i32, [vp, i32, sz, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ahip_elemwise": (i32, [vp, i32, p_i64, i32, p_vp, p_i64, i32, i32, vp]),
+    "ahip_elemwise_wg": (i32, [vp, i32, p_i64, i32, p_vp, p_i64, i32, i32, i32, vp]),
     "ahip_elemwise_tiled": (i32, [vp, i32, p_i64, i32, p_vp, p_i64, i32, i32, vp, vp, sz, vp]),
     "ahip_reduce_ws_bytes": (sz, []),
     "ahip_reduce_partials_bytes": (sz, []),

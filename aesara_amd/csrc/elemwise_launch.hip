@@ -93,6 +93,23 @@ int ahip_elemwise(ahip_fn_t k, int nd, const int64_t* shape, int nops, void* con
   return launch(k, stream_grid(items, block), 1, block, &a, stream);
 }
 
+int ahip_elemwise_wg(ahip_fn_t k, int nd, const int64_t* shape, int nops, void* const* ptrs,
+                     const int64_t* strides, int vec, int block, int wg_per_cu, void* stream) {
+  AHIP_REQUIRE(k != nullptr, "null kernel");
+  AHIP_REQUIRE(vec >= 1 && block >= 64 && block % 64 == 0 && wg_per_cu >= 1, "bad vec/block/wg_per_cu");
+  ahip_ew_args a;
+  int rc = pack_args(&a, nd, shape, nops, ptrs, strides);
+  if (rc) return rc;
+  if (a.n == 0) return AHIP_OK;
+  AHIP_REQUIRE(shape[nd - 1] % vec == 0, "inner extent %lld not divisible by vec %d",
+               (long long)shape[nd - 1], vec);
+  int64_t items = a.n / vec;
+  int64_t want = (items + block - 1) / block;
+  const int64_t cap = (int64_t)ahip_cu_count() * wg_per_cu;
+  if (want > cap) want = cap;
+  return launch(k, (uint32_t)(want < 1 ? 1 : want), 1, block, &a, stream);
+}
+
 int ahip_elemwise_reduce_all(ahip_fn_t k, int nd, const int64_t* shape, int nops,
                              void* const* ptrs, const int64_t* strides, int vec, int block,
                              void* out, void* ws, size_t ws_bytes, void* stream) {

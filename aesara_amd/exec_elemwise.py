@@ -653,7 +653,14 @@ class ElemwiseMixin:
                 self._ew_memo.clear()
             hit = self._ew_memo[mk] = (fn, spec.block, scalar)
         fn, block = hit[0], hit[1]
-        flat = [s for st in cstrides for s in st]
+        is_flat, flat = flat, [s for st in cstrides for s in st]
+        if big and is_flat and not knobs.is_set("STREAM_BPC"):
+            # read-once streams run fastest with FEW wavefronts in flight: 2 x 256 threads per CU
+            # (config 1b 64.3-65.4 -> 62.0-62.4 us, profiles/r05_cfg1b_stream_sweep3.txt)
+            self._launch("ahip_elemwise_wg", (fn, len(cshape), _i64arr(cshape), len(ops),
+                                              (_VP * len(ops))(*ptrs), _i64arr(flat), vec, block, 2,
+                                              self._stream()))
+            return
         self._launch("ahip_elemwise", (fn, len(cshape), _i64arr(cshape), len(ops),
                                 (_VP * len(ops))(*ptrs), _i64arr(flat), vec, block,
                                 self._stream()))
@@ -871,7 +878,7 @@ class ElemwiseMixin:
         # (streaming loads for big operands, BIG_STREAM, are NOT the default here: on re-read 128-256 MiB
         # inputs they won up to 6 % on five layouts and lost up to 24 % on four,
         # profiles/r05_axisred_nt_ab.txt; AESARA_HIP_NT=1 switches them on)
-        nt = TUNE["nt"] & 1
+        nt = bool(TUNE["nt"] & 1)
         mk = ("axis", id(scalar), tuple(out_refs), tuple(dtypes), tuple(classes), nk, nr, vec,
               idx64, mode, lanes, rspec["op"], rspec["acc"], out_dt, rspec["ref"], nt)
         hit = self._ew_memo.get(mk)

@@ -218,6 +218,14 @@ int ahip_occupancy(ahip_fn_t f, int block_threads, size_t dyn_lds_bytes, int* bl
 int ahip_elemwise(ahip_fn_t k, int nd, const int64_t* shape, int nops, void* const* ptrs,
                   const int64_t* strides /* [nops*nd] */, int vec, int block, void* stream);
 
+/* The same launch with the grid capped at `wg_per_cu` workgroups per CU instead of the library-wide
+ * stream_blocks_per_cu (ahip_set_param): streams whose operands are read once (>= 96 MiB each,
+ * non-temporal 16-byte accesses) run fastest with FEW wavefronts in flight — 2 x 256 threads per CU:
+ * BASELINE config 1b 64.3-65.4 -> 62.0-62.4 us (profiles/r05_cfg1b_stream_sweep3.txt).             */
+int ahip_elemwise_wg(ahip_fn_t k, int nd, const int64_t* shape, int nops, void* const* ptrs,
+                     const int64_t* strides /* [nops*nd] */, int vec, int block, int wg_per_cu,
+                     void* stream);
+
 /* ---- K3t: Elemwise (+ optional full CAReduce) with transposed operands --------------------
  * replaces: the same Elemwise._c_all / CAReduce._c_all loop nests (tensor/elemwise.py:835/:1522,
  * elemwise_cgen.py:228-305 per-operand strides) when some input has its unit stride along

@@ -10,14 +10,14 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 typedef double d2 __attribute__((ext_vector_type(2)));
 
-template <int NT, int U>
-__global__ __launch_bounds__(1024) void k_plain(const d2* __restrict__ x, size_t vec_per_wg, double* out) {
+template <int NT, int U, int TH = 1024>
+__global__ __launch_bounds__(TH) void k_plain(const d2* __restrict__ x, size_t vec_per_wg, double* out) {
   const d2* p = x + (size_t)blockIdx.x * vec_per_wg;
   double acc = 0;
-  for (size_t i = threadIdx.x; i + (U - 1) * 1024 < vec_per_wg; i += U * 1024) {
+  for (size_t i = threadIdx.x; i + (U - 1) * TH < vec_per_wg; i += U * TH) {
     d2 v[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = NT ? __builtin_nontemporal_load(p + i + u * 1024) : p[i + u * 1024];
+    for (int u = 0; u < U; ++u) v[u] = NT ? __builtin_nontemporal_load(p + i + u * TH) : p[i + u * TH];
 #pragma unroll
     for (int u = 0; u < U; ++u) acc += v[u].x + v[u].y;
   }
@@ -80,6 +80,11 @@ int main() {
     RUN("plain 16B loads, 1024 thr, 4 in flight", (k_plain<0, 4><<<WG, 1024>>>((const d2*)x, per / 16, out)));
     RUN("plain 16B loads, 1024 thr, 8 in flight", (k_plain<0, 8><<<WG, 1024>>>((const d2*)x, per / 16, out)));
     RUN("nt    16B loads, 1024 thr, 4 in flight", (k_plain<1, 4><<<WG, 1024>>>((const d2*)x, per / 16, out)));
+#define GRID(NT_, U_, TH_) RUN("nt=" #NT_ " 16B x " #U_ " in flight, " #TH_ " threads per CU", (k_plain<NT_, U_, TH_><<<WG, TH_>>>((const d2*)x, per / 16, out)))
+    GRID(1, 1, 1024); GRID(1, 2, 1024); GRID(1, 3, 1024); GRID(1, 4, 1024);
+    GRID(1, 1, 512); GRID(1, 2, 512); GRID(1, 3, 512); GRID(1, 4, 512); GRID(1, 8, 512);
+    GRID(1, 2, 256); GRID(1, 4, 256); GRID(1, 8, 256); GRID(1, 16, 256);
+    GRID(0, 1, 1024); GRID(0, 2, 512); GRID(0, 4, 512); GRID(0, 4, 256); GRID(0, 8, 256);
     RUN("LDS-DMA, 2 loader waves", (k_dma<2><<<WG, 128, 2 * 32768>>>(x, per, out)));
     RUN("LDS-DMA, 4 loader waves", (k_dma<4><<<WG, 256, 4 * 32768>>>(x, per, out)));
     RUN("LDS-DMA, 2 loader waves x 2 WG/CU", (k_dma<2><<<2 * WG, 128, 2 * 32768>>>(x, per / 2, out)));
