@@ -23,8 +23,9 @@ _def("RCCL", None, str, "path of the RCCL library the C-ABI communicator dlopens
 _def("ARENA_CAP_GB", 64.0, float, "replay arenas of all signatures together, GiB, before eviction")
 # ---- generated Elemwise / CAReduce kernels -----------------------------------------------------
 _def("UNROLL", None, int, "vectors in flight per lane of a flat stream (default: 2 up to 256 MiB, else 1)")
-_def("NT", 0, int, "bit 0: non-temporal loads, bit 1: non-temporal stores (flat streams)")
-_def("VECBYTES", 32, int, "bytes per lane per iteration of a flat stream")
+_def("NT", 0, int, "bit 0: non-temporal loads, bit 1: non-temporal stores (flat streams); unset: operands of 96 MiB or more "
+     "stream (16-byte non-temporal accesses, exec_elemwise.BIG_STREAM), setting it or VECBYTES switches that policy off")
+_def("VECBYTES", 32, int, "bytes per lane per iteration of a flat stream (unset: 16 for operands of 96 MiB or more, see NT)")
 _def("BLOCK", 256, int, "threads per workgroup of Elemwise kernels")
 _def("RED_BLOCK", None, int, "threads per workgroup of full reductions (default 1024)")
 _def("RED_UNROLL", 1, int, "axis-reduce loop unroll (1 = the default 8)")

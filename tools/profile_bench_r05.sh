@@ -54,7 +54,11 @@ cands = sorted(out.get("kernels", []), key=lambda k: -k["pct_of_gpu_time"])
 if algo:   # (other rows also run the headline kernel: take the match whose counter bytes fit this row)
     fit = [k for k in cands if per.get(k["name"], {}).get("hbm_bytes_per_launch_corrected")]
     if fit:
-        cands = sorted(fit, key=lambda k: abs(per[k["name"]]["hbm_bytes_per_launch_corrected"] / algo - 1.0))
+        # (several kernels may move this row's bytes — the headline row also runs the read-only
+        # ceiling kernel: among the matches within 2 % of the algorithmic bytes the most-called one)
+        close = [k for k in fit if abs(per[k["name"]]["hbm_bytes_per_launch_corrected"] / algo - 1.0) < 0.02]
+        cands = sorted(close, key=lambda k: -k["calls"]) if close else \
+            sorted(fit, key=lambda k: abs(per[k["name"]]["hbm_bytes_per_launch_corrected"] / algo - 1.0))
 out["row_kernel"] = cands[0]["name"] if cands else None
 tot = per.get(out["row_kernel"], {}).get("hbm_bytes_per_launch_corrected") if cands else None
 out["hbm_bytes_per_launch_corrected"] = tot
