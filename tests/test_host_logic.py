@@ -697,3 +697,46 @@ def test_two_tap_gradient_scan_maps_to_two_states_on_one_buffer():
     assert prog.tap_seq == {t2: 0} and prog.tap_top == {t2: 2}
     outs = p["inner"].outputs                                         # [out-tap 2, out-tap 1, nit-sots ...]
     assert prog.new_of_state[t1] == outs[0] and prog.new_of_state[t0] == outs[1]
+
+
+def test_streaming_policy_for_read_once_operands(monkeypatch):
+    """exec_elemwise.BIG_STREAM: a flat stream / Gemv matrix with an operand of 96 MiB or more takes
+    16 bytes per lane and load with non-temporal accesses (and the capped launch for plain
+    Elemwise); smaller operands keep 32-byte packs and cached loads; setting AESARA_HIP_NT (or
+    VECBYTES) switches the policy off.  Dry runs: which kernel specs and C-ABI entry points."""
+    from aesara_amd import exec_common as ec
+    from aesara_amd.device import DevArray, contiguous_strides
+    from aesara_amd.executor import PlanExecutor
+    from golden_util import CASES, case_plan
+
+    def fake(shape, dtype):
+        n = int(np.prod(shape))
+        return DevArray(ec._FakeBuf(max(n, 1), dtype), 0, tuple(shape), contiguous_strides(shape), dtype)
+
+    def case(name):
+        return next(c for c in CASES if c["name"] == name)
+    specs = []
+    orig = ec._Kernels.get.__func__
+
+    def get(cls, spec, load=True):
+        specs.append(spec)
+        return orig(cls, spec, load=load)
+    monkeypatch.setattr(ec._Kernels, "get", classmethod(get))
+
+    def run(name, args):
+        specs.clear()
+        ex = PlanExecutor(case_plan(case(name)), dry_run=True)
+        ex(*args)
+        return list(specs), list(ex.trace)
+    big2 = [fake((4096, 4096), "float64"), np.float64(0.1), np.float64(1.3)]
+    sp, _ = run("cfg2_gauss_sum", big2)
+    assert [(s.vec, int(s.nt), s.unroll) for s in sp if s.reduce] == [(2, 3, 2)]
+    sp, _ = run("cfg2_gauss_sum", [fake((2048, 2048), "float64"), np.float64(0.1), np.float64(1.3)])
+    assert [(s.vec, int(s.nt)) for s in sp if s.reduce] == [(4, 0)]            # 32 MiB: cached 32-byte packs
+    sp, tr = run("cfg1b_matrix_add", [fake((4096, 4096), "float64")] * 2)
+    assert [(s.vec, int(s.nt)) for s in sp] == [(2, 3)] and "ahip_elemwise_wg" in tr and "ahip_elemwise" not in tr
+    sp, tr = run("cfg1b_matrix_add", [fake((1024, 1024), "float64")] * 2)
+    assert [(s.vec, int(s.nt)) for s in sp] == [(4, 0)] and "ahip_elemwise" in tr and "ahip_elemwise_wg" not in tr
+    monkeypatch.setenv("AESARA_HIP_NT", "0")                                   # explicit: policy off
+    sp, tr = run("cfg1b_matrix_add", [fake((4096, 4096), "float64")] * 2)
+    assert [(s.vec, int(s.nt)) for s in sp] == [(4, 0)] and "ahip_elemwise" in tr
