@@ -875,10 +875,11 @@ class ElemwiseMixin:
         nslices = max(nslices, 1)
         idx64 = max(nkept, nred) >= (1 << 31) - 1
         out_dt = rspec["out"] if nslices == 1 else rspec["acc"]
-        # (streaming loads for big operands, BIG_STREAM, are NOT the default here: on re-read 128-256 MiB
-        # inputs they won up to 6 % on five layouts and lost up to 24 % on four,
-        # profiles/r05_axisred_nt_ab.txt; AESARA_HIP_NT=1 switches them on)
-        nt = bool(TUNE["nt"] & 1)
+        # (an operand of 96 MiB or more: streaming loads, BIG_STREAM — rotating (MALL-cold) inputs: 3-15 %
+        # faster on eight of nine layouts, a tie on the ninth, profiles/r05_axisred_cold_ab.txt; the SAME
+        # 128-256 MiB input re-read every call is partly served by the memory-side cache and mixed:
+        # up to 6 % faster on five layouts, up to 24 % slower on four, profiles/r05_axisred_nt_ab.txt)
+        nt = bool(TUNE["nt"] & 1) or (vec > 1 and self._big_stream(nkept * nred, dtypes[:nin], classes[:nin]))
         mk = ("axis", id(scalar), tuple(out_refs), tuple(dtypes), tuple(classes), nk, nr, vec,
               idx64, mode, lanes, rspec["op"], rspec["acc"], out_dt, rspec["ref"], nt)
         hit = self._ew_memo.get(mk)

@@ -716,3 +716,29 @@ def test_sampled_configs_at_full_shape_against_the_reference_c_linker(tmp_path, 
         assert shapes["X"] == [1 << 24, 256]
     else:
         assert shapes["x"][0] == 512 and shapes["x"][-1] == 1024
+
+
+@pytest.mark.parametrize("shape,axis,dtype", [((4096, 4096), 0, "float64"), ((4096, 4096), 1, "float64"),
+                                              ((16384, 4096), 0, "float32"), ((16384, 4096), 1, "float32"),
+                                              ((256, 512, 256), 1, "float32")])
+def test_big_axis_reductions_with_streaming_loads(shape, axis, dtype):
+    """Axis reductions over operands of 96 MiB and more read them with non-temporal 16-byte loads
+    (exec_elemwise.BIG_STREAM): sums against torch in float64 (CAReduce accumulates float32 sums in
+    float64, tensor/elemwise.py:1495), twice (replay), and against the cached-load kernel."""
+    import torch
+    from aesara_amd.executor import PlanExecutor
+    from aesara_amd.plan import Node, Plan, Var
+    nd = len(shape)
+    pl = Plan("axisred", {0: Var(0, dtype, [None] * nd), 1: Var(1, dtype, [None] * (nd - 1))}, [0], [1],
+              [Node("CAReduce", [0], [1], {"scalar_op": "add", "axis": [axis], "acc_dtype": "float64"})])
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    x = torch.randn(shape, dtype=getattr(torch, dtype), device="cuda", generator=g)
+    want = x.double().sum(dim=axis)
+    ex = PlanExecutor(pl, use_graph=True)
+    tol = 1e-12 if dtype == "float64" else 2e-6
+    for call in range(2):
+        (got,) = ex(x)
+        err = ((got.double() - want).norm() / want.norm()).item()
+        assert err < tol, err
+    ex.check()

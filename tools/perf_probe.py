@@ -117,8 +117,20 @@ def main():
                 ("float32", f32, (256, 512, 256), (1,), "add"), ("float32", f32, (256, 512, 256), (0, 2), "add")):
             ex = PlanExecutor(red_plan(dt, len(shape), axis, op), use_graph=G, borrow=True)
             x = randn(shape, tdt, 3)
-            d, w = timeit(lambda: ex(x), 50)
-            report("%s axis=%s %s %s" % (op, axis, dt, "x".join(map(str, shape))), d, w,
+            if os.environ.get("PROBE_ROTATE"):
+                # MALL-cold: rotate over enough copies that none is still in the 256 MiB memory-side cache
+                nrot = max(2, -(-(1 << 30) // (x.numel() * x.element_size())))
+                xs = [x] + [x.clone() for _ in range(nrot - 1)]
+                st = {"i": 0}
+
+                def call():
+                    st["i"] += 1
+                    ex(xs[st["i"] % nrot])
+                d, w = timeit(call, 60, warmup=nrot)
+            else:
+                d, w = timeit(lambda: ex(x), 50)
+            report("%s axis=%s %s %s%s" % (op, axis, dt, "x".join(map(str, shape)),
+                                           " (rotating: cold)" if os.environ.get("PROBE_ROTATE") else ""), d, w,
                    x.numel() * x.element_size(), "GB/s", 8000.0)
 
     if want("misc"):
