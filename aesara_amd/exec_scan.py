@@ -363,7 +363,7 @@ class ScanMixin:
             b = outs[j]
             # a mit-mot group writes its tap 1: one row after the one it reads as the running value
             g.out[j], g.out_rs[j], g.out_store[j], g.out_pos0[j] = \
-                b.ptr, b.strides[0], store[j], pos[j] + (1 if j < n_mm else 0)
+                b.ptr, b.strides[0], store[j], pos[j] + (prog.mm_first.get(j, 1) if j < n_mm else 0)
         _off, total = sp.xch_layout(prog, lens, 2 if f32 == "float64" else 1)
         wkey = (id(inner), key)
         ws = self._sp_ws.get(wkey)

@@ -33,8 +33,9 @@ after the same step, workgroup 0 stores the trip count for the one host read aft
 Eligibility (anything else runs the launch-list path, and ``PlanExecutor.scan_modes`` says which
 was taken): no shared outputs, do-while only on a condition behind a reduction, sit- / mit-sot outputs with taps down to -8 (tap -1 is
 the exchanged state; older taps are values the row owner produced itself and stay in its
-registers, usable element-wise), mit-mot groups only of the gradient form ([0, 1] -> [1], see
-``analyze``), the fused inner steps are Gemv
+registers, usable element-wise), mit-mot groups whose largest in-tap is their largest out-tap (the
+gradient forms [0, 1] -> [1], [0 .. m] -> [1 .. m], [0, 1, 3] -> [1, 3] ...: see ``analyze``), the fused
+inner steps are Gemv
 chains + Elemwise on float32 / float64 vectors of one length M, matrices are loop invariant (rows
 that are not whole 16-byte vectors are zero-padded by the executor), at least one exchanged
 vector, T >= 2, and the matrix rows of a workgroup fit on chip (LDS + VGPRs).
@@ -119,6 +120,7 @@ class Program:
         self.tap_top = {}           # mit-mot sequence var -> the tap it is (the group's largest)
         self.mm_extra = []          # [(slot, group, out tap)]: out-taps 2.. of a mit-mot group write the
         #                             group's buffer too — further output slots on the same buffer
+        self.mm_first = {}          # mit-mot group -> its smallest out-tap (the row its slot starts at)
         self.zero_d = set()         # 0-d values (reduction results and what is computed from them)
         self.cond = None            # do-while: the 0-d condition variable (as_while)
 
@@ -156,6 +158,7 @@ def _const1(plan, vid):
 
 
 RED_BASE = 1 << 20          # id of the vector a reduction folds: RED_BASE + its 0-d result's id
+FAKE_BASE = 1 << 21         # id of the unread one-step-ago value of a mit-mot out-tap: FAKE_BASE + its slot
 
 
 def analyze(inner, p, n_seqdots):
@@ -173,14 +176,23 @@ def analyze(inner, p, n_seqdots):
     # The gradient of a recurrence with taps [-1 .. -m] gives taps [0 .. m] -> [1 .. m] (in any
     # order): out-tap j of step i is what step i + 1 reads as tap j - 1 — m states, each with its
     # own output slot on the SAME buffer (the slot of out-tap j starts one row after the row tap
-    # j - 1 reads first), and the largest tap is the buffer-resident sequence.  Other tap sets (a
-    # value read again two or more steps after it was written) stay on the launch list.
+    # j - 1 reads first), and the largest tap is the buffer-resident sequence.
+    # General rule (round 5; taps [-1, -3] give [0, 1, 3] -> [1, 3]): when step i reads row i + a the
+    # last step that wrote it is the one whose out-tap b is the SMALLEST b > a (step i - (b - a): an
+    # out-tap <= a of an earlier step lands below, a larger one was overwritten since); in-tap a is
+    # that out-tap's value of d = b - a steps ago.  d = 1: a state as above; d >= 2: a value the ROW
+    # OWNER wrote itself d steps ago — it stays in its registers (usable element-wise only), like
+    # the older taps of a mit-sot output.  The largest in-tap must be the largest out-tap (the
+    # sequence entry that the step overwrites after reading it).  Vector class only.
     mm_in = [list(t) for t in p.get("mit_mot_in_slices", [])]
     mm_out = [list(t) for t in p.get("mit_mot_out_slices", [])]
     if len(mm_in) != len(mm_out) or any(
-            len(ti) < 2 or sorted(ti) != list(range(len(ti))) or sorted(to) != list(range(1, len(ti)))
+            len(ti) < 2 or len(set(ti)) != len(ti) or len(set(to)) != len(to) or not to or
+            min(ti) < 0 or min(to) < 1 or max(ti) != max(to) or max(ti) > 8
             for ti, to in zip(mm_in, mm_out)):
-        return None, "mit-mot taps other than [0 .. m] -> [1 .. m]"
+        return None, "mit-mot taps other than [.. top] -> [.. top]"
+    mm_general = any(sorted(ti) != list(range(len(ti))) or sorted(to) != list(range(1, len(ti)))
+                     for ti, to in zip(mm_in, mm_out))
     n_mm = len(mm_in)
     # sit-sot / mit-sot outputs: the tap -1 value is the recurrent state proper (may feed dots, is
     # exchanged); older taps (-2, -3, ...: scan_perform.pyx:321-340 hands the step one row per
@@ -201,21 +213,36 @@ def analyze(inner, p, n_seqdots):
     n_outer = n_rec + n_nit
     slot_of_mm = {}                                       # (group, out tap) -> output slot
     for g, ti in enumerate(mm_in):
-        m = len(ti) - 1
-        for j in range(1, m + 1):
-            if j == 1:
+        m, outs_g = max(ti), sorted(mm_out[g])
+        pr.mm_first[g] = outs_g[0]
+        for j in outs_g:
+            if j == outs_g[0]:
                 slot_of_mm[(g, j)] = g
             else:
                 slot_of_mm[(g, j)] = n_outer + len(pr.mm_extra)
                 pr.mm_extra.append((n_outer + len(pr.mm_extra), g, j))
+        read1 = set()
         for tap in ti:
             if tap < m:
-                pr.state[ins[idx]] = slot_of_mm[(g, tap + 1)]
+                b = min(bb for bb in outs_g if bb > tap)
+                sl = slot_of_mm[(g, b)]
+                if b - tap == 1:
+                    pr.state[ins[idx]] = sl
+                    read1.add(sl)
+                else:
+                    pr.older[ins[idx]] = (sl, b - tap)
+                    pr.depth[sl] = max(pr.depth.get(sl, 1), b - tap)
             else:
                 pr.seq[ins[idx]] = n_seqs + n_seqdots + g     # slot of the buffer-resident sequence
                 pr.tap_seq[ins[idx]] = g
                 pr.tap_top[ins[idx]] = m
             idx += 1
+        for j in outs_g:
+            sl = slot_of_mm[(g, j)]
+            if pr.depth.get(sl, 1) > 1 and sl not in read1:
+                # an out-tap that is read again only two or more steps later: its value of ONE
+                # step ago still has to pass through the owner's registers (a state nobody reads)
+                pr.state[FAKE_BASE + sl] = sl
     for k, tk in enumerate(taps):
         for tap in tk:
             if tap == -1:
@@ -262,6 +289,8 @@ def analyze(inner, p, n_seqdots):
             readers[v] = readers.get(v, 0) + 1
     if as_while and pr.mode != "vec":
         return None, "shared outputs / do-while"
+    if mm_general and pr.mode != "vec":
+        return None, "mit-mot taps other than [0 .. m] -> [1 .. m] on a matrix state"
     for st in steps:
         if st.kind == "node" and st.node.op in ("SpecifyShape", "ViewOp"):
             alias[st.outputs[0]] = st.inputs[0]      # value-preserving views: same vector / matrix

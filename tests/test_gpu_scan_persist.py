@@ -744,8 +744,11 @@ def test_elman_sequence_product_a_step_ahead(T, H, B):
 
 
 # ---- full reductions inside the step of the vector-state kernel (round 5) ------------------------
-RED_BOTH = ["scan_variant_0", "scan_variant_3", "scan_variant_6", "scan_variant_9"]        # forward + gradient Scan
-RED_FWD = ["scan_variant_2", "scan_variant_5", "scan_variant_8", "scan_variant_11"]        # forward Scan only
+RED_BOTH = ["scan_variant_0", "scan_variant_3", "scan_variant_6", "scan_variant_9",        # forward + gradient Scan
+            # (gradient Scans with mit-mot taps [0, 1, 3] -> [1, 3]: the out-tap read again two steps later
+            # stays in the row owner's registers, scan_persist.analyze)
+            "scan_variant_2", "scan_variant_5", "scan_variant_8", "scan_variant_11"]
+RED_FWD = []
 RED_ONE = ["scan_while_nitsot_matrix", "scan_red_rnn_normalised", "scan_red_rnn_until_f32"]
 
 
