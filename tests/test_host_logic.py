@@ -740,3 +740,38 @@ def test_streaming_policy_for_read_once_operands(monkeypatch):
     monkeypatch.setenv("AESARA_HIP_NT", "0")                                   # explicit: policy off
     sp, tr = run("cfg1b_matrix_add", [fake((4096, 4096), "float64")] * 2)
     assert [(s.vec, int(s.nt)) for s in sp] == [(4, 0)] and "ahip_elemwise" in tr
+
+
+def test_which_golden_scans_run_as_one_launch():
+    """The persistent-Scan class over the whole golden set, decided on the host (dry runs: analysis,
+    layout checks and kernel generation, no device): 91 of 96 Scans take a one-launch kernel; the
+    five that do not are named with the reason ``PlanExecutor.scan_modes`` gives — a silent
+    fall-back to the launch list of any other golden fails here, on CPU."""
+    from aesara_amd.executor import PlanExecutor
+    from golden_util import CASES, case_plan
+    from golden_inputs import make_input
+    expected_launch_list = {
+        "ifelse_in_scan_and_shapes": "step output is not a float64 vector",          # IfElse inside the step
+        "rnn_lm_loss_and_grads": "weight layout",                                     # non-square weights of a matrix state
+        "scan_nested_with_grad": "Shape_i",                                           # a shape node inside the step
+        "scan_seq_products_two_row_counts": "Gemm",                                   # a bare Gemm node in the step
+        "sp_rnn_proj_narrow_f32": "matrix layout",                                    # projection narrower than the state
+    }
+    total = persistent = 0
+    for c in CASES:
+        if "Scan" not in json.dumps(c["plan"]["nodes"])[:200000] and not any(
+                n["op"] == "Scan" for n in c["plan"]["nodes"]):
+            continue
+        ex = PlanExecutor(case_plan(c), dry_run=True)
+        try:
+            ex(*[make_input(s) for s in c["inputs"]])
+        except Exception:           # (a dry run cannot follow data-dependent control flow to the end)
+            pass
+        for mode in ex.scan_modes.values():
+            total += 1
+            if mode == "persistent":
+                persistent += 1
+            else:
+                want = expected_launch_list.get(c["name"])
+                assert want is not None and want in mode, (c["name"], mode)
+    assert (persistent, total) == (91, 96), (persistent, total)
