@@ -117,7 +117,7 @@ class ReplayMixin:
         """Remember a replay entry under the identities of the call's argument objects (second
         sighting of that tuple of ids: one-off arguments — Python floats filtered into new arrays
         on every call — never get here twice).  Device tensors are validated by identity (weak
-        reference: an id can be reused) and data pointer, small host float arrays by identity and
+        reference: an id can be reused), data pointer and layout, small host float arrays by identity and
         value (``inputs``: the same list with those arrays replaced by their cached device tensors,
         which the memo keeps alive — the entry's launches address them); anything else (index-like
         host integers, staged host arrays) is not memoized.  The generation number drops every
@@ -132,7 +132,8 @@ class ReplayMixin:
             if type(x) is torch.Tensor:
                 if not x.is_cuda:
                     return
-                chk.append((weakref.ref(x), x.data_ptr()))
+                # (layout too: ``x.t_()`` / ``x.resize_()`` keep identity and pointer)
+                chk.append((weakref.ref(x), (x.data_ptr(), x.shape, x.stride())))
             elif type(x) is np.ndarray and x.dtype.char in self._SMALL_FLOAT and x.size <= 16 \
                     and type(d) is torch.Tensor:
                 chk.append((weakref.ref(x), x.tobytes()))
@@ -198,7 +199,8 @@ class ReplayMixin:
             if m is not None:
                 if m[0] == self._memo_gen:
                     for x, (r, p_) in zip(inputs, m[2]):
-                        if r() is not x or (x.data_ptr() if type(x) is torch.Tensor else x.tobytes()) != p_:
+                        if r() is not x or ((x.data_ptr(), x.shape, x.stride()) if type(x) is torch.Tensor
+                                            else x.tobytes()) != p_:
                             break
                     else:
                         return self._replay(m[1], None)
