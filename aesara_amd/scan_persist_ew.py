@@ -154,7 +154,26 @@ def analyze(inner, p, n_pre):
     # values of two kinds (see the module docstring) only when the loop holds a reduction or mixes
     # 0-d values with arrays; a loop of one rank keeps the plain one-thread-per-element form
     ranks = {plan.vars[v].ndim for v in ins[:n_fixed - len(inv)] + ins[n_fixed:]}
+    # an ``IfElse`` on a 0-d condition between values the step computes element-wise anyway is a
+    # ``switch`` per element (ifelse.py:61 is lazy to save the untaken branch's WORK; both branches
+    # are pure Elemwise here and one thread evaluates both in registers)
+    from .fusion import Step
+    steps_ = []
     for st in inner.steps:
+        if st.kind == "node" and st.node.op == "IfElse":
+            n_o = len(st.outputs)
+            if len(st.inputs) != 1 + 2 * n_o or plan.vars[st.inputs[0]].ndim != 0:
+                return None, "step kind node (IfElse)"
+            for k, o in enumerate(st.outputs):
+                a_, b_ = st.inputs[1 + k], st.inputs[1 + n_o + k]
+                if not (plan.vars[a_].dtype == plan.vars[b_].dtype == plan.vars[o].dtype):
+                    return None, "IfElse branches of another dtype"
+                steps_.append(Step("elemwise", [st.inputs[0], a_, b_], [o], {
+                    "n_in": 3, "nodes": [{"op": "switch", "in": [["i", 0], ["i", 1], ["i", 2]],
+                                          "dtype": plan.vars[o].dtype}], "out": [["t", 0]]}, out_refs=[0]))
+        else:
+            steps_.append(st)
+    for st in steps_:
         if st.kind == "reduce":
             pr.nred += 1
         ranks.update(plan.vars[o].ndim for o in st.outputs)
@@ -166,7 +185,7 @@ def analyze(inner, p, n_pre):
             pr.cls[v] = 1 if scalar_like(v) else 0
         for v in inv:
             pr.cls[v] = 1 if plan.vars[v].ndim == 0 else 0       # (one element at run time: ``bc``)
-    for st in inner.steps:
+    for st in steps_:
         if st.kind == "node" and st.node.op in _ALIAS_OPS:
             alias[st.outputs[0]] = st.inputs[0]
             continue

@@ -744,14 +744,13 @@ def test_streaming_policy_for_read_once_operands(monkeypatch):
 
 def test_which_golden_scans_run_as_one_launch():
     """The persistent-Scan class over the whole golden set, decided on the host (dry runs: analysis,
-    layout checks and kernel generation, no device): 91 of 96 Scans take a one-launch kernel; the
-    five that do not are named with the reason ``PlanExecutor.scan_modes`` gives — a silent
+    layout checks and kernel generation, no device): 92 of 96 Scans take a one-launch kernel; the
+    four that do not are named with the reason ``PlanExecutor.scan_modes`` gives — a silent
     fall-back to the launch list of any other golden fails here, on CPU."""
     from aesara_amd.executor import PlanExecutor
     from golden_util import CASES, case_plan
     from golden_inputs import make_input
     expected_launch_list = {
-        "ifelse_in_scan_and_shapes": "step output is not a float64 vector",          # IfElse inside the step
         "rnn_lm_loss_and_grads": "weight layout",                                     # non-square weights of a matrix state
         "scan_nested_with_grad": "Shape_i",                                           # a shape node inside the step
         "scan_seq_products_two_row_counts": "Gemm",                                   # a bare Gemm node in the step
@@ -774,4 +773,4 @@ def test_which_golden_scans_run_as_one_launch():
             else:
                 want = expected_launch_list.get(c["name"])
                 assert want is not None and want in mode, (c["name"], mode)
-    assert (persistent, total) == (91, 96), (persistent, total)
+    assert (persistent, total) == (92, 96), (persistent, total)
