@@ -67,6 +67,13 @@ if KIND != "reference":
                     except Exception:                   # noqa: BLE001  (a dry run cannot follow
                         if os.environ.get("AESARA_HIP_SUITE_DRY_STRICT"):   # data-dependent control flow)
                             raise
+                    log = os.environ.get("AESARA_HIP_SUITE_SCANLOG")
+                    if log and dry.scan_modes:
+                        # (which Scans of the reference's tests take a one-launch kernel: one line per run)
+                        import json
+                        with open(log, "a") as f:
+                            f.write(json.dumps([os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0],
+                                                sorted(dry.scan_modes.values())]) + "\n")
                 return interp.run_plan(plan, a)
             return run
 
