@@ -157,6 +157,20 @@ __device__ __forceinline__ float fdiv_inv(float x, float c, float r, bool ok) {
   }
   return res;
 }
+// (K * y) / c with K = +-2^k a literal, correctly rounded like fdiv_inv: the real number is
+// y / (c / K); c / K and K * r = RN(1 / (c / K)) are exact scalings, loop invariant, so the scaling
+// multiply of every element goes away and the refinement runs on (y, c / K, K * r).  Full division
+// of the scaled operands when any of c, r, c / K, K * r is not a normal number.
+template <typename T> __device__ __forceinline__ T fdiv_inv_s(T y, T K, T c, T r, bool ok) {
+  const T cK = c * ((T)1 / K), rK = r * K;
+  const T q = y * rK;
+  T res = fma(fma(-q, cK, y), rK, q);
+  if (__builtin_expect(!(ok && recip_ok(cK, rK) && fabs(res) < (T)INFINITY), 0)) {
+    asm volatile("" ::: "memory");
+    res = (K * y) / c;
+  }
+  return res;
+}
 // tolerance mode (AESARA_HIP_FASTDIV=1): x * (1/c) without the refinement — at most 1.5 ulp from
 // the quotient (north_star's bar is 1e-6 rel); the full division when c or 1/c is not a normal number
 template <typename T> __device__ __forceinline__ T fdiv_rcp_s(T y, T K, T c, T r, bool ok) {
@@ -460,6 +474,10 @@ def scalar_node_expr(op, ins, in_dts, dt):
         return "log1mexp_(%s)" % c[0]
     if op == "softsign" and _is_float(dt):
         return "(%s / ((%s)1 + %s(%s)))" % (c[0], T, _fname("fabs", dt), c[0])
+    if op == "xlogx" and _is_float(dt):          # XlogX.c_code tensor/xlogx.py:27
+        return "(%s == (%s)0 ? (%s)0 : %s * %s(%s))" % (c[0], T, T, c[0], _fname("log", dt), c[0])
+    if op == "xlogy0" and _is_float(dt):         # XlogY0.c_code tensor/xlogx.py:58
+        return "(%s == (%s)0 ? (%s)0 : %s * %s(%s))" % (c[0], T, T, c[0], _fname("log", dt), c[1])
     if op == "psi" and _is_float(dt):
         return "(%s)psi_as103((double)%s)" % (T, c[0])
     if op == "tri_gamma" and _is_float(dt):
@@ -501,6 +519,42 @@ def invariant_nodes(scalar, inv_inputs):
     return inv
 
 
+# ops through which a perturbation of <= 1.5 ulp stays a perturbation of a few ulp (continuous, no
+# jumps, no integer results): what a quotient may pass through on its way to a float sum for the
+# reciprocal form of a division to be admissible (``sum_only_nodes``)
+_CONTINUOUS = {"add", "sub", "mul", "neg", "exp", "exp2", "expm1", "log", "log2", "log10", "log1p",
+               "sqr", "sqrt", "sin", "cos", "tanh", "sinh", "cosh", "arctan", "sigmoid", "softplus",
+               "true_div", "reciprocal", "identity", "abs", "erf", "erfc"}
+
+
+def sum_only_nodes(scalar, red, stored_refs):
+    """Scalar nodes whose value reaches memory ONLY as a term of the kernel's own floating-point
+    SUM (through continuous functions, never through an element-wise output, a comparison, a
+    rounding op or an integer cast).  Such a kernel's result already depends on the order of
+    summation at the 1e-16 level, so a quotient in that set may be formed as x * (1/c) (<= 1.5 ulp
+    from the IEEE quotient); every other division stays the correctly rounded one."""
+    if red is None or red.get("op") != "add" or not _is_float(red.get("acc", "")):
+        return set()
+    nodes, outs = scalar["nodes"], [list(o) for o in scalar["out"]]
+    stored_t = {outs[r][1] for r in stored_refs if outs[r][0] == "t"}
+    sink = outs[red["ref"]]
+    other_out_t = {o[1] for j, o in enumerate(outs) if o[0] == "t" and j != red["ref"]} | stored_t
+    ok = {}
+    for k in range(len(nodes) - 1, -1, -1):
+        good = k not in other_out_t and _is_float(nodes[k]["dtype"])
+        if good:
+            for m in range(k + 1, len(nodes)):
+                if any(r[0] == "t" and r[1] == k for r in nodes[m]["in"]):
+                    if nodes[m]["op"] not in _CONTINUOUS or not ok.get(m, False):
+                        good = False
+                        break
+        if good and not any(any(r[0] == "t" and r[1] == k for r in nodes[m]["in"])
+                            for m in range(k + 1, len(nodes))) and sink != ["t", k]:
+            good = False             # feeds nothing: leave it alone
+        ok[k] = good
+    return {k for k, g in ok.items() if g}
+
+
 def _is_pow2(v):
     try:
         m, _e = np.frexp(float(v))
@@ -510,7 +564,7 @@ def _is_pow2(v):
 
 
 def emit_scalar_body(scalar, in_exprs, in_dts, indent="      ", suffix="", hoisted=None,
-                     only=None, exp_tbl=None):
+                     only=None, exp_tbl=None, sum_only=()):
     """Lines computing the temporaries of a plan scalar expression; returns (lines, out_exprs,
     out_dtypes).  ``hoisted``: {node index: (name, recip_name | None)} of temporaries already
     computed before the loop (loop-invariant sub-expressions); ``only``: restrict emission to
@@ -547,7 +601,11 @@ def emit_scalar_body(scalar, in_exprs, in_dts, indent="      ", suffix="", hoist
             # (AESARA_HIP_FASTDIV=1, tolerance mode: the rounded product x * r alone, <= 1.5 ulp)
             e = None
             num = n["in"][0]
-            if knobs.get("FASTDIV") and num[0] == "t" and num[1] not in hoisted \
+            # AESARA_HIP_FASTDIV: 0 never / 1 always / 2 (default) only for a quotient that reaches
+            # memory solely as a term of this kernel's float sum (``sum_only_nodes``)
+            fd = knobs.get("FASTDIV")
+            fast = fd == 1 or (fd == 2 and k in sum_only)
+            if num[0] == "t" and num[1] not in hoisted \
                     and uses.get(num[1], 0) == 1 and list(num) not in [list(o) for o in scalar["out"]]:
                 # (K * y) / c with K = +-2^k a literal: scaling by a power of two is exact, so the
                 # quotient is y * (K * r) — K * r is loop invariant (the compiler hoists it), the
@@ -556,12 +614,14 @@ def emit_scalar_body(scalar, in_exprs, in_dts, indent="      ", suffix="", hoist
                 if m["op"] == "mul" and len(m["in"]) == 2 and m["dtype"] == dt:
                     for ci in (0, 1):
                         c_, y_ = m["in"][ci], m["in"][1 - ci]
-                        if c_[0] == "c" and _is_pow2(c_[1]) and ref(y_)[1] == dt:
-                            e = "fdiv_rcp_s(%s, %s, %s, %s)" % (ref(y_)[0], _lit(c_[1], dt), refs[1][0],
-                                                               hoisted[div[1]][1])
+                        if c_[0] == "c" and _is_pow2(c_[1]) and ref(y_)[1] == dt \
+                                and (fast or 2.0 ** -8 <= abs(float(c_[1])) <= 2.0 ** 8):
+                            e = "%s(%s, %s, %s, %s)" % (
+                                "fdiv_rcp_s" if fast else "fdiv_inv_s", ref(y_)[0],
+                                _lit(c_[1], dt), refs[1][0], hoisted[div[1]][1])
                             break
             if e is None:
-                e = "%s(%s, %s, %s)" % ("fdiv_rcp" if knobs.get("FASTDIV") else "fdiv_inv",
+                e = "%s(%s, %s, %s)" % ("fdiv_rcp" if fast else "fdiv_inv",
                                         _cast(refs[0][0], refs[0][1], dt), refs[1][0], hoisted[div[1]][1])
         elif exp_tbl and n["op"] == "exp" and dt == "float64":
             e = "exp_tbl64(%s, %s)" % (_cast(refs[0][0], refs[0][1], dt), exp_tbl)
@@ -704,7 +764,7 @@ class KernelSpec:
 
     def _variant(self):
         return "r4%d%d%d%d%d%s%s" % (self.early, self.blocked, self.trace, self.fast_exp, 0,
-                                     "H" if self.hjobs else "", "D" if knobs.get("FASTDIV") else "")
+                                     "H" if self.hjobs else "", "D%d" % knobs.get("FASTDIV"))
 
     def _key(self):
         import json
@@ -1230,7 +1290,8 @@ def generate(spec: KernelSpec):
                 ins.append(e)
             lines, outs, odts = emit_scalar_body(spec.scalar, ins, spec.in_dtypes,
                                                  suffix="_%d%s" % (v, sfx), hoisted=hoisted,
-                                                 exp_tbl=etbl)
+                                                 exp_tbl=etbl,
+                                                 sum_only=sum_only_nodes(spec.scalar, red, spec.out_refs))
             B.extend(lines)
             for k, ri in enumerate(spec.out_refs):
                 val = _cast(outs[ri], odts[ri], spec.out_dtypes[k])

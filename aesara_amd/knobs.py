@@ -32,9 +32,14 @@ _def("RED_UNROLL", 1, int, "axis-reduce loop unroll (1 = the default 8)")
 _def("COL_LANES", 128, int, "column-reduce strip width in lanes")
 _def("TILED", 1, int, "LDS-tiled form for transposed operands")
 _def("FASTEXP", 1, int, "float64 exp through the 64-entry table in LDS (0: ocml's exp)")
-_def("FASTDIV", 1, int, "x / c for a loop-invariant c (a broadcast scalar divisor): 1 = x * (1/c), <= 1.5 ulp from the "
-     "quotient (what the reference's own FAST_RUN canonicaliser does to constant divisors; north_star's bar is 1e-6 rel; "
-     "config 2: 28.4 -> 27.4 us per eval, r05); 0 = reciprocal + Markstein step: the correctly rounded quotient")
+_def("FASTDIV", 2, int, "x / c for a loop-invariant RUN-TIME c (a broadcast scalar divisor; constant divisors never "
+     "get here: the reference's canonicaliser has already turned them into a multiplication).  0 = always the hoisted "
+     "reciprocal + Markstein step: the correctly rounded IEEE quotient, what the reference computes; 1 = always "
+     "x * (1/c), <= 1.5 ulp from the quotient (exact quotients such as 21/7 are then inexact: floor / eq / int casts "
+     "downstream can differ — opt-in only); 2 (default) = x * (1/c) ONLY for a quotient that reaches memory solely as a "
+     "term of the kernel's own floating-point sum through continuous functions (codegen.sum_only_nodes: a result that "
+     "already depends on the order of summation), IEEE everywhere else — any quotient that is stored, compared, rounded "
+     "or cast is exact.  Config 2 (r06, one box): 26.9 us per eval with 0, 24.8 with 1 / 2")
 _def("EARLY", 1, int, "flat full reductions issue their first loads before the invariant prologue")
 _def("RED_BLOCKED", 2, int, "flat full reductions: 0 grid-stride walk, 1 one contiguous chunk per workgroup, "
      "2 (default) chunks ordered so that every XCD streams one contiguous eighth (r04 sweeps: 27.1 vs 27.7 us)")

@@ -42,6 +42,8 @@ SCALAR_OP_NAMES = {
     # tensor/math.py:2713 MulWithoutZeros (the CAReduce inside ProdWithoutZeros: grad of prod)
     "MulWithoutZeros": "mul_without_zeros",
     "ScalarSoftsign": "softsign",      # tensor/nnet/basic.py:2040: x / (1 + |x|)
+    # tensor/xlogx.py:7 XlogX (x == 0 ? 0 : x * log(x)), :36 XlogY0 (x == 0 ? 0 : x * log(y))
+    "XlogX": "xlogx", "XlogY0": "xlogy0",
 }
 
 
@@ -161,6 +163,9 @@ class _Ctx:
         t = v.type
         if not hasattr(t, "dtype"):
             raise UnsupportedOp(f"non-tensor variable type {t}")
+        if hasattr(t, "format") and type(t).__name__.startswith("Sparse"):
+            # (SparseTensorType subclasses TensorType: a scipy.sparse matrix is not a dense buffer)
+            raise UnsupportedOp(f"non-tensor variable type Sparse ({t})")
         if str(t.dtype) not in _PLAN_DTYPES:
             raise UnsupportedOp(f"dtype {t.dtype} of {v} has no HIP kernels (SURVEY §8a H2: "
                                 "float32/64, int8-64, uint8-64, bool)")

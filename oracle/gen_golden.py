@@ -1872,6 +1872,25 @@ def _():
 
 
 # ---------------------------------------------------------------------------------------
+# ---------------------------------------------------------------------------------------
+# round 6
+# ---------------------------------------------------------------------------------------
+@case("ew_exact_quotient_floor", exact=True)
+def _():
+    # a RUN-TIME scalar divisor must give the IEEE quotient (the reference divides; only
+    # constant divisors are folded into reciprocals by its canonicaliser): (7 k) / 7 == k exactly, so
+    # floor / eq / integer casts behind the division see integers (binning: floor(x / width)).
+    # Every quotient below reaches memory element-wise -> the correctly rounded path, bit for bit.
+    x, c, xd, w = at.fmatrix("x"), at.fscalar("c"), at.dmatrix("xd"), at.dscalar("w")
+    q32, q64 = x / c, xd / w
+    return [x, c, xd, w], [at.floor(q32), q32, at.cast(q32, "int32"), at.floor(q64), q64,
+                           at.cast(at.floor((-0.5 * xd) / w), "int64"), (2.0 * at.sqr(xd)) / w,
+                           # a COMPUTED loop-invariant divisor: the hoisted-reciprocal + Markstein path
+                           at.floor(xd / at.sqr(w)), (2.0 * xd) / at.sqr(w), (-0.5 * x) / (c * c + c)], \
+        [{"kind": "arange", "shape": [64, 33], "dtype": "float32", "scale": 7}, K(7.0, "float32"),
+         {"kind": "arange", "shape": [64, 33], "dtype": "float64", "scale": 1.3}, K(1.3, "float64")]
+
+
 def _close(a, b, exact, rtol, atol):
     a, b = np.asarray(a), np.asarray(b)
     if a.shape != b.shape or a.dtype != b.dtype:

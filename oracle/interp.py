@@ -132,11 +132,13 @@ _UNARY = {
     "tri_gamma": _trigamma_as121, "j0": _special("j0"), "j1": _special("j1"),
     "i0": _special("i0"), "i1": _special("i1"),
     "softsign": lambda x: x / (1.0 + np.abs(x)),     # tensor/nnet/basic.py:2048
+    "xlogx": lambda x: np.where(x == 0, 0, x * np.log(x)),       # tensor/xlogx.py:15 XlogX.impl
 }
 
 _BINARY = {
     "sub": np.subtract, "true_div": np.true_divide, "int_div": np.floor_divide,
     "mod": np.mod, "pow": np.power, "arctan2": np.arctan2,
+    "xlogy0": lambda x, y: np.where(x == 0, 0, x * np.log(y)),   # tensor/xlogx.py:44 XlogY0.impl
     "lt": np.less, "gt": np.greater, "le": np.less_equal, "ge": np.greater_equal,
     "eq": np.equal, "neq": np.not_equal,
 }
@@ -148,7 +150,8 @@ _FLOAT_FUNCS = {"sqrt", "exp", "exp2", "expm1", "log", "log2", "log10", "log1p",
                 "tan", "arcsin", "arccos", "arctan", "sinh", "cosh", "tanh", "arcsinh",
                 "arccosh", "arctanh", "sigmoid", "softplus", "erf", "erfc", "log1mexp",
                 "deg2rad", "rad2deg", "reciprocal", "true_div", "arctan2", "erfcx", "erfinv",
-                "erfcinv", "gamma", "gammaln", "psi", "tri_gamma", "j0", "j1", "i0", "i1", "softsign"}
+                "erfcinv", "gamma", "gammaln", "psi", "tri_gamma", "j0", "j1", "i0", "i1", "softsign",
+                "xlogx", "xlogy0"}
 
 
 def eval_scalar_expr(s, ins):

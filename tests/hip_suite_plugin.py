@@ -19,7 +19,8 @@ assertions.
                that every generated kernel the suites need is cross-compiled into the in-tree
                kernel cache (no device needed; the GPU box then only loads code objects).
 
-Outcomes are written to ``$AESARA_HIP_SUITE_REPORT`` (JSON: nodeid -> [outcome, message]).
+Outcomes are written to ``$AESARA_HIP_SUITE_REPORT`` (JSON: nodeid -> [outcome, message,
+[functions compiled through HipLinker, executor calls] during the test's setup + call]).
 """
 import json
 import os
@@ -81,10 +82,59 @@ if KIND != "reference":
             return HipLinker(return_numpy="all", executor_factory=_factory, **kw)
 
     config.mode = Mode(HipL(), HIP_QUERY)
+
+    # -- what a passing test PROVES: did it compile / run anything through HipLinker? -----------
+    # (a test of these files that builds no function, or passes its own Mode(linker="py"), passes
+    # without touching the HIP path: the summary counts those separately)
+    _HIP = {"compiled": 0, "executed": 0}
+    _jit_compile = HipLinker.jit_compile
+
+    def _counting_jit_compile(self, plan):
+        fn = _jit_compile(self, plan)
+        _HIP["compiled"] += 1
+
+        def counted(*a):
+            _HIP["executed"] += 1
+            return fn(*a)
+        for attr in ("close", "check", "enable_profile"):
+            if hasattr(fn, attr):
+                setattr(counted, attr, getattr(fn, attr))
+        counted.__wrapped__ = fn
+        return counted
+
+    if KIND != "device":
+        HipLinker.jit_compile = _counting_jit_compile
+    else:
+        # on the device the executor object itself is what ``linker.executor`` / the fast VM hold:
+        # it is marked, and counted in its own ``__call__`` (executors of inner plans are not)
+        from aesara_amd.executor import PlanExecutor as _PE
+        _pe_call = _PE.__call__
+
+        def _marking_jit_compile(self, plan):
+            ex = _jit_compile(self, plan)
+            _HIP["compiled"] += 1
+            try:
+                ex._suite_counted = True
+            except AttributeError:
+                pass
+            return ex
+
+        def _call(self, *a, **k):
+            if getattr(self, "_suite_counted", False):
+                _HIP["executed"] += 1
+            return _pe_call(self, *a, **k)
+        HipLinker.jit_compile = _marking_jit_compile
+        _PE.__call__ = _call
 else:
+    _HIP = {"compiled": 0, "executed": 0}
     # the same files with the reference's own default mode (C linker): which tests cannot pass in
     # this environment whatever the linker (NumPy 2, no pytest-benchmark ...)
     ae = ref_overlay.import_reference()
+
+def _KeepdimsMode(*a, **k):
+    """Stands in for ``aesara.compile.mode.Mode`` inside tests/tensor/test_keepdims.py only."""
+    return config.mode
+
 
 _IGNORED = [("numpy.core", DeprecationWarning), ("numpy._core", DeprecationWarning)]
 
@@ -99,6 +149,15 @@ def _filters():
 @pytest.hookimpl(hookwrapper=True)
 def pytest_runtest_setup(item):
     _filters()
+    item._hip_before = (_HIP["compiled"], _HIP["executed"])      # setup_method compiles count too
+    mod = getattr(item, "module", None)
+    if KIND != "reference" and mod is not None and mod.__name__.endswith("test_keepdims") \
+            and getattr(mod, "Mode", None) is not _KeepdimsMode:
+        # THE ONE EDIT of a test module: tests/tensor/test_keepdims.py builds every function with
+        # ``Mode(optimizer="fast_compile", linker="py")`` — its own Python linker, whatever the
+        # default mode.  The module-level name ``Mode`` is re-pointed at the HIP mode so that the
+        # file's 200 keepdims / multi-axis reductions run through HipLinker (test bodies untouched).
+        mod.Mode = _KeepdimsMode
     yield
 
 
@@ -106,6 +165,9 @@ def pytest_runtest_setup(item):
 def pytest_runtest_call(item):
     _filters()
     yield
+    c0, e0 = getattr(item, "_hip_before", (0, 0))
+    # user_properties travel with the report (also from an xdist worker to the controller)
+    item.user_properties.append(("through_hip", [_HIP["compiled"] - c0, _HIP["executed"] - e0]))
 
 
 @pytest.fixture
@@ -133,7 +195,8 @@ def pytest_runtest_logreport(report):
         out = report.outcome
         if hasattr(report, "wasxfail"):
             out = "xfailed" if report.outcome == "skipped" else "xpassed"
-        _OUT[report.nodeid] = [out, msg]
+        hip = dict(report.user_properties).get("through_hip", [0, 0])
+        _OUT[report.nodeid] = [out, msg, hip]
 
 
 def pytest_sessionfinish(session):

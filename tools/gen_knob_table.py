@@ -1,0 +1,21 @@
+#!/usr/bin/env python
+"""Rewrite DESIGN.md's switch table (§3.5) from the registry ``aesara_amd/knobs.py``."""
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from aesara_amd import knobs  # noqa: E402
+
+path = os.path.join(ROOT, "DESIGN.md")
+src = open(path).read()
+head = "| switch | default | what |\n|---|---|---|\n"
+i = src.index(head) + len(head)
+j = i
+while src[j:j + 1] == "|":
+    j = src.index("\n", j) + 1
+rows = "".join("| `%s` | %s | %s |\n" % (n, "—" if d is None else d, doc.replace("|", "/"))
+               for n, d, _c, doc in knobs.table())
+open(path, "w").write(src[:i] + rows + src[j:])
+print("wrote %d switches" % len(knobs.table()))
