@@ -173,6 +173,7 @@ SIGNATURES = {
     "ahip_cumulative": (i32, [i32, i32, vp, i64, i64, i64, i64, i64, i64, vp, vp, sz, vp]),
     "ahip_linearize_indices": (i32, [i32, p_vp, C.POINTER(C.c_int), p_i64, p_i64, p_i64, i64, vp,
                                      vp, vp]),
+    "ahip_searchsorted": (i32, [i32, vp, i64, i64, vp, i64, i32, vp, vp, vp]),
     "ahip_list_begin": (i32, []),
     "ahip_list_end": (i32, [p_vp]),
     "ahip_list_length": (i32, [vp]),

@@ -219,6 +219,54 @@ __device__ __forceinline__ double trigamma_as121(double x) {
   value += 0.5 * y + (1.0 + y * (0.1666666667 + y * (-0.03333333333 + y * (0.02380952381 + y * -0.03333333333)))) / z;
   return value;
 }
+// Regularised incomplete gamma functions (GammaInc :580 / GammaIncC :629 / Chi2SF :538 / GammaU :836
+// / GammaL :877: the reference's C bodies call GammaP / GammaQ / upperGamma / lowerGamma of
+// scalar/c_code/gamma.c): the power series for x < k + 1, the continued fraction (modified Lentz)
+// otherwise, both scaled by exp(k log x - x - lgamma(k)).  NaN for k <= 0 or x < 0 like the reference.
+__device__ inline double igam_series_(double k, double x) {
+  double term = 1.0 / k, sum = term, n = k;
+  for (int i = 0; i < 1024; ++i) {
+    n += 1.0; term *= x / n; sum += term;
+    if (fabs(term) < fabs(sum) * 2.2204460492503131e-16) break;
+  }
+  return sum;
+}
+__device__ inline double igam_cfrac_(double k, double x) {
+  const double tiny = 2.2204460492503131e-16 * 2.2204460492503131e-16 * 2.2204460492503131e-16;   // gamma.c TINY
+  double b = x + 1.0 - k, c = 1.0 / tiny, d = 1.0 / b, f = d;
+  for (int i = 1; i < 1024; ++i) {
+    const double a = -(double)i * ((double)i - k);
+    b += 2.0;
+    d = a * d + b; if (fabs(d) < tiny) d = tiny;
+    c = b + a / c; if (fabs(c) < tiny) c = tiny;
+    d = 1.0 / d;
+    const double e = d * c;
+    f *= e;
+    if (fabs(e - 1.0) < 2.2204460492503131e-16) break;
+  }
+  return f;
+}
+// upperGamma / lowerGamma of gamma.c: ALWAYS the continued fraction / the series (whatever x is)
+__device__ inline double gamma_upper_(double k, double x) {
+  if (!(k > 0.0) || !(x > 0.0)) return NAN;
+  return igam_cfrac_(k, x) * exp(k * log(x) - x);
+}
+__device__ inline double gamma_lower_(double k, double x) {
+  if (!(k > 0.0) || !(x > 0.0)) return NAN;
+  return igam_series_(k, x) * exp(k * log(x) - x);
+}
+__device__ inline double gamma_p_(double k, double x) {
+  if (!(k > 0.0) || !(x >= 0.0)) return NAN;
+  if (x == 0.0) return 0.0;
+  const double w = exp(k * log(x) - x - lgamma(k));
+  return x < k + 1.0 ? igam_series_(k, x) * w : 1.0 - igam_cfrac_(k, x) * w;
+}
+__device__ inline double gamma_q_(double k, double x) {
+  if (!(k > 0.0) || !(x >= 0.0)) return NAN;
+  if (x == 0.0) return 1.0;
+  const double w = exp(k * log(x) - x - lgamma(k));
+  return x < k + 1.0 ? 1.0 - igam_series_(k, x) * w : igam_cfrac_(k, x) * w;
+}
 __device__ __forceinline__ float log1mexp_(float x) { return x < -0.6931471805599453f ? log1pf(-expf(x)) : logf(-expm1f(x)); }
 __device__ __forceinline__ double log1mexp_(double x) { return x < -0.6931471805599453 ? log1p(-exp(x)) : log(-expm1(x)); }
 __device__ __forceinline__ float round_away(float x) { return x < 0 ? ceilf(x - 0.5f) : floorf(x + 0.5f); }
@@ -478,6 +526,13 @@ def scalar_node_expr(op, ins, in_dts, dt):
         return "(%s == (%s)0 ? (%s)0 : %s * %s(%s))" % (c[0], T, T, c[0], _fname("log", dt), c[0])
     if op == "xlogy0" and _is_float(dt):         # XlogY0.c_code tensor/xlogx.py:58
         return "(%s == (%s)0 ? (%s)0 : %s * %s(%s))" % (c[0], T, T, c[0], _fname("log", dt), c[1])
+    if op in ("gammainc", "gammaincc") and _is_float(dt):
+        return "(%s)%s((double)%s, (double)%s)" % (T, "gamma_p_" if op == "gammainc" else "gamma_q_", c[0], c[1])
+    if op == "chi2sf" and _is_float(dt):          # Chi2SF.c_code: 1 - GammaP(k / 2, x / 2), inputs (x, k)
+        return "(%s)gamma_q_((double)%s * 0.5, (double)%s * 0.5)" % (T, c[1], c[0])
+    if op in ("gammau", "gammal") and _is_float(dt):
+        return "(%s)%s((double)%s, (double)%s)" % (T, "gamma_upper_" if op == "gammau" else "gamma_lower_",
+                                                    c[0], c[1])
     if op == "psi" and _is_float(dt):
         return "(%s)psi_as103((double)%s)" % (T, c[0])
     if op == "tri_gamma" and _is_float(dt):

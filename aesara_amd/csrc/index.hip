@@ -776,6 +776,46 @@ __global__ __launch_bounds__(256) void nonzero_write_kernel(NzArgs a) {
   }
 }
 
+
+// ---- Searchsorted: one binary search per element of v over the sorted 1-d x -------------------
+// NumPy's order: NaN is larger than every number (np.sort puts NaNs last), so a < b is
+// "a < b, or b is NaN and a is not".
+struct SsArgs { const void* x; const void* v; const int64_t* sorter; int64_t* out; int64_t nx, xs, nv; int right; };
+AHIP_PTRS_BEGIN(SsArgs) AHIP_PTR1(x) AHIP_PTR1(v) AHIP_PTR1(sorter) AHIP_PTR1(out) AHIP_PTRS_END
+
+template <typename T> __device__ __forceinline__ bool ss_lt(T a, T b) { return a < b; }
+template <> __device__ __forceinline__ bool ss_lt<float>(float a, float b) { return a < b || (b != b && a == a); }
+template <> __device__ __forceinline__ bool ss_lt<double>(double a, double b) { return a < b || (b != b && a == a); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void searchsorted_kernel(SsArgs a) {
+  const T* x = static_cast<const T*>(a.x);
+  const T* v = static_cast<const T*>(a.v);
+  for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < a.nv;
+       j += (int64_t)gridDim.x * blockDim.x) {
+    const T key = v[j];
+    int64_t lo = 0, hi = a.nx;
+    while (lo < hi) {
+      const int64_t mid = lo + ((hi - lo) >> 1);
+      int64_t at = mid;
+      if (a.sorter) {                       // NumPy leaves out-of-range sorter entries undefined-but-safe
+        at = a.sorter[mid];
+        at = at < 0 ? 0 : (at >= a.nx ? a.nx - 1 : at);
+      }
+      const T e = x[at * a.xs];
+      const bool go_right = a.right ? !ss_lt<T>(key, e) : ss_lt<T>(e, key);
+      if (go_right) lo = mid + 1; else hi = mid;
+    }
+    a.out[j] = lo;
+  }
+}
+
+template <typename T>
+static int run_searchsorted(const SsArgs& a, hipStream_t s) {
+  AHIP_LAUNCH((searchsorted_kernel<T>), dim3(grid_for(a.nv)), dim3(256), 0, s, a);
+  return AHIP_OK;
+}
+
 }  // namespace
 
 void ahip_index_set_argmax_max_slices(int64_t v) { g_argmax_max_slices = v; }
@@ -914,6 +954,28 @@ int ahip_linearize_indices(int nidx, const void* const* idx, const int* idx_dtyp
   a.n = n; a.out = out; a.bad = bad_index; a.nidx = nidx;
   AHIP_LAUNCH(linearize_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), a);
   return AHIP_OK;
+}
+
+int ahip_searchsorted(int dtype, const void* x, int64_t nx, int64_t x_stride, const void* v, int64_t nv,
+                      int right, const int64_t* sorter, int64_t* out, void* stream) {
+  AHIP_REQUIRE(nx >= 0 && nv >= 0, "negative extent");
+  if (nv == 0) return AHIP_OK;
+  AHIP_REQUIRE(v && out && (x || nx == 0), "null argument");
+  SsArgs a{x, v, sorter, out, nx, x_stride, nv, right ? 1 : 0};
+  hipStream_t s = as_stream(stream);
+  switch (dtype) {
+    case AHIP_BOOL: case AHIP_U8: return run_searchsorted<uint8_t>(a, s);
+    case AHIP_I8: return run_searchsorted<int8_t>(a, s);
+    case AHIP_I16: return run_searchsorted<int16_t>(a, s);
+    case AHIP_U16: return run_searchsorted<uint16_t>(a, s);
+    case AHIP_I32: return run_searchsorted<int32_t>(a, s);
+    case AHIP_U32: return run_searchsorted<uint32_t>(a, s);
+    case AHIP_I64: return run_searchsorted<int64_t>(a, s);
+    case AHIP_U64: return run_searchsorted<uint64_t>(a, s);
+    case AHIP_F32: return run_searchsorted<float>(a, s);
+    case AHIP_F64: return run_searchsorted<double>(a, s);
+    default: ahip_set_error("searchsorted: unsupported dtype %d", dtype); return AHIP_EINVAL;
+  }
 }
 
 }  // extern "C"

@@ -521,6 +521,52 @@ class OpsMixin:
     def _op_Nonzero(self, node, args):
         return self._nonzero(args[0])
 
+    def _op_Default(self, node, args):
+        """reference: tensor/basic.py:1819 Default.perform — x, or a copy of `default` for x = None."""
+        if args[0] is None:
+            return [self.materialize(self.to_device(args[1]))]
+        return [args[0]]
+
+    def _op_Searchsorted(self, node, args):
+        """reference: tensor/extra_ops.py:144 SearchsortedOp.perform — np.searchsorted(x, v, side,
+        sorter): one binary search per element of ``v`` (csrc/index.hip ahip_searchsorted)."""
+        x, v = self.to_device(args[0]), self.contiguous(self.to_device(args[1]))
+        if x.ndim != 1:
+            raise ValueError("object too deep for desired array")
+        if x.dtype != v.dtype:
+            raise TypeError("Searchsorted operands must share one dtype")
+        sorter = None
+        if len(args) > 2:
+            sorter = self.contiguous(self.cast(self.to_device(args[2]), "int64"))
+            if sorter.ndim != 1 or sorter.shape[0] != x.shape[0]:
+                raise ValueError("sorter.size must equal a.size")
+        out = self.alloc(v.shape, "int64")
+        if out.size:
+            self._launch("ahip_searchsorted", (
+                dtype_code(x.dtype), _VP(x.ptr), x.shape[0], x.strides[0] if x.shape[0] > 1 else 1,
+                _VP(v.ptr), v.size, 1 if node.params["side"] == "right" else 0,
+                _VP(sorter.ptr) if sorter is not None else None, _VP(out.ptr), self._stream()))
+        return [out]
+
+    def _op_HostCall(self, node, args):
+        """An Op that IS a Python callable (``Print``'s print function, an ``as_op`` function:
+        printing.py:863, compile/ops.py:258): operands are copied to the host behind the kernels
+        that produce them, the callable runs, results (if any) are uploaded.  Never replayed: the
+        host read makes the call take the eager path."""
+        p = node.params
+        host = [a if not isinstance(a, DevArray) else self.host_array(a) for a in args]
+        res = p["fn"](*host)
+        if p.get("view"):
+            return [args[0]]
+        outs = []
+        for r, (dt, nd) in zip(res, p["otypes"]):
+            r = np.asarray(r)
+            if str(r.dtype) != dt or r.ndim != nd:
+                raise TypeError(f"{p.get('what', 'HostCall')}: the function returned {r.dtype}[{r.ndim}-d], "
+                                f"declared {dt}[{nd}-d]")
+            outs.append(self._from_numpy(np.ascontiguousarray(r)))
+        return outs
+
     def _adv_view(self, x, entries, extra):
         """Mixed advanced index (integer arrays + slices + newaxis): apply the basic entries as a
         view, move the dims addressed by arrays to the front (NumPy: tensor/subtensor.py:2607

@@ -45,6 +45,11 @@ HIP_QUERY = RewriteDatabaseQuery(
 )
 
 
+# (the reference names its queries — ``OPT_FAST_RUN.name = "OPT_FAST_RUN"``, compile/mode.py:265 — and
+# code keys off the name: ``"FAST_RUN" in get_default_mode().optimizer.name``)
+HIP_QUERY.name = "OPT_FAST_RUN_HIP"
+
+
 class HipLinker(JITLinker):
     """A ``Linker`` that runs a whole ``FunctionGraph`` as HIP kernels on an MI355X."""
 
@@ -104,8 +109,16 @@ class HipLinker(JITLinker):
     def fgraph_convert(self, fgraph, order=None, input_storage=None, output_storage=None,
                        storage_map=None, **kwargs):
         self._order = list(order) if order is not None else list(fgraph.toposort())
+        # inputs a destructive Op overwrites (``destroy_map`` on a graph input: only graphs the
+        # caller built with in-place Ops and compiled with ``accept_inplace`` / ``In(mutable=True)``
+        # — the HIP rewrite query never inserts them): the reference leaves the result in the
+        # caller's own array.  The executor never writes into an argument; the final content of
+        # such a buffer becomes a hidden plan output that is copied back after the call.
+        self._writeback = _destroyed_inputs(fgraph, self._order)
         self.plan = lower_fgraph(fgraph, order=order, name=getattr(fgraph, "name", None)
-                                 or "fgraph", inner_rewriter=hip_mode.optimizer)
+                                 or "fgraph", inner_rewriter=hip_mode.optimizer,
+                                 extra_outputs=[v for _i, v in self._writeback])
+        self._n_outputs = len(fgraph.outputs)
         # outputs that are ``updates=`` expressions go back into shared-variable cells
         # (types.py:1060-1069), never to the caller: they stay device tensors
         self._update_outputs = {fgraph.outputs[i]
@@ -114,14 +127,27 @@ class HipLinker(JITLinker):
 
     def jit_compile(self, plan):
         if self.executor_factory is not None:
-            return self.executor_factory(plan)
+            return self._with_writeback(self.executor_factory(plan))
         from .executor import PlanExecutor  # imports the C-ABI; fails loudly if missing
 
         ex = PlanExecutor(plan, use_graph=self.use_graph, check_indices=self.check_indices)
         if self.profile:
             ex.enable_profile()
         self.executor = ex
-        return ex
+        return self._with_writeback(ex)
+
+    def _with_writeback(self, ex):
+        wb = [i for i, _v in getattr(self, "_writeback", ())]
+        if not wb:
+            return ex
+        n = self._n_outputs
+
+        def call(*args):
+            res = ex(*args)
+            for k, i in enumerate(wb):
+                _write_back(args[i], res[n + k])
+            return res[:n]
+        return call
 
     def make_all(self, *args, **kwargs):
         """``JITLinker.make_all`` (link/basic.py:684-747) plus one change: the input cells handed
@@ -286,6 +312,37 @@ class HipLinker(JITLinker):
                 and (self.return_numpy == "all" or var not in getattr(self, "_update_outputs", ())):
             return out.detach().cpu().numpy()
         return out
+
+
+def _destroyed_inputs(fgraph, order):
+    """[(input position, variable holding the final content of that input's buffer)] for the
+    graph inputs some Op of the schedule destroys (``destroy_map``, graph/destroyhandler.py:286).
+    Chains of destructive Ops on the same buffer are followed; a destructive Op on a VIEW of an
+    input is not (the view's buffer is the executor's own copy)."""
+    owner_of = {v: i for i, v in enumerate(fgraph.inputs)}     # variable -> input whose buffer it is
+    final = {}
+    for node in order:
+        for oi, iis in (getattr(node.op, "destroy_map", None) or {}).items():
+            src = node.inputs[iis[0]]
+            if src in owner_of and getattr(src.type, "ndim", None) == getattr(node.outputs[oi].type, "ndim", -1):
+                owner_of[node.outputs[oi]] = owner_of[src]
+                final[owner_of[src]] = node.outputs[oi]
+    return sorted(final.items())
+
+
+def _write_back(dst, src):
+    """Leave ``src`` (a result of the call) in the caller's argument ``dst``."""
+    import numpy as np
+    if dst is None:
+        return
+    if hasattr(dst, "copy_") and hasattr(src, "detach"):       # device argument <- device result
+        if tuple(dst.shape) == tuple(src.shape):
+            dst.copy_(src)
+        return
+    if hasattr(src, "detach"):
+        src = src.detach().cpu().numpy()
+    if isinstance(dst, np.ndarray) and dst.flags.writeable and dst.shape == np.shape(src):
+        np.copyto(dst, np.asarray(src), casting="unsafe")
 
 
 def _is_scalar_type(var):

@@ -44,6 +44,9 @@ SCALAR_OP_NAMES = {
     "ScalarSoftsign": "softsign",      # tensor/nnet/basic.py:2040: x / (1 + |x|)
     # tensor/xlogx.py:7 XlogX (x == 0 ? 0 : x * log(x)), :36 XlogY0 (x == 0 ? 0 : x * log(y))
     "XlogX": "xlogx", "XlogY0": "xlogy0",
+    # scalar/math.py: the incomplete-gamma family that has C code in the reference (c_code/gamma.c)
+    "GammaInc": "gammainc", "GammaIncC": "gammaincc", "Chi2SF": "chi2sf", "GammaU": "gammau",
+    "GammaL": "gammal",
 }
 
 
@@ -151,6 +154,8 @@ class _Ctx:
         if v in self.vmap:
             return self.vmap[v]
         if isinstance(v, Constant):
+            if hasattr(v.type, "format") and type(v.type).__name__.startswith("Sparse"):
+                raise UnsupportedOp(f"non-tensor variable type Sparse ({v.type})")
             data = np.asarray(v.data)
             vid = self.plan.add_const(data, dtype=v.type.dtype, name=None)
             # keep static broadcast pattern of the constant's type
@@ -192,7 +197,7 @@ def _static_shape(t):
     return []  # aesara.scalar ScalarType (0-d)
 
 
-def lower_fgraph(fgraph, order=None, name="fgraph", inner_rewriter=None) -> Plan:
+def lower_fgraph(fgraph, order=None, name="fgraph", inner_rewriter=None, extra_outputs=()) -> Plan:
     """FunctionGraph -> Plan.  ``order`` is the linker's schedule (``Linker.schedule``,
     link/basic.py:222); defaults to ``fgraph.toposort()``.  ``inner_rewriter`` is applied to
     a clone of every Scan inner graph (the reference rewrites it lazily when ``Scan.fn`` is
@@ -215,7 +220,9 @@ def lower_fgraph(fgraph, order=None, name="fgraph", inner_rewriter=None) -> Plan
         for o in node.outputs:
             if o in ctx.vmap:
                 origin.setdefault(ctx.vmap[o], k)
-    plan.outputs = [ctx.vid(o) for o in fgraph.outputs]
+    # ``extra_outputs``: variables the linker needs next to the graph's outputs (the final content
+    # of an input buffer a destructive Op overwrites: linker.HipLinker write-back)
+    plan.outputs = [ctx.vid(o) for o in fgraph.outputs] + [ctx.vid(o) for o in extra_outputs]
     plan.var_origin = origin
     return plan
 
@@ -241,12 +248,45 @@ def _register_handlers():
     from aesara.tensor.subtensor import (AdvancedIncSubtensor1, AdvancedSubtensor1,
                                          IncSubtensor, Subtensor)
 
+    def _natural_dtype(scalar_op, node):
+        """Result dtype of a ``*_inplace`` scalar op's OWN arithmetic: its output type is
+        transferred from an input (``transfer_type(0)``, scalar/basic.py:4435 ff.), but the C body
+        ``z = x + y`` computes in the promoted type of the operands and converts on the store —
+        ``add_inplace(int64, float64)`` truncates the float sum.  None: nothing to separate."""
+        import aesara.scalar as aes
+        pref = getattr(scalar_op, "output_types_preference", None)
+        if not isinstance(pref, aes.basic.transfer_type):
+            return None
+        base = None
+        for mod in (aes.basic, aes.math):
+            for cand in vars(mod).values():
+                if type(cand) is type(scalar_op) and not isinstance(
+                        getattr(cand, "output_types_preference", None), aes.basic.transfer_type):
+                    base = cand
+                    break
+            if base is not None:
+                break
+        if base is None:
+            return None
+        try:
+            nat = base.output_types([aes.get_scalar_type(str(i.type.dtype)) for i in node.inputs])[0].dtype
+        except Exception:                                   # noqa: BLE001
+            return None
+        return str(nat) if str(nat) in _PLAN_DTYPES else None
+
     @hip_lower.register(Elemwise)
     def _(op, node, ctx):
         # reference: tensor/elemwise.py:304 Elemwise (perform :725, _c_all :835)
         s = lower_scalar_op(op.scalar_op, len(node.inputs))
         if len(s["nodes"]) == 1 and s["nodes"][0]["dtype"] is None:
-            s["nodes"][0]["dtype"] = str(node.outputs[0].type.dtype)
+            odt = str(node.outputs[0].type.dtype)
+            nat = _natural_dtype(op.scalar_op, node)
+            if nat is not None and nat != odt:
+                s["nodes"][0]["dtype"] = nat
+                s["nodes"].append({"op": "cast", "in": [["t", 0]], "dtype": odt})
+                s["out"] = [["t", 1]]
+            else:
+                s["nodes"][0]["dtype"] = odt
         if len(s["out"]) != len(node.outputs):
             raise UnsupportedOp("Elemwise output arity mismatch")
         ctx.emit("Elemwise", node, {"scalar": s})
@@ -828,6 +868,9 @@ def _register_handlers():
         # reference: tensor/extra_ops.py:283 CumOp (perform :311)
         ctx.emit("CumOp", node, {"axis": None if op.axis is None else int(op.axis),
                                  "mode": str(op.mode)})
+
+    from . import lower_more
+    lower_more.register(hip_lower, _static_shape, UnsupportedOp)
 
     @hip_lower.register(Scan)
     def _(op, node, ctx):

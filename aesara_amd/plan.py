@@ -101,6 +101,9 @@ def _params_to_json(p):
     for k, v in p.items():
         if isinstance(v, Plan):
             out[k] = {"__plan__": v.to_json()}
+        elif callable(v):
+            # HostCall: the Op is a Python callable (Print's print function, an as_op function)
+            raise TypeError("a plan with a host callback (%r) cannot be serialised" % (v,))
         else:
             out[k] = v
     return out

@@ -420,6 +420,14 @@ int ahip_nonzero_write(const int64_t* counts, int64_t n, int nd, const int64_t* 
 int ahip_linearize_indices(int nidx, const void* const* idx, const int* idx_dtypes,
                            const int64_t* idx_strides, const int64_t* dims, const int64_t* mults,
                            int64_t n, int64_t* out, int64_t* bad_index, void* stream);
+/* tensor/extra_ops.py:102 SearchsortedOp (perform :144 np.searchsorted(x, v, side, sorter)): for
+ * every element of the C-contiguous `v` (nv elements of `dtype`) the insertion point in the sorted
+ * 1-d `x` (nx elements of the same dtype, element stride x_stride) — leftmost (right = 0: number of
+ * elements < v[j]) or rightmost (right = 1: number of elements <= v[j]); NumPy's order, NaN above
+ * every number.  `sorter` (int64, nx entries, may be NULL): x[sorter] is the sorted sequence.
+ * out: int64[nv].                                                                                  */
+int ahip_searchsorted(int dtype, const void* x, int64_t nx, int64_t x_stride, const void* v, int64_t nv,
+                      int right, const int64_t* sorter, int64_t* out, void* stream);
 /* ---- K12: cumulative sum / product along one axis --------------------------------------------
  * replaces: tensor/extra_ops.py:283 CumOp (perform :311 np.cumsum / np.cumprod).  x is viewed as
  * [outer, n, inner] with element strides (x_so, x_sn, x_si); out is C-contiguous [outer, n, inner].

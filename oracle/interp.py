@@ -103,6 +103,58 @@ def _trigamma_as121(x):
     return out.astype(x.dtype if x.dtype.kind == "f" else "float64")
 
 
+def _igam(k, x, upper):
+    """scalar/c_code/gamma.c upperGamma / lowerGamma (what GammaU / GammaL's C bodies call): the
+    continued fraction (modified Lentz, :_cfrac) / the power series (:_series), whatever x is, times
+    exp(k log x - x); NaN for k <= 0 or x <= 0.  Element by element like the C loop."""
+    k, x = np.broadcast_arrays(np.asarray(k, "float64"), np.asarray(x, "float64"))
+    out = np.empty(k.shape, "float64")
+    eps = 2.2204460492503131e-16
+    tiny = eps * eps * eps
+    for idx in np.ndindex(k.shape):
+        n, xx = float(k[idx]), float(x[idx])
+        if not (n > 0) or not (xx > 0):
+            out[idx] = np.nan
+            continue
+        if upper:
+            b = xx + 1 - n
+            c = 1 / tiny
+            d = 1 / b
+            f = d
+            for i in range(1, 1024):
+                a = i * (n - i)
+                b += 2
+                d = a * d + b
+                if abs(d) < tiny:
+                    d = tiny
+                c = b + a / c
+                if abs(c) < tiny:
+                    c = tiny
+                d = 1 / d
+                e = d * c
+                f *= e
+                if abs(e - 1) < eps:
+                    break
+            val = f
+        else:
+            t = s_ = 1 / n
+            m = n
+            for _ in range(1024):
+                m += 1
+                t *= xx / m
+                s_ += t
+                if abs(t) < abs(s_) * eps:
+                    break
+            val = s_
+        out[idx] = val * np.exp(n * np.log(xx) - xx)
+    return out
+
+
+def _sp():
+    from scipy import special
+    return special
+
+
 def _special(name):
     def f(x):
         from scipy import special
@@ -139,6 +191,10 @@ _BINARY = {
     "sub": np.subtract, "true_div": np.true_divide, "int_div": np.floor_divide,
     "mod": np.mod, "pow": np.power, "arctan2": np.arctan2,
     "xlogy0": lambda x, y: np.where(x == 0, 0, x * np.log(y)),   # tensor/xlogx.py:44 XlogY0.impl
+    # scalar/math.py:580 GammaInc.st_impl ... :877 GammaL.st_impl (SciPy, like the reference's impl)
+    "gammainc": lambda k, x: _sp().gammainc(k, x), "gammaincc": lambda k, x: _sp().gammaincc(k, x),
+    "chi2sf": lambda x, k: _sp().gammaincc(k / 2.0, x / 2.0),
+    "gammau": lambda k, x: _igam(k, x, True), "gammal": lambda k, x: _igam(k, x, False),
     "lt": np.less, "gt": np.greater, "le": np.less_equal, "ge": np.greater_equal,
     "eq": np.equal, "neq": np.not_equal,
 }
@@ -151,7 +207,7 @@ _FLOAT_FUNCS = {"sqrt", "exp", "exp2", "expm1", "log", "log2", "log10", "log1p",
                 "arccosh", "arctanh", "sigmoid", "softplus", "erf", "erfc", "log1mexp",
                 "deg2rad", "rad2deg", "reciprocal", "true_div", "arctan2", "erfcx", "erfinv",
                 "erfcinv", "gamma", "gammaln", "psi", "tri_gamma", "j0", "j1", "i0", "i1", "softsign",
-                "xlogx", "xlogy0"}
+                "xlogx", "xlogy0", "gammainc", "gammaincc", "chi2sf", "gammau", "gammal"}
 
 
 def eval_scalar_expr(s, ins):
@@ -530,6 +586,18 @@ def run_plan(plan, inputs):
             ax = None if a[1] is None or np.asarray(a[1]).dtype == object else int(np.asarray(a[1]))
             fn = np.sort if op == "Sort" else np.argsort
             r = [np.asarray(fn(np.asarray(a[0]), axis=ax, kind="stable"), dtype=ov[0].dtype)]
+        elif op == "Default":
+            # reference: tensor/basic.py:1819 Default.perform
+            r = [np.array(a[1], copy=True) if a[0] is None or (a[0].dtype == object and a[0].ndim == 0
+                                                             and a[0].item() is None) else a[0]]
+        elif op == "Searchsorted":
+            # reference: tensor/extra_ops.py:144 SearchsortedOp.perform
+            r = [np.searchsorted(a[0], a[1], side=p["side"],
+                                 sorter=a[2] if len(a) > 2 else None).astype("int64")]
+        elif op == "HostCall":
+            # reference: printing.py:863 Print.perform / compile/ops.py:258 FromFunctionOp.perform
+            res = p["fn"](*a)
+            r = [a[0]] if p.get("view") else [np.asarray(x) for x in res]
         elif op == "Nonzero":
             # reference: tensor/basic.py:870 Nonzero.perform
             r = [np.asarray(i, dtype="int64") for i in np.nonzero(np.asarray(a[0]))]

@@ -5,7 +5,12 @@ files through ``aesara.function`` -> ``HipLinker`` -> ``PlanExecutor`` -> the C-
 ``pytest`` per call, several workers sharing the device).  A test that does not pass must be
 explained (fails with the reference's own linker in this image / UnsupportedOp for an out-of-scope
 dtype or Op / listed not-applicable); anything else fails here.  The summary is written to
-``gpurun_out/r05_reference_files.log`` when that directory can be created (copied to ``profiles/``)."""
+``gpurun_out/r06_reference_files.log`` when that directory can be created (copied to ``profiles/``).
+
+What the run PROVES is the count of passing tests that compiled at least one function through
+``HipLinker`` (``through_hip``: the plugin counts ``jit_compile`` calls and executor calls per test)
+— a test that builds no function, or names its own linker, passes without touching the HIP path and
+is not counted.  The assertion below is on that number."""
 import os
 
 import pytest
@@ -26,9 +31,13 @@ def test_reference_test_files_under_the_hip_mode_on_the_device():
     import torch
     assert torch.cuda.is_available()
     workers = max(2, min(12, (os.cpu_count() or 4) // 4))
-    log = os.path.join(ROOT, "gpurun_out", "r05_reference_files.log")
+    log = os.path.join(ROOT, "gpurun_out", "r06_reference_files.log")
     s, bad, text = rf.check("device", rf.FILES, workers=workers, log_path=log, timeout=3300)
     print(text)
     assert not bad, text
     c = s["counts"]
-    assert c["passed"] >= 3500, text
+    # round 5's file list: 967 tests through HipLinker; round 6 adds test_ifelse / test_sort /
+    # rewriting/test_elemwise / test_checkpoints / test_raise_op / test_updates / test_xlogx /
+    # test_math_scipy / compile/test_ops / test_inplace and test_keepdims with its Mode re-pointed
+    assert c["through_hip"] >= 2300, text
+    assert c["executed_hip"] >= 2200, text

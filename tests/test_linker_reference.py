@@ -304,7 +304,8 @@ def test_committed_plans_are_what_the_linker_lowers(ae):
     bad = []
     for name, fn, *_ in gen_golden.CASES:
         ins, outs, _specs = fn()
-        f = ae.function(ins, outs, mode=Mode(_oracle_linker(), HIP_QUERY), on_unused_input="ignore")
+        f = ae.function(ins, outs, mode=Mode(_oracle_linker(), HIP_QUERY), on_unused_input="ignore",
+                        accept_inplace=True)
         plan = f.maker.linker.plan
         plan.name = name
         if json.dumps(plan.to_json(), sort_keys=True) != json.dumps(committed[name], sort_keys=True):
