@@ -219,6 +219,23 @@ __device__ __forceinline__ double trigamma_as121(double x) {
   value += 0.5 * y + (1.0 + y * (0.1666666667 + y * (-0.03333333333 + y * (0.02380952381 + y * -0.03333333333)))) / z;
   return value;
 }
+// Gamma :283 (C: tgamma): exact at the small integers like the C library's (ocml's tgamma(1) is one
+// ulp low: truncating it into an integer output — gamma_inplace on an int64 array — gave 0)
+__device__ inline double gamma_(double x) {
+  if (x == floor(x) && x >= 1.0 && x <= 23.0) {
+    double p = 1.0;
+    for (int i = 2; i < (int)x; ++i) p *= (double)i;
+    return p;
+  }
+  return tgamma(x);
+}
+__device__ inline float gamma_(float x) { return (float)gamma_((double)x); }
+// I0 :1064 / I1 :1038 (scipy.special.i0 / i1): even / odd in x; the device library's routines are
+// evaluated on |x|
+__device__ inline double bessel_i0_(double x) { return cyl_bessel_i0(fabs(x)); }
+__device__ inline float bessel_i0_(float x) { return cyl_bessel_i0f(fabsf(x)); }
+__device__ inline double bessel_i1_(double x) { return copysign(cyl_bessel_i1(fabs(x)), x); }
+__device__ inline float bessel_i1_(float x) { return copysignf(cyl_bessel_i1f(fabsf(x)), x); }
 // Regularised incomplete gamma functions (GammaInc :580 / GammaIncC :629 / Chi2SF :538 / GammaU :836
 // / GammaL :877: the reference's C bodies call GammaP / GammaQ / upperGamma / lowerGamma of
 // scalar/c_code/gamma.c): the power series for x < k + 1, the continued fraction (modified Lentz)
@@ -384,8 +401,8 @@ _FLOAT_FN = {
     "erf": "erf", "erfc": "erfc",
     # scalar/math.py: Gamma :283 (tgamma), GammaLn :317 (lgamma), Erfcx :108, Erfinv :173,
     # Erfcinv :219, J0 :978 / J1 :947 (libm j0 / j1), I0 :1064 / I1 :1038 (scipy.special.i0 / i1)
-    "gamma": "tgamma", "gammaln": "lgamma", "erfcx": "erfcx", "erfinv": "erfinv",
-    "erfcinv": "erfcinv", "j0": "j0", "j1": "j1", "i0": "cyl_bessel_i0", "i1": "cyl_bessel_i1",
+    "gamma": "gamma_", "gammaln": "lgamma", "erfcx": "erfcx", "erfinv": "erfinv",
+    "erfcinv": "erfcinv", "j0": "j0", "j1": "j1", "i0": "bessel_i0_", "i1": "bessel_i1_",
 }
 
 _IDENT = {  # reduction identities
@@ -434,6 +451,8 @@ def _cast(expr, src_dt, dst_dt):
 
 
 def _fname(base, dt):
+    if base.endswith("_"):          # an overloaded wrapper of the preamble (float and double forms)
+        return base
     return base + ("f" if dt == "float32" else "")
 
 

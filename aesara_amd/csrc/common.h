@@ -47,6 +47,7 @@ int ahip_cu_count();  // cached after ahip_init / first use
 void ahip_gemm_set_small_max_tiles(int64_t v);
 void ahip_gemm_set_half_max_tiles(int64_t v);  // 64x64-tile window (ahip_set_param)
 void ahip_gemm_set_half_min_tiles(int64_t v);
+void ahip_gemm_set_half_ksplit(int64_t v);     // K groups inside a 64x64-tile workgroup (1 / 2 / 4)
 void ahip_gemm_set_skinny_nf(int64_t v);  // gemm.hip tuning knob (ahip_set_param)
 void ahip_gemv_set_col_blocks_per_cu(int64_t v);  // gemv.hip tuning knobs (ahip_set_param)
 void ahip_gemv_set_col_strip_lanes(int64_t v);

@@ -235,8 +235,13 @@ template <> __device__ __forceinline__ int frag_row<double>(int lane, int r) {
   return (lane >> 4) + 4 * r;
 }
 
-template <typename T, int AMODE, int BMODE, int EM, int H = 0>
-__global__ __launch_bounds__(Cfg<H>::THREADS, 4) void gemm_kernel(GemmArgs g) {
+// KS > 1 (64x64 tile only): K is cut into KS contiguous ranges, one per GROUP of 4 wavefronts inside
+// the workgroup (its own pair of LDS slab buffers); the groups' accumulators are summed through LDS
+// in group order (deterministic) and group 0 stores the tile.  For problems that give the chip one
+// 4-wave workgroup per CU (1024^3, 16384x64x1024): 2-4 waves per SIMD instead of 1, so the load
+// latency of a slab hides behind the other groups' MFMAs.  Needs K % (BK * KS) == 0.
+template <typename T, int AMODE, int BMODE, int EM, int H = 0, int KS = 1>
+__global__ __launch_bounds__(Cfg<H>::THREADS * KS, 4) void gemm_kernel(GemmArgs g) {
   constexpr bool EDGE = (EM != 0);
   constexpr int BM = Cfg<H>::BM, BN = Cfg<H>::BN, STG = Cfg<H>::STG, WN = Cfg<H>::WN;
   constexpr int FM = Cfg<H>::FM, FN = Cfg<H>::FN;
@@ -248,14 +253,20 @@ __global__ __launch_bounds__(Cfg<H>::THREADS, 4) void gemm_kernel(GemmArgs g) {
   using frag_t = typename Tr::frag_t;
   constexpr int BK = Tr::BK;
   constexpr int SLAB = (BM + BN) * ROW_BYTES;  // bytes per LDS buffer (A rows then B rows)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  extern __shared__ __attribute__((aligned(16))) char smem_all[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int GW = 2 * WN;                 // wavefronts per K group (= all of them for KS == 1)
+  const int grp = KS > 1 ? wave_all / GW : 0;
+  const int wave = KS > 1 ? wave_all % GW : wave_all;
   const int wm = wave / WN, wn = wave % WN;  // 2 x WN waves, (16 FM) x (16 FN) outputs each
   const bool stage_a = wave < WN;           // wave-uniform: which operand this wave stages
   const int stid = tid & (STG - 1);
+  char* const smem = smem_all + (KS > 1 ? grp * 2 * SLAB : 0);
+  const int64_t Kg = KS > 1 ? g.K / KS : g.K;            // this group's K extent ...
+  const int64_t kg0 = KS > 1 ? (int64_t)grp * Kg : 0;    // ... and where it starts
 
   // XCD-aware bijective remap of the linear workgroup id (speed only), then a grouped
   // row-major walk (8 tile-rows per group) for L2 reuse of the B panels.
@@ -281,11 +292,11 @@ __global__ __launch_bounds__(Cfg<H>::THREADS, 4) void gemm_kernel(GemmArgs g) {
   const int rows_b = (int)((g.N - n0) < BN ? (g.N - n0) : BN);
 
   // this wave's staging operand: base of its tile rows, strides, slab step in bytes
-  const char* sbase = stage_a
-      ? reinterpret_cast<const char*>(static_cast<const T*>(g.A) + z * g.a_bs + m0 * g.a_rs)
-      : reinterpret_cast<const char*>(static_cast<const T*>(g.B) + z * g.b_bs + n0 * g.b_cs);
   const int64_t s_rs = stage_a ? g.a_rs : g.b_cs;  // stride between tile rows (m / n)
   const int64_t s_ks = stage_a ? g.a_cs : g.b_rs;  // stride along k
+  const char* sbase = stage_a
+      ? reinterpret_cast<const char*>(static_cast<const T*>(g.A) + z * g.a_bs + m0 * g.a_rs + kg0 * s_ks)
+      : reinterpret_cast<const char*>(static_cast<const T*>(g.B) + z * g.b_bs + n0 * g.b_cs + kg0 * s_ks);
   const int s_rows = stage_a ? rows_a : rows_b;
   const int64_t slab_bytes = (int64_t)BK * s_ks * (int64_t)sizeof(T);
   // end of this operand's valid bytes (EM 2: bound of the load descriptors)
@@ -305,11 +316,11 @@ __global__ __launch_bounds__(Cfg<H>::THREADS, 4) void gemm_kernel(GemmArgs g) {
   // two register staging sets (slab parity): loads of slab t+2 are issued at the start of slab
   // t and stored to LDS at the end of slab t+1 (load-to-use distance: two slabs)
   vec_t r0[NV], r1[NV];
-  const int nslab = (int)((g.K + BK - 1) / BK);
+  const int nslab = (int)((Kg + BK - 1) / BK);
 
   auto gload = [&](vec_t (&r)[NV], int t) {
     const char* base = sbase + (int64_t)t * slab_bytes;
-    const int64_t krem = g.K - (int64_t)t * BK;
+    const int64_t krem = Kg - (int64_t)t * BK;
     int records = 0x7FFFFFFF;
     if constexpr (EM == 2) {
       const int64_t rem = send - base;
@@ -449,6 +460,33 @@ __global__ __launch_bounds__(Cfg<H>::THREADS, 4) void gemm_kernel(GemmArgs g) {
     slab(t, r0, r1);                         // loads slab t+2 (even set), stages t+1
     if (t + 1 < nslab) slab(t + 1, r1, r0);  // loads slab t+3 (odd set), stages t+2
   }
+  if constexpr (KS > 1) {
+    // the groups' partial tiles through LDS (the slab buffers are free: the loop ended on a
+    // barrier), summed by group 0 in group order
+    T* red = reinterpret_cast<T*>(smem_all);
+    constexpr int PER_WAVE = FM * FN * 4 * 64;
+    if (grp > 0) {
+      T* dst = red + ((grp - 1) * GW + wave) * PER_WAVE + lane;
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dst[((i * FN + j) * 4 + r) * 64] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (grp > 0) return;
+#pragma unroll
+    for (int g2 = 1; g2 < KS; ++g2) {
+      const T* src = red + ((g2 - 1) * GW + wave) * PER_WAVE + lane;
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][r] += src[((i * FN + j) * 4 + r) * 64];
+    }
+  }
   // ---- epilogue: C = alpha*acc + beta*Cin (or + the partial already folded into C) --------
   fold(!flushed);
 }
@@ -484,6 +522,7 @@ int64_t g_gemm_group = 8;          // tile-rows per walk group (ahip_set_param "
 // 16-row kernels win) and from two full rounds of big tiles on (4096x2048x1024: 148 -> 157)
 int64_t g_half_max_tiles = 448;    // used below this many 128x128 tiles ...
 int64_t g_half_min_tiles = 192;    // ... when the problem has at least this many 64x64 tiles
+int64_t g_half_ksplit = -1;        // K groups inside a 64x64-tile workgroup: -1 = by workgroup count, 1 / 2 / 4 forced
 int64_t g_small_max_tiles = 64;    // scalar-load form: below this many 128x128 tiles (x4 for the
                                    // vector-load form, see gemm_dispatch)
 
@@ -850,13 +889,13 @@ int operand_mode(const void* p, int64_t rs, int64_t ks, int64_t rows, int64_t K,
   return 2;
 }
 
-template <typename T, int AM, int BMd, int EDGE, int H = 0>
+template <typename T, int AM, int BMd, int EDGE, int H = 0, int KS = 1>
 int launch_gemm(const GemmArgs& g, int64_t batch, hipStream_t s) {
-  constexpr size_t lds = 2 * (Cfg<H>::BM + Cfg<H>::BN) * ROW_BYTES;
+  constexpr size_t lds = KS * 2 * (Cfg<H>::BM + Cfg<H>::BN) * ROW_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(gemm_kernel<T, AM, BMd, EDGE, H>),
+        reinterpret_cast<const void*>(gemm_kernel<T, AM, BMd, EDGE, H, KS>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       ahip_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -865,7 +904,7 @@ int launch_gemm(const GemmArgs& g, int64_t batch, hipStream_t s) {
     attr_set = true;
   }
   dim3 grid((unsigned)(g.tiles_m * g.tiles_n), 1, (unsigned)batch);
-  AHIP_LAUNCH((gemm_kernel<T, AM, BMd, EDGE, H>), grid, dim3(Cfg<H>::THREADS), lds, s, g);
+  AHIP_LAUNCH((gemm_kernel<T, AM, BMd, EDGE, H, KS>), grid, dim3(Cfg<H>::THREADS * KS), lds, s, g);
   return AHIP_OK;
 }
 
@@ -900,13 +939,13 @@ int edge_mode(const GemmArgs& g, int bm_ = BM, int bn_ = BN) {
 
 // the 64x64 tile: vector-staged operands and K a multiple of the slab only (everything else
 // keeps the 128x128 / 16-row kernels)
-template <typename T, int EDGE>
+template <typename T, int EDGE, int KS = 1>
 int dispatch_half(const GemmArgs& g, int am, int bm, int64_t batch, hipStream_t s) {
   switch (am * 3 + bm) {
-    case 0: return launch_gemm<T, 0, 0, EDGE, 1>(g, batch, s);
-    case 1: return launch_gemm<T, 0, 1, EDGE, 1>(g, batch, s);
-    case 3: return launch_gemm<T, 1, 0, EDGE, 1>(g, batch, s);
-    default: return launch_gemm<T, 1, 1, EDGE, 1>(g, batch, s);
+    case 0: return launch_gemm<T, 0, 0, EDGE, 1, KS>(g, batch, s);
+    case 1: return launch_gemm<T, 0, 1, EDGE, 1, KS>(g, batch, s);
+    case 3: return launch_gemm<T, 1, 0, EDGE, 1, KS>(g, batch, s);
+    default: return launch_gemm<T, 1, 1, EDGE, 1, KS>(g, batch, s);
   }
 }
 
@@ -939,12 +978,30 @@ int gemm_dispatch(GemmArgs& g, int64_t batch, hipStream_t s) {
     const int64_t t128 = (int64_t)g.tiles_m * g.tiles_n * batch;
     const int64_t tm64 = (g.M + 63) / 64, tn64 = (g.N + 63) / 64;
     // (exactly one big tile per CU is one full round of the chip: the big tile keeps it)
-    if (am < 2 && bm < 2 && g.K % Traits<T>::BK == 0 && t128 < g_half_max_tiles && t128 != 256 &&
+    // ... or whose extents leave most of a 128x128 tile empty (a batch of 64x64 products: the big
+    // tile would compute 4x the work): the 64-tiling wastes less than 2/3 of what the 128-tiling does
+    const double eff128 = (double)g.M * g.N / ((double)g.tiles_m * BM * g.tiles_n * BN);
+    const double eff64 = (double)g.M * g.N / ((double)tm64 * 64 * tn64 * 64);
+    const bool mostly_empty = eff128 * 1.5 < eff64;
+    if (am < 2 && bm < 2 && g.K % Traits<T>::BK == 0 &&
+        ((t128 < g_half_max_tiles && t128 != 256) || mostly_empty) &&
         tm64 * tn64 * batch >= g_half_min_tiles && tm64 * tn64 < (1LL << 31)) {
       g.tiles_m = (int)tm64;
       g.tiles_n = (int)tn64;
-      return edge_mode<T>(g, 64, 64) == 0 ? dispatch_half<T, 0>(g, am, bm, batch, s)
-                                          : dispatch_half<T, 2>(g, am, bm, batch, s);
+      // few workgroups (at most two per CU) and a long K: K groups inside the workgroup
+      const int64_t wgs = tm64 * tn64 * batch;
+      const int64_t cus = ahip_cu_count() > 0 ? ahip_cu_count() : 256;
+      int ks = (int)g_half_ksplit;
+      if (ks < 0) ks = wgs <= cus ? 4 : (wgs <= 2 * cus ? 2 : 1);
+      while (ks > 1 && (g.K % (Traits<T>::BK * ks) != 0 || g.K / ks > 2048 || g.K / ks < 4 * Traits<T>::BK))
+        ks >>= 1;
+      const bool interior = edge_mode<T>(g, 64, 64) == 0;
+      if (ks >= 4) return interior ? dispatch_half<T, 0, 4>(g, am, bm, batch, s)
+                                   : dispatch_half<T, 2, 4>(g, am, bm, batch, s);
+      if (ks == 2) return interior ? dispatch_half<T, 0, 2>(g, am, bm, batch, s)
+                                   : dispatch_half<T, 2, 2>(g, am, bm, batch, s);
+      return interior ? dispatch_half<T, 0>(g, am, bm, batch, s)
+                      : dispatch_half<T, 2>(g, am, bm, batch, s);
     }
   }
   // below one 128x128 tile per CU the 16-row kernels win when their vector-load form applies
@@ -1052,6 +1109,7 @@ void ahip_gemm_set_half_max_tiles(int64_t v) { g_half_max_tiles = v; }
 void ahip_gemm_set_half_min_tiles(int64_t v) { g_half_min_tiles = v; }
 void ahip_gemm_set_group(int64_t v) { g_gemm_group = v; }
 void ahip_gemm_set_skinny_nf(int64_t v) { g_skinny_nf = v; }
+void ahip_gemm_set_half_ksplit(int64_t v) { g_half_ksplit = v; }
 
 extern "C" {
 

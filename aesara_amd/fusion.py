@@ -54,9 +54,20 @@ class Step:
 def _inline_constants(step: Step, plan: Plan):
     """Fold size-1 plan constants into the scalar expression as literals."""
     keep, remap = [], {}
+
+    def foldable(vid):
+        v = plan.vars[vid]
+        return v.const is not None and len(v.const.get("data", ())) == 1
+    # a step whose operands are ALL size-1 constants keeps the one of the highest rank as a real
+    # operand: the step's shape (and the axes of a fused reduction) come from its operands
+    anchor = None
+    if step.inputs and all(foldable(v) for v in step.inputs):
+        anchor = max(step.inputs, key=lambda v: len(plan.vars[v].shape))
+        if not plan.vars[anchor].shape:
+            anchor = None
     for pos, vid in enumerate(step.inputs):
         v = plan.vars[vid]
-        if v.const is not None and len(v.const.get("data", ())) == 1:
+        if vid != anchor and foldable(vid):
             val = v.const["data"][0]
             remap[pos] = ["c", val, v.dtype]
         else:

@@ -608,6 +608,61 @@ def sec_cfg3b(c):
     return rows
 
 
+GEMM_SHAPES = (
+    # (row key = time_reference.py config, kind, shape, what)
+    ("bdot_64x512", "BatchedDot", (64, 512, 512, 512), "64 x (512x512x512)"),
+    ("bdot_1024x64", "BatchedDot", (1024, 64, 64, 64), "1024 x (64x64x64)"),
+    ("dot22_tall", "Dot22", (16384, 64, 1024), "16384x64x1024"),
+    ("dot22_wide", "Dot22", (64, 16384, 1024), "64x16384x1024"),
+)
+
+
+def sec_gemmshapes(c):
+    """BatchedDot (tensor/blas.py:2179) and Dot22 (:1659) away from the square headline: fp32, the
+    shapes VERDICT r5 names.  Each row is priced against the roof that bounds it: the MFMA peak
+    when the operands are re-used (2 M N K / 157.3 TFLOP/s), the HBM peak when the products are so
+    small that the operand bytes dominate (1024 x 64^3: 10.7 flop per byte < 157.3 / 8 = 19.7)."""
+    torch = c["torch"]
+    f32 = torch.float32
+    from aesara_amd.dist import subplan_for_outputs
+    rows = []
+    for key, kind, shp, what in GEMM_SHAPES:
+        if kind == "BatchedDot":
+            Bn, M, N, K = shp
+            plan = c["plan_of"]("batched_dot_f32")
+            A, B = c["randn"]((Bn, M, K), f32, 11), c["randn"]((Bn, K, N), f32, 12)
+            flops, byts = 2.0 * Bn * M * N * K, 4.0 * Bn * (M * K + K * N + M * N)
+            ref = torch.bmm(A.double(), B.double())
+        else:
+            M, N, K = shp
+            plan = subplan_for_outputs(c["plan_of"]("dot22_f32"), [0])
+            A, B = c["randn"]((M, K), f32, 13), c["randn"]((K, N), f32, 14)
+            flops, byts = 2.0 * M * N * K, 4.0 * (M * K + K * N + M * N)
+            ref = A.double() @ B.double()
+        ex = c["PlanExecutor"](plan, use_graph=c["G"], borrow=True)
+        (out,) = ex(A, B)
+        rel = (torch.linalg.norm(out.double() - ref) / torch.linalg.norm(ref)).item()
+        assert rel <= 1e-6, f"{kind} {what}: Frobenius rel err {rel}"
+        del ref
+        d, w = c["timer"].time(lambda: ex(A, B), 50, warmup=20)
+        mfma_ms = flops / (MFMA_F32_PEAK * 1e12) * 1e3
+        hbm_ms = byts / (HBM_PEAK_GBS * 1e9) * 1e3
+        if hbm_ms > mfma_ms:
+            r = roof("hbm", byts, d, HBM_PEAK_GBS, kernel="gemm.hip", mfma_frac=flops / (d * 1e-3) / 1e12 / MFMA_F32_PEAK,
+                     note="operand bytes bound this shape: %.1f flop per byte < %.1f = MFMA peak / HBM peak"
+                          % (flops / byts, MFMA_F32_PEAK * 1e3 / HBM_PEAK_GBS))
+        else:
+            r = roof("mfma", flops, d, MFMA_F32_PEAK, kernel="gemm.hip",
+                     hbm_frac=byts / (d * 1e-3) / 1e9 / HBM_PEAK_GBS)
+        rows.append({"config": "%s fp32 %s" % (kind, what), "key": key, "dtype": "f32",
+                     "evals_per_s": 1e3 / max(d, w), "roofline": r,
+                     "check": {"frobenius_rel_err_vs_fp64": rel, "bar": 1e-6}})
+        del ex, A, B, out
+        torch.cuda.empty_cache()
+    return rows
+
+
+
 def sec_cfg3a(c):
     torch = c["torch"]
     f64 = torch.float64
@@ -876,7 +931,7 @@ def sec_placed(c):
                              note="per-rank bytes of the towers it owns; kernel_ms = this rank")}
 
 
-SECONDARY = [("cfg3b", sec_cfg3b), ("cfg3a", sec_cfg3a), ("cfg1b", sec_cfg1b), ("cfg4", sec_cfg4),
+SECONDARY = [("cfg3b", sec_cfg3b), ("gemmshapes", sec_gemmshapes), ("cfg3a", sec_cfg3a), ("cfg1b", sec_cfg1b), ("cfg4", sec_cfg4),
              ("cfg5", sec_cfg5), ("placed", sec_placed)]
 
 
@@ -1010,8 +1065,8 @@ def cpu_baseline(np, ref_warm=None, secondary=None):
                 ref_warm.wait(timeout=300)
             import tempfile
             dump = tempfile.mkdtemp(prefix="aesara_ref_out_")
-            r = reference_rows(4.0, ["cfg2", "cfg1b", "cfg3a", "cfg3b", "cfg4_b1", "cfg4_b64", "cfg5"],
-                               dump_dir=dump)
+            r = reference_rows(4.0, ["cfg2", "cfg1b", "cfg3a", "cfg3b", "cfg4_b1", "cfg4_b64", "cfg5"]
+                               + [k for k, *_ in GEMM_SHAPES], dump_dir=dump, timeout=600)
             row = r["rows"]["cfg2"]
             res = {"value": 1e3 / row["ms_per_eval"], "unit": "evals/s", "cores": row["cores"],
                    "kind": "reference", "ms_per_eval": row["ms_per_eval"],
@@ -1073,6 +1128,8 @@ def cpu_baseline(np, ref_warm=None, secondary=None):
             for srow in secondary or ():
                 name = srow.get("config", "")
                 k = next((v for p_, v in key.items() if name.startswith(p_)), None)
+                if srow.get("key") in others:
+                    k = srow["key"]
                 if name.startswith("cfg4 Scan GRU") and "B=1" in name:
                     k = "cfg4_b1"
                 elif name.startswith("cfg4 Scan GRU") and "B=64" in name:

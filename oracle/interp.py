@@ -111,15 +111,16 @@ def _igam(k, x, upper):
     out = np.empty(k.shape, "float64")
     eps = 2.2204460492503131e-16
     tiny = eps * eps * eps
+    one = np.float64(1.0)                         # NumPy scalars: 1 / 0 is inf like in C, no exception
     for idx in np.ndindex(k.shape):
-        n, xx = float(k[idx]), float(x[idx])
+        n, xx = np.float64(k[idx]), np.float64(x[idx])
         if not (n > 0) or not (xx > 0):
             out[idx] = np.nan
             continue
         if upper:
             b = xx + 1 - n
-            c = 1 / tiny
-            d = 1 / b
+            c = one / tiny
+            d = one / b
             f = d
             for i in range(1, 1024):
                 a = i * (n - i)
@@ -130,14 +131,14 @@ def _igam(k, x, upper):
                 c = b + a / c
                 if abs(c) < tiny:
                     c = tiny
-                d = 1 / d
+                d = one / d
                 e = d * c
                 f *= e
                 if abs(e - 1) < eps:
                     break
             val = f
         else:
-            t = s_ = 1 / n
+            t = s_ = one / n
             m = n
             for _ in range(1024):
                 m += 1

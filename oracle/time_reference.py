@@ -22,6 +22,9 @@ import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ALL = ["cfg2", "cfg1b", "cfg3a", "cfg3b", "cfg4_b1", "cfg4_b64", "cfg5"]
+# BatchedDot / Dot22 away from the square case (bench.py sec_gemmshapes): (batch, M, N, K) / (M, N, K)
+GEMM_SHAPES = {"bdot_64x512": (64, 512, 512, 512), "bdot_1024x64": (1024, 64, 64, 64),
+               "dot22_tall": (16384, 64, 1024), "dot22_wide": (64, 16384, 1024)}
 
 
 def _normal_f32_parallel(np, seed, rows, cols):
@@ -72,6 +75,17 @@ def make_inputs(name, np, tiny=False, full=False):
         for k, nm in enumerate(("Wz", "Uz", "Wr", "Ur", "Wh", "Uh")):
             d[nm] = (np.random.default_rng(5 + k).standard_normal((H, H)) / np.sqrt(H)).astype("float32")
         return d
+    if name in GEMM_SHAPES:
+        shp = GEMM_SHAPES[name]
+        if tiny:
+            shp = tuple(min(8, v) for v in shp)
+        if len(shp) == 4:
+            Bn, M, N_, K = shp
+            return {"x": np.random.default_rng(11).standard_normal((Bn, M, K), dtype="float32"),
+                    "y": np.random.default_rng(12).standard_normal((Bn, K, N_), dtype="float32")}
+        M, N_, K = shp
+        return {"x": np.random.default_rng(13).standard_normal((M, K), dtype="float32"),
+                "y": np.random.default_rng(14).standard_normal((K, N_), dtype="float32")}
     if name == "cfg5":
         N, D = (256, 16) if tiny else (1 << 20, 256)
         if full and not tiny:
@@ -137,6 +151,16 @@ def build(ae, name, np, tiny=False, full=False):
         return f, (d["x"], d["h0"]), \
             "fp32 Scan GRU T=%d of 512 steps%s, H=%d B=%d (scan_perform.pyx loop, inner cvm " \
             "function)" % (T_, "" if T_ == 512 else " (x8 for the config)", H, B_), nthreads
+    if name in GEMM_SHAPES:
+        if d["x"].ndim == 3:
+            x, y = at.ftensor3("x"), at.ftensor3("y")
+            f = ae.function([x, y], at.batched_dot(x, y), mode=mode)      # tensor/blas.py:2179 BatchedDot
+            what = "fp32 BatchedDot %s (C batch_gemm: one sgemm per item)" % (d["x"].shape,)
+        else:
+            x, y = at.fmatrix("x"), at.fmatrix("y")
+            f = ae.function([x, y], at.dot(x, y), mode=mode)              # -> Dot22, tensor/blas.py:1659
+            what = "fp32 Dot22 %s @ %s" % (d["x"].shape, d["y"].shape)
+        return f, (d["x"], d["y"]), what, nthreads
     if name == "cfg5":
         N, D = d["X"].shape
         X, w, b, y = at.fmatrix("X"), at.fvector("w"), at.fscalar("b"), at.fvector("y")

@@ -26,7 +26,8 @@ BARS = {"cfg5": [1e-6, 1e-5, 1e-6]}
 
 
 def bar_for(cfg, i):
-    return BARS.get(cfg, [BAR] * (i + 1))[i] if cfg in BARS else BAR
+    bars = BARS.get(cfg)
+    return bars[i] if bars is not None and i < len(bars) else BAR
 
 
 def within_bars(cfg, errs):
@@ -41,6 +42,11 @@ CONFIGS = {
     "cfg4_b1": ("cfg4_gru_b1_f32", ("x", "h0", "Wz", "Uz", "Wr", "Ur", "Wh", "Uh"), (-1,)),
     "cfg4_b64": ("cfg4_gru_b8_f32", ("x", "h0", "Wz", "Uz", "Wr", "Ur", "Wh", "Uh"), (-1,)),
     "cfg5": ("cfg5_logistic", ("X", "w", "b", "y"), (0, 1, 2)),
+    # BatchedDot / Dot22 away from the square case (bench.py sec_gemmshapes)
+    "bdot_64x512": ("batched_dot_f32", ("x", "y"), (0,)),
+    "bdot_1024x64": ("batched_dot_f32", ("x", "y"), (0,)),
+    "dot22_tall": ("dot22_f32", ("x", "y"), (0,)),
+    "dot22_wide": ("dot22_f32", ("x", "y"), (0,)),
 }
 
 
@@ -68,7 +74,8 @@ def max_err(got, ref):
     return float(np.abs(got - ref).max() / (den if den > 0 else 1.0))
 
 
-FULL_SHAPE_ALWAYS = ("cfg2", "cfg1b", "cfg3a", "cfg3b")     # their timed rows ARE the BASELINE shapes
+FULL_SHAPE_ALWAYS = ("cfg2", "cfg1b", "cfg3a", "cfg3b", "bdot_64x512", "bdot_1024x64", "dot22_tall",
+                     "dot22_wide")     # their timed rows ARE the BASELINE shapes
 FULL_SHAPE_ONCE = ("cfg4_b1", "cfg4_b64", "cfg5")           # timed as samples; ``full=True`` below
 
 
@@ -105,6 +112,7 @@ def hip_vs_reference(dump_dir, configs=None, full=False):
         out[cfg] = {"rel_err": errs, "max": max(errs), "outputs": len(errs),
                     "max_abs_over_max_ref": [max_err(v, r) for v, r in zip(vals, refs)],
                     "ok": within_bars(cfg, errs), "bars": [bar_for(cfg, i) for i in range(len(errs))],
+                    "ok_strict_1e-6": all(e <= BAR for e in errs),     # next to the per-config bars
                     "full_shape": bool(full or cfg in FULL_SHAPE_ALWAYS),
                     "input_shapes": {n: list(d[n].shape) for n in names if d[n].ndim}}
         del ex, got, args, d
