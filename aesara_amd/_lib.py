@@ -195,7 +195,9 @@ SIGNATURES = {
     "ahip_event_create": (i32, [p_vp]),
     "ahip_event_record": (i32, [vp, vp]),
     "ahip_event_elapsed_ms": (i32, [vp, vp, C.POINTER(C.c_float)]),
+    "ahip_event_query": (i32, [vp]),
     "ahip_event_destroy": (i32, [vp]),
+    "ahip_comm_abort": (i32, [vp]),
 }
 
 

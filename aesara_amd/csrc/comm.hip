@@ -20,6 +20,7 @@ typedef int (*fn_get_uid)(nccl_uid*);
 typedef int (*fn_init_rank)(nccl_comm*, int, nccl_uid, int);
 typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, nccl_comm, hipStream_t);
 typedef int (*fn_destroy)(nccl_comm);
+typedef int (*fn_abort)(nccl_comm);
 typedef const char* (*fn_errstr)(int);
 
 struct Rccl {
@@ -28,6 +29,7 @@ struct Rccl {
   fn_init_rank init_rank = nullptr;
   fn_allreduce allreduce = nullptr;
   fn_destroy destroy = nullptr;
+  fn_abort abort = nullptr;
   fn_errstr errstr = nullptr;
 };
 Rccl g_rccl;
@@ -60,6 +62,7 @@ int load_rccl() {
   r.init_rank = (fn_init_rank)dlsym(h, "ncclCommInitRank");
   r.allreduce = (fn_allreduce)dlsym(h, "ncclAllReduce");
   r.destroy = (fn_destroy)dlsym(h, "ncclCommDestroy");
+  r.abort = (fn_abort)dlsym(h, "ncclCommAbort");      // optional
   r.errstr = (fn_errstr)dlsym(h, "ncclGetErrorString");
   if (!r.get_uid || !r.init_rank || !r.allreduce || !r.destroy) {
     ahip_set_error("RCCL library lacks ncclGetUniqueId / ncclCommInitRank / ncclAllReduce");
@@ -150,6 +153,16 @@ int ahip_allreduce(ahip_comm_t c, int dtype, int op, const void* sendbuf, void* 
   AHIP_REQUIRE(sendbuf && recvbuf, "null buffer");
   if (ahip_list_recording()) return ahip_list_record_allreduce(c, dtype, op, sendbuf, recvbuf, count);
   return ahip_comm_issue(c, dtype, op, sendbuf, recvbuf, count, as_stream(stream));
+}
+
+int ahip_comm_abort(ahip_comm_t c) {
+  // ncclCommAbort: frees the communicator AND terminates collectives that are stuck on the device
+  // (a peer that never arrived); ncclCommDestroy would wait for them
+  if (!c) return AHIP_OK;
+  if (g_rccl.abort) (void)g_rccl.abort(c->comm);
+  else if (g_rccl.destroy) (void)g_rccl.destroy(c->comm);
+  delete c;
+  return AHIP_OK;
 }
 
 int ahip_comm_destroy(ahip_comm_t c) {

@@ -443,6 +443,15 @@ int ahip_event_elapsed_ms(ahip_event_t start, ahip_event_t stop, float* ms) {
   return AHIP_OK;
 }
 
+int ahip_event_query(ahip_event_t e) {
+  AHIP_REQUIRE(e != nullptr, "null event");
+  hipError_t r = hipEventQuery(e->ev);
+  if (r == hipSuccess) return 0;
+  if (r == hipErrorNotReady) { (void)hipGetLastError(); return 1; }
+  ahip_set_error("hipEventQuery: %s", hipGetErrorString(r));
+  return AHIP_EHIP;
+}
+
 int ahip_event_destroy(ahip_event_t e) {
   if (!e) return AHIP_OK;
   (void)hipEventDestroy(e->ev);

@@ -568,6 +568,15 @@ class HipComm:
             lib.ahip_comm_destroy(self._h)
             self._h = None
 
+    def abort(self):
+        """``ncclCommAbort``: give the communicator up even if a collective is stuck on the device
+        (a watchdog's way out; ``close`` would wait for it).  Launch lists that recorded this
+        communicator must not be replayed afterwards."""
+        from ._lib import lib
+        if self._h:
+            lib.ahip_comm_abort(self._h)
+            self._h = None
+
     recorded = 0        # launch lists holding this communicator's handle
 
     def __del__(self):
@@ -761,6 +770,15 @@ def _call_single_list(self, local_inputs, sig, world):
         return None                       # packed buffers not built yet: ordinary first evaluation
     if not all(hasattr(ex, "trace_eager") for ex in self.execs):
         return None
+    # pass 1 below traces every round EAGERLY on the un-reduced local partials (the collective is
+    # issued once, by the list): a round behind an exchange whose HOST behaviour depends on values
+    # (the bad-index check of a gather / scatter, an Assert, the trip count of a do-while Scan)
+    # would see partial sums, raise spuriously or record another allocation trace than the
+    # combined values give — such plans keep the per-round path
+    if any(exchanges_before and _value_dependent_host_logic(p_k)
+           for exchanges_before, p_k in _rounds_behind_an_exchange(spec.rounds)):
+        self._no_list.add(key)
+        return None
 
     def run_rounds(recording):
         carried, results = {}, []
@@ -823,11 +841,35 @@ def _drop_list(self, key):
     self.group.recorded -= 1
 
 
+_VALUE_DEPENDENT = ("Assert", "AdvancedSubtensor1", "AdvancedSubtensor", "AdvancedIncSubtensor1",
+                    "AdvancedIncSubtensor", "Nonzero", "HostCall")
+
+
+def _value_dependent_host_logic(plan):
+    for n in plan.nodes:
+        if n.op in _VALUE_DEPENDENT:
+            return True
+        if n.op == "Scan" and (n.params.get("as_while") or _value_dependent_host_logic(n.params["inner"])):
+            return True
+    return False
+
+
+def _rounds_behind_an_exchange(rounds):
+    seen = False
+    for p_k, exchanges in rounds:
+        yield seen, p_k
+        seen = seen or bool(exchanges)
+
+
 def _check_after_list(self):
     """Error words (bad index, persistent-Scan time-out) of every round's executor, examined
-    after a single-list run as the per-round path does after each round (``check_indices``)."""
+    after a single-list run as the per-round path does after each round (``check_indices``:
+    True = the blocking read, "deferred" = the copy behind the launches, examined when it lands)."""
     for ex in self.execs:
-        if getattr(ex, "check_indices", False) and hasattr(ex, "_raise_bad_index"):
+        mode = getattr(ex, "check_indices", False)
+        if mode == "deferred" and hasattr(ex, "_deferred_check"):
+            ex._deferred_check()
+        elif mode and hasattr(ex, "_raise_bad_index"):
             ex._raise_bad_index()
 
 

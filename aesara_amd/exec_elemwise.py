@@ -926,8 +926,10 @@ class ElemwiseMixin:
             raise TypeError("copy_into needs equal dtypes")
         if nd > AHIP_MAXD and len(collapse_dims(list(dst.shape), [list(ss), list(dst.strides)])[0]) > AHIP_MAXD:
             # more non-mergeable dims than the copy kernel takes (``tile``: an 8-d DimShuffle view
-            # made contiguous for a Reshape): one copy per index of the outermost non-unit dim
-            d0 = next(d for d in range(nd) if dst.shape[d] != 1)
+            # made contiguous for a Reshape): one copy per index of the SMALLEST non-unit dim (the
+            # fewest launches: a large leading extent would otherwise put tens of thousands of
+            # copies into the launch list)
+            d0 = min((d for d in range(nd) if dst.shape[d] != 1), key=lambda d: dst.shape[d])
             rest = tuple(dst.shape[:d0]) + (1,) + tuple(dst.shape[d0 + 1:])
             sv = src.view(tuple(dst.shape), tuple(ss))
             for i in range(dst.shape[d0]):

@@ -493,6 +493,10 @@ class ReplayMixin:
         several buffer sets is shared by their entries: freed with the last of them)."""
         lst, graph = ent[0], ent[1]
         self._memo_gen += 1          # (memoized calls may point at this entry)
+        # the memo holds strong references to replay entries (arena, outputs, kept device
+        # tensors): dropped with the entry, or evicted arenas would stay resident in HBM
+        self._memo.clear()
+        self._memo_seen.clear()
         if graph is not None:
             lib.ahip_graph_destroy(graph)
         if lst is not None:

@@ -368,9 +368,14 @@ class ScanMixin:
         wkey = (id(inner), key)
         ws = self._sp_ws.get(wkey)
         if ws is None and not self.dry_run:
+            trace = spec.trace
+            nctl = 16 + (4 * (sp.TRACE_NT * sp.TRACE_MARKS + 4) if trace else 0)
             ws = (torch.zeros(max(total, 1), dtype=torch.int64, device=self.device),
-                  torch.zeros(16, dtype=torch.int32, device=self.device))
+                  torch.zeros(nctl, dtype=torch.int32, device=self.device))
             self._sp_ws[wkey] = ws
+            if trace:
+                sp.generate(spec)                 # (fills spec.marks when the kernel came from the cache)
+                self.sp_trace = (ws[1], list(spec.marks))
         if not self.dry_run:
             g.xch, g.ctl = ws[0].data_ptr(), ws[1].data_ptr()
         why = self._launch_persistent(ent[0], G, 64 * nw, g)

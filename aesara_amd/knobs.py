@@ -69,6 +69,7 @@ _def("SP_SLEEP", 1, int, "s_sleep between polls of the vector-state kernel")
 _def("SP_DELAY", 15, int, "vector-state kernel: s_sleep units (64 cycles) before the first poll of a hand-off "
      "(config 4 B = 1, 128 x 8 rows, 2 polling waves: 4.59 us per step with 0, 4.05 with 12, 4.27 with 20; "
      "256 x 4 rows, 4 polling waves: 3.52 / 3.42 / 3.38 / 3.37 / 3.43 with 10 / 12 / 14 / 16 / 18)")
+_def("SP_TRACE", 0, int, "vector-state kernel: stamp s_memtime at the phase marks (tools/sp_trace.py)")
 _def("SM_CHUNK", 32, int, "k-chunk of the matrix-state kernel's exchange")
 _def("SM_XMODE", None, str, "exchange form of the matrix-state kernel: frag | flag (default by registers)")
 _def("SM_EARLY", "first", str, "which product of a step starts before the hand-off: first | none")

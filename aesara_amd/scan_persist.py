@@ -55,6 +55,7 @@ SP_MAXSEQ = 28
 SP_MAXNSQ = 12
 SP_MAXOUT = 16
 SPIN_LIMIT = 1 << int(knobs.get("SPIN_LOG2"))
+TRACE_T0, TRACE_NT, TRACE_MARKS = 200, 32, 16      # steps traced, stamps per step (u64 each): tools/sp_trace.py
 LDS_BUDGET = 156 * 1024
 
 
@@ -459,10 +460,14 @@ class Spec:
                     "sleep": int(knobs.get("SP_SLEEP")),
                     "delay": int(knobs.get("SP_DELAY")),
                     "repoll": 0}      # (re-polling only the missing granules: measured null r03, removed)
+        # per-phase timeline (tools/sp_trace.py): thread 0 of workgroups 0 and G/2 stamps s_memtime
+        # at the marks of TRACE_NT steps into the control buffer's tail
+        self.trace = bool(int(knobs.get("SP_TRACE")))
+        self.marks = []
 
     def key(self):
         pr = self.prog
-        blob = json.dumps(["sp8", sorted(self.prog.older.items()), self.dtype, sorted(self.var.items()), sorted(self.place.items()), self.M, sorted(self.Ks.items()), sorted(self.lens.items()),
+        blob = json.dumps(["sp8" + ("t" if self.trace else ""), sorted(self.prog.older.items()), self.dtype, sorted(self.var.items()), sorted(self.place.items()), self.M, sorted(self.Ks.items()), sorted(self.lens.items()),
                            self.R, self.nw, sorted(pr.seq.items()), sorted(pr.state.items()),
                            sorted(pr.nsq.items()), sorted(pr.mats.items()),
                            [[ph["dots"], ph["ins"], ph["outs"], ph["scalar"], ph["out_refs"]]
@@ -539,6 +544,23 @@ def generate(spec: Spec):
     L.append("  const bool owner = lane < %d && myrow < %d;" % (RPW, M))
     L.append("  const unsigned base = __hip_atomic_load(a.ctl, %s);" % AG)
     L.append("  unsigned* errp = a.ctl + 1;")
+    marks = []
+    if spec.trace:
+        L.append("  const bool tr_on = threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2);")
+        L.append("  unsigned long long* tr = (unsigned long long*)(a.ctl + 16) + (blockIdx.x == 0 ? 0 : %d);"
+                 % (TRACE_NT * TRACE_MARKS + 4))
+        L.append("  if (tr_on) { tr[%d] = __builtin_amdgcn_s_memtime(); tr[%d] = __builtin_amdgcn_s_memrealtime(); }"
+                 % (TRACE_NT * TRACE_MARKS, TRACE_NT * TRACE_MARKS + 1))
+
+    def stamp(label):
+        """record s_memtime under `label` (trace builds only; marks are numbered in code order)"""
+        if not spec.trace:
+            return
+        k = len(marks)
+        marks.append(label)
+        assert k < TRACE_MARKS
+        L.append("    if (tr_on && t >= %d && t < %d) tr[(t - %d) * %d + %d] = __builtin_amdgcn_s_memtime();"
+                 % (TRACE_T0, TRACE_T0 + TRACE_NT, TRACE_T0, TRACE_MARKS, k))
     # ---- matrix rows -> LDS ------------------------------------------------------------------
     for av, slot in sorted(pr.mats.items(), key=lambda t: t[1]):
         K = spec.Ks[av]
@@ -670,6 +692,7 @@ def generate(spec: Spec):
     staged_this_step = set()
     for pi, ph in enumerate(pr.phases):
         L.append("    // ---- phase %d" % pi)
+        stamp("p%d start" % pi)
         # -- gather the dot vectors that are not staged yet
         need_sync = False
         delayed = False     # the first exchanged operand of a phase waits before its first poll
@@ -709,7 +732,9 @@ def generate(spec: Spec):
             L.append(ind + "}")
             L.append("    }")
         if need_sync:
+            stamp("p%d tags seen, staged" % pi)
             L.append("    __syncthreads();")
+            stamp("p%d barrier" % pi)
         # -- row dots: wavefront `wave` owns rows wave*RPW .. +RPW
         D = len(ph["dots"])
         for d, (a_, x) in enumerate(ph["dots"]):
@@ -750,6 +775,8 @@ def generate(spec: Spec):
                 for i in range(RPW):
                     L.append("      acc%d_%d_%d += shfl_xor_<%s>(acc%d_%d_%d, s);" % (pi, d, i, T, pi, d, i))
             L.append("    }")
+        if D:
+            stamp("p%d dots + fold" % pi)
         for d in range(D):
             sel = "acc%d_%d_%d" % (pi, d, RPW - 1)
             for i in range(RPW - 2, -1, -1):
@@ -786,6 +813,7 @@ def generate(spec: Spec):
                 L.append("      ((%s*)a.out[%d])[((a.out_pos0[%d] + t) %% a.out_store[%d]) * a.out_rs[%d] + myrow] = own_%d;"
                          % (T, j, j, j, j, o))
         L.append("    }")
+        stamp("p%d epilogue, published" % pi)
         if red:
             # -- the reduction: gather the whole vector the owners just published, fold it in one
             #    fixed order (lane l folds elements l, l + 64, ...; butterfly over the wavefront:
@@ -816,6 +844,10 @@ def generate(spec: Spec):
     if pr.cond is not None:
         L.append("    if (own_%d != 0) { steps_ = t + 1; break; }" % pr.cond)
     L.append("  }")
+    if spec.trace:
+        L.append("  if (tr_on) { tr[%d] = __builtin_amdgcn_s_memtime(); tr[%d] = __builtin_amdgcn_s_memrealtime(); }"
+                 % (TRACE_NT * TRACE_MARKS + 2, TRACE_NT * TRACE_MARKS + 3))
+        spec.marks = list(marks)
     # every workgroup read `base` before workgroup 0 can get here (it gathered, in its last
     # step, a vector that every workgroup published after reading `base`; T >= 2)
     L.append("  if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.ctl, base + (unsigned)a.T, %s);" % AG)

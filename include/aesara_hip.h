@@ -492,11 +492,15 @@ int ahip_comm_rank(ahip_comm_t c);
 int ahip_allreduce(ahip_comm_t c, int dtype, int op /* ahip_red_op */, const void* sendbuf,
                    void* recvbuf, int64_t count, void* stream);
 int ahip_comm_destroy(ahip_comm_t c);
+/* ncclCommAbort: like destroy, but collectives stuck on the device (a rank that never arrived) are
+ * terminated instead of waited for — what a watchdog calls before it falls back to another transport */
+int ahip_comm_abort(ahip_comm_t c);
 
 /* ---- timing on the launch stream (bench.py roofline leg) ----------------------------------- */
 int ahip_event_create(ahip_event_t* out);
 int ahip_event_record(ahip_event_t e, void* stream);
 int ahip_event_elapsed_ms(ahip_event_t start, ahip_event_t stop, float* ms); /* syncs on stop */
+int ahip_event_query(ahip_event_t e);   /* 0: everything before the record has finished, 1: not yet, < 0: error */
 int ahip_event_destroy(ahip_event_t e);
 
 #ifdef __cplusplus

@@ -154,8 +154,12 @@ def build(ae, name, np, tiny=False, full=False):
     if name in GEMM_SHAPES:
         if d["x"].ndim == 3:
             x, y = at.ftensor3("x"), at.ftensor3("y")
-            f = ae.function([x, y], at.batched_dot(x, y), mode=mode)      # tensor/blas.py:2179 BatchedDot
-            what = "fp32 BatchedDot %s (C batch_gemm: one sgemm per item)" % (d["x"].shape,)
+            # BatchedDot's C thunk (blas.py:2243 batch_gemm) links sgemm_ directly: with
+            # blas__ldflags == '' (no system BLAS in this image) the module does not load, so the
+            # reference itself runs the Op's Python perform (:2224: np.dot per item -> OpenBLAS)
+            f = ae.function([x, y], at.batched_dot(x, y), mode=Mode("py", "fast_run"))
+            what = "fp32 BatchedDot %s (BatchedDot.perform: np.dot per item; its C thunk needs a system " \
+                   "BLAS that this image lacks)" % (d["x"].shape,)
         else:
             x, y = at.fmatrix("x"), at.fmatrix("y")
             f = ae.function([x, y], at.dot(x, y), mode=mode)              # -> Dot22, tensor/blas.py:1659

@@ -220,9 +220,11 @@ def run(executor, files=None, workers=4, timeout=3000, extra=()):
     env = dict(os.environ, AESARA_HIP_SUITE_EXECUTOR=executor, AESARA_HIP_SUITE_REPORT=rep)
     env["PYTHONPATH"] = HERE + os.pathsep + env.get("PYTHONPATH", "")
     env.pop("AESARA_FLAGS", None)
+    # (--timeout: pytest-timeout — a test that hangs on the device is reported as a failure of THAT
+    # test instead of costing the whole run its time limit)
     cmd = [sys.executable, "-m", "pytest", "-p", "hip_suite_plugin", "-q", "--tb=no", "-p",
-           "no:cacheprovider", "-W", "ignore"] + (["-n", str(workers)] if workers > 1 else []) + \
-        list(extra) + files
+           "no:cacheprovider", "-W", "ignore", "--timeout", os.environ.get("AESARA_HIP_SUITE_TEST_TIMEOUT", "240")] + \
+        (["-n", str(workers)] if workers > 1 else []) + list(extra) + files
     try:
         p = subprocess.run(cmd, cwd=overlay_dir(), env=env, capture_output=True, text=True,
                            timeout=timeout)

@@ -129,7 +129,16 @@ def test_dry_run_shapes_and_kernel_generation(c):
     output shapes/dtypes must equal the reference's."""
     plan = case_plan(c)
     ex = PlanExecutor(plan, dry_run=True)
-    outs = ex(*case_inputs(c))
+    try:
+        outs = ex(*case_inputs(c))
+    except RuntimeError as e:
+        # an extent that is COMPUTED on the device (Repeat with a vector of repeats: the output
+        # length is the sum of the repeats) has no value in a dry run: everything up to that read
+        # has been checked, the rest runs on the GPU (tests/test_gpu_parity.py)
+        if "dry run: value of a computed device array is unknown" in str(e):
+            assert any(n.op == "Searchsorted" for n in plan.nodes), c["name"]
+            return
+        raise
     # a do-while Scan's trip count is data dependent: the dry run (no values) runs n_steps
     # ... and Nonzero / boolean masks have value-dependent lengths (the dry run takes the maximum)
     data_dependent = any((n.op == "Scan" and n.params.get("as_while")) or n.op == "Nonzero" or
