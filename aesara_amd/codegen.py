@@ -2016,22 +2016,23 @@ class RowChainSpec:
                slot]] (slots index RcArgs.ptr after the external operands)
     """
 
-    def __init__(self, ext, members, L, V, nch, lnd=1, block=256):
+    def __init__(self, ext, members, L, V, nch, lnd=1, block=256, nt=False):
         self.ext = [list(e) for e in ext]
         self.members, self.L, self.V, self.nch, self.block = members, L, V, nch, block
         self.lnd = lnd          # jointly-collapsed leading dims (row index -> coordinates)
+        self.nt = bool(nt)      # streaming (non-temporal) loads of the full operands: read-once rows
         assert L in (1, 2, 4, 8, 16, 32, 64) and block % 64 == 0 and 1 <= lnd <= RC_MAXLEAD
 
     def key(self):
-        fields = ["rc2", self.ext, self.L, self.V, self.nch, self.lnd, self.block,
+        fields = ["rc2" + ("n" if self.nt else ""), self.ext, self.L, self.V, self.nch, self.lnd, self.block,
                   [[m["ins"], m.get("reduce"), m.get("stores"), m.get("rowlike")]
                    for m in self.members]]
         return _memo_key([m["scalar"] for m in self.members], fields, self._key)
 
     def _key(self):
         import json
-        blob = json.dumps(["rc2", self.ext, self.members, self.L, self.V, self.nch, self.lnd,
-                           self.block],
+        blob = json.dumps(["rc2" + ("n" if self.nt else ""), self.ext, self.members, self.L, self.V, self.nch,
+                           self.lnd, self.block],
                           sort_keys=True)
         return hashlib.sha256(blob.encode()).hexdigest()[:24]
 
@@ -2079,8 +2080,8 @@ def generate_rowchain(spec: RowChainSpec):
             S.append("    const %s* __restrict__ xp%d = (const %s*)a.ptr[%d] + %s;"
                      % (ct, k, ct, k, row_off(k)))
             for c in range(NCH):
-                S.append("    Pack<%s, %d> x%d_%d = {}; if (ok%d) x%d_%d = *(const Pack<%s, %d>*)"
-                         "(xp%d + col%d);" % (ct, V, k, c, c, k, c, ct, V, k, c))
+                S.append("    Pack<%s, %d> x%d_%d = {}; if (ok%d) x%d_%d = %s((const Pack<%s, %d>*)"
+                         "(xp%d + col%d));" % (ct, V, k, c, c, k, c, "nt_load" if spec.nt else "*", ct, V, k, c))
         elif cls == "r":
             S.append("    const %s ro%d = ((const %s*)a.ptr[%d])[%s];" % (ct, k, ct, k, row_off(k)))
 

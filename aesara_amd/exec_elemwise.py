@@ -221,10 +221,15 @@ class ElemwiseMixin:
         # the spec costs more host time than everything else in this function)
         memo = ex.setdefault("_kernels", {})
         blk = 256 if not long_rows or K < 16384 else (512 if K < 65536 else 1024)
-        mkey = (tuple(ext), L, V, nch, len(lsh), self.dry_run, long_rows, blk)
+        # streaming policy (BIG_STREAM): full operands of 96 MiB or more are read once, with
+        # non-temporal loads (AESARA_HIP_RC_NT forces it on / off for the A/B)
+        big = N * K * width >= self.BIG_STREAM and not long_rows
+        if knobs.is_set("RC_NT"):
+            big = bool(int(knobs.get("RC_NT"))) and not long_rows
+        mkey = (tuple(ext), L, V, nch, len(lsh), self.dry_run, long_rows, blk, big)
         hit = memo.get(mkey)
         if hit is None:
-            spec = cg.RowChainSpec(ext, spec_members, L, V, nch, lnd=len(lsh), block=blk)
+            spec = cg.RowChainSpec(ext, spec_members, L, V, nch, lnd=len(lsh), block=blk, nt=big)
             key = ("long-" if long_rows else "") + spec.key()
             ent = _Kernels.cache.get(key) if not self.dry_run else \
                 ([None] if key in _Kernels.compiled else None)

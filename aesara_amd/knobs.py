@@ -40,6 +40,8 @@ _def("FASTDIV", 2, int, "x / c for a loop-invariant RUN-TIME c (a broadcast scal
      "term of the kernel's own floating-point sum through continuous functions (codegen.sum_only_nodes: a result that "
      "already depends on the order of summation), IEEE everywhere else — any quotient that is stored, compared, rounded "
      "or cast is exact.  Config 2 (r06, one box): 26.9 us per eval with 0, 24.8 with 1 / 2")
+_def("RC_NT", None, int, "row chains: non-temporal loads of the full operands (default: operands of 96 MiB or more; "
+     "0 / 1 forces it)")
 _def("EARLY", 1, int, "flat full reductions issue their first loads before the invariant prologue")
 _def("RED_BLOCKED", 2, int, "flat full reductions: 0 grid-stride walk, 1 one contiguous chunk per workgroup, "
      "2 (default) chunks ordered so that every XCD streams one contiguous eighth (r04 sweeps: 27.1 vs 27.7 us)")
@@ -69,6 +71,8 @@ _def("SP_SLEEP", 1, int, "s_sleep between polls of the vector-state kernel")
 _def("SP_DELAY", 15, int, "vector-state kernel: s_sleep units (64 cycles) before the first poll of a hand-off "
      "(config 4 B = 1, 128 x 8 rows, 2 polling waves: 4.59 us per step with 0, 4.05 with 12, 4.27 with 20; "
      "256 x 4 rows, 4 polling waves: 3.52 / 3.42 / 3.38 / 3.37 / 3.43 with 10 / 12 / 14 / 16 / 18)")
+_def("SP_EARLYDOTS", 1, int, "vector-state kernel: products on operands staged by an earlier phase of the step are "
+     "issued in front of the phase's hand-off wait (0: behind it, the round-5 order)")
 _def("SP_TRACE", 0, int, "vector-state kernel: stamp s_memtime at the phase marks (tools/sp_trace.py)")
 _def("SM_CHUNK", 32, int, "k-chunk of the matrix-state kernel's exchange")
 _def("SM_XMODE", None, str, "exchange form of the matrix-state kernel: frag | flag (default by registers)")

@@ -467,7 +467,7 @@ class Spec:
 
     def key(self):
         pr = self.prog
-        blob = json.dumps(["sp8" + ("t" if self.trace else ""), sorted(self.prog.older.items()), self.dtype, sorted(self.var.items()), sorted(self.place.items()), self.M, sorted(self.Ks.items()), sorted(self.lens.items()),
+        blob = json.dumps(["sp9" + ("t" if self.trace else "") + ("" if int(knobs.get("SP_EARLYDOTS")) else "n"), sorted(self.prog.older.items()), self.dtype, sorted(self.var.items()), sorted(self.place.items()), self.M, sorted(self.Ks.items()), sorted(self.lens.items()),
                            self.R, self.nw, sorted(pr.seq.items()), sorted(pr.state.items()),
                            sorted(pr.nsq.items()), sorted(pr.mats.items()),
                            [[ph["dots"], ph["ins"], ph["outs"], ph["scalar"], ph["out_refs"]]
@@ -689,10 +689,61 @@ def generate(spec: Spec):
                          % (guard, so, q * PT, q))
         return delayed
 
+    def emit_dot(pi, d, a_, x):
+        """accumulate dot d of phase pi: rows of matrix a_ (LDS or VGPRs) times the staged vector x"""
+        K = spec.Ks[a_]
+        K4 = K // VEC
+        if x in pr.nsq:
+            vsrc = "Il + %d" % inv_stage[x]
+        else:
+            kind = "prev" if x in pr.state else ("cur" if x not in pr.seq else "glob")
+            vsrc = "Vl[par] + %d" % stage[(x, kind)]
+        for i in range(RPW):
+            L.append("    %s acc%d_%d_%d = 0;" % (T, pi, d, i))
+        if a_ in in_reg:
+            slot = pr.mats[a_]
+            L.append("    {")
+            L.append("      const %s* vx = %s;" % (T, vsrc))
+            for q in range(K4 // 64):
+                L.append("      { const TV xv = *(const TV*)(vx + %d * (lane + %d));" % (VEC, 64 * q))
+                for i in range(RPW):
+                    L.append("        acc%d_%d_%d += %s;" % (pi, d, i, vdot("wr%d_%d_%d" % (slot, i, q), "xv")))
+                L.append("      }")
+            L.append("    }")
+            return
+        L.append("    {")
+        L.append("      const %s* vx = %s;" % (T, vsrc))
+        L.append("      const %s* wr = Wl + %d + (wave * %d) * %d;" % (T, woff[a_], RPW, K))
+        L.append("#pragma unroll")
+        L.append("      for (int k4 = lane; k4 < %d; k4 += 64) {" % K4)
+        L.append("        const TV xv = *(const TV*)(vx + %d * k4);" % VEC)
+        for i in range(RPW):
+            L.append("        { const TV wv = *(const TV*)(wr + %d + %d * k4); acc%d_%d_%d += %s; }"
+                     % (i * K, VEC, pi, d, i, vdot("wv", "xv")))
+        L.append("      }")
+        L.append("    }")
+
     staged_this_step = set()
     for pi, ph in enumerate(pr.phases):
         L.append("    // ---- phase %d" % pi)
         stamp("p%d start" % pi)
+        # -- dots whose vector operand is ALREADY staged (the state gathered by an earlier phase of
+        #    this step, an invariant vector) go in front of this phase's hand-off: their LDS reads and
+        #    FMAs run while the granules this phase waits for are still on their way (GRU: the z-gate
+        #    product U_z h sits in the phase that waits for r * h)
+        early_dots = set()
+        if int(knobs.get("SP_EARLYDOTS")):
+            for d, (a_, x) in enumerate(ph["dots"]):
+                if x in pr.nsq or (x, "prev" if x in pr.state else ("cur" if x not in pr.seq else "glob")) \
+                        in staged_this_step:
+                    early_dots.add(d)
+            if len(early_dots) == len(ph["dots"]):
+                early_dots = set()            # nothing to wait for in this phase: the plain order
+            for d, (a_, x) in enumerate(ph["dots"]):
+                if d in early_dots:
+                    emit_dot(pi, d, a_, x)
+            if early_dots:
+                stamp("p%d early dots" % pi)
         # -- gather the dot vectors that are not staged yet
         need_sync = False
         delayed = False     # the first exchanged operand of a phase waits before its first poll
@@ -738,37 +789,8 @@ def generate(spec: Spec):
         # -- row dots: wavefront `wave` owns rows wave*RPW .. +RPW
         D = len(ph["dots"])
         for d, (a_, x) in enumerate(ph["dots"]):
-            K = spec.Ks[a_]
-            K4 = K // VEC
-            if x in pr.nsq:
-                vsrc = "Il + %d" % inv_stage[x]
-            else:
-                kind = "prev" if x in pr.state else ("cur" if x not in pr.seq else "glob")
-                vsrc = "Vl[par] + %d" % stage[(x, kind)]
-            for i in range(RPW):
-                L.append("    %s acc%d_%d_%d = 0;" % (T, pi, d, i))
-            if a_ in in_reg:
-                slot = pr.mats[a_]
-                L.append("    {")
-                L.append("      const %s* vx = %s;" % (T, vsrc))
-                for q in range(K4 // 64):
-                    L.append("      { const TV xv = *(const TV*)(vx + %d * (lane + %d));" % (VEC, 64 * q))
-                    for i in range(RPW):
-                        L.append("        acc%d_%d_%d += %s;" % (pi, d, i, vdot("wr%d_%d_%d" % (slot, i, q), "xv")))
-                    L.append("      }")
-                L.append("    }")
-                continue
-            L.append("    {")
-            L.append("      const %s* vx = %s;" % (T, vsrc))
-            L.append("      const %s* wr = Wl + %d + (wave * %d) * %d;" % (T, woff[a_], RPW, K))
-            L.append("#pragma unroll")
-            L.append("      for (int k4 = lane; k4 < %d; k4 += 64) {" % K4)
-            L.append("        const TV xv = *(const TV*)(vx + %d * k4);" % VEC)
-            for i in range(RPW):
-                L.append("        { const TV wv = *(const TV*)(wr + %d + %d * k4); acc%d_%d_%d += %s; }"
-                         % (i * K, VEC, pi, d, i, vdot("wv", "xv")))
-            L.append("      }")
-            L.append("    }")
+            if d not in early_dots:
+                emit_dot(pi, d, a_, x)
         if D:
             L.append("    for (int s = 32; s > 0; s >>= 1) {")
             for d in range(D):

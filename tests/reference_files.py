@@ -223,7 +223,7 @@ def run(executor, files=None, workers=4, timeout=3000, extra=()):
     # (--timeout: pytest-timeout — a test that hangs on the device is reported as a failure of THAT
     # test instead of costing the whole run its time limit)
     cmd = [sys.executable, "-m", "pytest", "-p", "hip_suite_plugin", "-q", "--tb=no", "-p",
-           "no:cacheprovider", "-W", "ignore", "--timeout", os.environ.get("AESARA_HIP_SUITE_TEST_TIMEOUT", "240")] + \
+           "no:cacheprovider", "-W", "ignore", "--timeout", os.environ.get("AESARA_HIP_SUITE_TEST_TIMEOUT", "600")] + \
         (["-n", str(workers)] if workers > 1 else []) + list(extra) + files
     try:
         p = subprocess.run(cmd, cwd=overlay_dir(), env=env, capture_output=True, text=True,
@@ -245,6 +245,14 @@ def environment_failures():
         return {}
     with open(ENV_FILE) as f:
         return json.load(f)["failed"]
+
+
+# messages that are the ENVIRONMENT's whatever the linker under test (checked before everything else)
+_ENV_RULES = [
+    (re.compile(r"Key not found in unpickled KeyData file"),
+     "race in the REFERENCE'S OWN C-module cache (link/c/cmodule.py: key.pkl written by one pytest worker "
+     "while another reads it); the test compiles a comparison function with the C linker"),
+]
 
 
 def classify(report):
@@ -277,6 +285,11 @@ def classify(report):
                         pf["executed_hip"] += 1
             continue
         pf["not_passed"] += 1
+        envr = next((why for rx, why in _ENV_RULES if rx.search(msg)), None)
+        if envr is not None:
+            counts["environment"] += 1
+            detail["environment"][nid] = envr[:120]
+            continue
         na = next((why for pre, why in NOT_APPLICABLE.items()
                    if (nid.startswith(pre[:-1]) if pre.endswith("*") else nid == pre or nid.startswith(pre + "["))),
                   None)

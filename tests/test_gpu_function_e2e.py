@@ -80,7 +80,7 @@ def test_golden_case_through_aesara_function(gg, ae, name):
     import torch
     c = BY_NAME[name]
     ins, outs, _specs = _builder(gg, name)()
-    f = ae.function(ins, outs, mode="HIP", on_unused_input="ignore")
+    f = ae.function(ins, outs, mode="HIP", on_unused_input="ignore", accept_inplace=True)
     from aesara_amd.executor import PlanExecutor
     ex = f.maker.linker.executor
     assert isinstance(ex, PlanExecutor) and not ex.dry_run          # the real thing, no checker
