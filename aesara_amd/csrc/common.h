@@ -49,6 +49,7 @@ void ahip_gemm_set_half_max_tiles(int64_t v);  // 64x64-tile window (ahip_set_pa
 void ahip_gemm_set_half_min_tiles(int64_t v);
 void ahip_gemm_set_half_ksplit(int64_t v);     // K groups inside a 64x64-tile workgroup (1 / 2 / 4)
 void ahip_gemm_set_skinny_nf(int64_t v);  // gemm.hip tuning knob (ahip_set_param)
+void ahip_copy_set_stream_bytes(int64_t v);     // copy.hip: streaming loads from this many bytes on (ahip_set_param)
 void ahip_gemv_set_col_blocks_per_cu(int64_t v);  // gemv.hip tuning knobs (ahip_set_param)
 void ahip_gemv_set_col_strip_lanes(int64_t v);
 void ahip_index_set_argmax_max_slices(int64_t v);

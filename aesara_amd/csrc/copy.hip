@@ -24,7 +24,9 @@ template <typename T, int VEC> struct alignas(sizeof(T) * VEC) Pack { T v[VEC]; 
 template <typename T> __device__ __forceinline__ T acc_add(T a, T b) { return a + b; }
 template <> __device__ __forceinline__ bool acc_add<bool>(bool a, bool b) { return a || b; }
 
-template <typename T, int VEC, bool ACC>
+// NT: the source is read once and is too large to stay in the memory-side cache (the streaming
+// policy of the generated kernels, exec_elemwise.BIG_STREAM): non-temporal 16-byte loads
+template <typename T, int VEC, bool ACC, bool NT = false>
 __global__ __launch_bounds__(256) void copy_kernel(CopyArgs a) {
   const T* __restrict__ src = static_cast<const T*>(a.src);
   T* __restrict__ dst = static_cast<T*>(a.dst);
@@ -47,7 +49,14 @@ __global__ __launch_bounds__(256) void copy_kernel(CopyArgs a) {
       dst[dof] = v;
     } else {
       using P = Pack<T, VEC>;
-      P v = *reinterpret_cast<const P*>(src + so);
+      P v;
+      if constexpr (NT && sizeof(P) == 16) {
+        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+        const u4 raw = __builtin_nontemporal_load(reinterpret_cast<const u4*>(src + so));
+        v = __builtin_bit_cast(P, raw);
+      } else {
+        v = *reinterpret_cast<const P*>(src + so);
+      }
       if constexpr (ACC) {
         P o = *reinterpret_cast<const P*>(dst + dof);
 #pragma unroll
@@ -70,6 +79,8 @@ __global__ __launch_bounds__(256) void fill_kernel(FillArgs f) {
     dst[i] = value;
 }
 
+int64_t g_copy_stream_bytes = 96LL << 20;   // copies of at least this many bytes read their source with streaming loads
+
 unsigned stream_grid(int64_t items) {
   int64_t want = (items + 255) / 256;
   int64_t cap = (int64_t)ahip_cu_count() * 8;
@@ -82,7 +93,9 @@ template <typename T, bool ACC>
 int launch_copy(CopyArgs& a, int vec, hipStream_t s) {
   unsigned grid = stream_grid(a.items);
   constexpr int MAXV = 16 / sizeof(T);
-  if (vec == MAXV && MAXV > 1)
+  if (vec == MAXV && MAXV > 1 && !ACC && a.items * 16 >= g_copy_stream_bytes)
+    AHIP_LAUNCH((copy_kernel<T, MAXV, ACC, true>), dim3(grid), dim3(256), 0, s, a);
+  else if (vec == MAXV && MAXV > 1)
     AHIP_LAUNCH((copy_kernel<T, MAXV, ACC>), dim3(grid), dim3(256), 0, s, a);
   else
     AHIP_LAUNCH((copy_kernel<T, 1, ACC>), dim3(grid), dim3(256), 0, s, a);
@@ -118,6 +131,8 @@ __global__ __launch_bounds__(256) void arange_kernel(ArangeArgs a) {
 }
 
 }  // namespace
+
+void ahip_copy_set_stream_bytes(int64_t v) { g_copy_stream_bytes = v; }
 
 extern "C" {
 

@@ -72,6 +72,7 @@ int ahip_set_param(const char* name, int64_t value) {
   else if (!strcmp(name, "gemm_half_max_tiles")) ahip_gemm_set_half_max_tiles(value);
   else if (!strcmp(name, "gemm_half_min_tiles")) ahip_gemm_set_half_min_tiles(value);
   else if (!strcmp(name, "gemm_half_ksplit")) ahip_gemm_set_half_ksplit(value);
+  else if (!strcmp(name, "copy_stream_bytes")) ahip_copy_set_stream_bytes(value);
   else if (!strcmp(name, "gemv_col_blocks_per_cu")) ahip_gemv_set_col_blocks_per_cu(value);
   else if (!strcmp(name, "gemv_col_strip_lanes")) ahip_gemv_set_col_strip_lanes(value);
   else if (!strcmp(name, "argmax_max_slices")) ahip_index_set_argmax_max_slices(value);

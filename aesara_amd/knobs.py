@@ -57,6 +57,8 @@ _def("ARGMAX_SLICES", None, int, "maximum slices of a column argmax")
 _def("GEMM_GROUP", None, int, "tile-group width of the GEMM's XCD-aware block order")
 _def("GEMM_HALF_MAX", None, int, "largest 128x128-tile count that still takes the 64x64 tile")
 _def("GEMM_HALF_MIN", None, int, "smallest 128x128-tile count that takes the 64x64 tile")
+_def("COPY_STREAM_BYTES", None, int, "strided copies of at least this many bytes read their source with non-temporal "
+     "loads (default 96 MiB, the streaming policy; a huge value switches it off)")
 _def("GEMM_HALF_KSPLIT", None, int, "K groups inside a 64x64-tile workgroup (default: 4 up to one workgroup per CU, "
      "2 up to two, else 1; 1 / 2 / 4 forces it)")
 _def("GE_WAVES", 0, int, "waves per workgroup of the generated GEMM epilogue (0: automatic)")
