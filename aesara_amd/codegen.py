@@ -800,7 +800,9 @@ class KernelSpec:
         self.blocked = int(knobs.get("RED_BLOCKED") if blocked is None else blocked) if flat_all else 0
         # plain flat Elemwise streams (no reduction): the same walks, off unless measured better
         if reduce is None and tile_dim is None and nd == 1 and vec > 1:
-            self.blocked = int(knobs.get("STREAM_BLOCKED") if blocked is None else blocked)
+            # (plain Elemwise streams keep the grid-stride walk: the blocked walks lose there,
+            # profiles/r04_cfg1b_stream_walks.txt — the STREAM_BLOCKED switch is gone)
+            self.blocked = int(0 if blocked is None else blocked)
         if self.hjobs:
             assert flat_all and len(in_dtypes) + len(out_dtypes) <= 6, "hjobs: flat full reductions only"
             self.blocked = 1                    # a contiguous chunk per workgroup inside its job

@@ -28,8 +28,6 @@ _def("NT", 0, int, "bit 0: non-temporal loads, bit 1: non-temporal stores (flat 
 _def("VECBYTES", 32, int, "bytes per lane per iteration of a flat stream (unset: 16 for operands of 96 MiB or more, see NT)")
 _def("BLOCK", 256, int, "threads per workgroup of Elemwise kernels")
 _def("RED_BLOCK", None, int, "threads per workgroup of full reductions (default 1024)")
-_def("RED_UNROLL", 1, int, "axis-reduce loop unroll (1 = the default 8)")
-_def("COL_LANES", 128, int, "column-reduce strip width in lanes")
 _def("TILED", 1, int, "LDS-tiled form for transposed operands")
 _def("FASTEXP", 1, int, "float64 exp through the 64-entry table in LDS (0: ocml's exp)")
 _def("FASTDIV", 2, int, "x / c for a loop-invariant RUN-TIME c (a broadcast scalar divisor; constant divisors never "
@@ -45,7 +43,6 @@ _def("RC_NT", None, int, "row chains: non-temporal loads of the full operands (d
 _def("EARLY", 1, int, "flat full reductions issue their first loads before the invariant prologue")
 _def("RED_BLOCKED", 2, int, "flat full reductions: 0 grid-stride walk, 1 one contiguous chunk per workgroup, "
      "2 (default) chunks ordered so that every XCD streams one contiguous eighth (r04 sweeps: 27.1 vs 27.7 us)")
-_def("STREAM_BLOCKED", 0, int, "flat Elemwise streams: 0 grid-stride, 1 contiguous chunk per workgroup, 2 XCD-contiguous")
 _def("EW_TRACE", 0, int, "full reductions stamp s_memrealtime per workgroup into the workspace (tools/ew_trace.py)")
 _def("HFUSE", 1, int, "horizontal fusion of independent same-shape Elemwise/CAReduce steps into one launch")
 # ---- launch shapes owned by the C side (ahip_set_param) ----------------------------------------

@@ -648,17 +648,17 @@ def test_product_accumulators_leave_the_loop_as_one_product(name):
 
 
 def test_design_lists_every_switch_of_the_registry():
-    """DESIGN §3.5's table is generated from ``aesara_amd/knobs.py`` (``knobs.table()``): every
-    registered switch appears there with its current default, and nothing outside the registry
-    reads ``AESARA_HIP_*`` from the environment."""
+    """The switch table (``docs/SWITCHES.md``, DESIGN §3.5 points at it) is generated from
+    ``aesara_amd/knobs.py`` (``knobs.table()``): every registered switch appears there with its
+    current default, and nothing outside the registry reads ``AESARA_HIP_*`` from the environment."""
     import os
     import re
     from aesara_amd import knobs
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    design = open(os.path.join(root, "DESIGN.md")).read()
+    design = open(os.path.join(root, "docs", "SWITCHES.md")).read()
     for name, default, _cur, _doc in knobs.table():
         m = re.search(r"\| `%s` \| ([^|]*) \|" % re.escape(name), design)
-        assert m, f"{name} missing from DESIGN §3.5"
+        assert m, f"{name} missing from docs/SWITCHES.md"
         assert m.group(1).strip() == ("—" if default is None else str(default)), (name, m.group(1), default)
     pkg = os.path.join(root, "aesara_amd")
     for fn in os.listdir(pkg):

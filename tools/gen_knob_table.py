@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Rewrite DESIGN.md's switch table (§3.5) from the registry ``aesara_amd/knobs.py``."""
+"""Rewrite the switch table ``docs/SWITCHES.md`` (DESIGN.md §3.5 points at it) from the registry
+``aesara_amd/knobs.py``."""
 import os
 import re
 import sys
@@ -8,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from aesara_amd import knobs  # noqa: E402
 
-path = os.path.join(ROOT, "DESIGN.md")
+path = os.path.join(ROOT, "docs", "SWITCHES.md")
 src = open(path).read()
 head = "| switch | default | what |\n|---|---|---|\n"
 i = src.index(head) + len(head)
