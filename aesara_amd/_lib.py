@@ -165,6 +165,8 @@ SIGNATURES = {
                                             sz, vp, vp]),
     "ahip_sort_max_row": (i32, [i32]),
     "ahip_sort_rows": (i32, [i32, vp, i64, i64, i64, i64, vp, vp, vp]),
+    "ahip_sort_large_ws_bytes": (sz, [i32, i64, i64]),
+    "ahip_sort_rows_large": (i32, [i32, vp, i64, i64, i64, i64, vp, vp, vp, sz, vp]),
     "ahip_nonzero_write": (i32, [vp, i64, i32, p_i64, p_vp, vp]),
     "ahip_argmax_ws_bytes": (sz, [i32, i64, i64, i64, i64]),
     "ahip_argmax_rows": (i32, [i32, vp, i64, i64, i64, i64, vp, vp, sz, vp]),

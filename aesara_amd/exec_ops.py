@@ -465,10 +465,17 @@ class OpsMixin:
             rs = n
         else:
             rs = ost[0][0]
-        if n > int(lib.ahip_sort_max_row(dtype_code(x.dtype))):
-            raise NotImplementedError(f"sort along an axis of {n} elements (the row must fit in LDS)")
         out = self.alloc(lead + [n], "int64" if want_idx else x.dtype)
-        if out.size:
+        if out.size and n > int(lib.ahip_sort_max_row(dtype_code(x.dtype))):
+            # rows longer than LDS: chunks sorted in LDS, then rank-based merge passes
+            need = int(lib.ahip_sort_large_ws_bytes(dtype_code(x.dtype), rows, n))
+            ws = self.alloc((need,), "uint8")
+            self._launch("ahip_sort_rows_large", (dtype_code(x.dtype), _VP(v.ptr), rows, n, rs,
+                                                  v.strides[-1] if n > 1 else 1,
+                                                  None if want_idx else _VP(out.ptr),
+                                                  _VP(out.ptr) if want_idx else None, _VP(ws.ptr),
+                                                  need, self._stream()))
+        elif out.size:
             self._launch("ahip_sort_rows", (dtype_code(x.dtype), _VP(v.ptr), rows, n, rs,
                                             v.strides[-1] if n > 1 else 1,
                                             None if want_idx else _VP(out.ptr),

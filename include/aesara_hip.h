@@ -406,6 +406,13 @@ int ahip_scatter_add_rows_ordered(int dtype, void* dst, int64_t nrows, int64_t d
 int ahip_sort_max_row(int dtype);
 int ahip_sort_rows(int dtype, const void* x, int64_t rows, int64_t n, int64_t x_rs, int64_t x_cs,
                    void* keys_out, int64_t* idx_out, void* stream);
+/* rows LONGER than ahip_sort_max_row(): chunks of that many elements are sorted in LDS, then merged by
+ * log2(n / chunk) rank-based merge passes (one binary search per element; ties to the left run: the
+ * stable order).  `ws`: 16-byte aligned workspace of ahip_sort_large_ws_bytes() bytes (two key and two
+ * int64 position images of the [rows, n] array).                                                   */
+size_t ahip_sort_large_ws_bytes(int dtype, int64_t rows, int64_t n);
+int ahip_sort_rows_large(int dtype, const void* x, int64_t rows, int64_t n, int64_t x_rs, int64_t x_cs,
+                         void* keys_out, int64_t* idx_out, void* ws, size_t ws_bytes, void* stream);
 /* Nonzero, replaces tensor/basic.py:845 Nonzero (perform :870 np.nonzero) and boolean-mask
  * indexing built on it.  `counts` is the inclusive running count of set entries over the
  * C-order flattened array (n entries; the caller makes it with ahip_cumulative and reads

@@ -2058,6 +2058,23 @@ def _():
         [I((5, 7), "int64", 1, -9, 9), N((5, 7), seed=2)]
 
 
+@case("sort_rows_longer_than_lds", exact=True)
+def _():
+    # tensor/sort.py:29 SortOp / :150 ArgSortOp on rows that do not fit a workgroup's LDS (chunk sort +
+    # merge passes, csrc/sort.hip): NaNs last, ties in input order (stable), ragged lengths, several
+    # rows, an int8 row with many ties, and the Ops built on the sort (Unique, TopK) at that size
+    from aesara.tensor.sort import argtopk, topk
+    x, m, k8, ki = at.dvector("x"), at.fmatrix("m"), at.bvector("k8"), at.ivector("ki")
+    return [x, m, k8, ki], [
+        at.sort(x), at.argsort(x, kind="stable"), at.sort(m, axis=1), at.argsort(m, axis=0, kind="stable"),
+        at.sort(k8), at.argsort(k8, kind="stable"),
+        _xo.Unique(True, True, True)(ki)[0], _xo.Unique(True, True, True)(ki)[1],
+        _xo.Unique(True, True, True)(ki)[2], _xo.Unique(True, True, True)(ki)[3],
+        at.sort(topk(x[:20000], 777, sorted=False))], \
+        [{"kind": "normal_with_nan", "seed": 11, "shape": [33333], "dtype": "float64"},
+         N((3, 20011), "float32", 12), I((70001,), "int8", 13, -128, 127), I((50000,), "int32", 14, -3000, 3000)]
+
+
 def _close(a, b, exact, rtol, atol):
     a, b = np.asarray(a), np.asarray(b)
     if a.shape != b.shape or a.dtype != b.dtype:
