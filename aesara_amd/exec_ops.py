@@ -485,6 +485,26 @@ class OpsMixin:
         inv = [perm.index(d) for d in range(x.ndim)]
         return [out.view([out.shape[q] for q in inv], [out.strides[q] for q in inv])]
 
+    def _op_LexArgSortRows(self, node, args):
+        """Stable LEXICOGRAPHIC argsort of the rows of a matrix (first column most significant):
+        what ``np.unique(x, axis=k)`` orders its items by (tensor/extra_ops.py:1216).  One stable
+        argsort per column, last column first (LSD), each on the column gathered through the
+        permutation so far — the sort / gather kernels, no new one."""
+        x = self.to_device(args[0])
+        if x.ndim != 2:
+            raise ValueError("LexArgSortRows needs a matrix")
+        n, m = x.shape
+
+        class _P:
+            params = {"dtype": "int64"}
+        perm = self._op_ARange(_P, [np.int64(0), np.int64(n), np.int64(1)])[0]
+        for c in range(m - 1, -1, -1):
+            col = x.view((n,), (x.strides[0],), x.offset + c * x.strides[1])
+            keys = self._op_AdvancedSubtensor1(None, [col, perm])[0]
+            order = self._sort(None, [keys, np.int64(0)], True)[0]
+            perm = self._op_AdvancedSubtensor1(None, [perm, order])[0]
+        return [perm]
+
     def _op_Sort(self, node, args):
         return self._sort(node, args, False)
 

@@ -249,31 +249,58 @@ def register(hip_lower, static_shape, UnsupportedOp):                       # no
         # distances between run starts
         b = B(ctx)
         x = node.inputs[0]
-        if op.axis is not None and x.type.ndim != 1:
-            raise UnsupportedOp("Unique along an axis of a matrix / tensor (rows as items)")
         dt = str(x.type.dtype)
-        xf = b.flatten(ctx.vid(x))
-        n = b.shape_i(xf, 0)
+        rows_as_items = op.axis is not None and x.type.ndim != 1
         ax = b.const(0, "int64")
-        need_perm = op.return_index or op.return_inverse
-        if need_perm:
-            perm = b.raw("ArgSort", [xf, ax], "int64", [None], {"kind": "stable"})
-            xs = b.take_rows(xf, perm)
+        need_perm = op.return_index or op.return_inverse or rows_as_items
+        if rows_as_items:
+            # np.unique(x, axis=k): the slices along axis k are the items, ordered lexicographically
+            # (NumPy sorts them as records): axis k to the front, items flattened to rows, a
+            # LEXICOGRAPHIC stable argsort of the rows (LexArgSortRows: one stable column argsort
+            # per column, last column first), then the vector recipe with "row differs from the
+            # previous row" as the run-start flag
+            nd = x.type.ndim
+            k = int(op.axis) % nd
+            order = [k] + [d for d in range(nd) if d != k]
+            xt = b.dimshuffle(ctx.vid(x), order) if k else ctx.vid(x)
+            other = [b.shape_i(ctx.vid(x), d) for d in range(nd) if d != k]
+            n = b.shape_i(ctx.vid(x), k)
+            rows = b.reshape(xt, [n, b.lit(-1)])
+            perm = b.raw("LexArgSortRows", [rows], "int64", [None])
+            xs = b.take_rows(rows, perm)
+            hi2, lo2 = b.subtensor(xs, [slice(1, None, None)]), b.subtensor(xs, [slice(None, -1, None)])
+            ne2 = b.ew([hi2, lo2], "bool", [None, None], [("neq", "bool", [["i", 0], ["i", 1]])])
+            ne = b.careduce(ne2, "or", [1], "bool", "bool")
+            xf = None
         else:
-            xs = b.raw("Sort", [xf, ax], dt, [None], {"kind": "quicksort"})
-        hi, lo = b.subtensor(xs, [slice(1, None, None)]), b.subtensor(xs, [slice(None, -1, None)])
-        if dt.startswith("float"):
-            ne = b.ew([hi, lo], "bool", [None], [
-                ("neq", "bool", [["i", 0], ["i", 1]]), ("isnan", "bool", [["i", 0]]),
-                ("isnan", "bool", [["i", 1]]), ("and", "bool", [["t", 1], ["t", 2]]),
-                ("invert", "bool", [["t", 3]]), ("and", "bool", [["t", 0], ["t", 4]])])
-        else:
-            ne = b.ew([hi, lo], "bool", [None], [("neq", "bool", [["i", 0], ["i", 1]])])
+            xf = b.flatten(ctx.vid(x))
+            n = b.shape_i(xf, 0)
+            if need_perm:
+                perm = b.raw("ArgSort", [xf, ax], "int64", [None], {"kind": "stable"})
+                xs = b.take_rows(xf, perm)
+            else:
+                xs = b.raw("Sort", [xf, ax], dt, [None], {"kind": "quicksort"})
+            hi, lo = b.subtensor(xs, [slice(1, None, None)]), b.subtensor(xs, [slice(None, -1, None)])
+            if dt.startswith("float"):
+                ne = b.ew([hi, lo], "bool", [None], [
+                    ("neq", "bool", [["i", 0], ["i", 1]]), ("isnan", "bool", [["i", 0]]),
+                    ("isnan", "bool", [["i", 1]]), ("and", "bool", [["t", 1], ["t", 2]]),
+                    ("invert", "bool", [["t", 3]]), ("and", "bool", [["t", 0], ["t", 4]])])
+            else:
+                ne = b.ew([hi, lo], "bool", [None], [("neq", "bool", [["i", 0], ["i", 1]])])
         first = b.plan.add_const(np.ones((1,), "bool"), "bool")
         flag = b.raw("Subtensor", [b.join(0, [first, ne]), n], "bool", [None],
                      {"idx_list": [{"slice": [None, "in", None]}]})          # (n == 0: no run)
         pos = b.multi("Nonzero", [flag], [("int64", [None])])[0]
-        outs = [b.take_rows(xs, pos)]
+        uniq = b.take_rows(xs, pos)
+        if rows_as_items:
+            nu = b.shape_i(uniq, 0)
+            u = b.reshape(uniq, [nu] + other)
+            if k:
+                back = list(range(1, k + 1)) + [0] + list(range(k + 1, nd))
+                u = b.dimshuffle(u, back)
+            uniq = u
+        outs = [uniq]
         if op.return_index:
             outs.append(b.take_rows(perm, pos))
         if op.return_inverse:

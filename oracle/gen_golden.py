@@ -2075,6 +2075,17 @@ def _():
          N((3, 20011), "float32", 12), I((70001,), "int8", 13, -128, 127), I((50000,), "int32", 14, -3000, 3000)]
 
 
+@case("unique_rows_as_items", exact=True)
+def _():
+    # tensor/extra_ops.py:1152 Unique with an axis: the slices along it are the items (np.unique(x, axis=k):
+    # lexicographic order of the rows / columns), all four outputs, a 3-d input along its middle axis
+    m, t = at.imatrix("m"), at.ltensor3("t")
+    u0 = _xo.Unique(True, True, True, axis=0)(m)
+    u1 = _xo.Unique(True, True, True, axis=1)(m)
+    return [m, t], list(u0) + list(u1) + [_xo.Unique(False, False, False, axis=1)(t)], \
+        [I((40, 3), "int32", 21, 0, 3), I((5, 17, 2), "int64", 22, 0, 2)]
+
+
 def _close(a, b, exact, rtol, atol):
     a, b = np.asarray(a), np.asarray(b)
     if a.shape != b.shape or a.dtype != b.dtype:

@@ -599,6 +599,11 @@ def run_plan(plan, inputs):
             # reference: printing.py:863 Print.perform / compile/ops.py:258 FromFunctionOp.perform
             res = p["fn"](*a)
             r = [a[0]] if p.get("view") else [np.asarray(x) for x in res]
+        elif op == "LexArgSortRows":
+            # the order np.unique(x, axis=k) gives its items (tensor/extra_ops.py:1216): rows as
+            # records, first column most significant; np.lexsort is stable, last key primary
+            xx = np.asarray(a[0])
+            r = [np.lexsort(xx.T[::-1]).astype("int64") if xx.shape[1] else np.arange(xx.shape[0], dtype="int64")]
         elif op == "Nonzero":
             # reference: tensor/basic.py:870 Nonzero.perform
             r = [np.asarray(i, dtype="int64") for i in np.nonzero(np.asarray(a[0]))]

@@ -166,9 +166,6 @@ _RULES = [
      "NotImplementedError, scalar/math.py:276/746/829/940/1031/1290/1478/1510/1655): no compiled path to replace"),
     (re.compile(r"UnsupportedOp: scalar op (TimesN) is outside the HIP hot path"), "out_of_scope",
      "a toy ScalarOp defined inside tests/tensor/rewriting/test_elemwise.py (c_code only)"),
-    (re.compile(r"UnsupportedOp: (Unique along an axis) of a matrix / tensor"), "out_of_scope",
-     "PARTIAL LOWERING: Unique is lowered for vectors / the flattened form (axis=None); rows-as-items "
-     "(np.unique(x, axis=k), tensor/extra_ops.py:1216) needs a lexicographic row sort that is not built"),
     (re.compile(r"UnsupportedOp: CAReduce over scalar op (mean)"), "out_of_scope",
      "the legacy Mean(CAReduce) Op, tensor/math.py:1495 (at.mean() builds Sum / true_div, which is lowered)"),
 ]
