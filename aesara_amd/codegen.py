@@ -835,7 +835,7 @@ class KernelSpec:
     def key(self):
         fields = [self.in_dtypes, self.out_dtypes, self.out_refs, self.inner, self.nd, self.vec,
                   self.block, self.idx64, self.reduce, self.unroll, self.nt, self.invariant,
-                  self.tile_dim, "v11" if self.tile_dim else "v10", self._variant()]
+                  self.tile_dim, "v11" if self.tile_dim else "v10b", self._variant()]
         return _memo_key([self.scalar], fields, self._key)
 
     def _variant(self):
@@ -1452,8 +1452,20 @@ def generate(spec: KernelSpec):
         if red["kind"] == "row":
             assert G <= 64 and 64 % G == 0
             L.append("  const int gl = threadIdx.x %% %d;" % G)
-            L.append("  const i64 o = (i64)blockIdx.x * %d + threadIdx.x / %d;" % (spec.block // G, G))
+            # a workgroup walks the outputs with a grid stride (the launcher caps the grid at a
+            # few workgroups per CU): millions of short rows as one output per thread group would
+            # be bound by the rate at which wavefronts are DISPATCHED (max over 4 194 304 rows of
+            # 8: 32 768 workgroups of one 16-byte load per thread, 32 us = 0.52 of the HBM peak)
+            if red.get("short"):
+                # every output's reduced run is at most one vector per lane (rows of 8 ... 256
+                # elements): the inner loop below runs at most once, so the compiler may keep the
+                # loads of several outputs in flight
+                L.append("#pragma unroll 4")
+            L.append("  for (i64 ob = (i64)blockIdx.x * %d; ob < a.n; ob += (i64)gridDim.x * %d) {" %
+                     (spec.block // G, spec.block // G))
+            L.append("  const i64 o = ob + threadIdx.x / %d;" % G)
             L.append("  const bool valid = o < a.n;")
+            L.append("  acc = %s;" % red_identity(red["op"], red["acc"]))
             L.append("  i64 " + ", ".join("base%d = 0" % k for k in range(nops)) + ";")
             L.append("  if (valid) {")
             L.append("      i64 " + ", ".join("off%d = 0" % k for k in range(nops)) + ";")
@@ -1466,8 +1478,11 @@ def generate(spec: KernelSpec):
             L.append("  const i64 rbeg = (i64)blockIdx.y * per;")
             L.append("  const i64 rend = !valid ? 0 : ((rbeg + per < nredv) ? rbeg + per : nredv);")
             # consecutive iterations are independent: unrolling keeps several loads in flight
-            L.append("#pragma unroll %d" % (U if U > 1 else 8))
-            L.append("  for (i64 r0 = rbeg + gl; r0 < rend; r0 += %d) {" % G)
+            if red.get("short"):
+                L.append("  if (rbeg + gl < rend) { const i64 r0 = rbeg + gl;")
+            else:
+                L.append("#pragma unroll %d" % (U if U > 1 else 8))
+                L.append("  for (i64 r0 = rbeg + gl; r0 < rend; r0 += %d) {" % G)
             L.append("      i64 " + ", ".join("off%d = base%d" % (k, k) for k in range(nops)) + ";")
             L.append("      %s inner = 0;" % idx_t)
             if V > 1:
@@ -1487,6 +1502,7 @@ def generate(spec: KernelSpec):
                      (CTYPE[red["out"]], _store_val("acc", red["acc"], red["out"])))
             L.append("    else ((%s*)a.out)[(i64)blockIdx.y * a.n + o] = acc;" % CTYPE[red["acc"]])
             L.append("  }")
+            L.append("  }")      # (grid-stride walk over the outputs)
         else:
             TX = G
             assert (TX <= 64 and 64 % TX == 0 or TX % 64 == 0) and spec.block % TX == 0

@@ -41,6 +41,7 @@ static int launch(ahip_fn_t k, uint32_t gx, uint32_t gy, uint32_t block, const a
 // grid-stride over the rest (guide: Guideline 11).
 static int64_t g_stream_blocks_per_cu = 8;
 static int64_t g_reduce_blocks_per_cu = 8;
+static int64_t g_reduce_row_blocks_per_cu = 16;   // row-mode axis reductions: resident 256-thread workgroups per CU
 // flat full reductions (ahip_elemwise_reduce_all): 16 wavefronts per CU = ONE 1024-thread workgroup.
 // r04 timeline (tools/ew_trace.py): of two workgroups per CU the second is dispatched 1-3 us late
 // (8192 wavefronts launch at ~20 cycles each per shader engine) and loses every issue arbitration
@@ -63,6 +64,7 @@ size_t ahip_reduce_partials_bytes(void) { return (size_t)AHIP_MAX_PARTIALS * 16;
 size_t ahip_reduce_ws_bytes(void) { return (size_t)AHIP_MAX_PARTIALS * (16 + 64) + 4096; }
 
 int ahip_set_param(const char* name, int64_t value) {
+  if (name != nullptr && !strcmp(name, "reduce_row_blocks_per_cu") && value > 0) { g_reduce_row_blocks_per_cu = value; return AHIP_OK; }
   AHIP_REQUIRE(name != nullptr && value > 0, "bad parameter");
   if (!strcmp(name, "stream_blocks_per_cu")) g_stream_blocks_per_cu = value;
   else if (!strcmp(name, "reduce_blocks_per_cu")) g_reduce_blocks_per_cu = g_reduce_flat_blocks_per_cu = value;
@@ -251,6 +253,10 @@ int ahip_elemwise_reduce_axis(ahip_fn_t k, int mode, int nk, int nr, const int64
     AHIP_REQUIRE(shape[nk + nr - 1] % vec == 0, "reduced inner extent not divisible by vec");
     int groups = block / lanes;
     gx = (nkept + groups - 1) / groups;
+    // the kernel walks the outputs with a grid stride: a few resident workgroups per CU instead
+    // of one tiny workgroup per `groups` outputs (wavefront dispatch, not HBM, bound the latter)
+    const int64_t cap = (int64_t)ahip_cu_count() * g_reduce_row_blocks_per_cu;
+    if (nslices == 1 && gx > cap) gx = cap;
   } else {          // col: `lanes` threads x `vec` adjacent outputs per workgroup
     AHIP_REQUIRE(shape[nk - 1] % vec == 0, "kept inner extent not divisible by vec");
     gx = (nkept / vec + lanes - 1) / lanes;

@@ -885,14 +885,16 @@ class ElemwiseMixin:
         # 128-256 MiB input re-read every call is partly served by the memory-side cache and mixed:
         # up to 6 % faster on five layouts, up to 24 % slower on four, profiles/r05_axisred_nt_ab.txt)
         nt = bool(TUNE["nt"] & 1) or (vec > 1 and self._big_stream(nkept * nred, dtypes[:nin], classes[:nin]))
+        # (row mode, every run at most one vector per lane: the kernel drops its inner loop)
+        short = bool(mode == 0 and nslices == 1 and nred // vec <= lanes)
         mk = ("axis", id(scalar), tuple(out_refs), tuple(dtypes), tuple(classes), nk, nr, vec,
-              idx64, mode, lanes, rspec["op"], rspec["acc"], out_dt, rspec["ref"], nt)
+              idx64, mode, lanes, rspec["op"], rspec["acc"], out_dt, rspec["ref"], nt, short)
         hit = self._ew_memo.get(mk)
         if hit is None:
             spec = cg.KernelSpec(scalar, dtypes[:nin], dtypes[nin:], out_refs, classes,
                                  nk + nr, vec, idx64=idx64, unroll=TUNE["red_unroll"], nt=nt,
                                  reduce=dict(rspec, kind="row" if mode == 0 else "col", nk=nk,
-                                             nr=nr, lanes=lanes, out=out_dt))
+                                             nr=nr, lanes=lanes, out=out_dt, **({"short": True} if short else {})))
             (fn,) = _Kernels.get(spec, load=not self.dry_run)
             if len(self._ew_memo) > 4096:
                 self._ew_memo.clear()

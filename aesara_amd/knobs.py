@@ -46,6 +46,7 @@ _def("RED_BLOCKED", 2, int, "flat full reductions: 0 grid-stride walk, 1 one con
 _def("EW_TRACE", 0, int, "full reductions stamp s_memrealtime per workgroup into the workspace (tools/ew_trace.py)")
 _def("HFUSE", 1, int, "horizontal fusion of independent same-shape Elemwise/CAReduce steps into one launch")
 # ---- launch shapes owned by the C side (ahip_set_param) ----------------------------------------
+_def("RED_ROW_BPC", None, int, "workgroups per CU of row-mode axis reductions that walk many outputs (default 16)")
 _def("RED_BPC", None, int, "256-thread blocks per CU of full reductions")
 _def("STREAM_BPC", None, int, "256-thread blocks per CU of streaming Elemwise kernels")
 _def("GEMV_COL_BPC", None, int, "blocks per CU of the COL gemv")
