@@ -528,9 +528,20 @@ def test_sort_and_argsort_rows_against_torch_stable_sort():
             wv, wi = torch.sort(x, dim=axis, stable=True)
             assert torch.equal(torch.nan_to_num(vals, nan=1e30), torch.nan_to_num(wv, nan=1e30)), (shape, axis, dt)
             assert torch.equal(idx, wi), (shape, axis, dt)
-    ps, _ = plans("float64", 2)
-    with pytest.raises(NotImplementedError):
-        PlanExecutor(ps)(_randn((2, 5000), torch.float64, 1), np.int64(1))
+    # rows longer than LDS (round 6: chunk sort + rank-based merge passes), ragged, with NaNs and ties
+    for shape, axis, dt, tdt in (((2, 5000), 1, "float64", torch.float64), ((3, 100003), 1, "float32", torch.float32),
+                                 ((70001,), 0, "int32", torch.int32), ((1 << 20,), 0, "float32", torch.float32)):
+        if dt.startswith("float"):
+            x = torch.round(_randn(shape, tdt, 7) * 50)            # many ties
+            x.view(-1)[::997] = float("nan")
+        else:
+            x = torch.randint(-2000, 2000, shape, dtype=tdt, device="cuda")
+        ps, pa = plans(dt, len(shape))
+        (vals,) = PlanExecutor(ps)(x, np.int64(axis))
+        (idx,) = PlanExecutor(pa)(x, np.int64(axis))
+        wv, wi = torch.sort(x, dim=axis, stable=True)
+        assert torch.equal(torch.nan_to_num(vals, nan=1e30), torch.nan_to_num(wv, nan=1e30)), (shape, axis, dt)
+        assert torch.equal(idx, wi), (shape, axis, dt)
 
 
 @pytest.mark.parametrize("T,H,B,name", [(64, 256, 1, "gru_bptt_b1_f32"), (24, 128, 16, "gru_bptt_b4_f64"),

@@ -210,5 +210,43 @@ def test_torch_distributed_nccl_backend_world1():
         red = ShardedFunction(lambda b: [b], kinds, group=dist.group.WORLD)
         (o,), hs = red(ring[:8], async_op=True)
         assert hs == [] and o.data_ptr() == ring.data_ptr()     # world 1: nothing to combine
+        _bench_transport_guard(dist, torch)
     finally:
         dist.destroy_process_group()
+
+
+def _bench_transport_guard(dist, torch):
+    """``bench.guard_first_exchange`` (round 6): the first sharded evaluation of the C-ABI transport
+    under a wall-clock guard — an event polled from the host, ``ahip_comm_abort`` and the fall-back
+    decision over ``torch.distributed`` on a time-out or an exception.  (An N > 1 run is what it is
+    for; a box with one GPU exercises every line of it except the collective's peers.)"""
+    import importlib.util
+    import os
+    from aesara_amd._lib import check, lib
+    from aesara_amd.dist import HipComm
+    spec = importlib.util.spec_from_file_location(
+        "bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    buf = torch.ones(64, dtype=torch.float64, device="cuda")
+    # (1) a healthy exchange: completes, the communicator stays
+    g = HipComm(world=1, rank=0)
+    assert bench.guard_first_exchange(lambda: g.all_reduce(buf), g, C, lib, check, torch, dist, 0) is None
+    assert g._h
+    assert bench.wait_for_stream(C, lib, check, torch, 5.0) is True
+    # (2) the exchange raises: the communicator is aborted, the caller is told to fall back
+    def boom():
+        raise RuntimeError("no peer")
+    err = bench.guard_first_exchange(boom, g, C, lib, check, torch, dist, 1)
+    assert err and "no peer" in err and not g._h
+    # (3) the guard's time limit (0 s: "did not complete in time" without waiting): abort + fall-back
+    g2 = HipComm(world=1, rank=0)
+    old = bench.TRANSPORT_GUARD_S
+    bench.TRANSPORT_GUARD_S = 0.0
+    try:
+        err = bench.guard_first_exchange(lambda: g2.all_reduce(buf), g2, C, lib, check, torch, dist, 1)
+    finally:
+        bench.TRANSPORT_GUARD_S = old
+    assert err and "did not complete" in err and not g2._h
+    torch.cuda.synchronize()
+    assert float(buf.sum().item()) == 64.0
