@@ -50,6 +50,23 @@ class ScanMixin:
                 self.scan_modes.update(sub.scan_modes)
                 self.scan_notes.update(sub.scan_notes)
                 return res
+        if self.fuse and TUNE["scan_persist"] and p["n_nit_sot"] and not (
+                p.get("as_while") or p.get("n_shared_outs", 0) or p.get("mit_mot_in_slices")
+                or p["mit_sot_in_slices"] or p["sit_sot_in_slices"]):
+            # no recurrence at all (aesara.map, the row loops of jacobian / hessian / Rop): the step
+            # restated over whole sequences, evaluated ONCE (fusion.batch_map_step)
+            rows = self._inner.get(("rows", key))
+            if rows is None:
+                r = batch_map_step(inner_plan, p["n_seqs"])
+                rows = False
+                if r is not None:
+                    rows = PlanExecutor(r["plan"], use_graph=False, dry_run=self.dry_run, fuse=self.fuse,
+                                        device=None if self.dry_run else self.device.index)
+                self._inner[("rows", key)] = rows
+            if rows:
+                res = self._scan_all_rows(node, p, args, rows)
+                if res is not None:
+                    return res
         ent = self._inner.get(key)
         if ent is None:
             # loop-invariant view/shape nodes of the inner graph (the W.T DimShuffles of every
@@ -91,6 +108,43 @@ class ScanMixin:
         finally:
             inner._arena = None
             inner._capturing = False
+
+    def _scan_all_rows(self, node, p, args, rows):
+        """A Scan without recurrence as ONE evaluation of the step over whole sequences.  None:
+        take the step loop (no steps, a sequence shorter than the trip count — the loop raises the
+        reference's error —, an output buffer longer than the trip count)."""
+        n_seqs, n_nit = p["n_seqs"], p["n_nit_sot"]
+        n_steps = self.host_int(args[0])
+        if n_steps < 1:
+            return None
+        seqs = [self.to_device(a) for a in args[1:1 + n_seqs]]
+        keep = [self.host_int(a) for a in args[1 + n_seqs:1 + n_seqs + n_nit]]
+        if any(sq.shape[0] < n_steps for sq in seqs) or any(L < 1 or L > n_steps for L in keep):
+            return None
+        largs = [sq.view((n_steps,) + tuple(sq.shape[1:]), sq.strides) for sq in seqs]
+        largs += list(args[1 + n_seqs + n_nit:])
+        rows._arena, rows._capturing = self._arena, self._capturing
+        rows._root = self._root or self
+        try:
+            res = [self.to_device(r) for r in rows.run(largs)]
+        finally:
+            rows._arena = None
+            rows._capturing = False
+        self.scan_modes.update(rows.scan_modes)
+        self.scan_notes.update(rows.scan_notes)
+        # every output is a buffer of its own (never a view of an operand or of another output)
+        taken = [a.buf for a in largs if isinstance(a, DevArray)]
+        outs = []
+        for r, L in zip(res, keep):
+            if any(r.buf is b for b in taken):
+                r = self.materialize(r)
+            taken.append(r.buf)
+            if L < n_steps:          # scan_save_mem: only the last L rows are kept (scan/op.py:2105-2134)
+                r = r.view((L,) + tuple(r.shape[1:]), r.strides, r.offset + (n_steps - L) * r.strides[0])
+            outs.append(r)
+        self.scan_modes[node.outputs[0]] = "all-rows"
+        self.scan_notes[node.outputs[0]] = "no recurrence: the step evaluated once over whole sequences"
+        return outs
 
     @staticmethod
     def _mitmot_inplace(inner, n_seqs, mm_in, mm_out):

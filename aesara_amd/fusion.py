@@ -28,6 +28,8 @@ import copy
 from dataclasses import dataclass, field
 from typing import Any, Dict, List, Optional
 
+import numpy as np
+
 from ._lib import AHIP_MAXOPS
 from .plan import Node, Plan
 
@@ -1218,6 +1220,211 @@ def hoist_sequence_only(plan: Plan, seq_inputs: List[int], invariant: set):
     lp.outputs = [m[("r", o)] for o in outs]
     loop = Plan(plan.name + "_seqonly", plan.vars, list(plan.inputs) + outs, list(plan.outputs), keep)
     return loop, {"plan": lp, "seq_in": seq_in, "inv_in": inv_in, "outs": outs}
+
+
+_BATCH_ALIAS = ("ScalarFromTensor", "TensorFromScalar", "ViewOp", "DeepCopyOp")
+
+
+def batch_map_step(plan: Plan, n_seqs: int):
+    """A Scan WITHOUT recurrence (nit-sot outputs only: ``aesara.map``, the row loops of
+    ``gradient.jacobian`` / ``hessian`` and of ``Rop`` / ``Lop`` helpers — scan/basic.py:71 with no
+    ``outputs_info``) evaluates the same function on every sequence row; no step reads what another
+    step wrote (scan_perform.pyx:309-541 with n_mit_mot = n_mit_sot = n_sit_sot = 0), so the loop
+    is not a loop: this returns the step plan restated over WHOLE sequences — every per-step
+    value ``v[S]`` becomes ``V[T, S]``, invariants stay as they are — or None when a node has no
+    such restatement here.  Rules (``step`` = depends on a sequence row):
+
+    * 0-d glue (``ScalarFromTensor`` ...) : the same variable, now ``[T]``;
+    * ``Elemwise``: step operands as they are, invariant operands with a leading broadcastable dim;
+    * ``CAReduce`` / ``DimShuffle``: axes shifted by one; ``Shape_i`` of a step value: invariant;
+    * ``Subtensor(M, i_t, ...)`` of an invariant by the step's index: ``AdvancedSubtensor1(M, i)``
+      (the same bounds check and negative wrap, subtensor.py:756 / :2080), then the rest of the index;
+      of a step value by invariant indices: one more leading slice;
+    * ``IncSubtensor(base, val, i_t)`` (the unit vectors of a Jacobian loop: ``set_subtensor(zeros[i], 1)``):
+      ``base`` repeated T times, then ``B[arange(T), i] = val`` (``AdvancedIncSubtensor``; the (t, i_t)
+      pairs are distinct); on a step value with invariant indices: one more leading slice;
+    * ``Gemv(y, alpha, A, x_t, beta)`` with an invariant matrix: ``X @ A.T`` (``Dot22Scalar`` / ``Gemm``);
+    * ``Alloc(v_t, *shape)`` / ``Reshape(v_t, shape)`` / ``SpecifyShape(v_t, *shape)`` with an invariant
+      shape: the same node with T in front of the shape.
+
+    Returns ``{"plan": Plan(inputs = sequences + the other step-plan inputs), "outs": n}``."""
+    V = plan.vars
+    seqs = list(plan.inputs[:n_seqs])
+    if not seqs:
+        return None
+    bp = Plan(plan.name + "_allrows", {}, [], [], [])
+    step, m = set(seqs), {}
+
+    def nv(dtype, shape, const=None):
+        return bp.new_var(dtype, list(shape), None, const)
+
+    def emit(op, ins, dtype, shape, params=None):
+        o = nv(dtype, shape)
+        bp.nodes.append(Node(op, list(ins), [o], dict(params or {})))
+        return o
+
+    def get(v):
+        if v not in m:
+            src = V[v]
+            m[v] = nv(src.dtype, ([None] + list(src.shape)) if v in step else src.shape, src.const)
+        return m[v]
+
+    def lead(v):
+        """invariant ``v`` next to ``[T, ...]`` operands"""
+        src = V[v]
+        if src.const is not None and "data" in src.const:
+            c = dict(src.const)
+            c["shape"] = [1] + list(c["shape"])
+            return nv(src.dtype, [1] + list(src.shape), c)
+        return emit("DimShuffle", [get(v)], src.dtype, [1] + list(src.shape),
+                    {"new_order": ["x"] + list(range(src.ndim))})
+
+    def i64(x):
+        return bp.add_const(np.asarray(x, dtype="int64"), "int64")
+
+    for v in plan.inputs:
+        get(v)
+    bp.inputs = [m[v] for v in plan.inputs]
+    tlen = [None]
+
+    def T_():
+        if tlen[0] is None:
+            tlen[0] = emit("Shape_i", [m[seqs[0]]], "int64", [], {"i": 0})
+        return tlen[0]
+
+    def entries(idx_list, extra):
+        """[(entry, its dynamic inputs)]"""
+        extra, out = list(extra), []
+        for e in idx_list:
+            n_dyn = sum(1 for t in (e["slice"] if "slice" in e else [e["index"]]) if t == "in")
+            out.append((e, extra[:n_dyn]))
+            extra = extra[n_dyn:]
+        return out
+
+    full = {"slice": [None, None, None]}
+    for n in plan.nodes:
+        s_in = [i for i in n.inputs if i in step]
+        if not s_in:
+            if n.op == "Scan":
+                return None
+            bp.nodes.append(Node(n.op, [get(i) for i in n.inputs], [get(o) for o in n.outputs], dict(n.params)))
+            continue
+        o0 = n.outputs[0]
+        if n.op in _BATCH_ALIAS and len(n.inputs) == 1:
+            step.add(o0)
+            m[o0] = get(n.inputs[0])
+        elif n.op == "Elemwise":
+            step.update(n.outputs)
+            ins = [get(i) if i in step else lead(i) for i in n.inputs]
+            bp.nodes.append(Node("Elemwise", ins, [get(o) for o in n.outputs], dict(n.params)))
+        elif n.op == "CAReduce":
+            nd = V[n.inputs[0]].ndim
+            ax = n.params.get("axis")
+            ax = list(range(nd)) if ax is None else [a % nd for a in ax]
+            step.add(o0)
+            bp.nodes.append(Node("CAReduce", [get(n.inputs[0])], [get(o0)],
+                                 dict(n.params, axis=[a + 1 for a in ax])))
+        elif n.op == "DimShuffle":
+            step.add(o0)
+            bp.nodes.append(Node("DimShuffle", [get(n.inputs[0])], [get(o0)],
+                                 dict(n.params, new_order=[0] + [e if e == "x" else e + 1
+                                                                 for e in n.params["new_order"]])))
+        elif n.op == "Shape_i":
+            bp.nodes.append(Node("Shape_i", [get(n.inputs[0])], [get(o0)], {"i": int(n.params["i"]) + 1}))
+        elif n.op == "Subtensor":
+            x, ents = n.inputs[0], entries(n.params["idx_list"], n.inputs[1:])
+            if x in step:
+                if any(d in step for _e, dyn in ents for d in dyn):
+                    return None
+                step.add(o0)
+                bp.nodes.append(Node("Subtensor", [get(x)] + [get(d) for _e, dyn in ents for d in dyn],
+                                     [get(o0)], {"idx_list": [full] + [e for e, _d in ents]}))
+            else:
+                e0, d0 = ents[0]
+                if "index" not in e0 or len(d0) != 1 or d0[0] not in step or V[d0[0]].ndim != 0 or \
+                        any(d in step for _e, dyn in ents[1:] for d in dyn):
+                    return None
+                step.add(o0)
+                rows = emit("AdvancedSubtensor1", [get(x), get(d0[0])], V[x].dtype, [None] + list(V[x].shape[1:]))
+                if len(ents) == 1:
+                    m[o0] = rows
+                else:
+                    bp.nodes.append(Node("Subtensor", [rows] + [get(d) for _e, dyn in ents[1:] for d in dyn],
+                                         [get(o0)], {"idx_list": [full] + [e for e, _d in ents[1:]]}))
+        elif n.op == "IncSubtensor":
+            x, y = n.inputs[:2]
+            ents = entries(n.params["idx_list"], n.inputs[2:])
+            dyn_step = [d for _e, dyn in ents for d in dyn if d in step]
+            n_int = sum(1 for e, _d in ents if "index" in e)
+            if y in step and V[y].ndim != V[x].ndim - n_int:
+                return None          # (a value that broadcasts from the left would misalign under [T, ...])
+            step.add(o0)
+            if not dyn_step:
+                if x not in step:
+                    return None
+                bp.nodes.append(Node("IncSubtensor", [get(x), get(y)] + [get(d) for _e, dyn in ents for d in dyn],
+                                     [get(o0)], dict(n.params, idx_list=[full] + [e for e, _d in ents], inplace=False)))
+            else:
+                e0, d0 = ents[0]
+                if len(ents) != 1 or "index" not in e0 or len(d0) != 1 or V[d0[0]].ndim != 0:
+                    return None
+                if x in step:
+                    B = get(x)
+                else:
+                    dims = [T_()] + [emit("Shape_i", [get(x)], "int64", [], {"i": d}) for d in range(V[x].ndim)]
+                    B = emit("Alloc", [lead(x)] + dims, V[x].dtype, [None] + list(V[x].shape))
+                ar = emit("ARange", [i64(0), T_(), i64(1)], "int64", [None], {"dtype": "int64"})
+                bp.nodes.append(Node("AdvancedIncSubtensor", [B, get(y), ar, get(d0[0])], [get(o0)],
+                                     {"set_instead_of_inc": bool(n.params["set_instead_of_inc"]), "inplace": False}))
+        elif n.op == "Gemv":
+            y, alpha, A, x, beta = n.inputs
+            bv = V[beta]
+            beta0 = bv.const is not None and "data" in bv.const and len(bv.const["data"]) == 1 and \
+                float(bv.const["data"][0]) == 0.0
+            if A in step or alpha in step or beta in step or x not in step or V[A].ndim != 2 or \
+                    not (beta0 or y in step):
+                return None
+            step.add(o0)
+            at_ = emit("DimShuffle", [get(A)], V[A].dtype, [V[A].shape[1], V[A].shape[0]], {"new_order": [1, 0]})
+            if beta0:
+                bp.nodes.append(Node("Dot22Scalar", [get(x), at_, get(alpha)], [get(o0)], {}))
+            else:
+                bp.nodes.append(Node("Gemm", [get(y), get(alpha), get(x), at_, get(beta)], [get(o0)],
+                                     {"inplace": False}))
+        elif n.op == "SpecifyShape":
+            if any(i in step for i in n.inputs[1:]):
+                return None
+            step.add(o0)
+            nd = V[n.inputs[0]].ndim
+            bp.nodes.append(Node("SpecifyShape", [get(i) for i in n.inputs], [get(o0)],
+                                 {"dims": [d + 1 for d in n.params.get("dims", range(len(n.inputs) - 1))],
+                                  "ndim": int(n.params.get("ndim", nd)) + 1}))
+        elif n.op == "Reshape":
+            x, sv = n.inputs
+            if sv in step or V[sv].dtype != "int64" or V[sv].ndim != 1:
+                return None
+            step.add(o0)
+            t1 = emit("MakeVector", [T_()], "int64", [1], {"dtype": "int64"})
+            k = V[sv].shape[0]
+            shp = emit("Join", [i64(0), t1, get(sv)], "int64", [None if k is None else k + 1])
+            bp.nodes.append(Node("Reshape", [get(x), shp], [get(o0)], {"ndim": int(n.params["ndim"]) + 1}))
+        elif n.op == "Alloc":
+            if any(i in step for i in n.inputs[1:]) or V[n.inputs[0]].ndim != V[o0].ndim:
+                return None
+            step.add(o0)
+            bp.nodes.append(Node("Alloc", [get(n.inputs[0]), T_()] + [get(i) for i in n.inputs[1:]], [get(o0)],
+                                 dict(n.params)))
+        else:
+            return None
+    outs = []
+    for o in plan.outputs:
+        if o in step:
+            outs.append(get(o))
+        else:                              # the same value every step
+            dims = [T_()] + [emit("Shape_i", [get(o)], "int64", [], {"i": d}) for d in range(V[o].ndim)]
+            outs.append(emit("Alloc", [lead(o)] + dims, V[o].dtype, [None] + list(V[o].shape)))
+    bp.outputs = outs
+    return {"plan": bp, "outs": len(outs)}
 
 
 def hoist_sequence_dots(plan: Plan, seq_inputs: List[int], invariant: set):

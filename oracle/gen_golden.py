@@ -1012,6 +1012,47 @@ def _():
     return [x, W], [res], [N((12, 6), seed=1), N((6, 6), seed=2)]
 
 
+@case("scan_map_jacobian_rows", rtol=1e-12, atol=1e-12)
+def _():
+    """``gradient.jacobian`` (gradient.py:1930): a Scan over ``arange(n)`` with no recurrence whose
+    step takes row i of the gradient — the all-rows restatement (fusion.batch_map_step)."""
+    x, W = at.dvector("x"), at.dmatrix("W")
+    y = at.tanh(at.dot(W, x)) * x.sum()
+    return [x, W], [ae.gradient.jacobian(y, x)], [N((5,), seed=1), N((5, 5), seed=2, scale=0.5)]
+
+
+@case("scan_map_hessian_unit_vectors", rtol=1e-12, atol=1e-12)
+def _():
+    """``gradient.hessian`` (gradient.py:2027) of a scalar cost: the step differentiates one entry of
+    the gradient; plus a map whose step builds the unit vector e_i with ``set_subtensor`` and an
+    ``inc_subtensor`` on a per-step value."""
+    x, A = at.dvector("x"), at.dmatrix("A")
+    cost = at.sum(at.tanh(at.dot(A, x)) ** 2) + at.sum(x ** 3)
+    H = ae.gradient.hessian(cost, x)
+
+    def step(i, x, A):
+        e = at.set_subtensor(at.zeros_like(x)[i], 1.0)
+        u = at.dot(A, e) * x
+        return at.inc_subtensor(u[1], x[i]), at.sum(u * e)
+    (cols, diag), _ = ae.scan(step, sequences=[at.arange(x.shape[0])], non_sequences=[x, A])
+    return [x, A], [H, cols, diag], [N((4,), seed=3), N((4, 4), seed=4, scale=0.6)]
+
+
+@case("scan_map_rows_reduce_broadcast", rtol=1e-12, atol=1e-12)
+def _():
+    """Maps without recurrence over matrix rows: reductions, DimShuffle, an invariant operand, a
+    0-d result, a constant-per-step output, a negative index sequence into an invariant table, the
+    last rows only (``[-3:]``: scan_save_mem keeps three)."""
+    M, b, idx = at.dmatrix("M"), at.dvector("b"), at.lvector("idx")
+
+    def step(r, k, b, M):
+        z = at.exp(r - r.max()) * b
+        return z / z.sum(), (r.dimshuffle(0, "x") * b.dimshuffle("x", 0)).sum(axis=0), M[k, 1:] * 2.0, r.sum()
+    (sm, outer, picked, tot), _ = ae.scan(step, sequences=[M, idx], non_sequences=[b, M])
+    return [M, b, idx], [sm, outer[-3:], picked, tot], [N((9, 6), seed=5), N((6,), seed=6),
+                                                     I((9,), "int64", seed=7, low=-9, high=9)]
+
+
 @case("scan_nitsot_value_and_its_view", rtol=1e-12, atol=1e-12)
 def _():
     """Two nit-sot outputs that are the same value in two shapes (a vector and the [1, n] row view of

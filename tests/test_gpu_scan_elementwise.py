@@ -9,8 +9,9 @@ from golden_util import CASES, assert_matches, case_expected, case_inputs, case_
 
 pytestmark = pytest.mark.gpu
 
-ELEMENTWISE = ["scan_cumsum", "scan_taps", "scan_two_outputs", "scan_nitsot_map", "scan_while_cumsum",
-               "scan_while_never_stops"]
+ELEMENTWISE = ["scan_cumsum", "scan_taps", "scan_two_outputs", "scan_while_cumsum", "scan_while_never_stops"]
+NO_RECURRENCE = ["scan_nitsot_map", "scan_map_jacobian_rows", "scan_map_hessian_unit_vectors",
+                 "scan_map_rows_reduce_broadcast"]
 
 
 def _case(name):
@@ -43,6 +44,61 @@ def test_elementwise_scans_run_as_one_launch_and_match(name, use_graph):
     for g, r in zip(got, ref):
         np.testing.assert_array_equal(g, r)          # the same arithmetic, element by element
     ex.check()
+
+
+@pytest.mark.parametrize("name", NO_RECURRENCE)
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_scans_without_recurrence_are_one_evaluation_over_whole_sequences(name, use_graph):
+    """aesara.map / the row loops of gradient.jacobian and gradient.hessian (scan/basic.py:71 without
+    outputs_info; gradient.py:1930, :2027): no step reads what another wrote, so the step plan is
+    restated over whole sequences (fusion.batch_map_step) and evaluated once — results = the
+    reference's outputs = the launch-list path (to the goldens' tolerance: a Gemv per step there,
+    one GEMM here)."""
+    from aesara_amd import executor as E
+    c = _case(name)
+    ex = E.PlanExecutor(case_plan(c), use_graph=use_graph)
+    ins = case_inputs(c)
+    for it in range(3):
+        got = _np(ex(*ins))
+        assert_matches(c, got, case_expected(c), f"call {it}")
+    assert set(ex.scan_modes.values()) == {"all-rows"}, ex.scan_modes
+    E.TUNE["scan_persist"] = 0
+    try:
+        ex2 = E.PlanExecutor(case_plan(c), use_graph=use_graph)
+        ref = _np(ex2(*ins))
+        assert all(v.startswith("launch-list") for v in ex2.scan_modes.values())
+    finally:
+        E.TUNE["scan_persist"] = 1
+    assert_matches(c, ref, case_expected(c), "launch list")
+    ex.check()
+
+
+def test_jacobian_rows_at_size_and_index_errors():
+    """The golden Jacobian plan at n = 700 (700 steps -> one evaluation) against NumPy, outputs that
+    own their buffers across calls, and a step index out of range raising the reference's
+    IndexError (subtensor.py:756) from the whole-sequence gather."""
+    import torch
+    from aesara_amd import executor as E
+    c = _case("scan_map_jacobian_rows")
+    ex = E.PlanExecutor(case_plan(c))
+    n = 700
+    rng = np.random.default_rng(3)
+    x, W = rng.standard_normal(n), rng.standard_normal((n, n)) / np.sqrt(n)
+    (J,) = _np(ex(torch.from_numpy(x).cuda(), torch.from_numpy(W).cuda()))
+    t = np.tanh(W @ x)
+    want = ((1 - t * t) * x.sum())[:, None] * W + t[:, None] * np.ones(n)[None, :]
+    np.testing.assert_allclose(J, want, rtol=1e-10, atol=1e-12)
+    assert set(ex.scan_modes.values()) == {"all-rows"}
+    c2 = _case("scan_map_rows_reduce_broadcast")
+    ex2 = E.PlanExecutor(case_plan(c2))
+    M, b, idx = case_inputs(c2)
+    bad = np.array(idx, copy=True)
+    bad[4] = M.shape[0]
+    with pytest.raises(IndexError):
+        ex2(M, b, bad)
+        ex2.check()
+    got = _np(ex2(M, b, idx))
+    assert_matches(c2, got, case_expected(c2), "after the failed call")
 
 
 @pytest.mark.parametrize("name", ["scan_grad_taps", "scan_grad_taps_wide", "scan_grad_taps13"])

@@ -296,6 +296,46 @@ def test_device_filter_type_decisions():
     assert isinstance(t3, DeviceFilterType) and t3.shape == (None, 3)
 
 
+@pytest.mark.parametrize("name", ["scan_nitsot_map", "scan_map_jacobian_rows", "scan_map_hessian_unit_vectors",
+                                  "scan_map_rows_reduce_broadcast"])
+def test_scans_without_recurrence_restated_over_whole_sequences(name):
+    """fusion.batch_map_step: every Scan without recurrence of these goldens is replaced by ONE
+    evaluation of the restated step plan over whole sequences (host logic of
+    ``ScanMixin._scan_all_rows`` restated in NumPy: first n_steps rows in, last ``keep`` rows out) —
+    the outputs must still be the REFERENCE's (tests/golden), all through the oracle."""
+    import copy
+    import interp
+    from golden_util import CASES, assert_matches, case_expected, case_inputs, case_plan
+    from aesara_amd.fusion import batch_map_step
+    from aesara_amd.plan import Node
+    c = next(c for c in CASES if c["name"] == name)
+    plan = copy.copy(case_plan(c))
+    nodes, swapped = [], 0
+    for node in plan.nodes:
+        p = node.params
+        if node.op != "Scan" or p.get("as_while") or p.get("n_shared_outs", 0) or p.get("mit_mot_in_slices") \
+                or p["mit_sot_in_slices"] or p["sit_sot_in_slices"]:
+            nodes.append(node)
+            continue
+        r = batch_map_step(p["inner"], p["n_seqs"])
+        assert r is not None, [n.op for n in p["inner"].nodes]
+
+        def all_rows(*a, bp=r["plan"], n_seqs=p["n_seqs"], n_nit=p["n_nit_sot"]):
+            n_steps = int(a[0])
+            seqs = [np.asarray(s)[:n_steps] for s in a[1:1 + n_seqs]]
+            keep = [int(k) for k in a[1 + n_seqs:1 + n_seqs + n_nit]]
+            rows = interp.run_plan(bp, seqs + list(a[1 + n_seqs + n_nit:]))
+            assert all(x.shape[0] == n_steps for x in rows)
+            return [x[n_steps - k:] for x, k in zip(rows, keep)]
+        nodes.append(Node("HostCall", list(node.inputs), list(node.outputs), {"fn": all_rows}))
+        swapped += 1
+    assert swapped
+    plan.nodes = nodes
+    got = interp.run_plan(plan, case_inputs(c))
+    for g, e in zip(got, case_expected(c)):
+        assert_matches(c, g, e)
+
+
 @pytest.mark.parametrize("name", ["gru_bptt_b1_f32", "gru_bptt_b4_f32", "lstm_bptt_vec_f32", "cfg4_gru_b1_f32"])
 def test_sequence_only_hoisting_preserves_the_step(name):
     """fusion.hoist_sequence_only on the Scan inner plans of the golden recurrences and their
@@ -753,8 +793,8 @@ def test_streaming_policy_for_read_once_operands(monkeypatch):
 
 def test_which_golden_scans_run_as_one_launch():
     """The persistent-Scan class over the whole golden set, decided on the host (dry runs: analysis,
-    layout checks and kernel generation, no device): 92 of 96 Scans take a one-launch kernel; the
-    four that do not are named with the reason ``PlanExecutor.scan_modes`` gives — a silent
+    layout checks and kernel generation, no device): of 100 Scans 91 take a one-launch kernel and 5
+    (no recurrence) are one evaluation over whole sequences; the four that do neither are named with the reason ``PlanExecutor.scan_modes`` gives — a silent
     fall-back to the launch list of any other golden fails here, on CPU."""
     from aesara_amd.executor import PlanExecutor
     from golden_util import CASES, case_plan
@@ -765,7 +805,7 @@ def test_which_golden_scans_run_as_one_launch():
         "scan_seq_products_two_row_counts": "Gemm",                                   # a bare Gemm node in the step
         "sp_rnn_proj_narrow_f32": "matrix layout",                                    # projection narrower than the state
     }
-    total = persistent = 0
+    total = persistent = all_rows = 0
     for c in CASES:
         if "Scan" not in json.dumps(c["plan"]["nodes"])[:200000] and not any(
                 n["op"] == "Scan" for n in c["plan"]["nodes"]):
@@ -779,7 +819,9 @@ def test_which_golden_scans_run_as_one_launch():
             total += 1
             if mode == "persistent":
                 persistent += 1
+            elif mode == "all-rows":            # no recurrence: one evaluation over whole sequences
+                all_rows += 1
             else:
                 want = expected_launch_list.get(c["name"])
                 assert want is not None and want in mode, (c["name"], mode)
-    assert (persistent, total) == (92, 96), (persistent, total)
+    assert (persistent, all_rows, total) == (91, 5, 100), (persistent, all_rows, total)
