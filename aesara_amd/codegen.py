@@ -541,6 +541,14 @@ def scalar_node_expr(op, ins, in_dts, dt):
         return "log1mexp_(%s)" % c[0]
     if op == "softsign" and _is_float(dt):
         return "(%s / ((%s)1 + %s(%s)))" % (c[0], T, _fname("fabs", dt), c[0])
+    if op == "ultra_fast_sigmoid" and _is_float(dt):
+        # UltraFastScalarSigmoid.c_code tensor/nnet/sigm.py:54 (a piecewise tanh approximation): x and z
+        # are variables of the OUTPUT type, the arithmetic between them is double (its constants are)
+        return ("({ %(T)s ux_ = (%(T)s)(0.5 * (double)%(x)s); const double ua_ = ux_ >= (%(T)s)0 ? (double)ux_ "
+                ": (double)(%(T)s)(-ux_); double uz_ = ua_ < 1.7 ? (1.5 * ua_ / (1 + ua_)) : (ua_ < 3 ? "
+                "(0.935409070603099 + 0.0458812946797165 * (ua_ - 1.7)) : 0.99505475368673); "
+                "const %(T)s uzt_ = (%(T)s)(ux_ >= (%(T)s)0 ? uz_ : -uz_); (%(T)s)(0.5 * ((double)uzt_ + 1.)); })"
+                % {"T": T, "x": c[0]})
     if op == "xlogx" and _is_float(dt):          # XlogX.c_code tensor/xlogx.py:27
         return "(%s == (%s)0 ? (%s)0 : %s * %s(%s))" % (c[0], T, T, c[0], _fname("log", dt), c[0])
     if op == "xlogy0" and _is_float(dt):         # XlogY0.c_code tensor/xlogx.py:58

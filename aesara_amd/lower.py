@@ -44,6 +44,8 @@ SCALAR_OP_NAMES = {
     "ScalarSoftsign": "softsign",      # tensor/nnet/basic.py:2040: x / (1 + |x|)
     # tensor/xlogx.py:7 XlogX (x == 0 ? 0 : x * log(x)), :36 XlogY0 (x == 0 ? 0 : x * log(y))
     "XlogX": "xlogx", "XlogY0": "xlogy0",
+    # tensor/nnet/sigm.py:20 UltraFastScalarSigmoid (the rewrite `local_ultra_fast_sigmoid` puts it in place of Sigmoid)
+    "UltraFastScalarSigmoid": "ultra_fast_sigmoid",
     # scalar/math.py: the incomplete-gamma family that has C code in the reference (c_code/gamma.c)
     "GammaInc": "gammainc", "GammaIncC": "gammaincc", "Chi2SF": "chi2sf", "GammaU": "gammau",
     "GammaL": "gammal",

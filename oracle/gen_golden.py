@@ -2074,6 +2074,26 @@ def _():
     return [x, y], [xlogx(xz), xlogy0(xz, y), xlogy0(xz, at.zeros_like(y))], [U((7, 9), seed=1), U((7, 9), seed=2)]
 
 
+def _ultra_fast(dtype, n, seed):
+    # tensor/nnet/sigm.py:20 UltraFastScalarSigmoid (c_code :54): the three pieces of the tanh
+    # approximation on both signs (variables of the output type, double arithmetic between them).
+    # Not bit-exact by construction: the reference's own value of a + b * (x - 1.7) depends on whether
+    # its compiler contracts it into an fma (g++ -O3 -march=native does, NumPy does not)
+    from aesara.tensor.nnet.sigm import ultra_fast_sigmoid
+    x = at.vector("x", dtype=dtype)
+    return [x], [ultra_fast_sigmoid(x), ultra_fast_sigmoid(-x * 0.5) * 2], [N((n,), dtype, seed=seed, scale=4.0)]
+
+
+@case("ultra_fast_sigmoid_f64", rtol=1e-15, atol=2.3e-16)
+def _():
+    return _ultra_fast("float64", 257, 1)
+
+
+@case("ultra_fast_sigmoid_f32", rtol=2e-7, atol=1.2e-7)
+def _():
+    return _ultra_fast("float32", 300, 2)
+
+
 @case("incomplete_gamma_family", rtol=1e-9, atol=1e-12)
 def _():
     # scalar/math.py:580 GammaInc / :629 GammaIncC / :538 Chi2SF / :836 GammaU / :877 GammaL (the

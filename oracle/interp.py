@@ -34,6 +34,19 @@ def _softplus(x):
                                  np.where(x < 33.3, x + np.exp(-x), x))).astype(x.dtype)
 
 
+def _ultra_fast_sigmoid(x):
+    # tensor/nnet/sigm.py:54 UltraFastScalarSigmoid.c_code: x and z are variables of the output
+    # dtype, the expressions between them are evaluated in double
+    x = np.asarray(x)
+    dt = x.dtype
+    hx = (0.5 * x.astype(np.float64)).astype(dt)
+    a = np.abs(hx).astype(np.float64)
+    z = np.where(a < 1.7, 1.5 * a / (1 + a),
+                 np.where(a < 3, 0.935409070603099 + 0.0458812946797165 * (a - 1.7), 0.99505475368673))
+    z = np.where(hx >= 0, z, -z).astype(dt)
+    return (0.5 * (z.astype(np.float64) + 1.0)).astype(dt)
+
+
 def _sigmoid(x):
     # scalar/math.py:1110 Sigmoid.c_code: 1/(1+exp(-x))
     x = np.asarray(x)
@@ -186,6 +199,7 @@ _UNARY = {
     "i0": _special("i0"), "i1": _special("i1"),
     "softsign": lambda x: x / (1.0 + np.abs(x)),     # tensor/nnet/basic.py:2048
     "xlogx": lambda x: np.where(x == 0, 0, x * np.log(x)),       # tensor/xlogx.py:15 XlogX.impl
+    "ultra_fast_sigmoid": _ultra_fast_sigmoid,
 }
 
 _BINARY = {
@@ -208,7 +222,7 @@ _FLOAT_FUNCS = {"sqrt", "exp", "exp2", "expm1", "log", "log2", "log10", "log1p",
                 "arccosh", "arctanh", "sigmoid", "softplus", "erf", "erfc", "log1mexp",
                 "deg2rad", "rad2deg", "reciprocal", "true_div", "arctan2", "erfcx", "erfinv",
                 "erfcinv", "gamma", "gammaln", "psi", "tri_gamma", "j0", "j1", "i0", "i1", "softsign",
-                "xlogx", "xlogy0", "gammainc", "gammaincc", "chi2sf", "gammau", "gammal"}
+                "xlogx", "xlogy0", "gammainc", "gammaincc", "chi2sf", "gammau", "gammal", "ultra_fast_sigmoid"}
 
 
 def eval_scalar_expr(s, ins):

@@ -39,5 +39,7 @@ def test_reference_test_files_under_the_hip_mode_on_the_device():
     # round 5's file list: 967 tests through HipLinker; round 6 adds test_ifelse / test_sort /
     # rewriting/test_elemwise / test_checkpoints / test_raise_op / test_updates / test_xlogx /
     # test_math_scipy / compile/test_ops / test_inplace and test_keepdims with its Mode re-pointed
-    assert c["through_hip"] >= 2200, text
-    assert c["executed_hip"] >= 2100, text
+    # (+ the second batch: tensor/rewriting/test_{basic,math,subtensor,shape,special,uncanonicalize,extra_ops},
+    # compile/test_builders, scalar/test_{basic,math}, nnet/test_sigm: 331 more through HipLinker)
+    assert c["through_hip"] >= 2500, text
+    assert c["executed_hip"] >= 2350, text
