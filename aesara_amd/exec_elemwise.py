@@ -582,7 +582,7 @@ class ElemwiseMixin:
     def _run_elemwise(self, st: Step, env, out_targets=None):
         ins = self._operands(st, env)
         out_vars = [self.plan.vars[o] for o in st.outputs]
-        if all(not isinstance(x, DevArray) for x in ins):
+        if all(not isinstance(x, DevArray) for x in ins) and hostops.host_evaluable(st.scalar):
             # host glue (integer shape arithmetic)
             res = hostops.eval_scalar_host(st.scalar, [np.asarray(x) for x in ins])
             shape = np.broadcast_shapes(*[np.shape(x) for x in ins]) if ins else ()

@@ -22,6 +22,16 @@ _UN = {"neg": np.negative, "abs": np.abs, "sgn": np.sign, "sqr": np.square,
        "reciprocal": np.reciprocal, "round_half_to_even": np.around}
 
 
+_OTHER = ("cast", "second", "switch", "clip")
+
+
+def host_evaluable(scalar):
+    """Every op of the expression is one the host glue restates (anything else — arctan2 of two
+    ScalarType inputs, special functions — runs as a kernel on 0-d device values)."""
+    return all(n["op"] in _NARY or n["op"] in _CMP or n["op"] in _BIN or n["op"] in _UN or n["op"] in _OTHER
+               for n in scalar["nodes"])
+
+
 _HOST_MEMO = {}
 
 
@@ -58,6 +68,11 @@ def _eval_scalar_host(scalar, ins):
         for n in scalar["nodes"]:
             op, dt = n["op"], np.dtype(n["dtype"])
             a = [np.asarray(get(r)) for r in n["in"]]
+            if dt.kind == "f" and (op in _UN or op in _BIN):
+                # a float result of integer operands (upgrade_to_float ops, true_div): the reference's C
+                # body computes in the OUTPUT type (scalar/basic.py c_code: operands convert on use) —
+                # NumPy would pick float16 for int8 and an integer reciprocal
+                a = [x.astype(dt) if x.dtype.kind in "iub" else x for x in a]
             if op in _NARY:
                 r = a[0]
                 for x in a[1:]:

@@ -233,3 +233,36 @@ def test_more_nonmergeable_dims_than_a_kernel_takes_and_2d_batched_dot():
         np.testing.assert_allclose(r.cpu().numpy(), want, rtol=2e-5, atol=1e-5)
     with pytest.raises(TypeError):
         PlanExecutor(q)(_t(xv[:4]), _t(yv))
+
+
+def test_float_functions_of_host_scalars_compute_in_the_output_type():
+    """aesara.function([int8 scalar], op(x)) hands the executor HOST 0-d values (ScalarType inputs,
+    tests/scalar/test_basic.py:319 TestUpgradeToFloat): the result of an upgrade_to_float op is
+    computed in the OUTPUT type (scalar/basic.py c_code: operands convert on use) — reciprocal(int8)
+    is 1 / float32(x), not NumPy's integer reciprocal or a float16 detour — and an op outside the
+    host glue's integer arithmetic (arctan2) runs as a kernel on 0-d device values."""
+    from aesara_amd.plan import Node, Plan
+
+    def plan(op, n_in):
+        p = Plan("host_scalar_" + op, {}, [], [], [])
+        ins = [p.new_var("int8", []) for _ in range(n_in)]
+        o = p.new_var("float32", [])
+        p.inputs, p.outputs = ins, [o]
+        p.nodes = [Node("Elemwise", ins, [o], {"scalar": {"n_in": n_in, "nodes": [
+            {"op": op, "in": [["i", k] for k in range(n_in)], "dtype": "float32"}], "out": [["t", 0]]}})]
+        return p
+    for op, ref in (("reciprocal", lambda v: np.float32(1) / v), ("exp", np.exp), ("sqrt", np.sqrt),
+                    ("log", np.log), ("cos", np.cos), ("deg2rad", np.deg2rad)):
+        ex = PlanExecutor(plan(op, 1))
+        for x in (-127, -3, 2, 5, 88):
+            if op in ("sqrt", "log") and x < 0:
+                continue
+            (r,) = ex(np.int8(x))
+            r = np.asarray(r.cpu() if hasattr(r, "cpu") else r)
+            assert r.dtype == np.float32 and r.shape == ()
+            np.testing.assert_allclose(r, ref(np.float32(x)), rtol=2e-6)
+    ex = PlanExecutor(plan("arctan2", 2))
+    for x, y in ((-127, 3), (5, -7), (0, 0), (88, 127)):
+        (r,) = ex(np.int8(x), np.int8(y))
+        r = np.asarray(r.cpu() if hasattr(r, "cpu") else r)
+        np.testing.assert_allclose(r, np.arctan2(np.float32(x), np.float32(y)), rtol=2e-6, atol=1e-7)
