@@ -241,6 +241,7 @@ def test_float_functions_of_host_scalars_compute_in_the_output_type():
     computed in the OUTPUT type (scalar/basic.py c_code: operands convert on use) — reciprocal(int8)
     is 1 / float32(x), not NumPy's integer reciprocal or a float16 detour — and an op outside the
     host glue's integer arithmetic (arctan2) runs as a kernel on 0-d device values."""
+    from aesara_amd.executor import PlanExecutor
     from aesara_amd.plan import Node, Plan
 
     def plan(op, n_in):
