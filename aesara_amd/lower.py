@@ -164,6 +164,9 @@ class _Ctx:
             self.plan.vars[vid].shape = _static_shape(v.type)
             self.vmap[v] = vid
             return vid
+        if v in self.slices or type(v.type).__name__ == "SliceType":
+            # a MakeSlice result used as anything but the index of a Subtensor-family node (a graph output)
+            raise UnsupportedOp(f"non-tensor variable type SliceType ({v}): graph boundaries of a plan are tensors")
         raise KeyError(f"variable {v} not produced by any lowered node")
 
     def new(self, v):
