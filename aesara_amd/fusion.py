@@ -238,10 +238,21 @@ def _split_gemv(plan: Plan, node: Node, steps, producer) -> Step:
         sc = {"n_in": 2, "nodes": [{"op": "mul", "in": [["i", 0], ["i", 1]], "dtype": dt}],
               "out": [["t", 0]]}
         return Step("elemwise", [av, d_var], list(node.outputs), sc, out_refs=[0])
+    if beta.const is not None and len(beta.const.get("data", ())) == 1:
+        sc = {"n_in": 4, "nodes": [{"op": "mul", "in": [["i", 3], ["i", 0]], "dtype": dt},
+                                   {"op": "mul", "in": [["i", 1], ["i", 2]], "dtype": dt},
+                                   {"op": "add", "in": [["t", 0], ["t", 1]], "dtype": dt}],
+              "out": [["t", 2]]}
+        return Step("elemwise", [yv, av, d_var, bv], list(node.outputs), sc, out_refs=[0])
+    # a RUN-TIME beta: the same rule per evaluation — beta == 0 never reads y (tensor/blas.py:236
+    # Gemv.perform / BLAS xGEMV: a NaN or inf in y does not reach the result;
+    # tests/tensor/test_blas_c.py:146 test_nan_beta_0)
     sc = {"n_in": 4, "nodes": [{"op": "mul", "in": [["i", 3], ["i", 0]], "dtype": dt},
+                               {"op": "eq", "in": [["i", 3], ["c", 0.0, dt]], "dtype": "bool"},
+                               {"op": "switch", "in": [["t", 1], ["c", 0.0, dt], ["t", 0]], "dtype": dt},
                                {"op": "mul", "in": [["i", 1], ["i", 2]], "dtype": dt},
-                               {"op": "add", "in": [["t", 0], ["t", 1]], "dtype": dt}],
-          "out": [["t", 2]]}
+                               {"op": "add", "in": [["t", 2], ["t", 3]], "dtype": dt}],
+          "out": [["t", 4]]}
     return Step("elemwise", [yv, av, d_var, bv], list(node.outputs), sc, out_refs=[0])
 
 

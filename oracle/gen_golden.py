@@ -1012,6 +1012,17 @@ def _():
     return [x, W], [res], [N((12, 6), seed=1), N((6, 6), seed=2)]
 
 
+@case("gemv_runtime_beta_zero_ignores_y", rtol=1e-13, atol=0)
+def _():
+    """``a * y + dot(A, x)`` with a RUN-TIME scalar a (-> Gemv(y, 1, A, x, a)): a == 0 never reads y
+    (tensor/blas.py:236 Gemv.perform, BLAS xGEMV) — the NaNs of y do not reach the result
+    (tests/tensor/test_blas_c.py:146); the second output keeps them (a != 0)."""
+    A, x, x2, y, a, b = at.dmatrix("A"), at.dvector("x"), at.dvector("x2"), at.dvector("y"), at.dscalar("a"), at.dscalar("b")
+    return [A, x, x2, y, a, b], [a * y + at.dot(A, x), b * y + at.dot(A, x2)], \
+        [N((33, 17), seed=1), N((17,), seed=2), N((17,), seed=4),
+         {"kind": "normal_with_nan", "seed": 3, "shape": [33], "dtype": "float64"}, K(0.0, "float64"), K(0.5, "float64")]
+
+
 @case("scan_map_jacobian_rows", rtol=1e-12, atol=1e-12)
 def _():
     """``gradient.jacobian`` (gradient.py:1930): a Scan over ``arange(n)`` with no recurrence whose
