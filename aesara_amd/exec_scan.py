@@ -121,30 +121,110 @@ class ScanMixin:
         keep = [self.host_int(a) for a in args[1 + n_seqs:1 + n_seqs + n_nit]]
         if any(sq.shape[0] < n_steps for sq in seqs) or any(L < 1 or L > n_steps for L in keep):
             return None
-        largs = [sq.view((n_steps,) + tuple(sq.shape[1:]), sq.strides) for sq in seqs]
-        largs += list(args[1 + n_seqs + n_nit:])
-        rows._arena, rows._capturing = self._arena, self._capturing
-        rows._root = self._root or self
-        try:
-            res = [self.to_device(r) for r in rows.run(largs)]
-        finally:
-            rows._arena = None
-            rows._capturing = False
+        inv = list(args[1 + n_seqs + n_nit:])
+
+        def evaluate(t0, t1):
+            largs = [sq.view((t1 - t0,) + tuple(sq.shape[1:]), sq.strides, sq.offset + t0 * sq.strides[0])
+                     for sq in seqs] + inv
+            rows._arena, rows._capturing = self._arena, self._capturing
+            rows._root = self._root or self
+            try:
+                return largs, [self.to_device(r) for r in rows.run(largs)]
+            finally:
+                rows._arena = None
+                rows._capturing = False
+
+        # the whole-sequence intermediates are T times a step's (the unit vectors of a Jacobian loop
+        # alone are [T, n]): when their sum would not fit comfortably, the rows go in blocks
+        block = self._rows_block(rows, seqs, inv, n_steps)
+        if block >= n_steps:
+            largs, res = evaluate(0, n_steps)
+            # every output is a buffer of its own (never a view of an operand or of another output)
+            taken = [a.buf for a in largs if isinstance(a, DevArray)]
+            for k, r in enumerate(res):
+                if any(r.buf is b for b in taken):
+                    res[k] = r = self.materialize(r)
+                taken.append(r.buf)
+            note = "no recurrence: the step evaluated once over whole sequences"
+        else:
+            res = None
+            for t0 in range(0, n_steps, block):
+                t1 = min(n_steps, t0 + block)
+                _l, part = evaluate(t0, t1)
+                if res is None:
+                    res = [self.alloc((n_steps,) + tuple(r.shape[1:]), r.dtype) for r in part]
+                for full, r in zip(res, part):
+                    self.copy_into(full.view((t1 - t0,) + tuple(full.shape[1:]), full.strides,
+                                             full.offset + t0 * full.strides[0]), r)
+                del part
+            note = "no recurrence: the step evaluated over blocks of %d rows" % block
         self.scan_modes.update(rows.scan_modes)
         self.scan_notes.update(rows.scan_notes)
-        # every output is a buffer of its own (never a view of an operand or of another output)
-        taken = [a.buf for a in largs if isinstance(a, DevArray)]
         outs = []
         for r, L in zip(res, keep):
-            if any(r.buf is b for b in taken):
-                r = self.materialize(r)
-            taken.append(r.buf)
             if L < n_steps:          # scan_save_mem: only the last L rows are kept (scan/op.py:2105-2134)
                 r = r.view((L,) + tuple(r.shape[1:]), r.strides, r.offset + (n_steps - L) * r.strides[0])
             outs.append(r)
         self.scan_modes[node.outputs[0]] = "all-rows"
-        self.scan_notes[node.outputs[0]] = "no recurrence: the step evaluated once over whole sequences"
+        self.scan_notes[node.outputs[0]] = note
         return outs
+
+    def _rows_block(self, rows, seqs, inv, n_steps):
+        """Rows per evaluation of a whole-sequence step plan: all of them unless the bytes it would
+        allocate (counted by a DRY run of the same plan on the same shapes: host only, exact shape
+        propagation, memoised per shape signature) exceed ``ROWS_BYTES_CAP`` (default: a quarter of
+        the free device memory)."""
+        if self.dry_run:
+            return n_steps
+        cap = int(float(knobs.get("ROWS_BYTES_CAP_GB")) * (1 << 30))
+        if cap <= 0:
+            cap = torch.cuda.mem_get_info(self.device)[0] // 4
+
+        def sig(a, lead):
+            if isinstance(a, DevArray):
+                return (tuple(a.shape[1:]) if lead else tuple(a.shape), a.dtype)
+            return ("host", np.shape(a))
+        key = tuple(sig(a, True) for a in seqs) + tuple(sig(a, False) for a in inv)
+        memo = rows.__dict__.setdefault("_rows_bytes", {})
+        est = memo.get(key)
+        if est is None:
+            est = memo[key] = self._rows_bytes_per_row(rows, seqs, inv)
+        fixed, per_row = est
+        if per_row is None or fixed + per_row * n_steps <= cap:
+            return n_steps
+        return int(max(1, min(n_steps, (cap - fixed) // max(per_row, 1))))
+
+    def _rows_bytes_per_row(self, rows, seqs, inv):
+        """(bytes allocated whatever T is, bytes per row) of the whole-sequence plan, from dry runs
+        with 1 and 2 rows; (0, None) when a dry run cannot follow the plan (value-dependent shapes)."""
+        twin = rows.__dict__.get("_twin")
+        if twin is None:
+            twin = rows._twin = PlanExecutor(rows.plan, use_graph=False, dry_run=True, fuse=self.fuse)
+        count = [0]
+
+        def alloc(shape, dtype, _base=type(twin).alloc):
+            r = _base(twin, shape, dtype)
+            count[0] += r.size * ITEMSIZE[r.dtype]
+            return r
+        twin.alloc = alloc
+
+        def fake(a, t=None):
+            if not isinstance(a, DevArray):
+                return a
+            shape = tuple(a.shape) if t is None else (t,) + tuple(a.shape[1:])
+            return DevArray(_FakeBuf(max(_prod(shape), 1), a.dtype), 0, shape, contiguous_strides(shape), a.dtype)
+        got = []
+        try:
+            for t in (1, 2):
+                count[0] = 0
+                twin.run([fake(a, t) for a in seqs] + [fake(a) for a in inv])
+                got.append(count[0])
+        except Exception:                        # noqa: BLE001
+            return 0, None
+        finally:
+            del twin.alloc
+        per_row = max(got[1] - got[0], 0)
+        return max(got[0] - per_row, 0), per_row
 
     @staticmethod
     def _mitmot_inplace(inner, n_seqs, mm_in, mm_out):

@@ -62,6 +62,8 @@ _def("GEMM_HALF_KSPLIT", None, int, "K groups inside a 64x64-tile workgroup (def
 _def("GE_WAVES", 0, int, "waves per workgroup of the generated GEMM epilogue (0: automatic)")
 # ---- Scan ---------------------------------------------------------------------------------------
 _def("SCAN_PERSIST", 1, int, "Scan loops as ONE persistent kernel where the class allows")
+_def("ROWS_BYTES_CAP_GB", 0.0, float, "bytes a whole-sequence evaluation of a Scan without recurrence may allocate before "
+     "its rows go in blocks (GiB; 0: a quarter of the free device memory)")
 _def("COOP", 0, int, "persistent kernels through hipLaunchCooperativeKernel (launch-time size check)")
 _def("SCAN_ROWS", None, str, "rows x waves geometry of the vector-state persistent kernel")
 _def("SCAN_WAVES", 4, int, "waves per workgroup of the vector-state persistent kernel")

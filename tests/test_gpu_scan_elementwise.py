@@ -89,6 +89,20 @@ def test_jacobian_rows_at_size_and_index_errors():
     want = ((1 - t * t) * x.sum())[:, None] * W + t[:, None] * np.ones(n)[None, :]
     np.testing.assert_allclose(J, want, rtol=1e-10, atol=1e-12)
     assert set(ex.scan_modes.values()) == {"all-rows"}
+    assert "once" in list(ex.scan_notes.values())[0]
+    # the same evaluation with a byte budget of 1 MiB for its intermediates (7 x [700, 700] float64 = 27 MB
+    # all at once): the rows go in blocks, the result is the same
+    import os
+    os.environ["AESARA_HIP_ROWS_BYTES_CAP_GB"] = str(1.0 / 1024)
+    try:
+        for use_graph in (False, True):
+            exb = E.PlanExecutor(case_plan(c), use_graph=use_graph)
+            for _ in range(2):
+                (Jb,) = _np(exb(torch.from_numpy(x).cuda(), torch.from_numpy(W).cuda()))
+                np.testing.assert_array_equal(Jb, J)
+            assert "blocks of" in list(exb.scan_notes.values())[0], exb.scan_notes
+    finally:
+        del os.environ["AESARA_HIP_ROWS_BYTES_CAP_GB"]
     c2 = _case("scan_map_rows_reduce_broadcast")
     ex2 = E.PlanExecutor(case_plan(c2))
     M, b, idx = case_inputs(c2)
