@@ -1251,6 +1251,7 @@ def batch_map_step(plan: Plan, n_seqs: int):
     * ``Subtensor(M, i_t, ...)`` of an invariant by the step's index: ``AdvancedSubtensor1(M, i)``
       (the same bounds check and negative wrap, subtensor.py:756 / :2080), then the rest of the index;
       of a step value by invariant indices: one more leading slice;
+    * ``AdvancedSubtensor1(M, idx_t)`` with the step's index vector: one gather over all T * B indices;
     * ``IncSubtensor(base, val, i_t)`` (the unit vectors of a Jacobian loop: ``set_subtensor(zeros[i], 1)``):
       ``base`` repeated T times, then ``B[arange(T), i] = val`` (``AdvancedIncSubtensor``; the (t, i_t)
       pairs are distinct); on a step value with invariant indices: one more leading slice;
@@ -1362,6 +1363,20 @@ def batch_map_step(plan: Plan, n_seqs: int):
                 else:
                     bp.nodes.append(Node("Subtensor", [rows] + [get(d) for _e, dyn in ents[1:] for d in dyn],
                                          [get(o0)], {"idx_list": [full] + [e for e, _d in ents[1:]]}))
+        elif n.op == "AdvancedSubtensor1":
+            x, iv = n.inputs
+            if x in step or V[iv].ndim != 1:
+                return None
+            step.add(o0)
+            # rows of an invariant table by the step's index VECTOR (an embedding lookup per batch
+            # item): one gather over the T * B indices, unfolded to [T, B, ...]
+            flat = emit("Reshape", [get(iv), emit("MakeVector", [i64(-1)], "int64", [1], {"dtype": "int64"})],
+                        V[iv].dtype, [None], {"ndim": 1})
+            rows = emit("AdvancedSubtensor1", [get(x), flat], V[x].dtype, [None] + list(V[x].shape[1:]))
+            dims = [T_(), emit("Shape_i", [get(iv)], "int64", [], {"i": 1})] + \
+                [emit("Shape_i", [get(x)], "int64", [], {"i": d}) for d in range(1, V[x].ndim)]
+            shp = emit("MakeVector", dims, "int64", [len(dims)], {"dtype": "int64"})
+            bp.nodes.append(Node("Reshape", [rows, shp], [get(o0)], {"ndim": len(dims)}))
         elif n.op == "IncSubtensor":
             x, y = n.inputs[:2]
             ents = entries(n.params["idx_list"], n.inputs[2:])
@@ -1436,6 +1451,108 @@ def batch_map_step(plan: Plan, n_seqs: int):
             outs.append(emit("Alloc", [lead(o)] + dims, V[o].dtype, [None] + list(V[o].shape)))
     bp.outputs = outs
     return {"plan": bp, "outs": len(outs)}
+
+
+_GLUE_TARGETS = ("Subtensor", "AdvancedSubtensor1", "IncSubtensor")
+_GLUE_LEAVE = ("Elemwise", "CAReduce", "Gemv", "Dot", "Dot22", "Dot22Scalar", "Gemm")
+
+
+def push_out_sequence_glue(plan: Plan) -> Plan:
+    """Index glue on SEQUENCE rows inside a recurrent step — ``E[idx_t]`` of an embedding table by the
+    step's index (a scalar or a vector of a batch), ``set_subtensor(zeros[i_t], 1)``, with the index
+    arithmetic that feeds them — does not take part in the recurrence.  Inside the loop it costs a
+    host read of the index per step (``Subtensor`` is host-side view arithmetic here) and keeps the
+    loop off the persistent kernels; it is taken out as the reference's ``scan_pushout_seqs_ops``
+    (scan/rewriting.py) takes Elemwise on sequences out: the glue nodes and their sequence-only
+    ancestors are restated over whole sequences (:func:`batch_map_step`: one gather for all steps)
+    IN FRONT of the Scan, on the first ``n_steps`` rows of the sequences, and their results enter
+    the Scan as additional sequences.  What is left of the step (dots, Elemwise) is what the
+    sequence hoists and the persistent kernels already handle."""
+    out_nodes, changed = [], False
+    new_plan = Plan(plan.name, dict(plan.vars), list(plan.inputs), list(plan.outputs), [])
+    for node in plan.nodes:
+        p = node.params
+        if node.op != "Scan" or p.get("as_while") or not p["n_seqs"] or not (
+                p.get("mit_mot_in_slices") or p["mit_sot_in_slices"] or p["sit_sot_in_slices"]
+                or p.get("n_shared_outs", 0)):
+            # (a Scan without recurrence is restated as a whole, in blocks of rows when its
+            # intermediates are large: ScanMixin._scan_all_rows)
+            out_nodes.append(node)
+            continue
+        inner, n_seqs, n_non = p["inner"], p["n_seqs"], p["n_non_seqs"]
+        V = inner.vars
+        n_var = len(inner.inputs) - n_non
+        seq_vars, inv_vars = list(inner.inputs[:n_seqs]), list(inner.inputs[n_var:])
+        rec_inputs = set(inner.inputs[n_seqs:n_var])
+        prod = {o: n_ for n_ in inner.nodes for o in n_.outputs}
+        # 0: invariant / constant, 1: sequence-only, 2: touches the recurrence
+        cls = {v: 0 for v in inv_vars}
+        cls.update({v: 1 for v in seq_vars})
+        cls.update({v: 2 for v in rec_inputs})
+        for n_ in inner.nodes:
+            k = max([cls.get(i, 0) for i in n_.inputs] or [0])
+            if n_.op == "Scan":
+                k = 2
+            for o in n_.outputs:
+                cls[o] = k
+        targets = [n_ for n_ in inner.nodes if n_.op in _GLUE_TARGETS and cls[n_.outputs[0]] == 1]
+        if not targets:
+            out_nodes.append(node)
+            continue
+        take, stack = set(), list(targets)
+        while stack:                      # the targets and everything (not recurrent) they are computed from
+            n_ = stack.pop()
+            if id(n_) in take:
+                continue
+            take.add(id(n_))
+            stack.extend(prod[i] for i in n_.inputs if i in prod)
+        sub_nodes = [n_ for n_ in inner.nodes if id(n_) in take]
+        rest = [n_ for n_ in inner.nodes if id(n_) not in take]
+        if any(n_.op in _GLUE_TARGETS + ("ScalarFromTensor", "AdvancedIncSubtensor1", "Scan") for n_ in rest):
+            # index nodes that DO depend on the recurrence stay: the loop keeps its host reads and
+            # its place on the launch list whatever leaves it — nothing to gain
+            out_nodes.append(node)
+            continue
+        used = {i for n_ in rest for i in n_.inputs} | set(inner.outputs)
+        outs = [o for n_ in sub_nodes for o in n_.outputs if o in used and cls[o] == 1]
+        if not outs or any(o in used and cls[o] == 0 for n_ in sub_nodes for o in n_.outputs):
+            out_nodes.append(node)        # (an invariant intermediate is shared with the step: leave it)
+            continue
+        sub = Plan(inner.name + "_glue", dict(V), seq_vars + inv_vars, list(outs), sub_nodes)
+        r = batch_map_step(sub, n_seqs)
+        if r is None:
+            out_nodes.append(node)
+            continue
+        bp = r["plan"]
+        # splice the whole-sequence plan in front of the Scan
+        n_steps_v = node.inputs[0]
+        o_seqs = list(node.inputs[1:1 + n_seqs])
+        o_invs = list(node.inputs[len(node.inputs) - n_non:]) if n_non else []
+        m = {}
+        for bv, ov in zip(bp.inputs[:n_seqs], o_seqs):
+            src = new_plan.vars[ov]
+            cut = new_plan.new_var(src.dtype, [None] + list(src.shape[1:]))
+            out_nodes.append(Node("Subtensor", [ov, n_steps_v], [cut], {"idx_list": [{"slice": [None, "in", None]}]}))
+            m[bv] = cut
+        for bv, ov in zip(bp.inputs[n_seqs:], o_invs):
+            m[bv] = ov
+
+        def mv(v):
+            if v not in m:
+                src = bp.vars[v]
+                m[v] = new_plan.new_var(src.dtype, list(src.shape), src.name, src.const)
+            return m[v]
+        for n_ in bp.nodes:
+            out_nodes.append(Node(n_.op, [mv(i) for i in n_.inputs], [mv(o) for o in n_.outputs], dict(n_.params)))
+        new_inner = Plan(inner.name + "_noglue", V, seq_vars + outs + list(inner.inputs[n_seqs:]),
+                         list(inner.outputs), rest)
+        out_nodes.append(Node("Scan", [n_steps_v] + o_seqs + [mv(o) for o in bp.outputs] + list(node.inputs[1 + n_seqs:]),
+                              list(node.outputs), dict(p, n_seqs=n_seqs + len(outs), inner=new_inner)))
+        changed = True
+    if not changed:
+        return plan
+    new_plan.nodes = out_nodes
+    return new_plan
 
 
 def hoist_sequence_dots(plan: Plan, seq_inputs: List[int], invariant: set):

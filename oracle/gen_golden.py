@@ -1023,6 +1023,40 @@ def _():
          {"kind": "normal_with_nan", "seed": 3, "shape": [33], "dtype": "float64"}, K(0.0, "float64"), K(0.5, "float64")]
 
 
+@case("scan_embedding_lookup_in_step", rtol=1e-12, atol=1e-12)
+def _():
+    """An RNN whose step looks its input up itself — ``E[idx_t]`` by the step's index (a vector
+    state) — plus a step that builds ``one_hot(idx_t)`` with set_subtensor: index glue on sequence
+    rows inside a recurrent step (fusion.push_out_sequence_glue restates it over whole sequences
+    in front of the Scan; the loop that is left is the plain ``tanh(x_t + h U)`` recurrence)."""
+    idx, E, U, h0 = at.lvector("idx"), at.dmatrix("E"), at.dmatrix("U"), at.dvector("h0")
+
+    def step(i, h, E, U):
+        return at.tanh(E[i] + at.dot(h, U))
+    hs, _ = ae.scan(step, sequences=[idx], outputs_info=[h0], non_sequences=[E, U])
+
+    def step2(i, k, h, E, U):
+        e = at.set_subtensor(at.zeros_like(E[0])[k], 1.0)
+        return at.tanh(E[i + 1] * 0.5 + e + at.dot(h, U))
+    hs2, _ = ae.scan(step2, sequences=[idx, idx % 6], outputs_info=[h0], non_sequences=[E, U])
+    return [idx, E, U, h0], [hs, hs2[-1], ae.grad(hs.sum(), E)], \
+        [I((11,), "int64", seed=1, low=-9, high=9), N((10, 6), seed=2), N((6, 6), seed=3, scale=0.4), N((6,), seed=4)]
+
+
+@case("scan_embedding_lookup_batch_f32", rtol=2e-5, atol=2e-6)
+def _():
+    """The same for a BATCH of recurrences: ``E[idx_t]`` with the step's index VECTOR
+    (AdvancedSubtensor1 per step -> one gather over T * B indices), float32 matrix state."""
+    idx, E, U, h0 = at.lmatrix("idx"), at.fmatrix("E"), at.fmatrix("U"), at.fmatrix("h0")
+
+    def step(i, h, E, U):
+        return at.tanh(E[i] + at.dot(h, U))
+    hs, _ = ae.scan(step, sequences=[idx], outputs_info=[h0], non_sequences=[E, U])
+    return [idx, E, U, h0], [hs, ae.grad((hs[-1] ** 2).sum(), U)], \
+        [I((9, 16), "int64", seed=1, low=0, high=40), N((40, 64), "float32", seed=2),
+         N((64, 64), "float32", seed=3, scale=0.1), N((16, 64), "float32", seed=4)]
+
+
 @case("scan_map_jacobian_rows", rtol=1e-12, atol=1e-12)
 def _():
     """``gradient.jacobian`` (gradient.py:1930): a Scan over ``arange(n)`` with no recurrence whose

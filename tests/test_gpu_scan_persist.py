@@ -812,3 +812,38 @@ def test_vector_state_do_while_trip_counts(scale):
         np.testing.assert_allclose(ms, np.array(mx), rtol=2e-4, atol=2e-5)
     assert list(ex.scan_modes.values()) == ["persistent"], ex.scan_modes
     ex.check()
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_embedding_lookup_inside_the_step_leaves_the_loop(use_graph):
+    """``E[idx_t]`` inside a recurrent step (scalar index, vector state; index vector, float32 matrix
+    state) is restated over whole sequences in front of the Scan (fusion.push_out_sequence_glue): the
+    forward loops run on the persistent kernels, results = the reference's, and at T = 300 with a
+    10^4-row table = NumPy."""
+    import torch
+    from aesara_amd import executor as E
+    for name in ("scan_embedding_lookup_in_step", "scan_embedding_lookup_batch_f32"):
+        c = _case(name)
+        ex = E.PlanExecutor(case_plan(c), use_graph=use_graph)
+        for it in range(2):
+            assert_matches(c, _np(ex(*case_inputs(c))), case_expected(c), f"{name} call {it}")
+        assert list(ex.scan_modes.values())[0] == "persistent", ex.scan_modes
+    rng = np.random.default_rng(5)
+    T, B, V, H = 300, 32, 10000, 128
+    idx = rng.integers(0, V, (T, B))
+    Em = (rng.standard_normal((V, H)) * 0.5).astype("float32")
+    U = (rng.standard_normal((H, H)) / np.sqrt(H)).astype("float32")
+    h0 = (rng.standard_normal((B, H)) * 0.1).astype("float32")
+    ex = E.PlanExecutor(case_plan(_case("scan_embedding_lookup_batch_f32")), use_graph=use_graph)
+    hs = _np(ex(*(torch.from_numpy(a).cuda() for a in (idx, Em, U, h0))))[0]
+    h, want = h0.astype(np.float64), []
+    for t in range(T):
+        h = np.tanh(Em[idx[t]].astype(np.float64) + h @ U.astype(np.float64))
+        want.append(h)
+    np.testing.assert_allclose(hs, np.stack(want), rtol=2e-4, atol=2e-5)
+    assert list(ex.scan_modes.values())[0] == "persistent", ex.scan_modes
+    bad = np.array(idx, copy=True)
+    bad[7, 3] = V                      # out of range at step 7: the reference's IndexError
+    with pytest.raises(IndexError):
+        ex(*(torch.from_numpy(a).cuda() for a in (bad, Em, U, h0)))
+        ex.check()

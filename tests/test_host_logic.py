@@ -296,6 +296,37 @@ def test_device_filter_type_decisions():
     assert isinstance(t3, DeviceFilterType) and t3.shape == (None, 3)
 
 
+@pytest.mark.parametrize("name", ["scan_embedding_lookup_in_step", "scan_embedding_lookup_batch_f32"])
+def test_index_glue_on_sequence_rows_leaves_the_step(name):
+    """fusion.push_out_sequence_glue: ``E[idx_t]`` (scalar index / index vector of a batch) and the
+    ``set_subtensor(zeros[k_t], 1)`` unit vectors of a recurrent step are restated over whole
+    sequences in front of the Scan and enter it as sequences; the rewritten plan gives the
+    REFERENCE's outputs (oracle), the forward step has no index node left, and the dry run puts the
+    forward loop on a persistent kernel."""
+    import interp
+    from golden_util import CASES, assert_matches, case_expected, case_inputs, case_plan
+    from aesara_amd.executor import PlanExecutor
+    from aesara_amd.fusion import push_out_sequence_glue
+    c = next(c for c in CASES if c["name"] == name)
+    plan = case_plan(c)
+    p2 = push_out_sequence_glue(plan)
+    assert p2 is not plan
+    fwd = next(n for n in p2.nodes if n.op == "Scan")
+    assert not {"Subtensor", "AdvancedSubtensor1", "IncSubtensor", "ScalarFromTensor"} & {n.op for n in fwd.params["inner"].nodes}
+    assert fwd.params["n_seqs"] > next(n for n in plan.nodes if n.op == "Scan").params["n_seqs"]
+    assert len(fwd.params["inner"].inputs) == len(fwd.inputs) - 1 - fwd.params["n_nit_sot"] + \
+        sum(len(t) - 1 for t in fwd.params["mit_sot_in_slices"] + fwd.params.get("mit_mot_in_slices", []))
+    for g, e in zip(interp.run_plan(p2, case_inputs(c)), case_expected(c)):
+        assert_matches(c, g, e)
+    assert push_out_sequence_glue(p2) is p2              # nothing left to take out
+    ex = PlanExecutor(plan, dry_run=True)
+    try:
+        ex(*case_inputs(c))
+    except Exception:           # (the gradient Scan's scatter index is data a dry run cannot read)
+        pass
+    assert list(ex.scan_modes.values())[0] == "persistent", ex.scan_modes
+
+
 @pytest.mark.parametrize("name", ["scan_nitsot_map", "scan_map_jacobian_rows", "scan_map_hessian_unit_vectors",
                                   "scan_map_rows_reduce_broadcast"])
 def test_scans_without_recurrence_restated_over_whole_sequences(name):
@@ -793,8 +824,8 @@ def test_streaming_policy_for_read_once_operands(monkeypatch):
 
 def test_which_golden_scans_run_as_one_launch():
     """The persistent-Scan class over the whole golden set, decided on the host (dry runs: analysis,
-    layout checks and kernel generation, no device): of 100 Scans 91 take a one-launch kernel and 5
-    (no recurrence) are one evaluation over whole sequences; the four that do neither are named with the reason ``PlanExecutor.scan_modes`` gives — a silent
+    layout checks and kernel generation, no device): of 104 Scans 94 take a one-launch kernel and 5
+    (no recurrence) are one evaluation over whole sequences; the five that do neither are named with the reason ``PlanExecutor.scan_modes`` gives — a silent
     fall-back to the launch list of any other golden fails here, on CPU."""
     from aesara_amd.executor import PlanExecutor
     from golden_util import CASES, case_plan
@@ -804,6 +835,8 @@ def test_which_golden_scans_run_as_one_launch():
         "scan_nested_with_grad": "Shape_i",                                           # a shape node inside the step
         "scan_seq_products_two_row_counts": "Gemm",                                   # a bare Gemm node in the step
         "sp_rnn_proj_narrow_f32": "matrix layout",                                    # projection narrower than the state
+        # the GRADIENT Scan of a step that looks its input up itself: dE[idx_t] += delta_t, a recurrent scatter
+        "scan_embedding_lookup_in_step": "ScalarFromTensor",
     }
     total = persistent = all_rows = 0
     for c in CASES:
@@ -824,4 +857,4 @@ def test_which_golden_scans_run_as_one_launch():
             else:
                 want = expected_launch_list.get(c["name"])
                 assert want is not None and want in mode, (c["name"], mode)
-    assert (persistent, all_rows, total) == (91, 5, 100), (persistent, all_rows, total)
+    assert (persistent, all_rows, total) == (94, 5, 104), (persistent, all_rows, total)
