@@ -26,18 +26,23 @@ class ScanMixin:
             # buffer length is known only now)
             alt = self._inner.get(("sunk", key))
             if alt is None:
-                need, same = [], []
+                need, same, le2 = [], [], []
                 wrap = Plan("scan_%d_sunk" % node.outputs[0], dict(self.plan.vars), list(node.inputs),
                             list(node.outputs), [node])
-                wrap2 = push_out_product_accumulators(wrap, need, same)
+                if not hasattr(self, "_zero_vars"):
+                    self._zero_vars, self._last_only = zero_filled_vars(self.plan), read_last_row_only(self.plan)
+                wrap2 = push_out_product_accumulators(wrap, need, same, zeros=self._zero_vars,
+                                                      last_only=self._last_only, need_le2=le2)
                 alt = False
-                if wrap2 is not wrap and need:
+                if wrap2 is not wrap:
                     sub = PlanExecutor(wrap2, use_graph=False, dry_run=self.dry_run, fuse=self.fuse,
                                        device=None if self.dry_run else self.device.index)
                     alt = (sub, [node.inputs.index(v) for v in need],
-                           [(node.inputs.index(a_), node.inputs.index(b_)) for a_, b_ in same])
+                           [(node.inputs.index(a_), node.inputs.index(b_)) for a_, b_ in same],
+                           [node.inputs.index(v) for v in le2])
                 self._inner[("sunk", key)] = alt
             if alt and all(getattr(args[i], "shape", (0,))[0] == 1 for i in alt[1]) and \
+                    all(getattr(args[i], "shape", (0,))[0] in (1, 2) for i in alt[3]) and \
                     all(self.host_int(args[i]) == self.host_int(args[j]) for i, j in alt[2]):
                 sub = alt[0]
                 sub._arena, sub._capturing = self._arena, self._capturing

@@ -630,7 +630,28 @@ def push_out_accumulators(plan: Plan) -> Plan:
     return plan
 
 
-def push_out_product_accumulators(plan: Plan, need_one_row: list = None, need_equal: list = None) -> Plan:
+def zero_filled_vars(plan: Plan) -> set:
+    """Variables of ``plan`` that are ``Alloc`` of a constant 0 (``zeros_like`` of the front end)."""
+    out = set()
+    for n_ in plan.nodes:
+        if n_.op == "Alloc":
+            c = plan.vars[n_.inputs[0]].const
+            if c is not None and "data" in c and len(c["data"]) == 1 and float(c["data"][0]) == 0.0:
+                out.add(n_.outputs[0])
+    return out
+
+
+def read_last_row_only(plan: Plan) -> set:
+    """Variables of ``plan`` whose every use is ``v[-1]`` (what the caller of a Scan accumulator reads)."""
+    uses = {}
+    for n_ in plan.nodes:
+        for k, i in enumerate(n_.inputs):
+            uses.setdefault(i, []).append(n_.op == "Subtensor" and k == 0 and n_.params.get("idx_list") == [{"index": -1}])
+    return {v for v, u in uses.items() if all(u) and v not in plan.outputs}
+
+
+def push_out_product_accumulators(plan: Plan, need_one_row: list = None, need_equal: list = None,
+                                  zeros: set = None, last_only: set = None, need_le2: list = None) -> Plan:
     """The weight gradient a gradient Scan accumulates IN the loop — ``acc_t = acc_{t-1} + a_t^T @ g_t``
     (``Gemm(acc, alpha, A_t, B_t, 1)``; for a vector state the outer product ``Ger(acc, alpha, x_t,
     y_t)``) in a sit-sot output — is what the reference's ``PushOutDot1`` (scan/rewriting.py) turns
@@ -681,15 +702,39 @@ def push_out_product_accumulators(plan: Plan, need_one_row: list = None, need_eq
         iclients = inner.clients()
         V = plan.vars
         found = []         # (q, alpha, "gemm" | "ger", a var, b var)
+        zero_set = zero_filled_vars(plan) if zeros is None else zeros
+        last_set = read_last_row_only(plan) if last_only is None else last_only
+        n_var_ = len(inner.inputs) - p["n_non_seqs"]
+        inner_zero = {iv for iv, ov in zip(inner.inputs[n_var_:], node.inputs[len(node.inputs) - p["n_non_seqs"]:])
+                      if ov in zero_set} if p["n_non_seqs"] else set()
+
+        def is_acc(v, tq_):
+            """v is the accumulator tap itself, or ``tap + zeros`` (what the gradient of a lookup
+            leaves: acc + inc_subtensor(zeros[i], g) rewritten to inc_subtensor((acc + zeros)[i], g))"""
+            if v == tq_:
+                return True
+            pn_ = iprod.get(v)
+            if pn_ is None or pn_.op != "Elemwise" or len(pn_.inputs) != 2 or len(iclients[v]) != 1:
+                return False
+            sc_ = pn_.params["scalar"]
+            return (tq_ in pn_.inputs and any(i in inner_zero for i in pn_.inputs) and len(sc_["nodes"]) == 1
+                    and sc_["nodes"][0]["op"] == "add"
+                    and sorted(map(tuple, sc_["nodes"][0]["in"])) == [("i", 0), ("i", 1)] and sc_["out"] == [["t", 0]]
+                    and inner.vars[v].shape == inner.vars[tq_].shape)
         for q in range(n_ss):
             if ss[q] != [-1]:
                 continue
             tq, oq = inner.inputs[tap0 + q], inner.outputs[out0 + q]
             upd = iprod.get(oq)
             init_buf = node.inputs[base_in + q]
-            if upd is None or (need_one_row is None and V[init_buf].shape[0] != 1) or \
-                    len(iclients[tq]) != 1 or len(iclients[oq]) != 1 or \
+            scatter = upd is not None and upd.op in ("IncSubtensor", "AdvancedIncSubtensor1")
+            if upd is None or len(iclients[tq]) != 1 or len(iclients[oq]) != 1 or \
                     inner.vars[oq].dtype not in ("float32", "float64"):
+                continue
+            if scatter and node.outputs[base_out + q] not in last_set and need_le2 is None:
+                continue          # (a scatter accumulator: only its LAST row may be read, or — decided by
+                #                    the caller at run time — the buffer holds at most two rows)
+            if not scatter and need_one_row is None and V[init_buf].shape[0] != 1:
                 continue
             if upd.op == "Gemm" and upd.inputs[0] == tq and cval(inner, upd.inputs[1]) is not None and \
                     cval(inner, upd.inputs[4]) == 1.0 and tq not in upd.inputs[1:]:
@@ -697,6 +742,16 @@ def push_out_product_accumulators(plan: Plan, need_one_row: list = None, need_eq
             elif upd.op == "Ger" and upd.inputs[0] == tq and cval(inner, upd.inputs[1]) is not None and \
                     tq not in upd.inputs[1:]:
                 found.append((q, cval(inner, upd.inputs[1]), "ger", upd.inputs[2], upd.inputs[3]))
+            elif upd.op == "IncSubtensor" and is_acc(upd.inputs[0], tq) and not upd.params["set_instead_of_inc"] and \
+                    upd.params["idx_list"] == [{"index": "in"}] and len(upd.inputs) == 3 and tq not in upd.inputs[1:] \
+                    and inner.vars[upd.inputs[1]].ndim == inner.vars[tq].ndim - 1:
+                # acc[i_t] += v_t (the gradient of a table whose rows the step looks up itself,
+                # subtensor.py:1419 IncSubtensor): acc_T = acc_0 with rows v_1 .. v_T added at i_1 .. i_T
+                found.append((q, 1.0, "scatter", upd.inputs[1], upd.inputs[2]))
+            elif upd.op == "AdvancedIncSubtensor1" and is_acc(upd.inputs[0], tq) and not upd.params["set_instead_of_inc"] \
+                    and tq not in upd.inputs[1:] and inner.vars[upd.inputs[2]].ndim == 1 and \
+                    inner.vars[upd.inputs[1]].ndim == inner.vars[tq].ndim:
+                found.append((q, 1.0, "scatter1", upd.inputs[1], upd.inputs[2]))
         if not found:
             out_nodes.append(node)
             continue
@@ -711,6 +766,8 @@ def push_out_product_accumulators(plan: Plan, need_one_row: list = None, need_eq
             """outer variable holding [T, ...] = the value of inner variable v at every step (None:
             not a per-step value we can take out)"""
             pn = iprod.get(v)
+            if pn is not None and pn.op in ("ScalarFromTensor", "TensorFromScalar"):
+                return rows_of(pn.inputs[0])
             if pn is not None and pn.op == "DimShuffle":
                 r = rows_of(pn.inputs[0])
                 if r is None:
@@ -768,6 +825,60 @@ def push_out_product_accumulators(plan: Plan, need_one_row: list = None, need_eq
             old = node.outputs[base_out + q]
             init_buf = node.inputs[base_in + q]
             dt = V[old].dtype
+            if kind in ("scatter", "scatter1"):
+                # ra: the added rows [T, ...] ([T, B, ...]), rb: their indices [T] ([T, B])
+                neg = plan.add_const(-1, "int64")
+                base = plan.new_var(dt, list(V[init_buf].shape[1:]))
+                post.append(Node("Subtensor", [init_buf], [base], {"idx_list": [{"index": 0}]}))
+
+                def scatter_sum(rv, iv):
+                    """acc_0 with the rows ``rv`` added at ``iv`` (in step order per destination row)"""
+                    if kind == "scatter1":
+                        dims = [neg] + [plan.new_var("int64", []) for _ in range(V[init_buf].ndim - 2)]
+                        for d_, dv in enumerate(dims[1:]):
+                            post.append(Node("Shape_i", [init_buf], [dv], {"i": d_ + 2}))
+                        sv, si = plan.new_var("int64", [len(dims)]), plan.new_var("int64", [1])
+                        post.append(Node("MakeVector", dims, [sv], {"dtype": "int64"}))
+                        post.append(Node("MakeVector", [neg], [si], {"dtype": "int64"}))
+                        rv2, iv2 = plan.new_var(dt, [None] * len(dims)), plan.new_var(inner.vars[b].dtype, [None])
+                        post.append(Node("Reshape", [rv, sv], [rv2], {"ndim": len(dims)}))
+                        post.append(Node("Reshape", [iv, si], [iv2], {"ndim": 1}))
+                        rv, iv = rv2, iv2
+                    out_ = plan.new_var(dt, list(V[init_buf].shape[1:]))
+                    post.append(Node("AdvancedIncSubtensor1", [base, rv, iv], [out_],
+                                     {"set_instead_of_inc": False, "inplace": False}))
+                    return out_
+                summed = scatter_sum(ra, rb)
+                buf = init_buf
+                if old not in last_set:
+                    # a buffer of TWO rows keeps [acc_{T-1}, acc_T] (chronological, scan/op.py:2105): the row
+                    # before the last is the same sum over the first T - 1 steps
+                    if need_le2 is None:
+                        del post[mark[0]:]
+                        continue
+                    tm1 = plan.new_var("int64", [])
+                    post.append(Node("Elemwise", [n_steps_v, plan.add_const(1, "int64")], [tm1], {"scalar": {
+                        "n_in": 2, "nodes": [{"op": "sub", "in": [["i", 0], ["i", 1]], "dtype": "int64"}], "out": [["t", 0]]}}))
+                    cut = []
+                    for v_ in (ra, rb):
+                        c_ = plan.new_var(plan.vars[v_].dtype, list(plan.vars[v_].shape))
+                        post.append(Node("Subtensor", [v_, tm1], [c_], {"idx_list": [{"slice": [None, "in", None]}]}))
+                        cut.append(c_)
+                    prev = scatter_sum(*cut)
+                    prev3 = plan.new_var(dt, [1] + list(V[init_buf].shape[1:]))
+                    post.append(Node("DimShuffle", [prev], [prev3],
+                                     {"new_order": ["x"] + list(range(V[init_buf].ndim - 1))}))
+                    buf = plan.new_var(dt, list(V[old].shape))
+                    post.append(Node("IncSubtensor", [init_buf, prev3], [buf],
+                                     {"idx_list": [{"slice": [-2, -1, None]}], "set_instead_of_inc": True, "inplace": False}))
+                    need_le2.append(init_buf)
+                # the buffer the caller allocated, its last row = the final sum
+                new = plan.new_var(dt, list(V[old].shape))
+                post.append(Node("IncSubtensor", [buf, summed], [new],
+                                 {"idx_list": [{"index": -1}], "set_instead_of_inc": True, "inplace": False}))
+                replaced[old] = new
+                done.append(q)
+                continue
             if kind == "gemm":
                 # sum_t A_t[m, k] @ B_t[k, n] = [m, T*k] @ [T*k, n]
                 at_ = plan.new_var(dt, [None, None, None])

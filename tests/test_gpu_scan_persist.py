@@ -827,7 +827,8 @@ def test_embedding_lookup_inside_the_step_leaves_the_loop(use_graph):
         ex = E.PlanExecutor(case_plan(c), use_graph=use_graph)
         for it in range(2):
             assert_matches(c, _np(ex(*case_inputs(c))), case_expected(c), f"{name} call {it}")
-        assert list(ex.scan_modes.values())[0] == "persistent", ex.scan_modes
+        # (forward AND gradient Scan: dE[idx_t] += delta_t leaves its loop as one scatter-add)
+        assert set(ex.scan_modes.values()) == {"persistent"} and len(ex.scan_modes) == 2, ex.scan_modes
     rng = np.random.default_rng(5)
     T, B, V, H = 300, 32, 10000, 128
     idx = rng.integers(0, V, (T, B))
@@ -835,13 +836,26 @@ def test_embedding_lookup_inside_the_step_leaves_the_loop(use_graph):
     U = (rng.standard_normal((H, H)) / np.sqrt(H)).astype("float32")
     h0 = (rng.standard_normal((B, H)) * 0.1).astype("float32")
     ex = E.PlanExecutor(case_plan(_case("scan_embedding_lookup_batch_f32")), use_graph=use_graph)
-    hs = _np(ex(*(torch.from_numpy(a).cuda() for a in (idx, Em, U, h0))))[0]
+    hs, dU, dE = _np(ex(*(torch.from_numpy(a).cuda() for a in (idx, Em, U, h0))))
     h, want = h0.astype(np.float64), []
+    U64 = U.astype(np.float64)
     for t in range(T):
-        h = np.tanh(Em[idx[t]].astype(np.float64) + h @ U.astype(np.float64))
+        h = np.tanh(Em[idx[t]].astype(np.float64) + h @ U64)
         want.append(h)
     np.testing.assert_allclose(hs, np.stack(want), rtol=2e-4, atol=2e-5)
-    assert list(ex.scan_modes.values())[0] == "persistent", ex.scan_modes
+    # cost = sum(h_T^2): back through time in float64; the table's gradient is a scatter of the
+    # per-step pre-activation gradients (every index repeats ~ T * B / V times)
+    g = 2.0 * want[-1]
+    dU_w, dE_w = np.zeros((H, H)), np.zeros((V, H))
+    for t in range(T - 1, -1, -1):
+        da = g * (1.0 - want[t] ** 2)
+        hp = want[t - 1] if t else h0.astype(np.float64)
+        dU_w += hp.T @ da
+        np.add.at(dE_w, idx[t], da)
+        g = da @ U64.T
+    np.testing.assert_allclose(dU, dU_w, rtol=2e-3, atol=2e-5 * np.abs(dU_w).max())
+    np.testing.assert_allclose(dE, dE_w, rtol=2e-3, atol=2e-5 * np.abs(dE_w).max())
+    assert set(ex.scan_modes.values()) == {"persistent"}, ex.scan_modes
     bad = np.array(idx, copy=True)
     bad[7, 3] = V                      # out of range at step 7: the reference's IndexError
     with pytest.raises(IndexError):
