@@ -937,7 +937,8 @@ def push_out_product_accumulators(plan: Plan, need_one_row: list = None, need_eq
         p["inner"] = new_inner
         p["sit_sot_in_slices"] = [t for q, t in enumerate(ss) if q not in dq]
         p["n_nit_sot"] = n_nit + len(new_nits)
-        out_nodes.append(Node("Scan", new_inputs, new_outputs, p))
+        if new_outputs:          # (every output was an accumulator over sequence rows: no loop is left)
+            out_nodes.append(Node("Scan", new_inputs, new_outputs, p))
         out_nodes.extend(post)
     if not changed:
         return orig

@@ -1043,6 +1043,16 @@ def _():
         [I((11,), "int64", seed=1, low=-9, high=9), N((10, 6), seed=2), N((6, 6), seed=3, scale=0.4), N((6,), seed=4)]
 
 
+@case("scan_grad_of_row_lookup", rtol=1e-12, atol=1e-12)
+def _():
+    """tests/scan/test_basic.py:3138 (test_grad_bug_disconnected_input): the gradient of a map that
+    looks rows of W up by a sequence of indices — the gradient Scan's ONLY output is the scatter
+    accumulator ``dW[i_t] += g_t`` over sequence rows: with the scatter taken out no loop is left."""
+    v, W = at.lvector("v"), at.dmatrix("W")
+    y, _ = ae.scan(lambda i, W: W[i] * 2.0, sequences=v, outputs_info=None, non_sequences=W)
+    return [v, W], [ae.grad((y ** 2).sum(), W), y], [I((7,), "int64", seed=1, low=-4, high=4), N((4, 3), seed=2)]
+
+
 @case("scan_embedding_lookup_batch_f32", rtol=2e-5, atol=2e-6, ref_py=True)
 def _():
     """The same for a BATCH of recurrences: ``E[idx_t]`` with the step's index VECTOR
