@@ -865,13 +865,25 @@ def push_out_product_accumulators(plan: Plan, need_one_row: list = None, need_eq
                         post.append(Node("Subtensor", [v_, tm1], [c_], {"idx_list": [{"slice": [None, "in", None]}]}))
                         cut.append(c_)
                     prev = scatter_sum(*cut)
-                    prev3 = plan.new_var(dt, [1] + list(V[init_buf].shape[1:]))
-                    post.append(Node("DimShuffle", [prev], [prev3],
-                                     {"new_order": ["x"] + list(range(V[init_buf].ndim - 1))}))
-                    buf = plan.new_var(dt, list(V[old].shape))
-                    post.append(Node("IncSubtensor", [init_buf, prev3], [buf],
-                                     {"idx_list": [{"slice": [-2, -1, None]}], "set_instead_of_inc": True, "inplace": False}))
+                    # [acc_{T-1}; acc_T] written once, cut to the caller's one or two rows (a view): the
+                    # sums of a large table are not copied through the buffer twice
+                    both = []
+                    for v_ in (prev, summed):
+                        r3 = plan.new_var(dt, [1] + list(V[init_buf].shape[1:]))
+                        post.append(Node("DimShuffle", [v_], [r3], {"new_order": ["x"] + list(range(V[init_buf].ndim - 1))}))
+                        both.append(r3)
+                    two = plan.new_var(dt, [2] + list(V[init_buf].shape[1:]))
+                    post.append(Node("Join", [plan.add_const(0, "int64")] + both, [two], {}))
+                    s_, ms_ = plan.new_var("int64", []), plan.new_var("int64", [])
+                    post.append(Node("Shape_i", [init_buf], [s_], {"i": 0}))
+                    post.append(Node("Elemwise", [s_], [ms_], {"scalar": {
+                        "n_in": 1, "nodes": [{"op": "neg", "in": [["i", 0]], "dtype": "int64"}], "out": [["t", 0]]}}))
+                    new = plan.new_var(dt, list(V[old].shape))
+                    post.append(Node("Subtensor", [two, ms_], [new], {"idx_list": [{"slice": ["in", None, None]}]}))
                     need_le2.append(init_buf)
+                    replaced[old] = new
+                    done.append(q)
+                    continue
                 # the buffer the caller allocated, its last row = the final sum
                 new = plan.new_var(dt, list(V[old].shape))
                 post.append(Node("IncSubtensor", [buf, summed], [new],
